@@ -1,0 +1,103 @@
+"""Pin the GPT CPU oracle against fixtures minted by running the reference's own code (tools/make_golden_gpt.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gpt_oracle as G
+
+
+def load_case(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, f"gpt_{tag}.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]),
+                      max_mel_tokens=int(c[4]), number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))
+    sd["mel_head.bias"][cfg.stop_mel_token] += float(z["eos_bias"])
+    return z, cfg, sd
+
+
+def gen_params(z):
+    g = z["gen"]
+    return G.GenParams(do_sample=bool(g[0]), num_beams=int(g[1]), top_p=float(g[2]), top_k=int(g[3]),
+                       temperature=float(g[4]), repetition_penalty=float(g[5]), length_penalty=float(g[6]),
+                       max_generate_length=int(z["max_gen"]))
+
+
+@pytest.mark.parametrize("tag", ["greedy", "greedy_nokv", "sample", "beam", "beam_sample", "greedy_mid"])
+def test_codes_match_reference(golden_dir, tag):
+    z, cfg, sd = load_case(golden_dir, tag)
+    gp = gen_params(z)
+    u = torch.from_numpy(z["uniforms"])
+    if gp.num_beams == 1:
+        u = u[..., 0]
+    conds = G.conds_latent_campplus(sd, torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"]))
+    with torch.no_grad():
+        codes = G.inference_speech(sd, cfg, conds, torch.from_numpy(z["text"]), torch.from_numpy(z["langs"]), gp,
+                                   uniforms=u, kv_cache=bool(z["kv_cache"]))
+    assert codes.shape == z["codes"].shape
+    assert np.array_equal(codes.numpy(), z["codes"])
+
+
+def test_latent_pass_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "gpt_latent.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]),
+                      max_mel_tokens=int(c[4]), number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))
+    sd["mel_head.bias"][cfg.stop_mel_token] += float(z["eos_bias"])
+    B = z["text"].shape[0]
+    conds = G.conds_latent_campplus(sd, torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"])).repeat(B, 1, 1)
+    with torch.no_grad():
+        lat = G.forward_latent(sd, cfg, conds, torch.from_numpy(z["text"]), torch.from_numpy(z["text_lens"]),
+                               torch.from_numpy(z["mel_codes"]), torch.from_numpy(z["mel_lens"]))
+    np.testing.assert_allclose(lat.numpy(), z["latent"], rtol=0, atol=2e-5)
+
+
+def test_padding_invariance(golden_dir):
+    """tests/padding_test.py:45-99 of the reference, as a property: unpadded == left-padded == batched."""
+    z, cfg, sd = load_case(golden_dir, "greedy")
+    gp = gen_params(z)
+    text = torch.from_numpy(z["text"])
+    langs = torch.from_numpy(z["langs"])
+    conds = G.conds_latent_campplus(sd, torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"]))
+    for b in range(text.shape[0]):
+        n = int((text[b] != cfg.stop_text_token).sum())
+        with torch.no_grad():
+            solo = G.inference_speech(sd, cfg, conds, text[b:b + 1, :n], langs[b:b + 1], gp)
+        ref = z["codes"][b]
+        k = min(solo.shape[1], len(ref))
+        assert np.array_equal(solo[0, :k].numpy(), ref[:k])
+        assert np.all(ref[k:] == cfg.stop_mel_token)
+
+
+def test_kv_cache_position_quirk(golden_dir):
+    """kv_cache=True feeds mel position k+1 to the k-th generated token; kv_cache=False re-embeds 0..n-1
+     -- the two modes must differ on the same inputs."""
+    z, cfg, sd = load_case(golden_dir, "greedy_mid")
+    gp = gen_params(z)
+    conds = G.conds_latent_campplus(sd, torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"]))
+    args = (sd, cfg, conds, torch.from_numpy(z["text"])[:1], torch.from_numpy(z["langs"])[:1], gp)
+    with torch.no_grad():
+        a = G.inference_speech(*args, kv_cache=True)
+        b = G.inference_speech(*args, kv_cache=False)
+    assert a[0, 0] == b[0, 0]                       # first token: both use position 0
+    assert not torch.equal(a[:, :6], b[:, :6])
+
+
+def test_processors_vs_installed_hf():
+    tr = pytest.importorskip("transformers")
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                        TopKLogitsWarper, TopPLogitsWarper)
+    g = torch.Generator().manual_seed(0)
+    scores = torch.randn(4, 500, generator=g) * 3
+    ids = torch.randint(0, 500, (4, 17), generator=g)
+    for min_keep, nb in ((1, 1), (2, 3)):
+        ref = RepetitionPenaltyLogitsProcessor(10.0)(ids, scores.clone())
+        ref = TemperatureLogitsWarper(0.8)(ids, ref)
+        ref = TopKLogitsWarper(30, min_tokens_to_keep=min_keep)(ids, ref)
+        ref = TopPLogitsWarper(0.8, min_tokens_to_keep=min_keep)(ids, ref)
+        mine = G.process_scores(scores.clone(), ids, G.GenParams(do_sample=True, num_beams=nb))
+        assert torch.equal(torch.isinf(ref), torch.isinf(mine))
+        assert torch.allclose(ref[~torch.isinf(ref)], mine[~torch.isinf(mine)], atol=0, rtol=0)

@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""Mint GPT golden vectors by running the REFERENCE's own code (build container only).
+
+What runs here is reference source, read from /root/reference at run time (never copied into this repo):
+  * `GPT2InferenceModel`, `LearnedPositionEmbeddings`, `null_position_embeddings` and the `UnifiedVoice`
+    methods `prepare_gpt_inputs`, `inference_speech`, `forward`, `get_logits`, `set_text_padding`,
+    `set_mel_padding`, `build_aligned_inputs_and_targets` are extracted from `indextts/gpt/model_v2.py` by
+    AST and exec'd (the module itself is not importable under transformers 5.15 -- tools/ref_shim.py);
+  * `generate()` / `_sample` / `_beam_search` / `_get_logits_processor` are the reference's vendored
+    `indextts/gpt/transformers_generation_utils.py` + `transformers_beam_search.py` (tools/ref_shim.py);
+  * the transformer blocks are the installed HF `GPT2Model(attn_implementation="eager")` with `wpe` nulled
+    exactly as `build_hf_gpt_transformer` does (model_v2.py:259-279) behind a thin adapter that converts the
+    legacy KV tuples the vendored mixin carries to/from the 5.15 cache object;
+  * logits processors are the installed `transformers.generation.logits_process` classes.
+`torch.multinomial` is replaced (only inside sampled runs) by inverse-CDF draws from a stored uniform stream,
+since the RNG stream itself cannot be reproduced on a device; that stream is part of the fixture.
+
+Outputs tests/golden/gpt_*.npz (inputs, uniforms, reference token ids / latents; weights are regenerated
+from the seed by oracle.gpt_oracle.synth_weights) and prints oracle-vs-reference agreement.
+"""
+import ast
+import functools
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import ref_shim  # noqa: E402
+
+gu, _log = ref_shim.load_ref_generation_utils()
+
+from transformers import GPT2Config, GPT2Model, GenerationConfig, LogitsProcessorList  # noqa: E402
+from transformers.cache_utils import DynamicCache  # noqa: E402
+from transformers.generation.logits_process import TypicalLogitsWarper as HFTypical  # noqa: E402
+from transformers.modeling_outputs import CausalLMOutputWithCrossAttentions  # noqa: E402
+
+from oracle import gpt_oracle as G  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+MODEL_V2 = "/root/reference/indextts/gpt/model_v2.py"
+
+LEGACY_GENCFG = {"return_legacy_cache", "forced_decoder_ids"}     # attributes 4.52's GenerationConfig had
+# transformers 4.52.1 GenerationConfig defaults (5.15 initialises every field to None)
+DEFAULTS_4_52 = dict(
+    max_length=20, min_length=0, early_stopping=False, do_sample=False, num_beams=1, num_beam_groups=1,
+    use_cache=True, temperature=1.0, top_k=50, top_p=1.0, typical_p=1.0, epsilon_cutoff=0.0, eta_cutoff=0.0,
+    diversity_penalty=0.0, repetition_penalty=1.0, encoder_repetition_penalty=1.0, length_penalty=1.0,
+    no_repeat_ngram_size=0, encoder_no_repeat_ngram_size=0, renormalize_logits=False, remove_invalid_values=False,
+    token_healing=False, num_return_sequences=1, output_attentions=False, output_hidden_states=False,
+    output_scores=False, return_dict_in_generate=False)
+
+
+class LegacyGenerationConfig(GenerationConfig):
+    def __getattr__(self, k):
+        if k in LEGACY_GENCFG:
+            return None
+        raise AttributeError(k)
+
+
+class HarnessPreTrainedModel(nn.Module, gu.GenerationMixin):
+    """Stands in for the vendored GPT2PreTrainedModel base: just enough for the vendored generate()."""
+    main_input_name = "input_ids"
+    _supports_cache_class = False
+    _is_stateful = False
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.generation_config = LegacyGenerationConfig(**DEFAULTS_4_52)
+
+    @property
+    def device(self):
+        return torch.device("cpu")
+
+    def can_generate(self):
+        return True
+
+
+class TransformerAdapter(nn.Module):
+    """Installed HF GPT2Model behind the 4.52-era call signature (legacy KV tuples in/out)."""
+
+    def __init__(self, gpt):
+        super().__init__()
+        self.gpt = gpt
+
+    def forward(self, inputs_embeds=None, past_key_values=None, attention_mask=None, use_cache=None,
+                return_dict=None, **unused):
+        cache = None
+        if past_key_values is not None:
+            cache = DynamicCache()
+            for li, (k, v) in enumerate(past_key_values):
+                cache.update(k, v, li)
+        elif use_cache:
+            cache = DynamicCache()
+        out = self.gpt(inputs_embeds=inputs_embeds, past_key_values=cache, attention_mask=attention_mask,
+                       use_cache=bool(use_cache), return_dict=True)
+        pkv = None
+        if out.past_key_values is not None:
+            c = out.past_key_values
+            pkv = tuple((c.layers[i].keys, c.layers[i].values) for i in range(len(c.layers)))
+        out.past_key_values = pkv
+        return out
+
+
+def extract(names_top, methods_of=None, method_names=()):
+    """Pull class/function definitions (and selected methods of a class) out of model_v2.py as source."""
+    src = open(MODEL_V2).read()
+    tree = ast.parse(src)
+    out = {}
+    for node in tree.body:
+        if isinstance(node, (ast.ClassDef, ast.FunctionDef)) and node.name in names_top:
+            out[node.name] = ast.get_source_segment(src, node)
+        if isinstance(node, ast.ClassDef) and node.name == methods_of:
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name in method_names:
+                    import textwrap
+                    out[sub.name] = textwrap.dedent(ast.get_source_segment(src, sub, padded=True))
+    return out
+
+
+def build_reference(sd, cfg: G.GPTConfig, kv_cache=True):
+    ns = dict(torch=torch, nn=nn, F=F, functools=functools, GPT2PreTrainedModel=HarnessPreTrainedModel,
+              CausalLMOutputWithCrossAttentions=CausalLMOutputWithCrossAttentions,
+              LogitsProcessorList=LogitsProcessorList, TypicalLogitsWarper=HFTypical,
+              get_device_map=None, assert_device_map=None)
+    pieces = extract({"GPT2InferenceModel", "LearnedPositionEmbeddings", "null_position_embeddings"},
+                     "UnifiedVoice", ("prepare_gpt_inputs", "inference_speech", "forward", "get_logits",
+                                      "set_text_padding", "set_mel_padding", "build_aligned_inputs_and_targets"))
+    for name in ("null_position_embeddings", "LearnedPositionEmbeddings", "GPT2InferenceModel"):
+        exec(compile(pieces[name], MODEL_V2 + ":" + name, "exec"), ns)
+
+    class RefUnifiedVoice(nn.Module):
+        pass
+
+    for name in ("prepare_gpt_inputs", "inference_speech", "forward", "get_logits", "set_text_padding",
+                 "set_mel_padding", "build_aligned_inputs_and_targets"):
+        exec(compile(pieces[name], MODEL_V2 + ":" + name, "exec"), ns)
+        setattr(RefUnifiedVoice, name, ns[name])
+
+    D = cfg.model_dim
+    uv = RefUnifiedVoice()
+    # attributes UnifiedVoice.__init__ sets (model_v2.py:334-410)
+    uv.start_text_token, uv.stop_text_token = cfg.start_text_token, cfg.stop_text_token
+    uv.start_mel_token, uv.stop_mel_token = cfg.start_mel_token, cfg.stop_mel_token
+    uv.max_mel_tokens, uv.max_text_tokens = cfg.max_mel_tokens, cfg.max_text_tokens
+    uv.spk_cond_mode = "campplus"
+    uv.accel_engine = None
+    uv.spk_emb_proj = nn.Linear(192, D)
+    uv.text_embedding = nn.Embedding(cfg.number_text_tokens * cfg.types + 1, D)
+    uv.lang_embedding = nn.Embedding(cfg.n_langs, D)
+    uv.mel_embedding = nn.Embedding(cfg.number_mel_codes, D)
+    uv.mel_pos_embedding = ns["LearnedPositionEmbeddings"](cfg.n_mel_pos, D)
+    uv.text_pos_embedding = ns["LearnedPositionEmbeddings"](cfg.n_text_pos, D)
+    uv.final_norm = nn.LayerNorm(D)
+    uv.mel_head = nn.Linear(D, cfg.number_mel_codes)
+    uv.text_head = nn.Linear(D, cfg.number_text_tokens * cfg.types + 1)
+    hf_cfg = GPT2Config(vocab_size=256, n_positions=cfg.n_mel_pos + cfg.n_text_pos, n_embd=D, n_layer=cfg.layers,
+                        n_head=cfg.heads, attn_implementation="eager")
+    gpt = GPT2Model(hf_cfg)
+    del gpt.wpe
+    gpt.wpe = functools.partial(ns["null_position_embeddings"], dim=D)        # model_v2.py:273-275
+    del gpt.wte
+    uv.gpt = TransformerAdapter(gpt)
+    missing, unexpected = uv.load_state_dict({("gpt.gpt." + k[4:] if k.startswith("gpt.") else k): v
+                                              for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all(m.startswith("text_head") for m in missing), missing
+    gen_cfg = GPT2Config(vocab_size=cfg.number_mel_codes, n_positions=cfg.max_mel_tokens + cfg.max_text_tokens + 2,
+                         n_embd=D, n_layer=cfg.layers, n_head=cfg.heads, use_cache=True)
+    # post_init_gpt2_config (model_v2.py:466-474)
+    uv.inference_model = ns["GPT2InferenceModel"](gen_cfg, uv.gpt, uv.mel_pos_embedding, uv.mel_embedding,
+                                                   uv.final_norm, uv.mel_head, kv_cache=kv_cache).eval()
+    return uv.eval()
+
+
+class UniformMultinomial:
+    """Context manager: torch.multinomial -> inverse-CDF draws from a stored uniform stream."""
+
+    def __init__(self, uniforms: torch.Tensor):
+        self.u = uniforms
+        self.step = 0
+
+    def __call__(self, probs, num_samples=1, replacement=False, **kw):
+        rows = []
+        for b in range(probs.shape[0]):
+            us = self.u[self.step, b]
+            if num_samples == 1:
+                rows.append([G.inverse_cdf_pick(probs[b], float(us.reshape(-1)[0]))])
+            else:
+                rows.append(G.multinomial_wo_replacement(probs[b], num_samples, us))
+        self.step += 1
+        return torch.tensor(rows, dtype=torch.long)
+
+    def __enter__(self):
+        self._orig = torch.multinomial
+        torch.multinomial = self
+        return self
+
+    def __exit__(self, *a):
+        torch.multinomial = self._orig
+
+
+def ragged_text(g, B, L, n_text, lens):
+    t = torch.randint(2, n_text, (B, L), generator=g)
+    for b, n in enumerate(lens):
+        t[b, n:] = 1                      # stop_text_token padding, stripped + left-padded by prepare_gpt_inputs
+    return t
+
+
+def main():
+    cases = {
+        # tag: (cfg kwargs, seed, B, L, lens, gen kwargs, kv_cache, eos_bias)
+        "greedy": (dict(layers=3, model_dim=128, heads=2), 21, 3, 10, [10, 7, 4],
+                   dict(do_sample=False, num_beams=1, repetition_penalty=10.0), True, 2.2),
+        "greedy_nokv": (dict(layers=2, model_dim=128, heads=2), 22, 2, 8, [8, 5],
+                        dict(do_sample=False, num_beams=1, repetition_penalty=10.0), False, 2.2),
+        "sample": (dict(layers=3, model_dim=128, heads=2), 23, 3, 10, [10, 6, 9],
+                   dict(do_sample=True, num_beams=1, top_p=0.8, top_k=30, temperature=0.8, repetition_penalty=10.0),
+                   True, 1.9),
+        "beam": (dict(layers=2, model_dim=128, heads=2), 24, 2, 9, [9, 6],
+                 dict(do_sample=False, num_beams=3, repetition_penalty=10.0, length_penalty=0.0), True, 2.0),
+        "beam_sample": (dict(layers=2, model_dim=128, heads=2), 25, 3, 9, [9, 5, 7],
+                        dict(do_sample=True, num_beams=3, top_p=0.8, top_k=30, temperature=0.8,
+                             repetition_penalty=10.0, length_penalty=0.0), True, 1.5),
+        "greedy_mid": (dict(layers=4, model_dim=256, heads=4), 26, 4, 16, [16, 12, 9, 16],
+                       dict(do_sample=False, num_beams=1, repetition_penalty=10.0), True, 2.5),
+    }
+    max_gen = 28
+    for tag, (ck, seed, B, L, lens, gk, kv, eos_bias) in cases.items():
+        cfg = G.GPTConfig(max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200, **ck)
+        sd = G.synth_weights(cfg, seed=seed)
+        sd["mel_head.bias"][cfg.stop_mel_token] += eos_bias          # make EOS reachable at ragged steps
+        g = torch.Generator().manual_seed(seed + 100)
+        text = ragged_text(g, B, L, cfg.number_text_tokens, lens)
+        style = torch.randn(1, 192, generator=g)
+        emo_vec = torch.randn(1, cfg.model_dim, generator=g) * 0.1
+        langs = torch.randint(0, cfg.n_langs, (B,), generator=g)
+        nb = gk.get("num_beams", 1)
+        uniforms = torch.rand(max_gen + 2, B, 2 * nb if nb > 1 else 1, generator=g, dtype=torch.float64)
+        uv = build_reference(sd, cfg, kv_cache=kv)
+        with torch.no_grad(), UniformMultinomial(uniforms):
+            codes, spk_lat = uv.inference_speech(torch.zeros(1, 4, 2), text, langs=langs, emo_vec=emo_vec,
+                                                 campplus_embedding=style, max_generate_length=max_gen, **gk)
+        # oracle
+        gp = G.GenParams(max_generate_length=max_gen, **gk)
+        conds = G.conds_latent_campplus(sd, style, emo_vec)
+        u = uniforms if nb > 1 else uniforms[..., 0]
+        with torch.no_grad():
+            oc = G.inference_speech(sd, cfg, conds, text, langs, gp, uniforms=u, kv_cache=kv)
+        same = codes.shape == oc.shape and bool((codes == oc).all())
+        eos_at = [(int((r == cfg.stop_mel_token).nonzero()[0]) if (r == cfg.stop_mel_token).any() else -1) for r in codes]
+        print(f"{tag}: ref codes {tuple(codes.shape)} eos_at={eos_at} oracle==reference: {same}")
+        if not same:
+            print(codes, oc)
+        np.savez_compressed(
+            os.path.join(GOLD, f"gpt_{tag}.npz"), text=text.numpy(), style=style.numpy(), emo_vec=emo_vec.numpy(),
+            langs=langs.numpy(), uniforms=uniforms.numpy(), codes=codes.numpy(), seed=np.int64(seed),
+            eos_bias=np.float64(eos_bias), kv_cache=np.bool_(kv), max_gen=np.int64(max_gen),
+            cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens, cfg.max_mel_tokens,
+                          cfg.number_text_tokens]),
+            gen=np.array([int(gk.get("do_sample", False)), nb, gk.get("top_p", 1.0), gk.get("top_k", 0),
+                          gk.get("temperature", 1.0), gk.get("repetition_penalty", 1.0),
+                          gk.get("length_penalty", 1.0)], dtype=np.float64))
+
+        if tag == "greedy":
+            # teacher-forced latent pass (UnifiedVoice.forward, model_v2.py:596-646) on the generated codes
+            tl = torch.tensor(lens)
+            ml = torch.tensor([max(2, (eos_at[b] if eos_at[b] >= 0 else codes.shape[1]) - 0) for b in range(B)])
+            mel_codes = codes[:, : int(ml.max())].clone()
+            condsB = conds.repeat(B, 1, 1)
+            with torch.no_grad():
+                # do_spk_cond=False: speech_conditioning_latent is used as-is; emo_vec given
+                spk = F.linear(style, sd["spk_emb_proj.weight"], sd["spk_emb_proj.bias"]).unsqueeze(0).repeat(B, 1, 1)
+                lat_ref = uv.forward(spk, text.clone(), tl, mel_codes.clone(), ml, None, emo_vec=emo_vec.repeat(B, 1),
+                                     do_spk_cond=False)
+                lat_o = G.forward_latent(sd, cfg, condsB, text, tl, mel_codes, ml)
+            d = (lat_ref - lat_o).abs().max().item()
+            print(f"  latent pass: ref {tuple(lat_ref.shape)} oracle max|d| = {d:.3e}")
+            np.savez_compressed(os.path.join(GOLD, "gpt_latent.npz"), text=text.numpy(), text_lens=tl.numpy(),
+                                mel_codes=mel_codes.numpy(), mel_lens=ml.numpy(), style=style.numpy(),
+                                emo_vec=emo_vec.numpy(), latent=lat_ref.numpy().astype(np.float32),
+                                seed=np.int64(seed), eos_bias=np.float64(eos_bias),
+                                cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens,
+                                              cfg.max_mel_tokens, cfg.number_text_tokens]))
+
+
+if __name__ == "__main__":
+    main()
