@@ -1,0 +1,90 @@
+"""ctypes binding of the C ABI declared in include/indextts_hip.h.
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libindextts_hip.so")
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+vp = C.c_void_p
+
+
+class BigVGANConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("upsample_initial_channel", C.c_int32), ("num_upsamples", C.c_int32),
+        ("upsample_rates", C.c_int32 * 8), ("upsample_kernel_sizes", C.c_int32 * 8), ("num_kernels", C.c_int32),
+        ("resblock_kernel_sizes", C.c_int32 * 4), ("num_dilations", C.c_int32),
+        ("resblock_dilations", (C.c_int32 * 4) * 4), ("snake_logscale", C.c_int32), ("activation", C.c_int32),
+        ("use_tanh_at_final", C.c_int32), ("use_bias_at_final", C.c_int32), ("cond_dim", C.c_int32),
+        ("cond_in_each_up_layer", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/indextts_hip.h declares must appear here
+SIGNATURES = {
+    "itts_abi_version": (C.c_int, []),
+    "itts_last_error": (C.c_char_p, []),
+    "itts_device_count": (C.c_int, []),
+    "itts_aa_act_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "itts_packed_conv_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "itts_pack_conv1d_weight": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
+    "itts_pack_convT_weight": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "itts_conv1d_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      vp, C.c_int, C.c_int, C.c_float, vp]),
+    "itts_conv_transpose1d_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, vp, C.c_int, vp]),
+    "itts_bigvgan_create": (C.c_int, [C.POINTER(BigVGANConfig), C.POINTER(vp)]),
+    "itts_bigvgan_load_tensor": (C.c_int, [vp, C.c_char_p, vp, c_i64p, C.c_int]),
+    "itts_bigvgan_finalize": (C.c_int, [vp]),
+    "itts_bigvgan_destroy": (None, [vp]),
+    "itts_bigvgan_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int]),
+    "itts_bigvgan_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+}
+
+_lib = None
+
+
+class HipEngineError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libindextts_hip.so (fails loudly; there is no CPU fallback on the product path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipEngineError(
+                f"{LIB_PATH} is missing: build it with `python index-tts_amd/build.py` (hipcc, gfx950). "
+                "The engine has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.itts_abi_version() != 1:
+            raise HipEngineError("libindextts_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().itts_last_error().decode(errors="replace")
+        raise HipEngineError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Raw address of a torch tensor (device or host) or None."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

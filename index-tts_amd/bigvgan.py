@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference BigVGAN vocoder classes, backed by the HIP engine.
+
+Reference interface mirrored (same names / argument meaning):
+  * v2 / v2.5: `indextts/s2mel/modules/bigvgan/bigvgan.py::BigVGAN` -- `BigVGAN(h, use_cuda_kernel)`,
+    `BigVGAN.from_pretrained(dir)`, `.remove_weight_norm()`, `.eval()`, `.to(device)`, `model(mel) -> (B,1,T*256)`
+    (call site `indextts/infer_v2_5.py:224-233,850`).
+  * v1 / v1.5: `indextts/BigVGAN/models.py::BigVGAN` -- `model(latent (B,T,D), mel_ref^T) -> (wav, None)`
+    (call site `indextts/infer.py:647`).  The ECAPA-TDNN speaker encoder stays a PyTorch module supplied by the
+    caller (`speaker_encoder=`); its embedding is cached per reference clip instead of being recomputed per call.
+Extra (not in the reference): `lens=` for ragged batches -- every row is bounded at its own length so the result
+per row equals the reference run at B=1.
+"""
+import ctypes as C
+import json
+import os
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+_V2_DEFAULTS = dict(
+    num_mels=80, upsample_rates=[4, 4, 2, 2, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4, 4, 4],
+    upsample_initial_channel=1536, resblock_kernel_sizes=[3, 7, 11],
+    resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], activation="snakebeta", snake_logscale=True,
+    use_tanh_at_final=True, use_bias_at_final=True, resblock="1")
+
+
+def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """`remove_weight_norm()` at load time: weight = g * v / ||v|| (norm over all dims but 0)."""
+    out = dict(sd)
+    for k in list(sd.keys()):
+        if k.endswith(".weight_g"):
+            base, g, v = k[:-9], sd[k], sd[k[:-9] + ".weight_v"]
+        elif k.endswith(".parametrizations.weight.original0"):
+            base = k[: -len(".parametrizations.weight.original0")]
+            g, v = sd[k], sd[base + ".parametrizations.weight.original1"]
+        else:
+            continue
+        dims = tuple(range(1, v.dim()))
+        out[base + ".weight"] = v * (g / v.norm(2, dim=dims, keepdim=True))
+        for suf in (".weight_g", ".weight_v", ".parametrizations.weight.original0",
+                    ".parametrizations.weight.original1"):
+            out.pop(base + suf, None)
+    return out
+
+
+class BigVGAN:
+    """BigVGAN generator on the HIP engine.  `h` is the reference hparams mapping (config.json)."""
+
+    def __init__(self, h, use_cuda_kernel: bool = False, cond_dim: int = 0, in_channels: Optional[int] = None,
+                 cond_in_each_up_layer: bool = True, speaker_encoder=None):
+        hp = dict(_V2_DEFAULTS)
+        hp.update(dict(h))
+        if str(hp.get("resblock", "1")) != "1":
+            raise NotImplementedError("only AMPBlock1 (resblock='1') is used by the IndexTTS checkpoints")
+        if hp["activation"] not in ("snakebeta", "snake"):
+            raise NotImplementedError("activation incorrectly specified. check the config file and look for 'activation'.")
+        self.h = hp
+        self.use_cuda_kernel = use_cuda_kernel        # accepted for signature parity; the HIP kernels are always used
+        self.cond_dim = int(cond_dim)
+        self.speaker_encoder = speaker_encoder
+        self._spk_cache = {}
+        self.num_upsamples = len(hp["upsample_rates"])
+        self.num_kernels = len(hp["resblock_kernel_sizes"])
+        self.total_up = 1
+        for u in hp["upsample_rates"]:
+            self.total_up *= int(u)
+        cfg = _lib.BigVGANConfig()
+        cfg.in_channels = int(in_channels if in_channels is not None else hp["num_mels"])
+        cfg.upsample_initial_channel = int(hp["upsample_initial_channel"])
+        cfg.num_upsamples = self.num_upsamples
+        for i, (u, k) in enumerate(zip(hp["upsample_rates"], hp["upsample_kernel_sizes"])):
+            cfg.upsample_rates[i], cfg.upsample_kernel_sizes[i] = int(u), int(k)
+        cfg.num_kernels = self.num_kernels
+        nd = len(hp["resblock_dilation_sizes"][0])
+        cfg.num_dilations = nd
+        for j, k in enumerate(hp["resblock_kernel_sizes"]):
+            cfg.resblock_kernel_sizes[j] = int(k)
+            if len(hp["resblock_dilation_sizes"][j]) != nd:
+                raise ValueError("all resblocks must have the same number of dilations")
+            for d, dv in enumerate(hp["resblock_dilation_sizes"][j]):
+                cfg.resblock_dilations[j][d] = int(dv)
+        cfg.snake_logscale = int(bool(hp.get("snake_logscale", True)))
+        cfg.activation = 0 if hp["activation"] == "snakebeta" else 1
+        cfg.use_tanh_at_final = int(bool(hp.get("use_tanh_at_final", True)))
+        cfg.use_bias_at_final = int(bool(hp.get("use_bias_at_final", True)))
+        cfg.cond_dim = self.cond_dim
+        cfg.cond_in_each_up_layer = int(bool(cond_in_each_up_layer))
+        self._cfg = cfg
+        self.in_channels = cfg.in_channels
+        self._h = C.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.itts_bigvgan_create(C.byref(cfg), C.byref(self._h)), "itts_bigvgan_create")
+        self._loaded = False
+        self._ws = None
+        self.device = None
+
+    # ---- checkpoint loading --------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Reference state-dict names; weight-norm is folded here."""
+        L = _lib.lib()
+        sd = fold_weight_norm({k: v for k, v in sd.items()})
+        skipped = []
+        for name, t in sd.items():
+            if name.startswith("speaker_encoder.") or name.endswith("num_batches_tracked") or name == "logit_scale":
+                skipped.append(name)
+                continue
+            t = t.detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            rc = L.itts_bigvgan_load_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim())
+            if rc != 0:
+                if strict:
+                    _lib.check(rc, f"itts_bigvgan_load_tensor({name})")
+                skipped.append(name)
+        _lib.check(L.itts_bigvgan_finalize(self._h), "itts_bigvgan_finalize")
+        self._loaded = True
+        return skipped
+
+    @classmethod
+    def from_pretrained(cls, model_dir: str, use_cuda_kernel: bool = False, **kw):
+        """Loads `config.json` + `bigvgan_generator.pt` from a local directory (bigvgan.py:413-492, offline)."""
+        with open(os.path.join(model_dir, "config.json")) as f:
+            h = json.load(f)
+        model = cls(h, use_cuda_kernel=use_cuda_kernel, **kw)
+        ck = torch.load(os.path.join(model_dir, "bigvgan_generator.pt"), map_location="cpu")
+        model.load_state_dict(ck["generator"] if "generator" in ck else ck)
+        return model
+
+    def remove_weight_norm(self):      # folded at load; kept for call-site compatibility
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    def float(self):
+        return self
+
+    # ---- forward -------------------------------------------------------------------------------------------
+    def _workspace(self, B: int, T: int, device) -> torch.Tensor:
+        need = _lib.lib().itts_bigvgan_workspace_bytes(self._h, B, T)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def speaker_embedding(self, mel_ref: torch.Tensor, lens=None, key=None) -> torch.Tensor:
+        """v1: ECAPA-TDNN embedding of the reference mel (models.py:202), cached per `key`."""
+        if self.speaker_encoder is None:
+            raise RuntimeError("this BigVGAN was built without a speaker_encoder; pass speaker_embedding=")
+        if key is not None and key in self._spk_cache:
+            return self._spk_cache[key]
+        with torch.no_grad():
+            e = self.speaker_encoder(mel_ref, lens)
+        e = e.reshape(e.shape[0], -1).float().contiguous()
+        if key is not None:
+            self._spk_cache[key] = e
+        return e
+
+    def forward(self, x: torch.Tensor, mel_ref: Optional[torch.Tensor] = None, lens: Optional[torch.Tensor] = None,
+                speaker_embedding: Optional[torch.Tensor] = None):
+        if not self._loaded:
+            raise RuntimeError("BigVGAN: load_state_dict() first")
+        if not x.is_cuda:
+            raise _lib.HipEngineError("BigVGAN (HIP engine) needs a CUDA/HIP tensor; there is no CPU path")
+        v1 = self.cond_dim > 0
+        if v1:
+            x = x.transpose(1, 2)                       # latent (B,T,D) -> (B,D,T)  (models.py:222)
+            if speaker_embedding is None:
+                speaker_embedding = self.speaker_embedding(mel_ref)
+            spk = speaker_embedding.reshape(-1, self.cond_dim).float().contiguous()
+            if spk.shape[0] == 1 and x.shape[0] > 1:
+                spk = spk.expand(x.shape[0], -1).contiguous()
+        else:
+            spk = None
+        x = x.float().contiguous()
+        B, Cin, T = x.shape
+        if Cin != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} input channels, got {Cin}")
+        wav = torch.empty(B, 1, T * self.total_up, dtype=torch.float32, device=x.device)
+        if B == 0 or T == 0:
+            return (wav, None) if v1 else wav
+        lens_t = None
+        if lens is not None:
+            lens_t = torch.as_tensor(lens, dtype=torch.int32, device=x.device).contiguous()
+            if lens_t.numel() != B:
+                raise ValueError("lens must have one entry per batch row")
+        ws = self._workspace(B, T, x.device)
+        rc = _lib.lib().itts_bigvgan_forward(self._h, _lib.ptr(x), _lib.ptr(lens_t), _lib.ptr(spk), _lib.ptr(wav), B, T,
+                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "itts_bigvgan_forward")
+        return (wav, None) if v1 else wav
+
+    __call__ = forward
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.lib().itts_bigvgan_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+# ---- unit-level ops (1:1 with the reference's fused op and torch layers) ------------------------------------------
+def anti_alias_activation(x, up_filter, down_filter, alpha, beta, lens=None, logscale=True):
+    """Drop-in for `anti_alias_activation_cuda.forward(inputs, up_ftr, down_ftr, alpha, beta)`
+    (alias_free_activation/cuda/activation1d.py:23-27)."""
+    if not x.is_cuda:
+        raise _lib.HipEngineError("anti_alias_activation needs a device tensor")
+    x = x.float().contiguous()
+    y = torch.empty_like(x)
+    B, Cc, T = x.shape
+    dev = x.device
+    f = lambda t: t.detach().reshape(-1).to(dev, torch.float32).contiguous()
+    a, b, fu, fd = f(alpha), f(beta), f(up_filter), f(down_filter)
+    lens_t = None if lens is None else torch.as_tensor(lens, dtype=torch.int32, device=dev).contiguous()
+    _lib.check(_lib.lib().itts_aa_act_forward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(a), _lib.ptr(b), _lib.ptr(fu),
+                                              _lib.ptr(fd), B, Cc, T, _lib.ptr(lens_t), 1, int(logscale),
+                                              _lib.stream_ptr()), "itts_aa_act_forward")
+    return y
+
+
+def pack_conv1d_weight(w: torch.Tensor) -> torch.Tensor:
+    w = w.detach().to("cpu", torch.float32).contiguous()
+    Cout, Cin, k = w.shape
+    L = _lib.lib()
+    out = torch.empty(L.itts_packed_conv_floats(Cout, Cin, k), dtype=torch.float32)
+    _lib.check(L.itts_pack_conv1d_weight(_lib.ptr(w), Cout, Cin, k, _lib.ptr(out)), "itts_pack_conv1d_weight")
+    return out
+
+
+def pack_convT_weight(w: torch.Tensor, u: int) -> torch.Tensor:
+    w = w.detach().to("cpu", torch.float32).contiguous()
+    Cin, Cout, k = w.shape
+    L = _lib.lib()
+    per = L.itts_packed_conv_floats(Cout, Cin, 2)
+    out = torch.empty(per * u, dtype=torch.float32)
+    for r in range(u):
+        _lib.check(L.itts_pack_convT_weight(_lib.ptr(w), Cin, Cout, k, u, r, C.c_void_p(out.data_ptr() + 4 * per * r)),
+                   "itts_pack_convT_weight")
+    return out
+
+
+def conv1d(x, w_packed, bias, Cout, k, dilation=1, res=None, lens=None, len_mult=1, out=None, acc_mode=0, div=1.0):
+    x = x.float().contiguous()
+    B, Cin, T = x.shape
+    y = out if out is not None else torch.empty(B, Cout, T, dtype=torch.float32, device=x.device)
+    lens_t = None if lens is None else torch.as_tensor(lens, dtype=torch.int32, device=x.device).contiguous()
+    _lib.check(_lib.lib().itts_conv1d_forward(_lib.ptr(x), _lib.ptr(w_packed), _lib.ptr(bias), None, _lib.ptr(res),
+                                              _lib.ptr(y), B, Cin, Cout, T, k, dilation, _lib.ptr(lens_t), len_mult,
+                                              acc_mode, float(div), _lib.stream_ptr()), "itts_conv1d_forward")
+    return y
+
+
+def conv_transpose1d(x, w_packed, bias, Cout, k, u, lens=None):
+    x = x.float().contiguous()
+    B, Cin, T = x.shape
+    y = torch.zeros(B, Cout, T * u, dtype=torch.float32, device=x.device)
+    lens_t = None if lens is None else torch.as_tensor(lens, dtype=torch.int32, device=x.device).contiguous()
+    _lib.check(_lib.lib().itts_conv_transpose1d_forward(_lib.ptr(x), _lib.ptr(w_packed), _lib.ptr(bias), None,
+                                                        _lib.ptr(y), B, Cin, Cout, T, k, u, _lib.ptr(lens_t), 1,
+                                                        _lib.stream_ptr()), "itts_conv_transpose1d_forward")
+    return y

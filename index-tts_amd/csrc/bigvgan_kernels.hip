@@ -1,0 +1,311 @@
+// BigVGAN vocoder kernels for gfx950 (MI355X).  fp32 in / fp32 out, exact-f32 MFMA for the contractions.
+//
+// Reference arithmetic being replaced (paths relative to the reference repo root):
+//   Activation1d  up(12-tap, x2) -> SnakeBeta -> down(12-tap, /2)
+//       indextts/s2mel/modules/bigvgan/alias_free_activation/torch/{act.py:25-30,resample.py:29-58,filter.py:93-101}
+//       fused CUDA form: .../alias_free_activation/cuda/anti_alias_activation_cuda.cu:43-179
+//   Conv1d / ConvTranspose1d of the generator: indextts/s2mel/modules/bigvgan/bigvgan.py:132-141,300-316,360-386
+//
+// Design notes (MI355X-first):
+//   * A Conv1d with C_in*k = 2k..17k terms per output IS a dense contraction: it runs as an implicit GEMM on
+//     v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bitwise an fmaf chain, so the 1e-4 RMS gate holds; the
+//     f32 MFMA rate equals the f32 VALU peak, 157 TF, but needs 1 VGPR per operand and no LDS bandwidth).
+//     M = C_out (weights, A operand, pre-packed in fragment order -> one coalesced 1 KiB float4 load per wave
+//     feeds 4 K-steps), N = time (B operand read from an LDS tile [ci][t] with the dilation halo), K = (tap, ci).
+//   * ConvTranspose1d(stride u, k = 2u) is u phase convolutions with 2 taps each over the same kernel.
+//   * Every kernel takes per-row lengths so a ragged batch gives the B=1 result for each row: zero padding for
+//     convs, replicate padding for the activation at the row's OWN end (ragged batches).
+#include "bigvgan_kernels.h"
+
+#define AA_TILE 1024
+
+// --------------------------------------------------------------------------------------------------------------
+// Anti-aliased SnakeBeta activation:  y = down2(snake(up2(x)))
+//   u[2q]   = 2*sum_j fu[1+2j]*x[clamp(q+2-j)],  u[2q+1] = 2*sum_j fu[2j]*x[clamp(q+3-j)]      (j = 0..5)
+//   v[i]    = u[i] + 1/(exp(beta)+1e-9) * sin(u[i]*exp(alpha))^2
+//   y[t]    = sum_{j<12} fd[j] * v[clamp(2t+j-5, 0, 2T-1)]
+// grid (ceil(T/AA_TILE), C, B), 256 threads.  LDS: x tile (+6 halo each side), v tile (2x rate, +6 halo).
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aa_act_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                     const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                     const float* __restrict__ fu, const float* __restrict__ fd,
+                                                     int C, int T, const int* __restrict__ lens, int len_mult,
+                                                     int logscale) {
+    __shared__ float xs[AA_TILE + 16];
+    __shared__ float vs[2 * AA_TILE + 16];
+    __shared__ float fus[12], fds[12];
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int t0 = blockIdx.x * AA_TILE;
+    const int len = lens ? min(lens[b] * len_mult, T) : T;
+    if (t0 >= len) return;
+    const int tid = threadIdx.x;
+    if (tid < 12) { fus[tid] = fu[tid]; fds[tid] = fd[tid]; }
+    const float* xr = x + ((size_t)b * C + c) * T;
+    float* yr = y + ((size_t)b * C + c) * T;
+    float a_e = alpha[c], b_e = beta[c];
+    if (logscale) { a_e = expf(a_e); b_e = expf(b_e); }
+    const float inv_b = 1.0f / (b_e + 1e-9f);
+    const int n_out = min(AA_TILE, len - t0);
+    // x window: x[clamp(t0-6+cidx)], cidx in [0, n_out+12)
+    for (int i = tid; i < n_out + 12; i += 256) {
+        int t = t0 - 6 + i;
+        t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
+        xs[i] = xr[t];
+    }
+    __syncthreads();
+    // v window: i = 2*t0-6+vi, vi in [0, 2*n_out+12)
+    const int two_len_m1 = 2 * len - 1;
+    for (int vi = tid; vi < 2 * n_out + 12; vi += 256) {
+        int i = 2 * t0 - 6 + vi;
+        i = i < 0 ? 0 : (i > two_len_m1 ? two_len_m1 : i);
+        const int q = i >> 1;
+        const int base = q - (t0 - 6);          // xs index of x[q]
+        float u = 0.f;
+        if (i & 1) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) u = fmaf(fus[2 * j], xs[base + 3 - j], u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) u = fmaf(fus[1 + 2 * j], xs[base + 2 - j], u);
+        }
+        u *= 2.0f;
+        const float s = sinf(u * a_e);
+        vs[vi] = u + inv_b * s * s;
+    }
+    __syncthreads();
+    for (int i = tid; i < n_out; i += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc = fmaf(fds[j], vs[2 * i + j + 1], acc);
+        yr[t0 + i] = acc;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
+//   out[b, co, n(m)] = epi( sum_{j<k} sum_{ci} w[co][ci][j] * x[b, ci, m + tap_base + j*tap_step] )
+//   n(m) = m*ostride + ooff.   Regular Conv1d: tap_base = -(k-1)/2*d, tap_step = d, ostride 1, ooff 0.
+//   ConvTranspose1d phase r (stride u, pad p): taps {r, r+u} read x[m], x[m-1]; n = m*u + r - p.
+// Packed weights (host side, itts_pack_conv_weight): wpk[co_sub][j][ci/8][lane][s] =
+//   w[co_sub*32 + (lane&31)][ (ci/8)*8 + 2*s + (lane>>5) ][j]      (zero rows for co >= C_out)
+// so one float4 per lane = the A fragments of 4 consecutive K-steps (K-step = 2 input channels of one tap).
+// Block = 256 threads = WM x WN waves, each wave MT x NT tiles of 32x32.
+// --------------------------------------------------------------------------------------------------------------
+#define CI_CHUNK 32
+#define CONV_HALO 64   // >= (k-1)*|tap_step| : (11-1)*5 = 50
+
+
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    constexpr int BM = WM * MT * 32;
+    constexpr int BN = WN * NT * 32;
+    constexpr int LDW = BN + CONV_HALO;
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [CI_CHUNK][LDW]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w / WN, wn = w % WN;
+    const int b = blockIdx.y;
+    const int m0 = blockIdx.x * BN;
+    const int co0 = blockIdx.z * BM;
+    const int len_in = a.lens ? min(a.lens[b] * a.len_mult_in, a.Tin) : a.Tin;
+    const int len_out = a.lens ? min(a.lens[b] * a.len_mult_out, a.Tout) : a.Tout;
+    const int m_count = len_in + a.m_extra;
+    if (m0 >= m_count) return;
+
+    const int span = (a.k - 1) * (a.tap_step < 0 ? -a.tap_step : a.tap_step);
+    const int last_off = a.tap_base + (a.k - 1) * a.tap_step;
+    const int min_off = a.tap_base < last_off ? a.tap_base : last_off;
+    const int W = BN + span;
+    const int n_cosub = (a.Cout + 31) >> 5;
+    const int cin8 = a.Cin >> 3;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* xb = a.x + (size_t)b * a.Cin * a.Tin;
+    const int lane_row = lane >> 5;          // which of the 2 input channels of a K-step
+    const int lane_col = lane & 31;
+
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += CI_CHUNK) {
+        const int ci_cnt = min(CI_CHUNK, a.Cin - ci0);
+        __syncthreads();   // previous chunk fully consumed
+        for (int r = w; r < ci_cnt; r += 4) {
+            const float* xr = xb + (size_t)(ci0 + r) * a.Tin;
+            for (int c = lane; c < W; c += 64) {
+                const int t = m0 + min_off + c;
+                xs[r * LDW + c] = (t >= 0 && t < len_in) ? xr[t] : 0.f;
+            }
+        }
+        __syncthreads();
+
+        const int cp4n = ci_cnt >> 3;
+        const int nit = a.k * cp4n;
+        f32x4 afr[MT], afr_next[MT];
+        auto load_a = [&](int it, f32x4* dst) {
+            const int j = it / cp4n, cp4 = it - j * cp4n;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int co_sub = (co0 >> 5) + wm * MT + mt;
+                if (co_sub < n_cosub) {
+                    const f32x4* p = reinterpret_cast<const f32x4*>(a.wpk) +
+                                     ((size_t)(co_sub * a.k + j) * cin8 + ((ci0 >> 3) + cp4)) * 64 + lane;
+                    dst[mt] = *p;
+                } else {
+                    dst[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        };
+        load_a(0, afr);
+        for (int it = 0; it < nit; ++it) {
+            if (it + 1 < nit) load_a(it + 1, afr_next);
+            const int j = it / cp4n, cp4 = it - j * cp4n;
+            const int colb = wn * NT * 32 + lane_col + (a.tap_base + j * a.tap_step - min_off);
+            const float* xrow = xs + (cp4 * 8 + lane_row) * LDW + colb;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float bfr[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bfr[nt] = xrow[s * 2 * LDW + nt * 32];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[mt][s], bfr[nt], acc[mt][nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) afr[mt] = afr_next[mt];
+        }
+    }
+
+    // epilogue: C/D layout col(N) = lane&31, row(M) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int m = m0 + (wn * NT + nt) * 32 + lane_col;
+            const int n = m * a.ostride + a.ooff;
+            const bool n_ok = (m < m_count) && (n >= 0) && (n < len_out);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_row;
+                if (n_ok && co < a.Cout) {
+                    float v = acc[mt][nt][r];
+                    if (a.bias) v += a.bias[co];
+                    if (a.bias_b) v += a.bias_b[(size_t)b * a.Cout + co];
+                    const size_t o = ((size_t)b * a.Cout + co) * a.Tout + n;
+                    if (a.res) v += a.res[o];
+                    if (a.acc_mode == 1) v = a.y[o] + v;
+                    else if (a.acc_mode == 2) v = (a.y[o] + v) / a.div;
+                    a.y[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// conv_post: C_in -> 1 channel, k taps, optional bias, then clamp(-1,1) or tanh; writes 0 beyond the row length.
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int Cin, int T, int k, const int* __restrict__ lens,
+                                                        int len_mult, int use_tanh) {
+    extern __shared__ float ws[];   // [Cin*k]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < Cin * k; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int len = lens ? min(lens[b] * len_mult, T) : T;
+    float acc = 0.f;
+    if (t < len) {
+        const int pad = (k - 1) / 2;
+        acc = bias ? bias[0] : 0.f;
+        const float* xb = x + (size_t)b * Cin * T;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* xr = xb + (size_t)ci * T;
+            for (int j = 0; j < k; ++j) {
+                const int tt = t + j - pad;
+                if (tt >= 0 && tt < len) acc = fmaf(ws[ci * k + j], xr[tt], acc);
+            }
+        }
+        acc = use_tanh ? tanhf(acc) : fminf(1.0f, fmaxf(-1.0f, acc));
+    }
+    y[(size_t)b * T + t] = acc;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// v1 speaker conditioning: out[b][co] = bias[co] + sum_d w[co][d] * spk[b][d]   (1x1 conv of a length-1 signal,
+// indextts/BigVGAN/models.py:191-197,226,236)
+// --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cond_bias_kernel(const float* __restrict__ spk, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int Cout, int cond_dim) {
+    const int b = blockIdx.y;
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= Cout) return;
+    float acc = bias ? bias[co] : 0.f;
+    const float* wr = w + (size_t)co * cond_dim;
+    const float* sr = spk + (size_t)b * cond_dim;
+    for (int d = 0; d < cond_dim; ++d) acc = fmaf(wr[d], sr[d], acc);
+    out[(size_t)b * Cout + co] = acc;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// host launchers (called from capi_bigvgan.hip)
+// --------------------------------------------------------------------------------------------------------------
+int launch_aa_act(const float* x, float* y, const float* alpha, const float* beta, const float* fu, const float* fd,
+                  int B, int C, int T, const int* lens, int len_mult, int logscale, hipStream_t st) {
+    if (B <= 0 || C <= 0 || T <= 0) return ITTS_OK;
+    dim3 grid(ceil_div(T, AA_TILE), C, B);
+    hipLaunchKernelGGL(aa_act_kernel, grid, dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+template <int WM, int WN, int MT, int NT>
+static int launch_conv_cfg(const ConvArgs& a, int B, int m_total, hipStream_t st) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    const size_t lds = (size_t)CI_CHUNK * (BN + CONV_HALO) * sizeof(float);
+    dim3 grid(ceil_div(m_total, BN), B, ceil_div(a.Cout, BM));
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, MT, NT>), grid, dim3(256), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+int launch_conv(const ConvArgs& a, int B, hipStream_t st) {
+    if (B <= 0) return ITTS_OK;
+    if (a.Cin % 8 != 0) { itts_set_error("conv: C_in=%d must be a multiple of 8", a.Cin); return ITTS_ERR_ARG; }
+    const int span = (a.k - 1) * (a.tap_step < 0 ? -a.tap_step : a.tap_step);
+    if (span > CONV_HALO) { itts_set_error("conv: tap span %d exceeds halo %d", span, CONV_HALO); return ITTS_ERR_ARG; }
+    const int m_total = a.Tin + a.m_extra;
+    const int n_cosub = (a.Cout + 31) / 32;
+    if (n_cosub >= 4) return launch_conv_cfg<2, 2, 2, 2>(a, B, m_total, st);
+    if (n_cosub == 3) return launch_conv_cfg<1, 4, 3, 2>(a, B, m_total, st);
+    if (n_cosub == 2) return launch_conv_cfg<1, 4, 2, 2>(a, B, m_total, st);
+    return launch_conv_cfg<1, 4, 1, 2>(a, B, m_total, st);
+}
+
+int launch_conv_post(const float* x, float* y, const float* w, const float* bias, int B, int Cin, int T, int k,
+                     const int* lens, int len_mult, int use_tanh, hipStream_t st) {
+    if (B <= 0 || T <= 0) return ITTS_OK;
+    dim3 grid(ceil_div(T, 256), B);
+    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), (size_t)Cin * k * sizeof(float), st, x, y, w, bias, Cin, T, k,
+                       lens, len_mult, use_tanh);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+int launch_cond_bias(const float* spk, const float* w, const float* bias, float* out, int B, int Cout, int cond_dim,
+                     hipStream_t st) {
+    if (B <= 0 || Cout <= 0) return ITTS_OK;
+    dim3 grid(ceil_div(Cout, 256), B);
+    hipLaunchKernelGGL(cond_bias_kernel, grid, dim3(256), 0, st, spk, w, bias, out, Cout, cond_dim);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}

@@ -1,0 +1,565 @@
+// C-ABI entry points for the BigVGAN vocoder (see include/indextts_hip.h for the reference call sites replaced).
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/indextts_hip.h"
+#include "bigvgan_kernels.h"
+
+// ---- error plumbing (shared by all capi_* files) -------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void itts_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* itts_last_error(void) { return g_err; }
+extern "C" int itts_abi_version(void) { return ITTS_ABI_VERSION; }
+extern "C" int itts_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        itts_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return n;
+}
+
+// ---- host-side packing ---------------------------------------------------------------------------------------
+extern "C" size_t itts_packed_conv_floats(int Cout, int Cin, int k) {
+    return (size_t)((Cout + 31) / 32) * k * (Cin / 8) * 64 * 4;
+}
+
+// generic packer over an accessor w(co, ci, j)
+template <class F>
+static void pack_generic(F w, int Cout, int Cin, int k, float* out) {
+    const int n_cosub = (Cout + 31) / 32, cin8 = Cin / 8;
+    for (int cs = 0; cs < n_cosub; ++cs)
+        for (int j = 0; j < k; ++j)
+            for (int c8 = 0; c8 < cin8; ++c8)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s) {
+                        const int co = cs * 32 + (lane & 31);
+                        const int ci = c8 * 8 + 2 * s + (lane >> 5);
+                        const size_t o = ((((size_t)cs * k + j) * cin8 + c8) * 64 + lane) * 4 + s;
+                        out[o] = co < Cout ? w(co, ci, j) : 0.f;
+                    }
+}
+
+extern "C" int itts_pack_conv1d_weight(const float* w, int Cout, int Cin, int k, float* out) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || Cin % 8 || k <= 0) {
+        itts_set_error("pack_conv1d: bad args Cout=%d Cin=%d k=%d (C_in must be a multiple of 8)", Cout, Cin, k);
+        return ITTS_ERR_ARG;
+    }
+    pack_generic([&](int co, int ci, int j) { return w[((size_t)co * Cin + ci) * k + j]; }, Cout, Cin, k, out);
+    return ITTS_OK;
+}
+
+extern "C" int itts_pack_convT_weight(const float* w, int Cin, int Cout, int k, int u, int phase, float* out) {
+    if (!w || !out || Cin % 8 || k != 2 * u || phase < 0 || phase >= u) {
+        itts_set_error("pack_convT: bad args Cin=%d Cout=%d k=%d u=%d phase=%d (need k == 2u)", Cin, Cout, k, u, phase);
+        return ITTS_ERR_ARG;
+    }
+    // tap jj of phase r uses kernel index r + jj*u and reads x[m - jj]
+    pack_generic([&](int co, int ci, int jj) { return w[((size_t)ci * Cout + co) * k + phase + jj * u]; }, Cout, Cin, 2,
+                 out);
+    return ITTS_OK;
+}
+
+// ---- unit entry points ---------------------------------------------------------------------------------------
+extern "C" int itts_aa_act_forward(const float* x, float* y, const float* alpha, const float* beta,
+                                   const float* up_filter, const float* down_filter, int B, int C, int T,
+                                   const int32_t* lens, int len_mult, int logscale, void* stream) {
+    if (!x || !y || !alpha || !beta || !up_filter || !down_filter || B < 0 || C < 0 || T < 0) {
+        itts_set_error("aa_act: null pointer or negative dim");
+        return ITTS_ERR_ARG;
+    }
+    if (B > 65535 || C > 65535) { itts_set_error("aa_act: B, C must be <= 65535"); return ITTS_ERR_ARG; }
+    return launch_aa_act(x, y, alpha, beta, up_filter, down_filter, B, C, T, lens, len_mult < 1 ? 1 : len_mult,
+                         logscale, (hipStream_t)stream);
+}
+
+static int conv1d_impl(const float* x, const float* wpk, const float* bias, const float* bias_b, const float* res,
+                       float* y, int B, int Cin, int Cout, int T, int k, int dil, const int* lens, int len_mult,
+                       int acc_mode, float div, hipStream_t st) {
+    ConvArgs a;
+    a.x = x; a.y = y; a.wpk = wpk; a.bias = bias; a.bias_b = bias_b; a.res = res; a.lens = lens;
+    a.len_mult_in = a.len_mult_out = len_mult;
+    a.Cin = Cin; a.Cout = Cout; a.Tin = T; a.Tout = T;
+    a.k = k; a.tap_base = -((k - 1) / 2) * dil; a.tap_step = dil; a.ostride = 1; a.ooff = 0; a.m_extra = 0;
+    a.acc_mode = acc_mode; a.div = div;
+    return launch_conv(a, B, st);
+}
+
+extern "C" int itts_conv1d_forward(const float* x, const float* wpk, const float* bias, const float* bias_b,
+                                   const float* res, float* y, int B, int Cin, int Cout, int T, int k, int dilation,
+                                   const int32_t* lens, int len_mult, int acc_mode, float div, void* stream) {
+    if (!x || !wpk || !y || B < 0 || T < 0 || k < 1 || (k & 1) == 0 || dilation < 1) {
+        itts_set_error("conv1d: bad args (odd k, dilation >= 1 required)");
+        return ITTS_ERR_ARG;
+    }
+    if (B > 65535) { itts_set_error("conv1d: B must be <= 65535"); return ITTS_ERR_ARG; }
+    if (T == 0 || B == 0) return ITTS_OK;
+    return conv1d_impl(x, wpk, bias, bias_b, res, y, B, Cin, Cout, T, k, dilation, lens, len_mult < 1 ? 1 : len_mult,
+                       acc_mode, div, (hipStream_t)stream);
+}
+
+static int convT_impl(const float* x, const float* wpk_phases, const float* bias, const float* bias_b, float* y, int B,
+                      int Cin, int Cout, int Tin, int k, int u, const int* lens, int len_mult_in, hipStream_t st) {
+    const int p = (k - u) / 2;
+    const size_t per_phase = itts_packed_conv_floats(Cout, Cin, 2);
+    for (int r = 0; r < u; ++r) {
+        ConvArgs a;
+        a.x = x; a.y = y; a.wpk = wpk_phases + per_phase * r; a.bias = bias; a.bias_b = bias_b; a.res = nullptr;
+        a.lens = lens; a.len_mult_in = len_mult_in; a.len_mult_out = len_mult_in * u;
+        a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tin * u;
+        a.k = 2; a.tap_base = 0; a.tap_step = -1; a.ostride = u; a.ooff = r - p; a.m_extra = 1;
+        a.acc_mode = 0; a.div = 1.f;
+        int rc = launch_conv(a, B, st);
+        if (rc) return rc;
+    }
+    return ITTS_OK;
+}
+
+extern "C" int itts_conv_transpose1d_forward(const float* x, const float* wpk_phases, const float* bias,
+                                             const float* bias_b, float* y, int B, int Cin, int Cout, int Tin, int k,
+                                             int u, const int32_t* lens, int len_mult_in, void* stream) {
+    if (!x || !wpk_phases || !y || k != 2 * u || u < 1 || ((k - u) & 1)) {
+        itts_set_error("conv_transpose1d: need k == 2u and even k-u (k=%d u=%d)", k, u);
+        return ITTS_ERR_ARG;
+    }
+    if (B <= 0 || Tin <= 0) return ITTS_OK;
+    return convT_impl(x, wpk_phases, bias, bias_b, y, B, Cin, Cout, Tin, k, u, lens, len_mult_in < 1 ? 1 : len_mult_in,
+                      (hipStream_t)stream);
+}
+
+// ---- model object --------------------------------------------------------------------------------------------
+struct DevBuf {
+    float* p = nullptr;
+    size_t n = 0;
+};
+struct ConvL {
+    int Cin = 0, Cout = 0, k = 0;
+    DevBuf w, b;
+    bool has_w = false, has_b = false;
+};
+struct ActL {
+    int C = 0;
+    DevBuf alpha, beta, fu, fd;
+    bool has_a = false, has_b = false, has_fu = false, has_fd = false;
+};
+
+struct itts_bigvgan {
+    itts_bigvgan_config cfg;
+    ConvL conv_pre;
+    std::vector<ConvL> ups;             // w = u packed phases
+    std::vector<ConvL> convs1, convs2;  // [resblock n][dilation d] flattened n*ND + d
+    std::vector<ActL> acts;             // [n][2*ND] flattened
+    ActL act_post;
+    DevBuf post_w, post_b;
+    bool has_post_w = false, has_post_b = false;
+    ConvL cond_layer;                   // raw [Cout][cond_dim] (not packed)
+    std::vector<ConvL> conds;
+    DevBuf default_filter;
+    bool finalized = false;
+    std::vector<float*> owned;
+    int total_up = 1;
+};
+
+static int upload(itts_bigvgan* h, const float* host, size_t n, DevBuf* dst) {
+    if (dst->p) {   // reload: replace
+        dst->p = nullptr;
+    }
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, n * sizeof(float)));
+    h->owned.push_back(d);
+    HIP_TRY(hipMemcpy(d, host, n * sizeof(float), hipMemcpyHostToDevice));
+    dst->p = d;
+    dst->n = n;
+    return ITTS_OK;
+}
+
+static int stage_channels(const itts_bigvgan_config& c, int i) { return c.upsample_initial_channel >> (i + 1); }
+
+extern "C" int itts_bigvgan_create(const itts_bigvgan_config* cfg, itts_bigvgan** out) {
+    if (!cfg || !out) { itts_set_error("bigvgan_create: null"); return ITTS_ERR_ARG; }
+    const itts_bigvgan_config& c = *cfg;
+    if (c.num_upsamples < 1 || c.num_upsamples > 8 || c.num_kernels < 1 || c.num_kernels > 4 || c.num_dilations < 1 ||
+        c.num_dilations > 4 || c.in_channels % 8 || c.in_channels <= 0) {
+        itts_set_error("bigvgan_create: unsupported config (ups=%d kernels=%d dil=%d in=%d)", c.num_upsamples,
+                       c.num_kernels, c.num_dilations, c.in_channels);
+        return ITTS_ERR_ARG;
+    }
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        if (c.upsample_kernel_sizes[i] != 2 * c.upsample_rates[i]) {
+            itts_set_error("bigvgan_create: upsampler %d needs k == 2*stride (k=%d u=%d)", i, c.upsample_kernel_sizes[i],
+                           c.upsample_rates[i]);
+            return ITTS_ERR_ARG;
+        }
+        if (stage_channels(c, i) < 1 || (c.upsample_initial_channel >> i) % 8) {
+            itts_set_error("bigvgan_create: channel count at stage %d not a multiple of 8", i);
+            return ITTS_ERR_ARG;
+        }
+    }
+    if (stage_channels(c, c.num_upsamples - 1) % 8) {
+        itts_set_error("bigvgan_create: final channel count %d not a multiple of 8", stage_channels(c, c.num_upsamples - 1));
+        return ITTS_ERR_ARG;
+    }
+    for (int j = 0; j < c.num_kernels; ++j) {
+        if ((c.resblock_kernel_sizes[j] & 1) == 0) { itts_set_error("even resblock kernel"); return ITTS_ERR_ARG; }
+        for (int d = 0; d < c.num_dilations; ++d)
+            if ((c.resblock_kernel_sizes[j] - 1) * c.resblock_dilations[j][d] > 64) {
+                itts_set_error("bigvgan_create: receptive span of k=%d d=%d exceeds the 64-sample LDS halo",
+                               c.resblock_kernel_sizes[j], c.resblock_dilations[j][d]);
+                return ITTS_ERR_ARG;
+            }
+    }
+    itts_bigvgan* h = new itts_bigvgan();
+    h->cfg = c;
+    const int nres = c.num_upsamples * c.num_kernels;
+    h->ups.resize(c.num_upsamples);
+    h->conds.resize(c.num_upsamples);
+    h->convs1.resize((size_t)nres * c.num_dilations);
+    h->convs2.resize((size_t)nres * c.num_dilations);
+    h->acts.resize((size_t)nres * 2 * c.num_dilations);
+    h->total_up = 1;
+    for (int i = 0; i < c.num_upsamples; ++i) h->total_up *= c.upsample_rates[i];
+    *out = h;
+    return ITTS_OK;
+}
+
+extern "C" void itts_bigvgan_destroy(itts_bigvgan* h) {
+    if (!h) return;
+    for (float* p : h->owned) (void)hipFree(p);
+    delete h;
+}
+
+static bool parse_idx(const char*& s, int* v) {
+    if (*s < '0' || *s > '9') return false;
+    int x = 0;
+    while (*s >= '0' && *s <= '9') x = x * 10 + (*s++ - '0');
+    *v = x;
+    return true;
+}
+static bool eat(const char*& s, const char* lit) {
+    size_t n = strlen(lit);
+    if (strncmp(s, lit, n) == 0) { s += n; return true; }
+    return false;
+}
+
+static int load_conv(itts_bigvgan* h, ConvL* L, const char* what, const float* data, const int64_t* shape, int ndim,
+                     int Cout, int Cin, int k) {
+    if (!strcmp(what, "weight")) {
+        if (ndim != 3 || shape[0] != Cout || shape[1] != Cin || shape[2] != k) {
+            itts_set_error("conv weight shape mismatch: got [%lld,%lld,%lld] want [%d,%d,%d]", (long long)shape[0],
+                           (long long)(ndim > 1 ? shape[1] : -1), (long long)(ndim > 2 ? shape[2] : -1), Cout, Cin, k);
+            return ITTS_ERR_ARG;
+        }
+        std::vector<float> pk(itts_packed_conv_floats(Cout, Cin, k));
+        int rc = itts_pack_conv1d_weight(data, Cout, Cin, k, pk.data());
+        if (rc) return rc;
+        L->Cin = Cin; L->Cout = Cout; L->k = k; L->has_w = true;
+        return upload(h, pk.data(), pk.size(), &L->w);
+    }
+    if (!strcmp(what, "bias")) {
+        if (ndim != 1 || shape[0] != Cout) { itts_set_error("conv bias shape mismatch"); return ITTS_ERR_ARG; }
+        L->has_b = true;
+        return upload(h, data, Cout, &L->b);
+    }
+    itts_set_error("unknown conv tensor '%s'", what);
+    return ITTS_ERR_ARG;
+}
+
+static int load_act(itts_bigvgan* h, ActL* A, const char* what, const float* data, const int64_t* shape, int ndim, int C) {
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    A->C = C;
+    if (!strcmp(what, "act.alpha") || !strcmp(what, "act.beta")) {
+        if ((int)n != C) { itts_set_error("activation param has %zu elements, want %d", n, C); return ITTS_ERR_ARG; }
+        if (what[4] == 'a') { A->has_a = true; return upload(h, data, n, &A->alpha); }
+        A->has_b = true;
+        return upload(h, data, n, &A->beta);
+    }
+    if (!strcmp(what, "upsample.filter") || !strcmp(what, "downsample.lowpass.filter")) {
+        if (n != 12) { itts_set_error("anti-alias filter must have 12 taps, got %zu", n); return ITTS_ERR_ARG; }
+        if (what[0] == 'u') { A->has_fu = true; return upload(h, data, n, &A->fu); }
+        A->has_fd = true;
+        return upload(h, data, n, &A->fd);
+    }
+    itts_set_error("unknown activation tensor '%s'", what);
+    return ITTS_ERR_ARG;
+}
+
+extern "C" int itts_bigvgan_load_tensor(itts_bigvgan* h, const char* name, const float* data, const int64_t* shape,
+                                        int ndim) {
+    if (!h || !name || !data || !shape || ndim < 1 || ndim > 3) { itts_set_error("load_tensor: bad args"); return ITTS_ERR_ARG; }
+    const itts_bigvgan_config& c = h->cfg;
+    const char* s = name;
+    int i, j, d;
+    h->finalized = false;
+    if (eat(s, "conv_pre.")) return load_conv(h, &h->conv_pre, s, data, shape, ndim, c.upsample_initial_channel, c.in_channels, 7);
+    if (eat(s, "conv_post.")) {
+        const int ch = stage_channels(c, c.num_upsamples - 1);
+        if (!strcmp(s, "weight")) {
+            if (ndim != 3 || shape[0] != 1 || shape[1] != ch || shape[2] != 7) { itts_set_error("conv_post.weight shape"); return ITTS_ERR_ARG; }
+            h->has_post_w = true;
+            return upload(h, data, (size_t)ch * 7, &h->post_w);
+        }
+        if (!strcmp(s, "bias")) { h->has_post_b = true; return upload(h, data, 1, &h->post_b); }
+    }
+    if (eat(s, "ups.")) {
+        if (!parse_idx(s, &i) || i >= c.num_upsamples || !eat(s, ".0.")) { itts_set_error("bad name %s", name); return ITTS_ERR_ARG; }
+        const int Cin = c.upsample_initial_channel >> i, Cout = stage_channels(c, i);
+        const int k = c.upsample_kernel_sizes[i], u = c.upsample_rates[i];
+        ConvL* L = &h->ups[i];
+        if (!strcmp(s, "weight")) {
+            if (ndim != 3 || shape[0] != Cin || shape[1] != Cout || shape[2] != k) { itts_set_error("%s: shape mismatch", name); return ITTS_ERR_ARG; }
+            const size_t per = itts_packed_conv_floats(Cout, Cin, 2);
+            std::vector<float> pk(per * u);
+            for (int r = 0; r < u; ++r) {
+                int rc = itts_pack_convT_weight(data, Cin, Cout, k, u, r, pk.data() + per * r);
+                if (rc) return rc;
+            }
+            L->Cin = Cin; L->Cout = Cout; L->k = k; L->has_w = true;
+            return upload(h, pk.data(), pk.size(), &L->w);
+        }
+        if (!strcmp(s, "bias")) {
+            if (ndim != 1 || shape[0] != Cout) { itts_set_error("%s: shape mismatch", name); return ITTS_ERR_ARG; }
+            L->has_b = true;
+            return upload(h, data, Cout, &L->b);
+        }
+    }
+    if (eat(s, "resblocks.")) {
+        if (!parse_idx(s, &i) || i >= c.num_upsamples * c.num_kernels || !eat(s, ".")) { itts_set_error("bad name %s", name); return ITTS_ERR_ARG; }
+        const int ch = stage_channels(c, i / c.num_kernels);
+        const int k = c.resblock_kernel_sizes[i % c.num_kernels];
+        if (eat(s, "convs1.")) {
+            if (!parse_idx(s, &d) || d >= c.num_dilations || !eat(s, ".")) { itts_set_error("bad name %s", name); return ITTS_ERR_ARG; }
+            return load_conv(h, &h->convs1[(size_t)i * c.num_dilations + d], s, data, shape, ndim, ch, ch, k);
+        }
+        if (eat(s, "convs2.")) {
+            if (!parse_idx(s, &d) || d >= c.num_dilations || !eat(s, ".")) { itts_set_error("bad name %s", name); return ITTS_ERR_ARG; }
+            return load_conv(h, &h->convs2[(size_t)i * c.num_dilations + d], s, data, shape, ndim, ch, ch, k);
+        }
+        if (eat(s, "activations.")) {
+            if (!parse_idx(s, &j) || j >= 2 * c.num_dilations || !eat(s, ".")) { itts_set_error("bad name %s", name); return ITTS_ERR_ARG; }
+            return load_act(h, &h->acts[(size_t)i * 2 * c.num_dilations + j], s, data, shape, ndim, ch);
+        }
+    }
+    if (eat(s, "activation_post.")) return load_act(h, &h->act_post, s, data, shape, ndim, stage_channels(c, c.num_upsamples - 1));
+    if (c.cond_dim > 0 && eat(s, "cond_layer.")) {
+        ConvL* L = &h->cond_layer;
+        const int Cout = c.upsample_initial_channel;
+        if (!strcmp(s, "weight")) { L->has_w = true; L->Cout = Cout; return upload(h, data, (size_t)Cout * c.cond_dim, &L->w); }
+        if (!strcmp(s, "bias")) { L->has_b = true; return upload(h, data, Cout, &L->b); }
+    }
+    if (c.cond_dim > 0 && eat(s, "conds.")) {
+        if (!parse_idx(s, &i) || i >= c.num_upsamples || !eat(s, ".")) { itts_set_error("bad name %s", name); return ITTS_ERR_ARG; }
+        ConvL* L = &h->conds[i];
+        const int Cout = stage_channels(c, i);
+        if (!strcmp(s, "weight")) { L->has_w = true; L->Cout = Cout; return upload(h, data, (size_t)Cout * c.cond_dim, &L->w); }
+        if (!strcmp(s, "bias")) { L->has_b = true; return upload(h, data, Cout, &L->b); }
+    }
+    itts_set_error("bigvgan_load_tensor: unrecognised tensor name '%s'", name);
+    return ITTS_ERR_ARG;
+}
+
+// Kaiser-windowed sinc, 12 taps, cutoff 0.25, half-width 0.3 (filter.py:30-62) for checkpoints without filter buffers.
+static double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    for (int k = 1; k < 64; ++k) {
+        term *= (x / (2.0 * k)) * (x / (2.0 * k));
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+static void default_filter12(float* f) {
+    const int K = 12, half = 6;
+    const double cutoff = 0.25, half_width = 0.3, pi = 3.14159265358979323846;
+    const double delta_f = 4 * half_width;
+    const double A = 2.285 * (half - 1) * pi * delta_f + 7.95;
+    double beta = 0.0;
+    if (A > 50.0) beta = 0.1102 * (A - 8.7);
+    else if (A >= 21.0) beta = 0.5842 * pow(A - 21.0, 0.4) + 0.07886 * (A - 21.0);
+    double v[12], sum = 0;
+    for (int n = 0; n < K; ++n) {
+        const double r = 2.0 * n / (K - 1) - 1.0;
+        const double win = bessel_i0(beta * sqrt(1.0 - r * r)) / bessel_i0(beta);
+        const double t = (n - half) + 0.5;
+        const double xx = 2 * cutoff * t;
+        const double sinc = xx == 0 ? 1.0 : sin(pi * xx) / (pi * xx);
+        v[n] = 2 * cutoff * win * sinc;
+        sum += v[n];
+    }
+    for (int n = 0; n < K; ++n) f[n] = (float)(v[n] / sum);
+}
+
+extern "C" int itts_bigvgan_finalize(itts_bigvgan* h) {
+    if (!h) { itts_set_error("finalize: null"); return ITTS_ERR_ARG; }
+    const itts_bigvgan_config& c = h->cfg;
+    std::string missing;
+    auto need = [&](bool ok, const std::string& n) { if (!ok) missing += n + " "; };
+    need(h->conv_pre.has_w, "conv_pre.weight");
+    need(h->conv_pre.has_b, "conv_pre.bias");
+    need(h->has_post_w, "conv_post.weight");
+    if (c.use_bias_at_final) need(h->has_post_b, "conv_post.bias");
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        need(h->ups[i].has_w, "ups." + std::to_string(i) + ".0.weight");
+        need(h->ups[i].has_b, "ups." + std::to_string(i) + ".0.bias");
+        if (c.cond_dim > 0 && c.cond_in_each_up_layer) need(h->conds[i].has_w && h->conds[i].has_b, "conds." + std::to_string(i));
+    }
+    if (c.cond_dim > 0) need(h->cond_layer.has_w && h->cond_layer.has_b, "cond_layer");
+    for (size_t n = 0; n < h->convs1.size(); ++n) {
+        need(h->convs1[n].has_w && h->convs1[n].has_b, "resblocks.convs1#" + std::to_string(n));
+        need(h->convs2[n].has_w && h->convs2[n].has_b, "resblocks.convs2#" + std::to_string(n));
+    }
+    bool need_default = false;
+    for (size_t n = 0; n < h->acts.size(); ++n) {
+        need(h->acts[n].has_a && (c.activation == 1 || h->acts[n].has_b), "resblocks.activations#" + std::to_string(n));
+        if (!h->acts[n].has_fu || !h->acts[n].has_fd) need_default = true;
+    }
+    need(h->act_post.has_a && (c.activation == 1 || h->act_post.has_b), "activation_post");
+    if (!h->act_post.has_fu || !h->act_post.has_fd) need_default = true;
+    if (!missing.empty()) {
+        itts_set_error("bigvgan_finalize: missing tensors: %s", missing.c_str());
+        return ITTS_ERR_STATE;
+    }
+    if (need_default && !h->default_filter.p) {
+        float f[12];
+        default_filter12(f);
+        int rc = upload(h, f, 12, &h->default_filter);
+        if (rc) return rc;
+    }
+    auto fix = [&](ActL& a) {
+        if (!a.has_fu) a.fu = h->default_filter;
+        if (!a.has_fd) a.fd = h->default_filter;
+        if (c.activation == 1) a.beta = a.alpha;   // Snake: same parameter for frequency and magnitude
+    };
+    for (auto& a : h->acts) fix(a);
+    fix(h->act_post);
+    h->finalized = true;
+    return ITTS_OK;
+}
+
+static size_t max_stage_floats(const itts_bigvgan* h, int B, int T) {
+    const itts_bigvgan_config& c = h->cfg;
+    size_t mx = (size_t)c.upsample_initial_channel * T;
+    size_t t = T;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        t *= c.upsample_rates[i];
+        size_t v = (size_t)stage_channels(c, i) * t;
+        if (v > mx) mx = v;
+    }
+    return mx * (size_t)B;
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t itts_bigvgan_workspace_bytes(const itts_bigvgan* h, int B, int T) {
+    if (!h || B <= 0 || T <= 0) return 0;
+    const itts_bigvgan_config& c = h->cfg;
+    size_t cond = 0;
+    if (c.cond_dim > 0) {
+        cond = align256((size_t)B * c.upsample_initial_channel * 4);
+        for (int i = 0; i < c.num_upsamples; ++i) cond += align256((size_t)B * stage_channels(c, i) * 4);
+    }
+    return 7 * align256(max_stage_floats(h, B, T) * sizeof(float)) + cond + 256;
+}
+
+extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32_t* lens, const float* spk, float* wav,
+                                    int B, int T, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !x || !wav || !workspace) { itts_set_error("bigvgan_forward: null pointer"); return ITTS_ERR_ARG; }
+    if (!h->finalized) { itts_set_error("bigvgan_forward: call itts_bigvgan_finalize first"); return ITTS_ERR_STATE; }
+    if (B <= 0 || T <= 0) return ITTS_OK;
+    if (B > 65535) { itts_set_error("bigvgan_forward: B must be <= 65535"); return ITTS_ERR_ARG; }
+    const itts_bigvgan_config& c = h->cfg;
+    if (c.cond_dim > 0 && !spk) { itts_set_error("bigvgan_forward: this model needs a speaker embedding"); return ITTS_ERR_ARG; }
+    if (workspace_bytes < itts_bigvgan_workspace_bytes(h, B, T)) {
+        itts_set_error("bigvgan_forward: workspace too small (%zu < %zu)", workspace_bytes, itts_bigvgan_workspace_bytes(h, B, T));
+        return ITTS_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bufsz = align256(max_stage_floats(h, B, T) * sizeof(float));
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    float* buf[7];
+    for (int i = 0; i < 7; ++i) buf[i] = (float*)(base + bufsz * i);
+    char* condp = base + bufsz * 7;
+    float *P = buf[0], *X = buf[1], *XS = buf[2], *T1 = buf[3], *T2 = buf[4], *RA = buf[5], *RB = buf[6];
+    const int ND = c.num_dilations;
+    int rc;
+
+    // speaker-conditioning biases (v1): bias_b[b][co] = cond_i(spk[b])
+    const float* cond0 = nullptr;
+    std::vector<const float*> cond_up(c.num_upsamples, nullptr);
+    if (c.cond_dim > 0) {
+        float* p = (float*)condp;
+        rc = launch_cond_bias(spk, h->cond_layer.w.p, h->cond_layer.b.p, p, B, c.upsample_initial_channel, c.cond_dim, st);
+        if (rc) return rc;
+        cond0 = p;
+        condp += align256((size_t)B * c.upsample_initial_channel * 4);
+        if (c.cond_in_each_up_layer)
+            for (int i = 0; i < c.num_upsamples; ++i) {
+                float* q = (float*)condp;
+                rc = launch_cond_bias(spk, h->conds[i].w.p, h->conds[i].b.p, q, B, stage_channels(c, i), c.cond_dim, st);
+                if (rc) return rc;
+                cond_up[i] = q;
+                condp += align256((size_t)B * stage_channels(c, i) * 4);
+            }
+    }
+
+    // conv_pre (bigvgan.py:362; v1 models.py:224-226)
+    rc = conv1d_impl(x, h->conv_pre.w.p, h->conv_pre.b.p, cond0, nullptr, P, B, c.in_channels, c.upsample_initial_channel, T,
+                     7, 1, lens, 1, 0, 1.f, st);
+    if (rc) return rc;
+
+    int t_cur = T, mult = 1;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        const int Cin = c.upsample_initial_channel >> i, ch = stage_channels(c, i);
+        const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+        rc = convT_impl(P, h->ups[i].w.p, h->ups[i].b.p, cond_up[i], X, B, Cin, ch, t_cur, k, u, lens, mult, st);
+        if (rc) return rc;
+        t_cur *= u;
+        mult *= u;
+        for (int j = 0; j < c.num_kernels; ++j) {
+            const int n = i * c.num_kernels + j;
+            const int kk = c.resblock_kernel_sizes[j];
+            const float* cur = X;
+            for (int d = 0; d < ND; ++d) {
+                const ActL& a1 = h->acts[(size_t)n * 2 * ND + 2 * d];
+                const ActL& a2 = h->acts[(size_t)n * 2 * ND + 2 * d + 1];
+                const ConvL& c1 = h->convs1[(size_t)n * ND + d];
+                const ConvL& c2 = h->convs2[(size_t)n * ND + d];
+                rc = launch_aa_act(cur, T1, a1.alpha.p, a1.beta.p, a1.fu.p, a1.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st);
+                if (rc) return rc;
+                rc = conv1d_impl(T1, c1.w.p, c1.b.p, nullptr, nullptr, T2, B, ch, ch, t_cur, kk, c.resblock_dilations[j][d], lens, mult, 0, 1.f, st);
+                if (rc) return rc;
+                rc = launch_aa_act(T2, T1, a2.alpha.p, a2.beta.p, a2.fu.p, a2.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st);
+                if (rc) return rc;
+                if (d < ND - 1) {
+                    float* nxt = (cur == RA) ? RB : RA;
+                    rc = conv1d_impl(T1, c2.w.p, c2.b.p, nullptr, cur, nxt, B, ch, ch, t_cur, kk, 1, lens, mult, 0, 1.f, st);
+                    if (rc) return rc;
+                    cur = nxt;
+                } else {
+                    // block output r_j = conv2(..) + cur, folded into the MRF sum: xs = r_0; xs += r_1; ...; /num_kernels
+                    int mode = (j == 0) ? 0 : 1;
+                    if (j == c.num_kernels - 1) mode = (c.num_kernels == 1) ? 0 : 2;
+                    rc = conv1d_impl(T1, c2.w.p, c2.b.p, nullptr, cur, XS, B, ch, ch, t_cur, kk, 1, lens, mult, mode, (float)c.num_kernels, st);
+                    if (rc) return rc;
+                }
+            }
+        }
+        float* tmp = P; P = XS; XS = tmp;
+    }
+    const int ch = stage_channels(c, c.num_upsamples - 1);
+    rc = launch_aa_act(P, T1, h->act_post.alpha.p, h->act_post.beta.p, h->act_post.fu.p, h->act_post.fd.p, B, ch, t_cur, lens, mult,
+                       c.snake_logscale, st);
+    if (rc) return rc;
+    return launch_conv_post(T1, wav, h->post_w.p, c.use_bias_at_final ? h->post_b.p : nullptr, B, ch, t_cur, 7, lens, mult,
+                            c.use_tanh_at_final, st);
+}

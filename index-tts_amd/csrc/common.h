@@ -1,0 +1,59 @@
+// Shared device/host helpers for the gfx950 kernels (wave = 64 lanes everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define ITTS_OK 0
+#define ITTS_ERR_ARG 1
+#define ITTS_ERR_HIP 2
+#define ITTS_ERR_STATE 3
+#define ITTS_ERR_NOMEM 4
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            itts_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return ITTS_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+void itts_set_error(const char* fmt, ...);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float bf16_to_f32(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even, NaN-preserving (same rule as torch .bfloat16())
+__device__ __forceinline__ u16 f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+#endif
+
+static inline u16 host_f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
