@@ -139,7 +139,7 @@ def test_generator_vs_reference_golden(bv, golden_dir, tag):
 
 def test_generator_ragged_batch_rows_equal_solo(bv):
     """Batched, zero-padded rows bounded at their own length == each row alone (the B=1 reference semantics)."""
-    h = dict(O.V2_HPARAMS, upsample_initial_channel=128)
+    h = dict(O.V2_HPARAMS, upsample_initial_channel=512)
     sd = O.synth_weights(h, seed=77)
     m = _model(bv, h, sd)
     g = torch.Generator().manual_seed(3)
@@ -157,7 +157,7 @@ def test_generator_ragged_batch_rows_equal_solo(bv):
 
 def test_generator_v1_variant(bv):
     """v1: latent input (B,T,D), speaker conditioning adds after conv_pre and each upsampler, tanh epilogue."""
-    h = dict(O.V2_HPARAMS, upsample_initial_channel=128, use_tanh_at_final=True, use_bias_at_final=True,
+    h = dict(O.V2_HPARAMS, upsample_initial_channel=512, use_tanh_at_final=True, use_bias_at_final=True,
              upsample_rates=[4, 4, 4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 8, 8, 4, 4])
     sd = O.synth_weights(h, seed=5, cond_dim=64, in_dim=48, post_gain=0.2)
     m = _model(bv, h, sd, cond_dim=64, in_channels=48)

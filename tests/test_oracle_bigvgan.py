@@ -55,7 +55,7 @@ def test_weight_norm_folding():
 
 def test_v1_variant_runs():
     """v1 generator: latent input, speaker conditioning adds, tanh epilogue (indextts/BigVGAN/models.py:201-250)."""
-    h = dict(O.V2_HPARAMS, upsample_initial_channel=128, use_tanh_at_final=True, use_bias_at_final=True,
+    h = dict(O.V2_HPARAMS, upsample_initial_channel=512, use_tanh_at_final=True, use_bias_at_final=True,
              upsample_rates=[4, 4, 4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4, 4, 4])
     sd = O.synth_weights(h, seed=5, cond_dim=16, in_dim=24)
     g = torch.Generator().manual_seed(1)

@@ -75,9 +75,9 @@ def main():
     # ---- generator goldens ----
     cases = {
         # tag: (hparam overrides, seed, B, T_mel)
-        "small": (dict(upsample_initial_channel=64), 11, 2, 9, 0.04),
-        "loud": (dict(upsample_initial_channel=64), 13, 1, 5, 0.35),
-        "mid": (dict(upsample_initial_channel=192), 12, 1, 20, 0.04),
+        "small": (dict(upsample_initial_channel=512), 11, 2, 9, 0.04),
+        "loud": (dict(upsample_initial_channel=512), 13, 1, 5, 0.35),
+        "mid": (dict(upsample_initial_channel=1024), 12, 1, 20, 0.04),
         "full": (dict(), 1234, 1, 12, 0.04),
     }
     for tag, (ov, seed, B, T, pg) in cases.items():
