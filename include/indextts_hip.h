@@ -93,6 +93,79 @@ size_t itts_bigvgan_workspace_bytes(const itts_bigvgan* h, int B, int T);
 int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32_t* lens, const float* spk, float* wav, int B,
                          int T, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * GPT speech-token decoder
+ * ---------------------------------------------------------------------------------------------------------- */
+#define ITTS_PREC_F32 0   /* parity mode: f32 weights / KV / MFMA (v_mfma_f32_16x16x4_f32, exact f32) */
+#define ITTS_PREC_BF16 1  /* bf16 weights / KV / GEMM inputs, f32 accumulate and residual stream */
+
+typedef struct {
+    int32_t layers, model_dim, heads;   /* head_dim = model_dim / heads must be 64 */
+    int32_t vocab;                      /* number_mel_codes (8194) */
+    int32_t n_mel_pos;                  /* rows of mel_pos_embedding (max_mel_tokens + 2 + max_conditioning_inputs) */
+    int32_t precision;                  /* ITTS_PREC_* */
+    int32_t start_mel_token, stop_mel_token;
+    float ln_eps;                       /* 1e-5 (GPT2Config.layer_norm_epsilon / nn.LayerNorm default) */
+} itts_gpt_config;
+
+typedef struct {
+    int32_t do_sample;                  /* 0: argmax (HF greedy), 1: multinomial after the warpers */
+    int32_t num_beams;                  /* 1 (beam search is handled by the host-side scorer) */
+    int32_t top_k;                      /* 1..64 when do_sample */
+    int32_t min_tokens_to_keep;         /* 1 (2 under beams) */
+    int32_t max_new_tokens;             /* max_generate_length */
+    int32_t pos_offset;                 /* 2: HF kv-cache position rule (k-th token at mel position k+1, 1-based k);
+                                           1: kv_cache=False rule (positions 0..n-1), model_v2.py:145-161 */
+    float top_p, temperature, repetition_penalty, length_penalty;
+    uint64_t seed;                      /* device RNG seed when no uniform stream is supplied */
+} itts_gen_params;
+
+typedef struct itts_gpt itts_gpt;
+
+/* host-side packing of a [K][N] (transposed=0, HF Conv1D) or [N][K] (transposed=1, nn.Linear) f32 matrix into
+ * MFMA B-fragment order for the given precision (pure CPU). */
+size_t itts_packed_gemm_bytes(int K, int N, int precision);
+int itts_pack_gemm_weight(const float* w, int K, int N, int transposed, int precision, void* out);
+
+/* replaces: UnifiedVoice.__init__/load_checkpoint/post_init_gpt2_config for the decoder stack
+ *   (indextts/gpt/model_v2.py:305-493, indextts/utils/checkpoint.py:22-35).  Tensors by reference state-dict name:
+ *   gpt.h.{i}.{ln_1,ln_2}.{weight,bias}, gpt.h.{i}.attn.{c_attn,c_proj}.{weight,bias}, gpt.h.{i}.mlp.{c_fc,c_proj}.*,
+ *   gpt.ln_f.*, final_norm.*, mel_head.*, mel_embedding.weight, mel_pos_embedding.emb.weight (host f32 pointers). */
+int itts_gpt_create(const itts_gpt_config* cfg, itts_gpt** out);
+int itts_gpt_load_tensor(itts_gpt* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int itts_gpt_finalize(itts_gpt* h);
+void itts_gpt_destroy(itts_gpt* h);
+size_t itts_gpt_workspace_bytes(const itts_gpt* h, int nseq, int S, int Tmax);
+
+/* replaces: GPT2InferenceModel.generate(...) as called by UnifiedVoice.inference_speech
+ *   (indextts/gpt/model_v2.py:815-820 -> vendored GenerationMixin._sample, transformers_generation_utils.py:3123-3297;
+ *    per-step forward model_v2.py:121-198; KV cache transformers_gpt2.py:325-328).
+ * prefix_embeds [nseq][S][D] f32 device: rows = [left pad][cond][text] embeddings followed by the start-mel row
+ *   (mel_embedding[start]+mel_pos[0]) -- what prepare_gpt_inputs + the prefill branch of forward build.
+ * pad_lens [nseq] int32 device (left-pad length per row) or NULL.  penalty_ids: host ints already "in input_ids"
+ *   for the repetition penalty (the fake prefix id 1 and start_mel).
+ * uniforms: optional device f64 [max_new_tokens][nseq] stream for sampled modes (else seeded device RNG).
+ * codes_out [nseq][max_new_tokens] int64 device, pre-filled with stop_mel; *n_steps_out = columns generated before
+ *   every row finished (HF returns sequences of that length).  Runs on an internal stream ordered after/before
+ *   `stream`; the per-token step is one hipGraph replay when use_graph != 0. */
+int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int nseq, int S,
+                      const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids,
+                      const double* uniforms, int64_t* codes_out, int32_t* n_steps_out, void* workspace,
+                      size_t workspace_bytes, int use_graph, void* stream);
+/* HIP-event timings of the last itts_gpt_generate call on its internal stream */
+int itts_gpt_last_timing(const itts_gpt* h, float* prefill_ms, float* decode_ms, int32_t* steps);
+
+/* replaces: UnifiedVoice.forward(..., return_latent=True) transformer pass (model_v2.py:596-646, get_logits
+ *   :528-554; call site indextts/infer_v2.py:636-651): x [nseq][S][D] -> final_norm(ln_f(blocks(x))) [nseq][S][D]. */
+int itts_gpt_forward_latent(itts_gpt* h, const float* x, int nseq, int S, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* unit-level ops for the parity tests: C[M,N] = A[M,K] * W + bias (A in the precision's activation dtype), LayerNorm */
+int itts_gemm_forward(const void* A, const void* Wp, const float* bias, float* out, int M, int N, int K, int precision,
+                      int prefill_tiles, int gelu, void* stream);
+int itts_layernorm_forward(const float* x, const float* gamma, const float* beta, const float* gamma2,
+                           const float* beta2, float* out, int rows, int D, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

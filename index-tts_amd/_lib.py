@@ -25,6 +25,19 @@ class BigVGANConfig(C.Structure):
     ]
 
 
+class GPTConfig(C.Structure):
+    _fields_ = [("layers", C.c_int32), ("model_dim", C.c_int32), ("heads", C.c_int32), ("vocab", C.c_int32),
+                ("n_mel_pos", C.c_int32), ("precision", C.c_int32), ("start_mel_token", C.c_int32),
+                ("stop_mel_token", C.c_int32), ("ln_eps", C.c_float)]
+
+
+class GenParams(C.Structure):
+    _fields_ = [("do_sample", C.c_int32), ("num_beams", C.c_int32), ("top_k", C.c_int32),
+                ("min_tokens_to_keep", C.c_int32), ("max_new_tokens", C.c_int32), ("pos_offset", C.c_int32),
+                ("top_p", C.c_float), ("temperature", C.c_float), ("repetition_penalty", C.c_float),
+                ("length_penalty", C.c_float), ("seed", C.c_uint64)]
+
+
 # name -> (restype, argtypes); every symbol include/indextts_hip.h declares must appear here
 SIGNATURES = {
     "itts_abi_version": (C.c_int, []),
@@ -44,6 +57,19 @@ SIGNATURES = {
     "itts_bigvgan_destroy": (None, [vp]),
     "itts_bigvgan_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int]),
     "itts_bigvgan_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "itts_packed_gemm_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "itts_pack_gemm_weight": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "itts_gpt_create": (C.c_int, [C.POINTER(GPTConfig), C.POINTER(vp)]),
+    "itts_gpt_load_tensor": (C.c_int, [vp, C.c_char_p, vp, c_i64p, C.c_int]),
+    "itts_gpt_finalize": (C.c_int, [vp]),
+    "itts_gpt_destroy": (None, [vp]),
+    "itts_gpt_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int]),
+    "itts_gpt_generate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.POINTER(GenParams), c_i32p, C.c_int, vp, vp,
+                                    C.POINTER(C.c_int32), vp, C.c_size_t, C.c_int, vp]),
+    "itts_gpt_last_timing": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "itts_gpt_forward_latent": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
+    "itts_gemm_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "itts_layernorm_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
 }
 
 _lib = None

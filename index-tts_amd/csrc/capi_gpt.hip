@@ -1,0 +1,530 @@
+// C-ABI entry points for the GPT speech-token decoder (see include/indextts_hip.h for the reference call sites).
+#include <math.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/indextts_hip.h"
+#include "gpt_kernels.h"
+
+// ---- host-side weight packing ----------------------------------------------------------------------------------
+extern "C" size_t itts_packed_gemm_bytes(int K, int N, int precision) {
+    const int KB = precision == PREC_BF16 ? 32 : 16;
+    return (size_t)((N + 15) / 16) * (K / KB) * 64 * 16;
+}
+
+// w: [K][N] row-major (HF Conv1D) when transposed == 0, [N][K] (nn.Linear) when transposed != 0
+extern "C" int itts_pack_gemm_weight(const float* w, int K, int N, int transposed, int precision, void* out) {
+    const int KB = precision == PREC_BF16 ? 32 : 16;
+    if (!w || !out || K <= 0 || N <= 0 || K % KB) {
+        itts_set_error("pack_gemm: K=%d must be a positive multiple of %d", K, KB);
+        return ITTS_ERR_ARG;
+    }
+    const int ntiles = (N + 15) / 16, nkb = K / KB, per = KB / 4;   // per = k elements per lane
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int kb = 0; kb < nkb; ++kb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = nt * 16 + (lane & 15);
+                const size_t base = (((size_t)nt * nkb + kb) * 64 + lane);
+                for (int j = 0; j < per; ++j) {
+                    const int k = kb * KB + (lane >> 4) * per + j;
+                    float v = 0.f;
+                    if (n < N) v = transposed ? w[(size_t)n * K + k] : w[(size_t)k * N + n];
+                    if (precision == PREC_BF16) ((u16*)out)[base * 8 + j] = host_f32_to_bf16(v);
+                    else ((float*)out)[base * 4 + j] = v;
+                }
+            }
+    return ITTS_OK;
+}
+
+// ---- model object ----------------------------------------------------------------------------------------------
+struct GLayer {
+    float *ln1_g = 0, *ln1_b = 0, *ln2_g = 0, *ln2_b = 0;
+    void *w_qkv = 0, *w_proj = 0, *w_fc = 0, *w_fc2 = 0;
+    float *b_qkv = 0, *b_proj = 0, *b_fc = 0, *b_fc2 = 0;
+};
+
+struct itts_gpt {
+    itts_gpt_config cfg;
+    std::vector<GLayer> layers;
+    float *lnf_g = 0, *lnf_b = 0, *fn_g = 0, *fn_b = 0;
+    void* w_head = 0;
+    float* b_head = 0;
+    float *mel_emb = 0, *mel_pos = 0;
+    std::vector<void*> owned;
+    bool finalized = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_t2 = nullptr;
+    int* host_flag = nullptr;          // pinned
+    unsigned char* host_fin = nullptr; // pinned, capacity fin_cap
+    int fin_cap = 0;
+    float last_prefill_ms = 0, last_decode_ms = 0;
+    int last_steps = 0;
+};
+
+static int g_upload(itts_gpt* h, const void* host, size_t bytes, void** dst) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    h->owned.push_back(d);
+    HIP_TRY(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+    *dst = d;
+    return ITTS_OK;
+}
+
+extern "C" int itts_gpt_create(const itts_gpt_config* cfg, itts_gpt** out) {
+    if (!cfg || !out) { itts_set_error("gpt_create: null"); return ITTS_ERR_ARG; }
+    const itts_gpt_config& c = *cfg;
+    const int KB = c.precision == PREC_BF16 ? 32 : 16;
+    if (c.layers < 1 || c.heads < 1 || c.model_dim != c.heads * 64 || c.model_dim % KB || c.vocab < 2 ||
+        (c.precision != PREC_F32 && c.precision != PREC_BF16) || c.n_mel_pos < 3) {
+        itts_set_error("gpt_create: unsupported config (layers=%d dim=%d heads=%d: head_dim must be 64; vocab=%d prec=%d)",
+                       c.layers, c.model_dim, c.heads, c.vocab, c.precision);
+        return ITTS_ERR_ARG;
+    }
+    itts_gpt* h = new itts_gpt();
+    h->cfg = c;
+    h->layers.resize(c.layers);
+    *out = h;
+    return ITTS_OK;
+}
+
+extern "C" void itts_gpt_destroy(itts_gpt* h) {
+    if (!h) return;
+    for (void* p : h->owned) (void)hipFree(p);
+    if (h->host_flag) (void)hipHostFree(h->host_flag);
+    if (h->host_fin) (void)hipHostFree(h->host_fin);
+    if (h->ev_in) { (void)hipEventDestroy(h->ev_in); (void)hipEventDestroy(h->ev_out); (void)hipEventDestroy(h->ev_t0);
+                    (void)hipEventDestroy(h->ev_t1); (void)hipEventDestroy(h->ev_t2); }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static bool g_eat(const char*& s, const char* lit) {
+    size_t n = strlen(lit);
+    if (strncmp(s, lit, n) == 0) { s += n; return true; }
+    return false;
+}
+
+static size_t numel(const int64_t* shape, int ndim) {
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    return n;
+}
+
+static int load_vec(itts_gpt* h, const float* data, const int64_t* shape, int ndim, size_t want, float** dst, const char* name) {
+    if (numel(shape, ndim) != want) { itts_set_error("%s: expected %zu elements, got %zu", name, want, numel(shape, ndim)); return ITTS_ERR_ARG; }
+    return g_upload(h, data, want * sizeof(float), (void**)dst);
+}
+
+static int load_mat(itts_gpt* h, const float* data, const int64_t* shape, int ndim, int K, int N, int transposed, void** dst,
+                    const char* name) {
+    const int64_t d0 = transposed ? N : K, d1 = transposed ? K : N;
+    if (ndim != 2 || shape[0] != d0 || shape[1] != d1) {
+        itts_set_error("%s: expected shape [%lld,%lld]", name, (long long)d0, (long long)d1);
+        return ITTS_ERR_ARG;
+    }
+    std::vector<char> pk(itts_packed_gemm_bytes(K, N, h->cfg.precision));
+    int rc = itts_pack_gemm_weight(data, K, N, transposed, h->cfg.precision, pk.data());
+    if (rc) return rc;
+    return g_upload(h, pk.data(), pk.size(), dst);
+}
+
+// Reference state-dict names: gpt.h.{i}.{ln_1,attn.c_attn,attn.c_proj,ln_2,mlp.c_fc,mlp.c_proj}.{weight,bias},
+// gpt.ln_f, final_norm, mel_head, mel_embedding.weight, mel_pos_embedding.emb.weight.  HF Conv1D weights are [in, out].
+extern "C" int itts_gpt_load_tensor(itts_gpt* h, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!h || !name || !data || !shape || ndim < 1 || ndim > 2) { itts_set_error("gpt_load_tensor: bad args"); return ITTS_ERR_ARG; }
+    const itts_gpt_config& c = h->cfg;
+    const int D = c.model_dim;
+    const char* s = name;
+    h->finalized = false;
+    if (g_eat(s, "gpt.h.")) {
+        int i = 0;
+        if (*s < '0' || *s > '9') { itts_set_error("bad name %s", name); return ITTS_ERR_ARG; }
+        while (*s >= '0' && *s <= '9') i = i * 10 + (*s++ - '0');
+        if (i >= c.layers || !g_eat(s, ".")) { itts_set_error("bad layer index in %s", name); return ITTS_ERR_ARG; }
+        GLayer& L = h->layers[i];
+        if (!strcmp(s, "ln_1.weight")) return load_vec(h, data, shape, ndim, D, &L.ln1_g, name);
+        if (!strcmp(s, "ln_1.bias")) return load_vec(h, data, shape, ndim, D, &L.ln1_b, name);
+        if (!strcmp(s, "ln_2.weight")) return load_vec(h, data, shape, ndim, D, &L.ln2_g, name);
+        if (!strcmp(s, "ln_2.bias")) return load_vec(h, data, shape, ndim, D, &L.ln2_b, name);
+        if (!strcmp(s, "attn.c_attn.weight")) return load_mat(h, data, shape, ndim, D, 3 * D, 0, &L.w_qkv, name);
+        if (!strcmp(s, "attn.c_attn.bias")) return load_vec(h, data, shape, ndim, 3 * D, &L.b_qkv, name);
+        if (!strcmp(s, "attn.c_proj.weight")) return load_mat(h, data, shape, ndim, D, D, 0, &L.w_proj, name);
+        if (!strcmp(s, "attn.c_proj.bias")) return load_vec(h, data, shape, ndim, D, &L.b_proj, name);
+        if (!strcmp(s, "mlp.c_fc.weight")) return load_mat(h, data, shape, ndim, D, 4 * D, 0, &L.w_fc, name);
+        if (!strcmp(s, "mlp.c_fc.bias")) return load_vec(h, data, shape, ndim, 4 * D, &L.b_fc, name);
+        if (!strcmp(s, "mlp.c_proj.weight")) return load_mat(h, data, shape, ndim, 4 * D, D, 0, &L.w_fc2, name);
+        if (!strcmp(s, "mlp.c_proj.bias")) return load_vec(h, data, shape, ndim, D, &L.b_fc2, name);
+    }
+    if (!strcmp(name, "gpt.ln_f.weight")) return load_vec(h, data, shape, ndim, D, &h->lnf_g, name);
+    if (!strcmp(name, "gpt.ln_f.bias")) return load_vec(h, data, shape, ndim, D, &h->lnf_b, name);
+    if (!strcmp(name, "final_norm.weight")) return load_vec(h, data, shape, ndim, D, &h->fn_g, name);
+    if (!strcmp(name, "final_norm.bias")) return load_vec(h, data, shape, ndim, D, &h->fn_b, name);
+    if (!strcmp(name, "mel_head.weight")) return load_mat(h, data, shape, ndim, D, c.vocab, 1, &h->w_head, name);
+    if (!strcmp(name, "mel_head.bias")) return load_vec(h, data, shape, ndim, c.vocab, &h->b_head, name);
+    if (!strcmp(name, "mel_embedding.weight")) return load_vec(h, data, shape, ndim, (size_t)c.vocab * D, &h->mel_emb, name);
+    if (!strcmp(name, "mel_pos_embedding.emb.weight")) return load_vec(h, data, shape, ndim, (size_t)c.n_mel_pos * D, &h->mel_pos, name);
+    itts_set_error("gpt_load_tensor: unrecognised tensor name '%s'", name);
+    return ITTS_ERR_ARG;
+}
+
+extern "C" int itts_gpt_finalize(itts_gpt* h) {
+    if (!h) { itts_set_error("gpt_finalize: null"); return ITTS_ERR_ARG; }
+    std::string missing;
+    for (size_t i = 0; i < h->layers.size(); ++i) {
+        const GLayer& L = h->layers[i];
+        if (!L.ln1_g || !L.ln1_b || !L.ln2_g || !L.ln2_b || !L.w_qkv || !L.w_proj || !L.w_fc || !L.w_fc2 || !L.b_qkv || !L.b_proj ||
+            !L.b_fc || !L.b_fc2)
+            missing += "gpt.h." + std::to_string(i) + ".* ";
+    }
+    if (!h->lnf_g || !h->lnf_b) missing += "gpt.ln_f ";
+    if (!h->fn_g || !h->fn_b) missing += "final_norm ";
+    if (!h->w_head || !h->b_head) missing += "mel_head ";
+    if (!h->mel_emb) missing += "mel_embedding.weight ";
+    if (!h->mel_pos) missing += "mel_pos_embedding.emb.weight ";
+    if (!missing.empty()) { itts_set_error("gpt_finalize: missing tensors: %s", missing.c_str()); return ITTS_ERR_STATE; }
+    if (!h->stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&h->ev_t0));
+        HIP_TRY(hipEventCreate(&h->ev_t1));
+        HIP_TRY(hipEventCreate(&h->ev_t2));
+        HIP_TRY(hipHostMalloc((void**)&h->host_flag, 64, hipHostMallocDefault));
+    }
+    h->finalized = true;
+    return ITTS_OK;
+}
+
+// ---- workspace -------------------------------------------------------------------------------------------------
+static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct GptWs {
+    char *kc, *vc;      // [L][nseq][H][Tmax][64] cache dtype
+    float* x;           // [rows][D]
+    char* hbuf;         // [rows][D] act
+    float* qbuf;        // [rows][D]
+    char* attn;         // [rows][D] act
+    char* fc;           // [rows][4D] act
+    float* partial;     // [4][nseq][D]
+    char* hlast;        // [nseq][D] act
+    float* logits;      // [nseq][V]
+    unsigned char* seen;     // [nseq][V]
+    unsigned char* finished; // [nseq]
+    int* state;         // [0] step, [1] pos
+    int* pad;           // [nseq]
+    int* pen_ids;       // [16]
+    size_t total;
+    size_t layer_cache_bytes;
+};
+
+static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tmax) {
+    GptWs w;
+    const size_t esz = c.precision == PREC_BF16 ? 2 : 4;
+    const size_t D = c.model_dim, rows = (size_t)nseq * S;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += a256(bytes); return p; };
+    w.layer_cache_bytes = a256((size_t)nseq * D * Tmax * esz);
+    w.kc = take(w.layer_cache_bytes * c.layers);
+    w.vc = take(w.layer_cache_bytes * c.layers);
+    w.x = (float*)take(rows * D * 4);
+    w.hbuf = take(rows * D * esz);
+    w.qbuf = (float*)take(rows * D * 4);
+    w.attn = take(rows * D * esz);
+    w.fc = take(rows * 4 * D * esz);
+    w.partial = (float*)take((size_t)4 * nseq * D * 4);
+    w.hlast = take((size_t)nseq * D * esz);
+    w.logits = (float*)take((size_t)nseq * c.vocab * 4);
+    w.seen = (unsigned char*)take((size_t)nseq * c.vocab);
+    w.finished = (unsigned char*)take(nseq);
+    w.state = (int*)take(64);
+    w.pad = (int*)take((size_t)nseq * 4);
+    w.pen_ids = (int*)take(64);
+    w.total = off + 256;
+    return w;
+}
+
+extern "C" size_t itts_gpt_workspace_bytes(const itts_gpt* h, int nseq, int S, int Tmax) {
+    if (!h || nseq <= 0 || S <= 0 || Tmax < S) return 0;
+    return carve(h->cfg, nullptr, nseq, S, Tmax).total;
+}
+
+// ---- small state kernels ---------------------------------------------------------------------------------------
+__global__ void set_state_kernel(int* state, int step, int pos) { state[0] = step; state[1] = pos; }
+__global__ void fill_i64_kernel(long long* p, long long v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void mark_seen_kernel(unsigned char* seen, const int* ids, int n_ids, int V) {
+    const int b = blockIdx.x;
+    if ((int)threadIdx.x < n_ids) {
+        const int id = ids[threadIdx.x];
+        if (id >= 0 && id < V) seen[(size_t)b * V + id] = 1;
+    }
+}
+
+// ---- one transformer pass --------------------------------------------------------------------------------------
+// rows = nseq*S new positions (S = 1 for a decode step).  prefill: direct residual epilogues + big-tile GEMMs;
+// decode: split-K partials reduced inside the next LayerNorm kernel.
+static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bool prefill, const int* pos_ptr, const int* pad,
+                      bool* pending, hipStream_t st) {
+    const itts_gpt_config& c = h->cfg;
+    const int D = c.model_dim, prec = c.precision, rows = nseq * S;
+    int rc;
+    const float* pend_bias = nullptr;   // bias of a GEMM whose partials are pending reduction
+    for (int l = 0; l < c.layers; ++l) {
+        const GLayer& L = h->layers[l];
+        LnArgs ln{};
+        ln.x = w.x; ln.partial = pend_bias ? w.partial : nullptr; ln.nsplit = 4; ln.bias_prev = pend_bias;
+        ln.g1 = L.ln1_g; ln.b1 = L.ln1_b; ln.g2 = nullptr; ln.b2 = nullptr; ln.out = w.hbuf; ln.out_f32 = 0;
+        ln.rows = rows; ln.D = D; ln.in_row_mul = 1; ln.in_row_add = 0; ln.eps = c.ln_eps;
+        if ((rc = launch_ln(ln, prec, st))) return rc;
+        pend_bias = nullptr;
+
+        GemmArgs g{};
+        g.A = w.hbuf; g.lda = D; g.Wp = L.w_qkv; g.bias = L.b_qkv; g.M = rows; g.N = 3 * D; g.K = D; g.nsplit = 1; g.epi = EPI_QKV;
+        g.qbuf = w.qbuf; g.kcache = w.kc + w.layer_cache_bytes * l; g.vcache = w.vc + w.layer_cache_bytes * l;
+        g.pos_ptr = pos_ptr; g.S = S; g.H = c.heads; g.Tmax = Tmax; g.D = D;
+        if ((rc = launch_gemm(g, prec, prefill, st))) return rc;
+
+        AttnArgs at{};
+        at.qbuf = w.qbuf; at.kcache = g.kcache; at.vcache = g.vcache; at.pad = pad; at.row_map = nullptr; at.pos_ptr = pos_ptr;
+        at.out = w.attn; at.nseq = nseq; at.H = c.heads; at.nq = S; at.Tmax = Tmax; at.D = D;
+        if ((rc = launch_attention(at, prec, st))) return rc;
+
+        GemmArgs p{};
+        p.A = w.attn; p.lda = D; p.Wp = L.w_proj; p.bias = L.b_proj; p.M = rows; p.N = D; p.K = D; p.D = D;
+        if (prefill) { p.nsplit = 1; p.epi = EPI_RESIDUAL; p.out_f32 = w.x; p.ldo = D; }
+        else { p.nsplit = 4; p.epi = EPI_PARTIAL; p.partial = w.partial; }
+        if ((rc = launch_gemm(p, prec, prefill, st))) return rc;
+
+        LnArgs ln2 = ln;
+        ln2.partial = prefill ? nullptr : w.partial; ln2.bias_prev = prefill ? nullptr : L.b_proj;
+        ln2.g1 = L.ln2_g; ln2.b1 = L.ln2_b;
+        if ((rc = launch_ln(ln2, prec, st))) return rc;
+
+        GemmArgs f{};
+        f.A = w.hbuf; f.lda = D; f.Wp = L.w_fc; f.bias = L.b_fc; f.M = rows; f.N = 4 * D; f.K = D; f.nsplit = 1; f.epi = EPI_GELU_ACT;
+        f.out_act = w.fc; f.ldo = 4 * D; f.D = D;
+        if ((rc = launch_gemm(f, prec, prefill, st))) return rc;
+
+        GemmArgs f2{};
+        f2.A = w.fc; f2.lda = 4 * D; f2.Wp = L.w_fc2; f2.bias = L.b_fc2; f2.M = rows; f2.N = D; f2.K = 4 * D; f2.D = D;
+        if (prefill) { f2.nsplit = 1; f2.epi = EPI_RESIDUAL; f2.out_f32 = w.x; f2.ldo = D; }
+        else { f2.nsplit = 4; f2.epi = EPI_PARTIAL; f2.partial = w.partial; pend_bias = L.b_fc2; }
+        if ((rc = launch_gemm(f2, prec, prefill, st))) return rc;
+    }
+    *pending = pend_bias != nullptr;   // decode: the last FC2's partials are reduced by the caller's final LayerNorm
+    return ITTS_OK;
+}
+
+// final norm(s) + head: rows_out rows, input row r*mul+add
+static int run_head(itts_gpt* h, const GptWs& w, int nseq, int mul, int add, bool pending, hipStream_t st) {
+    const itts_gpt_config& c = h->cfg;
+    const int D = c.model_dim, prec = c.precision;
+    int rc;
+    LnArgs ln{};
+    ln.x = w.x; ln.partial = pending ? w.partial : nullptr; ln.nsplit = 4; ln.bias_prev = pending ? h->layers.back().b_fc2 : nullptr;
+    ln.g1 = h->lnf_g; ln.b1 = h->lnf_b; ln.g2 = h->fn_g; ln.b2 = h->fn_b; ln.out = w.hlast; ln.out_f32 = 0;
+    ln.rows = nseq; ln.D = D; ln.in_row_mul = mul; ln.in_row_add = add; ln.eps = c.ln_eps;
+    if ((rc = launch_ln(ln, prec, st))) return rc;
+    GemmArgs g{};
+    g.A = w.hlast; g.lda = D; g.Wp = h->w_head; g.bias = h->b_head; g.M = nseq; g.N = c.vocab; g.K = D; g.nsplit = 1;
+    g.epi = EPI_STORE_F32; g.out_f32 = w.logits; g.ldo = c.vocab; g.D = D;
+    return launch_gemm(g, prec, false, st);
+}
+
+static SampleArgs make_sample(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, int nseq, long long* tokens,
+                              const double* uniforms) {
+    const itts_gpt_config& c = h->cfg;
+    SampleArgs s{};
+    s.logits = w.logits; s.seen = w.seen; s.finished = w.finished; s.tokens = tokens; s.step_ptr = w.state;
+    s.uniforms = uniforms; s.seed = gp.seed; s.B = nseq; s.V = c.vocab; s.max_new = gp.max_new_tokens;
+    s.do_sample = gp.do_sample; s.top_k = gp.top_k; s.min_keep = gp.min_tokens_to_keep < 1 ? 1 : gp.min_tokens_to_keep;
+    s.top_p = gp.top_p; s.temperature = gp.temperature; s.rep_penalty = gp.repetition_penalty;
+    s.stop_token = c.stop_mel_token; s.mel_emb = h->mel_emb; s.mel_pos = h->mel_pos; s.x_next = w.x; s.D = c.model_dim;
+    s.pos_offset = gp.pos_offset; s.n_mel_pos = c.n_mel_pos;
+    return s;
+}
+
+static int decode_step(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, int nseq, int Tmax, long long* tokens,
+                       const double* uniforms, hipStream_t st) {
+    bool pending = false;
+    int rc = run_layers(h, w, nseq, 1, Tmax, false, w.state + 1, w.pad, &pending, st);
+    if (rc) return rc;
+    if ((rc = run_head(h, w, nseq, 1, 0, pending, st))) return rc;
+    SampleArgs s = make_sample(h, w, gp, nseq, tokens, uniforms);
+    if ((rc = launch_sample(s, st))) return rc;
+    return launch_advance(w.state, w.state + 1, st);
+}
+
+extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int nseq, int S,
+                                 const itts_gen_params* gpp, const int32_t* penalty_ids, int n_penalty_ids,
+                                 const double* uniforms, int64_t* codes_out, int32_t* n_steps_out, void* workspace,
+                                 size_t workspace_bytes, int use_graph, void* caller_stream) {
+    if (!h || !prefix_embeds || !gpp || !codes_out || !n_steps_out || !workspace) { itts_set_error("gpt_generate: null pointer"); return ITTS_ERR_ARG; }
+    if (!h->finalized) { itts_set_error("gpt_generate: call itts_gpt_finalize first"); return ITTS_ERR_STATE; }
+    const itts_gpt_config& c = h->cfg;
+    const itts_gen_params gp = *gpp;
+    if (nseq <= 0 || S <= 0 || gp.max_new_tokens <= 0) { itts_set_error("gpt_generate: nseq, S, max_new_tokens must be > 0"); return ITTS_ERR_ARG; }
+    if (gp.num_beams != 1) { itts_set_error("gpt_generate: num_beams=%d not supported by the device loop yet (use 1)", gp.num_beams); return ITTS_ERR_ARG; }
+    if (gp.max_new_tokens + gp.pos_offset > c.n_mel_pos + 1) {
+        itts_set_error("gpt_generate: max_new_tokens=%d exceeds the mel position table (%d rows)", gp.max_new_tokens, c.n_mel_pos);
+        return ITTS_ERR_ARG;
+    }
+    if (n_penalty_ids < 0 || n_penalty_ids > 16) { itts_set_error("gpt_generate: at most 16 initial penalty ids"); return ITTS_ERR_ARG; }
+    if ((size_t)nseq * c.heads > 2147483647u / 4 || S > 65535) { itts_set_error("gpt_generate: batch too large"); return ITTS_ERR_ARG; }
+    const int Tmax = S + gp.max_new_tokens;
+    const GptWs w0 = carve(c, nullptr, nseq, S, Tmax);
+    if (workspace_bytes < w0.total) { itts_set_error("gpt_generate: workspace too small (%zu < %zu)", workspace_bytes, w0.total); return ITTS_ERR_ARG; }
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const GptWs w = carve(c, base, nseq, S, Tmax);
+    hipStream_t st = h->stream, cs = (hipStream_t)caller_stream;
+    long long* tokens = (long long*)codes_out;
+    int rc;
+
+    if (h->fin_cap < nseq) {
+        if (h->host_fin) (void)hipHostFree(h->host_fin);
+        HIP_TRY(hipHostMalloc((void**)&h->host_fin, (size_t)nseq, hipHostMallocDefault));
+        h->fin_cap = nseq;
+    }
+    // order after the caller's stream
+    HIP_TRY(hipEventRecord(h->ev_in, cs));
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_in, 0));
+
+    // ---- state init ----
+    HIP_TRY(hipMemsetAsync(w.seen, 0, (size_t)nseq * c.vocab, st));
+    HIP_TRY(hipMemsetAsync(w.finished, 0, nseq, st));
+    if (pad_lens) HIP_TRY(hipMemcpyAsync(w.pad, pad_lens, (size_t)nseq * 4, hipMemcpyDeviceToDevice, st));
+    else HIP_TRY(hipMemsetAsync(w.pad, 0, (size_t)nseq * 4, st));
+    if (n_penalty_ids > 0) {
+        HIP_TRY(hipMemcpyAsync(w.pen_ids, penalty_ids, (size_t)n_penalty_ids * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(mark_seen_kernel, dim3(nseq), dim3(64), 0, st, w.seen, w.pen_ids, n_penalty_ids, c.vocab);
+    }
+    {
+        const size_t n = (size_t)nseq * gp.max_new_tokens;
+        hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tokens, (long long)c.stop_mel_token, n);
+    }
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 0, 0);
+    HIP_TRY(hipMemcpyAsync(w.x, prefix_embeds, (size_t)nseq * S * c.model_dim * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+
+    // ---- prefill: all S positions, logits of the last one, first token ----
+    HIP_TRY(hipEventRecord(h->ev_t0, st));
+    bool pending = false;
+    rc = run_layers(h, w, nseq, S, Tmax, true, w.state + 1, w.pad, &pending, st);
+    if (rc) return rc;
+    if ((rc = run_head(h, w, nseq, S, S - 1, pending, st))) return rc;
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 0, S);
+    {
+        SampleArgs s = make_sample(h, w, gp, nseq, tokens, uniforms);
+        if ((rc = launch_sample(s, st))) return rc;
+    }
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 1, S);
+    HIP_TRY(hipEventRecord(h->ev_t1, st));
+
+    // ---- decode loop ----
+    int steps = 1;
+    bool graph_ok = false;
+    hipGraphExec_t exec = nullptr;
+    if (use_graph && gp.max_new_tokens > 1) {
+        // capture one decode step (all step-varying state lives in device memory)
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            rc = decode_step(h, w, gp, nseq, Tmax, tokens, uniforms, st);
+            e = hipStreamEndCapture(st, &graph);
+            if (rc == ITTS_OK && e == hipSuccess && graph) {
+                e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                graph_ok = (e == hipSuccess && exec);
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        if (!graph_ok) {
+            (void)hipGetLastError();
+            itts_set_error("gpt_generate: hipGraph capture failed (%s); rerun with use_graph=0", hipGetErrorString(e));
+            return ITTS_ERR_HIP;
+        }
+    }
+    const int check_every = 8;
+    while (steps < gp.max_new_tokens) {
+        if (graph_ok) { HIP_TRY(hipGraphLaunch(exec, st)); }
+        else if ((rc = decode_step(h, w, gp, nseq, Tmax, tokens, uniforms, st))) return rc;
+        ++steps;
+        if (steps % check_every == 0 && steps < gp.max_new_tokens) {
+            HIP_TRY(hipMemcpyAsync(h->host_fin, w.finished, nseq, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            bool all = true;
+            for (int i = 0; i < nseq; ++i) all = all && h->host_fin[i];
+            if (all) break;
+        }
+    }
+    HIP_TRY(hipEventRecord(h->ev_t2, st));
+    HIP_TRY(hipEventRecord(h->ev_out, st));
+    HIP_TRY(hipStreamWaitEvent(cs, h->ev_out, 0));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (exec) (void)hipGraphExecDestroy(exec);
+    (void)hipEventElapsedTime(&h->last_prefill_ms, h->ev_t0, h->ev_t1);
+    (void)hipEventElapsedTime(&h->last_decode_ms, h->ev_t1, h->ev_t2);
+    h->last_steps = steps;
+    *n_steps_out = steps;
+    return ITTS_OK;
+}
+
+extern "C" int itts_gpt_last_timing(const itts_gpt* h, float* prefill_ms, float* decode_ms, int32_t* steps) {
+    if (!h) return ITTS_ERR_ARG;
+    if (prefill_ms) *prefill_ms = h->last_prefill_ms;
+    if (decode_ms) *decode_ms = h->last_decode_ms;
+    if (steps) *steps = h->last_steps;
+    return ITTS_OK;
+}
+
+// Teacher-forced pass over full sequences: out = final_norm(ln_f(stack(x)))  (UnifiedVoice.forward / get_logits,
+// indextts/gpt/model_v2.py:528-554,596-646).  x [nseq][S][D] f32 device, out [nseq][S][D] f32 device.
+extern "C" int itts_gpt_forward_latent(itts_gpt* h, const float* x, int nseq, int S, float* out, void* workspace,
+                                       size_t workspace_bytes, void* caller_stream) {
+    if (!h || !x || !out || !workspace) { itts_set_error("gpt_forward_latent: null pointer"); return ITTS_ERR_ARG; }
+    if (!h->finalized) { itts_set_error("gpt_forward_latent: call itts_gpt_finalize first"); return ITTS_ERR_STATE; }
+    const itts_gpt_config& c = h->cfg;
+    if (nseq <= 0 || S <= 0 || S > 65535) { itts_set_error("gpt_forward_latent: bad shape"); return ITTS_ERR_ARG; }
+    const GptWs w0 = carve(c, nullptr, nseq, S, S);
+    if (workspace_bytes < w0.total) { itts_set_error("gpt_forward_latent: workspace too small (%zu < %zu)", workspace_bytes, w0.total); return ITTS_ERR_ARG; }
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const GptWs w = carve(c, base, nseq, S, S);
+    hipStream_t st = h->stream, cs = (hipStream_t)caller_stream;
+    HIP_TRY(hipEventRecord(h->ev_in, cs));
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_in, 0));
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 0, 0);
+    HIP_TRY(hipMemcpyAsync(w.x, x, (size_t)nseq * S * c.model_dim * 4, hipMemcpyDeviceToDevice, st));
+    bool pending = false;
+    int rc = run_layers(h, w, nseq, S, S, true, w.state + 1, nullptr, &pending, st);
+    if (rc) return rc;
+    LnArgs ln{};
+    ln.x = w.x; ln.g1 = h->lnf_g; ln.b1 = h->lnf_b; ln.g2 = h->fn_g; ln.b2 = h->fn_b; ln.out = out; ln.out_f32 = 1;
+    ln.rows = nseq * S; ln.D = c.model_dim; ln.in_row_mul = 1; ln.in_row_add = 0; ln.eps = c.ln_eps; ln.nsplit = 1;
+    if ((rc = launch_ln(ln, c.precision, st))) return rc;
+    HIP_TRY(hipEventRecord(h->ev_out, st));
+    HIP_TRY(hipStreamWaitEvent(cs, h->ev_out, 0));
+    HIP_TRY(hipStreamSynchronize(st));
+    return ITTS_OK;
+}
+
+// ---- unit-level entry points (parity tests) --------------------------------------------------------------------
+extern "C" int itts_gemm_forward(const void* A, const void* Wp, const float* bias, float* out, int M, int N, int K,
+                                 int precision, int prefill_tiles, int gelu, void* stream) {
+    if (!A || !Wp || !out) { itts_set_error("gemm_forward: null pointer"); return ITTS_ERR_ARG; }
+    GemmArgs g{};
+    g.A = A; g.lda = K; g.Wp = Wp; g.bias = bias; g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.D = N;
+    g.epi = EPI_STORE_F32; g.out_f32 = out; g.ldo = N;
+    (void)gelu;
+    return launch_gemm(g, precision, prefill_tiles != 0, (hipStream_t)stream);
+}
+
+extern "C" int itts_layernorm_forward(const float* x, const float* gamma, const float* beta, const float* gamma2,
+                                      const float* beta2, float* out, int rows, int D, float eps, void* stream) {
+    if (!x || !gamma || !beta || !out) { itts_set_error("layernorm_forward: null pointer"); return ITTS_ERR_ARG; }
+    LnArgs ln{};
+    ln.x = const_cast<float*>(x); ln.g1 = gamma; ln.b1 = beta; ln.g2 = gamma2; ln.b2 = beta2; ln.out = out; ln.out_f32 = 1;
+    ln.rows = rows; ln.D = D; ln.in_row_mul = 1; ln.in_row_add = 0; ln.eps = eps; ln.nsplit = 1;
+    return launch_ln(ln, PREC_F32, (hipStream_t)stream);
+}

@@ -1,0 +1,70 @@
+// Launcher prototypes for the GPT decoder kernels (gpt_kernels.hip), shared with capi_gpt.hip.
+#pragma once
+#include "common.h"
+
+enum { PREC_F32 = 0, PREC_BF16 = 1 };
+
+// ---- LayerNorm with fused split-K reduce / bias / residual update ---------------------------------------------
+struct LnArgs {
+    float* x;                // [rows_in][D] residual stream (updated in place when partial/bias_prev given)
+    const float* partial;    // [nsplit][rows][D] f32 partial GEMM outputs or null
+    int nsplit;
+    const float* bias_prev;  // [D] bias of the GEMM whose partials are being reduced, or null
+    const float* g1; const float* b1;   // first LayerNorm affine
+    const float* g2; const float* b2;   // optional second LayerNorm (ln_f -> final_norm), null to skip
+    void* out;               // [rows][D] act dtype (bf16 / f32) or f32 when out_f32 != 0
+    int out_f32;
+    int rows, D;
+    int in_row_mul, in_row_add;   // input row of output row r = r*mul + add (gather of last rows); 1,0 = identity
+    float eps;
+};
+int launch_ln(const LnArgs& a, int prec, hipStream_t st);
+
+// ---- GEMM  C[M,N] = A[M,K] * W[K,N]  on MFMA ------------------------------------------------------------------
+enum { EPI_STORE_F32 = 0, EPI_GELU_ACT = 1, EPI_PARTIAL = 2, EPI_RESIDUAL = 3, EPI_QKV = 4 };
+struct GemmArgs {
+    const void* A; int lda;          // act dtype [M][lda]
+    const void* Wp;                  // packed weights (itts_pack_gemm_weight)
+    const float* bias;               // [N] or null
+    int M, N, K;
+    int nsplit;                      // K slices (EPI_PARTIAL), else 1
+    int epi;
+    float* out_f32; int ldo;         // EPI_STORE_F32 / EPI_RESIDUAL (in-place add)
+    void* out_act;                   // EPI_GELU_ACT: act dtype [M][ldo]
+    float* partial;                  // EPI_PARTIAL: [nsplit][M][N]
+    // EPI_QKV: n < D -> qbuf[m][n]; D <= n < 2D -> K cache; else V cache, at cache position *pos_ptr + (m % S)
+    float* qbuf; void* kcache; void* vcache;
+    const int* pos_ptr; int S, H, Tmax, D;
+};
+int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);
+
+// ---- attention over the KV cache ------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* qbuf;       // [nseq*nq][D]
+    const void* kcache; const void* vcache;   // [nseq][H][Tmax][64] cache dtype
+    const int* pad;          // [nseq] first valid key (left padding), or null
+    const int* row_map;      // [nseq][Tmax] physical row holding position t of sequence b (beam indirection) or null
+    const int* pos_ptr;      // cache index of query 0
+    void* out;               // [nseq*nq][D] act dtype
+    int nseq, H, nq, Tmax, D;
+};
+int launch_attention(const AttnArgs& a, int prec, hipStream_t st);
+
+// ---- token selection ------------------------------------------------------------------------------------------
+struct SampleArgs {
+    const float* logits;     // [B][V]
+    unsigned char* seen;     // [B][V] ids already in input_ids (repetition penalty set)
+    unsigned char* finished; // [B]
+    long long* tokens;       // [B][max_new]
+    const int* step_ptr;     // generated-token index of this step
+    const double* uniforms;  // [max_new][B] or null (then an internal counter RNG with `seed` is used)
+    unsigned long long seed;
+    int B, V, max_new;
+    int do_sample, top_k, min_keep;
+    float top_p, temperature, rep_penalty;
+    int stop_token;
+    // next-step embedding: x_next[b] = mel_emb[tok] + mel_pos[step + pos_offset]
+    const float* mel_emb; const float* mel_pos; float* x_next; int D; int pos_offset; int n_mel_pos;
+};
+int launch_sample(const SampleArgs& a, hipStream_t st);
+int launch_advance(int* step_ptr, int* pos_ptr, hipStream_t st);

@@ -1,0 +1,579 @@
+// GPT-2 speech-token decoder kernels for gfx950 (MI355X).
+//
+// Reference arithmetic replaced (paths relative to the reference repo root):
+//   GPT2Block / GPT2Attention / GPT2MLP     indextts/gpt/transformers_gpt2.py:591-667,129-348,571-585
+//   KV concat per step (torch.cat)          indextts/gpt/transformers_gpt2.py:325-328  -> in-place cache append
+//   ln_f + lm_head = final_norm o mel_head  indextts/gpt/model_v2.py:54,186
+//   logits processors + token selection     indextts/gpt/transformers_generation_utils.py:900-901,1035-1044,3220-3256
+//   decode-step embedding + position rule   indextts/gpt/model_v2.py:158-161
+//
+// Two precisions share every kernel: PREC_F32 (parity mode: f32 weights/KV, v_mfma_f32_16x16x4_f32 = exact f32)
+// and PREC_BF16 (weights/KV/GEMM inputs bf16, v_mfma_f32_16x16x32_bf16, f32 accumulate).  The residual stream,
+// LayerNorm statistics, softmax and logits are f32 in both.
+//
+// Decode is HBM-bound (weights once per step + B x KV): weights are pre-packed in MFMA B-fragment order so each
+// wave-level load is one contiguous 1 KiB (16 B/lane); a block's 4 waves split K and reduce through LDS so even
+// N = 1280 gives >= 240 blocks (with 4 K-slices); K/V rows are read as 16 B per lane (8 or 16 lanes per key).
+#include "gpt_kernels.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+// ================================================================================================================
+// LayerNorm (+ fused split-K reduce, bias, residual write-back, optional second LayerNorm)
+// one wave per row, NE = D/64 elements per lane kept in registers
+// ================================================================================================================
+template <int NE, bool OUT_BF16>
+__global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + w;
+    if (r >= a.rows) return;
+    const int D = a.D;
+    const size_t in_r = (size_t)r * a.in_row_mul + a.in_row_add;
+    float* xr = a.x + in_r * D;
+    float v[NE];
+    const bool upd = (a.partial != nullptr) || (a.bias_prev != nullptr);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int idx = lane + 64 * i;
+        float val = xr[idx];
+        if (a.partial) {
+            float p = 0.f;
+            for (int s = 0; s < a.nsplit; ++s) p += a.partial[((size_t)s * a.rows + r) * D + idx];
+            val += p;
+        }
+        if (a.bias_prev) val += a.bias_prev[idx];
+        if (upd) xr[idx] = val;
+        v[i] = val;
+    }
+    const float invD = 1.0f / (float)D;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) s += v[i];
+    float mean = wave_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { const float d = v[i] - mean; q += d * d; }
+    float rstd = 1.0f / sqrtf(wave_sum(q) * invD + a.eps);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int idx = lane + 64 * i;
+        v[i] = (v[i] - mean) * rstd * a.g1[idx] + a.b1[idx];
+    }
+    if (a.g2) {
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) s += v[i];
+        mean = wave_sum(s) * invD;
+        q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { const float d = v[i] - mean; q += d * d; }
+        rstd = 1.0f / sqrtf(wave_sum(q) * invD + a.eps);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int idx = lane + 64 * i;
+            v[i] = (v[i] - mean) * rstd * a.g2[idx] + a.b2[idx];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int idx = lane + 64 * i;
+        if (OUT_BF16 && !a.out_f32) ((u16*)a.out)[(size_t)r * D + idx] = f32_to_bf16(v[i]);
+        else ((float*)a.out)[(size_t)r * D + idx] = v[i];
+    }
+}
+
+template <bool OUT_BF16>
+static int launch_ln_t(const LnArgs& a, hipStream_t st) {
+    dim3 grid(ceil_div(a.rows, 4));
+#define LN_CASE(NE) case NE: hipLaunchKernelGGL((ln_kernel<NE, OUT_BF16>), grid, dim3(256), 0, st, a); break;
+    switch (a.D / 64) {
+        LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(12) LN_CASE(16) LN_CASE(20) LN_CASE(24) LN_CASE(32)
+        default:
+            itts_set_error("layernorm: model_dim %d unsupported (need 64 * {2,4,8,12,16,20,24,32})", a.D);
+            return ITTS_ERR_ARG;
+    }
+#undef LN_CASE
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+int launch_ln(const LnArgs& a, int prec, hipStream_t st) {
+    if (a.rows <= 0) return ITTS_OK;
+    if (a.D % 64) { itts_set_error("layernorm: D %% 64 != 0"); return ITTS_ERR_ARG; }
+    return prec == PREC_BF16 ? launch_ln_t<true>(a, st) : launch_ln_t<false>(a, st);
+}
+
+// ================================================================================================================
+// GEMM on MFMA.  Packed weights: [N/16][K/KB][64 lanes][16 bytes]
+//   bf16 (KB = 32): lane holds W[kb*32 + (lane>>4)*8 + j][nt*16 + (lane&15)], j = 0..7
+//   f32  (KB = 16): lane holds W[kb*16 + (lane>>4)*4 + j][nt*16 + (lane&15)], j = 0..3 (MFMA j of the group)
+// A is row-major act dtype; the matching 16 bytes of row (lane&15) are loaded straight from global (L2-resident).
+// ================================================================================================================
+__device__ __forceinline__ float gelu_new_f(float x) {
+    const float c = 0.7978845608028654f;   // sqrt(2/pi)
+    return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
+}
+
+template <bool BF16>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, int mbase, int nbase, int lane, int z, f32x4 v) {
+    const int n = nbase + (lane & 15);
+    if (n >= a.N) return;
+    const float bias = (a.bias && a.epi != EPI_PARTIAL) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = mbase + (lane >> 4) * 4 + r;
+        if (m >= a.M) continue;
+        const float val = v[r] + bias;
+        switch (a.epi) {
+            case EPI_STORE_F32: a.out_f32[(size_t)m * a.ldo + n] = val; break;
+            case EPI_RESIDUAL: a.out_f32[(size_t)m * a.ldo + n] += val; break;
+            case EPI_GELU_ACT: {
+                const float g = gelu_new_f(val);
+                if (BF16) ((u16*)a.out_act)[(size_t)m * a.ldo + n] = f32_to_bf16(g);
+                else ((float*)a.out_act)[(size_t)m * a.ldo + n] = g;
+                break;
+            }
+            case EPI_PARTIAL: a.partial[((size_t)z * a.M + m) * a.N + n] = val; break;
+            case EPI_QKV: {
+                const int b = m / a.S, si = m - b * a.S;
+                const int which = n / a.D, c = n - which * a.D;
+                if (which == 0) {
+                    a.qbuf[(size_t)m * a.D + c] = val;
+                } else {
+                    const int pos = *a.pos_ptr + si;
+                    const size_t o = (((size_t)b * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
+                    void* cache = which == 1 ? a.kcache : a.vcache;
+                    if (BF16) ((u16*)cache)[o] = f32_to_bf16(val);
+                    else ((float*)cache)[o] = val;
+                }
+                break;
+            }
+        }
+    }
+}
+
+template <bool BF16, int MT, int NT, bool KSPLIT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+    constexpr int KB = BF16 ? 32 : 16;
+    constexpr int ESZ = BF16 ? 2 : 4;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // KSPLIT: [4][MT*NT][64] f32x4
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nkb = a.K / KB;
+    const int z = blockIdx.z;
+    const int kb_lo = (int)((long long)z * nkb / a.nsplit);
+    const int kb_hi = (int)((long long)(z + 1) * nkb / a.nsplit);
+    const int ntiles = (a.N + 15) >> 4;
+    const int nt0 = KSPLIT ? blockIdx.x * NT : (blockIdx.x * 4 + w) * NT;
+    const int kb_start = KSPLIT ? kb_lo + w : kb_lo;
+    const int kb_step = KSPLIT ? 4 : 1;
+    const int m0 = blockIdx.y * MT * 16;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const char* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = m0 + mt * 16 + (lane & 15);
+        m = m < a.M ? m : a.M - 1;
+        arow[mt] = (const char*)a.A + ((size_t)m * a.lda + (lane >> 4) * (KB / 4)) * ESZ;
+    }
+    const uint4* wp[NT];
+    bool nt_ok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        nt_ok[nt] = (nt0 + nt) < ntiles;
+        const int t = nt_ok[nt] ? nt0 + nt : ntiles - 1;
+        wp[nt] = (const uint4*)a.Wp + (size_t)t * nkb * 64 + lane;
+    }
+
+#pragma unroll 2
+    for (int kb = kb_start; kb < kb_hi; kb += kb_step) {
+        uint4 af[MT], bfr[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *(const uint4*)(arow[mt] + (size_t)kb * KB * ESZ);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bfr[nt] = wp[nt][(size_t)kb * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (BF16) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, af[mt]), __builtin_bit_cast(bf16x8_t, bfr[nt]), acc[mt][nt], 0, 0, 0);
+                } else {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[mt].x), __uint_as_float(bfr[nt].x), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[mt].y), __uint_as_float(bfr[nt].y), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[mt].z), __uint_as_float(bfr[nt].z), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[mt].w), __uint_as_float(bfr[nt].w), acc[mt][nt], 0, 0, 0);
+                }
+            }
+    }
+
+    if constexpr (KSPLIT) {
+        f32x4* r4 = (f32x4*)red;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) r4[((size_t)w * (MT * NT) + mt * NT + nt) * 64 + lane] = acc[mt][nt];
+        __syncthreads();
+        for (int tile = w; tile < MT * NT; tile += 4) {
+            f32x4 s = r4[(size_t)tile * 64 + lane];
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) {
+                const f32x4 o = r4[((size_t)ww * (MT * NT) + tile) * 64 + lane];
+                s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+            }
+            const int mt = tile / NT, nt = tile - mt * NT;
+            if ((nt0 + nt) < ntiles) gemm_epilogue<BF16>(a, m0 + mt * 16, (nt0 + nt) * 16, lane, z, s);
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (nt_ok[nt]) gemm_epilogue<BF16>(a, m0 + mt * 16, (nt0 + nt) * 16, lane, z, acc[mt][nt]);
+    }
+}
+
+template <bool BF16, int MT, int NT, bool KSPLIT>
+static int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
+    const int ntiles = (a.N + 15) / 16;
+    const int per_block = KSPLIT ? NT : 4 * NT;
+    dim3 grid(ceil_div(ntiles, per_block), ceil_div(a.M, MT * 16), a.nsplit);
+    const size_t lds = KSPLIT ? (size_t)4 * MT * NT * 64 * 16 : 0;
+    hipLaunchKernelGGL((gemm_kernel<BF16, MT, NT, KSPLIT>), grid, dim3(256), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+template <bool BF16>
+static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
+    if (prefill) return launch_gemm_cfg<BF16, 8, 2, false>(a, st);
+    if (a.M <= 16) return launch_gemm_cfg<BF16, 1, 1, true>(a, st);
+    if (a.M <= 32) return launch_gemm_cfg<BF16, 2, 1, true>(a, st);
+    return launch_gemm_cfg<BF16, 4, 1, true>(a, st);
+}
+
+int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st) {
+    if (a.M <= 0 || a.N <= 0) return ITTS_OK;
+    const int KB = prec == PREC_BF16 ? 32 : 16;
+    if (a.K % KB || a.nsplit < 1 || (a.K / KB) < a.nsplit) {
+        itts_set_error("gemm: K=%d must be a multiple of %d and >= nsplit=%d blocks", a.K, KB, a.nsplit);
+        return ITTS_ERR_ARG;
+    }
+    if (a.nsplit > 1 && a.epi != EPI_PARTIAL) { itts_set_error("gemm: split-K needs EPI_PARTIAL"); return ITTS_ERR_ARG; }
+    return prec == PREC_BF16 ? launch_gemm_t<true>(a, prefill, st) : launch_gemm_t<false>(a, prefill, st);
+}
+
+// ================================================================================================================
+// Attention of one query against the KV cache (decode: nq = 1; prefill / latent pass: one block per query).
+//   keys pad[b] .. pos0+qi, softmax in f32, exact skip of left-pad keys (additive finfo.min mask == weight 0).
+// block = 4 waves; LPK lanes share one key row (16 B each): bf16 8 lanes x 8 dims, f32 16 lanes x 4 dims.
+// ================================================================================================================
+template <bool BF16>
+__device__ __forceinline__ float exp_sel(float x) { return BF16 ? __expf(x) : expf(x); }
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+    constexpr int LPK = BF16 ? 8 : 16;      // lanes per key
+    constexpr int DPL = 64 / LPK;           // dims per lane
+    constexpr int KPW = 64 / LPK;           // keys per wave-load
+    __shared__ float sm_m[4], sm_l[4], sm_acc[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int qi = blockIdx.y;
+    const int last = *a.pos_ptr + qi;
+    const int first = a.pad ? a.pad[b] : 0;
+    const int sub = lane % LPK, grp = lane / LPK;
+    const size_t qrow = (size_t)b * a.nq + qi;
+
+    float q[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) q[d] = a.qbuf[qrow * a.D + h * 64 + sub * DPL + d];
+
+    float m_run = -INFINITY, l_run = 0.f, acc[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) acc[d] = 0.f;
+
+    for (int t0 = first + w * KPW; t0 <= last; t0 += 4 * KPW) {
+        const int t = t0 + grp;
+        const bool ok = t <= last;
+        const int tc = ok ? t : last;
+        const int prow = a.row_map ? a.row_map[(size_t)b * a.Tmax + tc] : b;
+        const size_t off = (((size_t)prow * a.H + h) * a.Tmax + tc) * 64 + sub * DPL;
+        float kf[DPL], vf[DPL];
+        if constexpr (BF16) {
+            const uint4 kr = *(const uint4*)((const u16*)a.kcache + off);
+            const uint4 vr = *(const uint4*)((const u16*)a.vcache + off);
+            const uint32_t kw[4] = {kr.x, kr.y, kr.z, kr.w}, vw[4] = {vr.x, vr.y, vr.z, vr.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kf[2 * i] = __uint_as_float(kw[i] << 16);
+                kf[2 * i + 1] = __uint_as_float(kw[i] & 0xffff0000u);
+                vf[2 * i] = __uint_as_float(vw[i] << 16);
+                vf[2 * i + 1] = __uint_as_float(vw[i] & 0xffff0000u);
+            }
+        } else {
+            const float4 kr = *(const float4*)((const float*)a.kcache + off);
+            const float4 vr = *(const float4*)((const float*)a.vcache + off);
+            kf[0] = kr.x; kf[1] = kr.y; kf[2] = kr.z; kf[3] = kr.w;
+            vf[0] = vr.x; vf[1] = vr.y; vf[2] = vr.z; vf[3] = vr.w;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) s = fmaf(q[d], kf[d], s);
+#pragma unroll
+        for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+        s *= 0.125f;    // / sqrt(64)
+        if (ok) {
+            const float nm = fmaxf(m_run, s);
+            const float sc = exp_sel<BF16>(m_run - nm);      // m_run = -inf -> 0
+            const float p = exp_sel<BF16>(s - nm);
+            l_run = l_run * sc + p;
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) acc[d] = acc[d] * sc + p * vf[d];
+            m_run = nm;
+        }
+    }
+    // merge the KPW key groups of the wave
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        const float om = __shfl_xor(m_run, o, 64), ol = __shfl_xor(l_run, o, 64);
+        const float nm = fmaxf(m_run, om);
+        const float sa = (m_run == -INFINITY) ? 0.f : exp_sel<BF16>(m_run - nm);
+        const float sb = (om == -INFINITY) ? 0.f : exp_sel<BF16>(om - nm);
+        l_run = l_run * sa + ol * sb;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) {
+            const float oa = __shfl_xor(acc[d], o, 64);
+            acc[d] = acc[d] * sa + oa * sb;
+        }
+        m_run = nm;
+    }
+    if (lane < LPK) {
+        sm_m[w] = m_run;
+        sm_l[w] = l_run;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) sm_acc[w][sub * DPL + d] = acc[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int d = threadIdx.x;
+        float nm = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float l = 0.f, o = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float sc = (sm_m[ww] == -INFINITY) ? 0.f : exp_sel<BF16>(sm_m[ww] - nm);
+            l += sm_l[ww] * sc;
+            o += sm_acc[ww][d] * sc;
+        }
+        const float r = l > 0.f ? o / l : 0.f;
+        const size_t oo = qrow * a.D + h * 64 + d;
+        if (BF16) ((u16*)a.out)[oo] = f32_to_bf16(r);
+        else ((float*)a.out)[oo] = r;
+    }
+}
+
+int launch_attention(const AttnArgs& a, int prec, hipStream_t st) {
+    if (a.nseq <= 0 || a.nq <= 0) return ITTS_OK;
+    if (a.D != a.H * 64) { itts_set_error("attention: head_dim must be 64 (D=%d H=%d)", a.D, a.H); return ITTS_ERR_ARG; }
+    if (a.nq > 65535) { itts_set_error("attention: more than 65535 queries per sequence"); return ITTS_ERR_ARG; }
+    dim3 grid(a.nseq * a.H, a.nq);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// ================================================================================================================
+// Token selection for one step: repetition penalty -> [temperature -> top-k -> top-p -> inverse-CDF draw] | argmax,
+// finished rows forced to the pad (= stop) token, seen-set / finished update, and the next step's input embedding.
+// One block per row.  Processor order and domains: generation_utils.py:900-901,1035-1044; sampling :3247-3256.
+// ================================================================================================================
+#define SAMPLE_CAP 128
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ double rng_uniform(unsigned long long seed, unsigned long long a, unsigned long long b) {
+    unsigned long long x = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xBF58476D1CE4E5B9ull * (b + 1);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+    extern __shared__ float sl[];                    // [V] processed scores
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_mask, s_kk, s_count;
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    __shared__ int s_tok;
+    __shared__ int cand_i[SAMPLE_CAP];
+    __shared__ float cand_v[SAMPLE_CAP];
+    const int b = blockIdx.x, tid = threadIdx.x, V = a.V;
+    const int step = *a.step_ptr;
+    const float* lg = a.logits + (size_t)b * V;
+    unsigned char* seen = a.seen + (size_t)b * V;
+    const bool pen = a.rep_penalty != 1.0f;
+    const bool temp = a.do_sample && a.temperature != 1.0f;
+    for (int i = tid; i < V; i += 256) {
+        float x = lg[i];
+        if (pen && seen[i]) x = x < 0.f ? x * a.rep_penalty : x / a.rep_penalty;
+        if (temp) x = x / a.temperature;
+        sl[i] = x;
+    }
+    __syncthreads();
+
+    if (!a.do_sample) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < V; i += 256) {
+            const float x = sl[i];
+            if (x > bv) { bv = x; bi = i; }        // ascending i per thread: first max kept
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int ww = 1; ww < 4; ++ww)
+                if (red_v[ww] > bv || (red_v[ww] == bv && red_i[ww] < bi)) { bv = red_v[ww]; bi = red_i[ww]; }
+            s_tok = bi == 0x7fffffff ? 0 : bi;
+        }
+    } else {
+        // ---- top-k threshold by 4-pass radix select on order-preserving keys ----
+        const int k = max(a.top_k, a.min_keep) < V ? max(a.top_k, a.min_keep) : V;
+        if (tid == 0) { s_prefix = 0; s_mask = 0; s_kk = (unsigned)k; s_count = 0; }
+        for (int pass = 3; pass >= 0; --pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix, mask = s_mask;
+            const int shift = pass * 8;
+            for (int i = tid; i < V; i += 256) {
+                const uint32_t key = f2key(sl[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned cum = 0, kk = s_kk;
+                int bsel = 0;
+                for (int bb = 255; bb >= 0; --bb) {
+                    if (cum + hist[bb] >= kk) { bsel = bb; break; }
+                    cum += hist[bb];
+                }
+                s_prefix = prefix | ((unsigned)bsel << shift);
+                s_mask = mask | (255u << shift);
+                s_kk = kk - cum;
+            }
+            __syncthreads();
+        }
+        const uint32_t kth = s_prefix;
+        for (int i = tid; i < V; i += 256) {
+            if (f2key(sl[i]) >= kth) {
+                const unsigned slot = atomicAdd(&s_count, 1u);
+                if (slot < SAMPLE_CAP) { cand_i[slot] = i; cand_v[slot] = sl[i]; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int n = (int)(s_count < SAMPLE_CAP ? s_count : SAMPLE_CAP);
+            // sort ascending by (value, index)
+            for (int i = 1; i < n; ++i) {
+                const float v = cand_v[i];
+                const int ix = cand_i[i];
+                int j = i - 1;
+                while (j >= 0 && (cand_v[j] > v || (cand_v[j] == v && cand_i[j] > ix))) {
+                    cand_v[j + 1] = cand_v[j]; cand_i[j + 1] = cand_i[j]; --j;
+                }
+                cand_v[j + 1] = v; cand_i[j + 1] = ix;
+            }
+            int lo = 0;                                   // first kept element after top-p
+            if (a.top_p < 1.0f) {
+                const float mx = cand_v[n - 1];
+                float sum = 0.f;
+                for (int i = 0; i < n; ++i) sum += expf(cand_v[i] - mx);
+                const float thr = (float)(1.0 - (double)a.top_p);
+                double cum = 0.0;
+                const int keep = a.min_keep < 1 ? 1 : a.min_keep;
+                for (int i = 0; i < n - keep; ++i) {
+                    cum += (double)(expf(cand_v[i] - mx) / sum);
+                    if ((float)cum <= thr) lo = i + 1; else break;
+                }
+            }
+            // renormalised softmax over the kept set, inverse CDF in vocabulary order
+            const float mx = cand_v[n - 1];
+            float sum = 0.f;
+            for (int i = lo; i < n; ++i) sum += expf(cand_v[i] - mx);
+            for (int i = lo; i < n; ++i) cand_v[i] = expf(cand_v[i] - mx) / sum;
+            for (int i = lo + 1; i < n; ++i) {            // sort kept by index
+                const float v = cand_v[i];
+                const int ix = cand_i[i];
+                int j = i - 1;
+                while (j >= lo && cand_i[j] > ix) { cand_v[j + 1] = cand_v[j]; cand_i[j + 1] = cand_i[j]; --j; }
+                cand_v[j + 1] = v; cand_i[j + 1] = ix;
+            }
+            double total = 0.0;
+            for (int i = lo; i < n; ++i) total += (double)cand_v[i];
+            const double u = a.uniforms ? a.uniforms[(size_t)step * a.B + b] : rng_uniform(a.seed, (unsigned long long)step, (unsigned long long)b);
+            const double tgt = u * total;
+            double cum = 0.0;
+            int pick = cand_i[n - 1];
+            for (int i = lo; i < n; ++i) {
+                cum += (double)cand_v[i];
+                if (cum > tgt) { pick = cand_i[i]; break; }
+            }
+            s_tok = pick;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int tok = s_tok;
+        if (a.finished[b]) tok = a.stop_token;               // :3256 finished rows emit pad (= stop)
+        a.tokens[(size_t)b * a.max_new + step] = tok;
+        if (tok == a.stop_token) a.finished[b] = 1;
+        seen[tok] = 1;
+        s_tok = tok;
+    }
+    __syncthreads();
+    if (a.x_next) {
+        const int tok = s_tok;
+        int p = step + a.pos_offset;
+        p = p < a.n_mel_pos ? p : a.n_mel_pos - 1;
+        for (int d = tid; d < a.D; d += 256)
+            a.x_next[(size_t)b * a.D + d] = a.mel_emb[(size_t)tok * a.D + d] + a.mel_pos[(size_t)p * a.D + d];
+    }
+}
+
+int launch_sample(const SampleArgs& a, hipStream_t st) {
+    if (a.B <= 0) return ITTS_OK;
+    if (a.do_sample && (a.top_k <= 0 || a.top_k > 64)) {
+        itts_set_error("sampling: top_k must be in 1..64 on the device path (got %d)", a.top_k);
+        return ITTS_ERR_ARG;
+    }
+    hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), (size_t)a.V * sizeof(float), st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+__global__ void advance_kernel(int* step_ptr, int* pos_ptr) {
+    *step_ptr += 1;
+    *pos_ptr += 1;
+}
+
+int launch_advance(int* step_ptr, int* pos_ptr, hipStream_t st) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, step_ptr, pos_ptr);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}

@@ -1,0 +1,297 @@
+"""Host-side mirror of the reference `UnifiedVoice` decode interface, backed by the HIP engine.
+
+Reference interface mirrored (indextts/gpt/model_v2.py): `UnifiedVoice(**cfg.gpt, spk_cond_mode="campplus")`,
+`.load_state_dict`, `.post_init_gpt2_config(kv_cache=, half=)`, `.prepare_gpt_inputs(conds, text, langs)` (:648-714),
+`.inference_speech(...)` (:716-825) returning `(codes[:, trunc_index:], speech_conditioning_latent)`, and the
+teacher-forced `.forward(...)` latent pass (:596-646).  Input assembly (embedding gathers, left padding) is torch
+plumbing on the device; the transformer stack, KV cache, logits processors, token selection and the per-token loop run
+inside `libindextts_hip.so` (`itts_gpt_generate`), one hipGraph replay per token.
+
+Prompt encoders (Conformer/Perceiver emotion encoder, CAMPPlus) are out of this path: pass
+`emo_vec=` / `campplus_embedding=` computed by the PyTorch-ROCm modules, as `indextts/infer_v2_5.py:762-781` does.
+"""
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+
+class UnifiedVoice:
+    def __init__(self, layers=8, model_dim=512, heads=8, max_text_tokens=120, max_mel_tokens=250,
+                 max_conditioning_inputs=1, mel_length_compression=1024, number_text_tokens=256, start_text_token=0,
+                 stop_text_token=1, number_mel_codes=8194, start_mel_token=8192, stop_mel_token=8193,
+                 train_solo_embeddings=False, use_mel_codes_as_input=True, checkpointing=True, types=1,
+                 condition_num_latent=32, condition_type="perceiver", condition_module=None, emo_condition_module=None,
+                 use_accel=False, spk_cond_mode="campplus", precision="bf16", device="cuda:0", **_unused):
+        if spk_cond_mode != "campplus":
+            raise NotImplementedError("engine implements the v2.5 'campplus' conditioning path; v1/v2 conditioning "
+                                      "encoders stay on PyTorch -- pass conds_latent= to inference_speech()")
+        self.layers, self.model_dim, self.heads = layers, model_dim, heads
+        self.max_text_tokens, self.max_mel_tokens = max_text_tokens, max_mel_tokens
+        self.max_conditioning_inputs = max_conditioning_inputs
+        self.number_text_tokens, self.number_mel_codes = number_text_tokens, number_mel_codes
+        self.start_text_token, self.stop_text_token = start_text_token, stop_text_token
+        self.start_mel_token, self.stop_mel_token = start_mel_token, stop_mel_token
+        self.types = types
+        self.spk_cond_mode = spk_cond_mode
+        self.device = torch.device(device)
+        self.precision = {"bf16": 1, "bfloat16": 1, "fp32": 0, "float32": 0, "f32": 0}[precision]
+        self.kv_cache = True
+        self.use_graph = True
+        self.n_mel_pos = max_mel_tokens + 2 + max_conditioning_inputs
+        self.n_text_pos = max_text_tokens + 2
+        cfg = _lib.GPTConfig()
+        cfg.layers, cfg.model_dim, cfg.heads = layers, model_dim, heads
+        cfg.vocab, cfg.n_mel_pos, cfg.precision = number_mel_codes, self.n_mel_pos, self.precision
+        cfg.start_mel_token, cfg.stop_mel_token, cfg.ln_eps = start_mel_token, stop_mel_token, 1e-5
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().itts_gpt_create(C.byref(cfg), C.byref(self._h)), "itts_gpt_create")
+        self._emb: Dict[str, torch.Tensor] = {}
+        self._loaded = False
+        self._ws = None
+        self.last_timing = None
+
+    # ---- checkpoint ------------------------------------------------------------------------------------------
+    _ENGINE_PREFIXES = ("gpt.h.", "gpt.ln_f.", "final_norm.", "mel_head.")
+    _HOST_TENSORS = ("mel_embedding.weight", "mel_pos_embedding.emb.weight", "text_embedding.weight",
+                     "text_pos_embedding.emb.weight", "lang_embedding.weight", "spk_emb_proj.weight",
+                     "spk_emb_proj.bias")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        """Reference `gpt.pth` names (`strict=False` like indextts/utils/checkpoint.py:22-29); returns ignored keys."""
+        L = _lib.lib()
+        ignored = []
+        for name, t in sd.items():
+            if name in self._HOST_TENSORS:
+                self._emb[name] = t.detach().to(self.device, torch.float32).contiguous()
+            if name.startswith(self._ENGINE_PREFIXES) or name in ("mel_embedding.weight", "mel_pos_embedding.emb.weight"):
+                if name.endswith(".attn.bias") or name.endswith(".attn.masked_bias"):
+                    ignored.append(name)      # HF causal-mask buffers
+                    continue
+                tt = t.detach().to("cpu", torch.float32).contiguous()
+                shape = (C.c_int64 * tt.dim())(*tt.shape)
+                _lib.check(L.itts_gpt_load_tensor(self._h, name.encode(), C.c_void_p(tt.data_ptr()), shape, tt.dim()),
+                           f"itts_gpt_load_tensor({name})")
+            elif name not in self._HOST_TENSORS:
+                ignored.append(name)
+        _lib.check(L.itts_gpt_finalize(self._h), "itts_gpt_finalize")
+        missing = [n for n in self._HOST_TENSORS if n not in self._emb and n != "lang_embedding.weight"]
+        if missing:
+            raise _lib.HipEngineError(f"UnifiedVoice.load_state_dict: missing {missing}")
+        self._loaded = True
+        return ignored
+
+    def post_init_gpt2_config(self, use_deepspeed=False, kv_cache=False, half=False):
+        """model_v2.py:422-493.  kv_cache=False reproduces the reference's no-cache position rule (positions 0..n-1)
+        -- the engine always keeps a KV cache; only the mel position index changes."""
+        self.kv_cache = bool(kv_cache)
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    # ---- input assembly (model_v2.py:648-714) ------------------------------------------------------------------
+    def prepare_gpt_inputs(self, conditional_latents: torch.Tensor, text_inputs: torch.Tensor,
+                           langs: Optional[torch.Tensor] = None):
+        dev = self.device
+        text_inputs = text_inputs.to(dev)
+        conditional_latents = conditional_latents.to(dev, torch.float32)
+        b, L = text_inputs.shape[:2]
+        single_cond = conditional_latents.ndim == 3 and conditional_latents.shape[0] == 1
+        if not single_cond:
+            assert conditional_latents.shape[0] == b, f"batch size mismatch: {conditional_latents.shape[0]} vs {b}"
+        n_cond = conditional_latents.shape[1]
+        target_len = n_cond + L + 2
+        valid = (text_inputs != self.stop_text_token) & (text_inputs != self.start_text_token)
+        n_valid = valid.sum(dim=1)                                     # (b,)
+        padding = L - n_valid                                           # left pad per row
+        # gather valid ids to the right end of an (b, L+2) row: [pad..][start][ids][stop]
+        order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)          # valid ids first, in order
+        ids_sorted = torch.gather(text_inputs.long(), 1, order)
+        rows = torch.full((b, L + 2), self.stop_text_token, dtype=torch.long, device=dev)
+        ar = torch.arange(L + 2, device=dev)[None, :]
+        start_col = padding[:, None]
+        rel = ar - start_col                                            # position within [start, ids..., stop]
+        in_ids = (rel >= 1) & (rel <= n_valid[:, None])
+        src = (rel - 1).clamp(0, L - 1)
+        rows = torch.where(in_ids, torch.gather(ids_sorted, 1, src), rows)
+        rows = torch.where(rel == 0, torch.full_like(rows, self.start_text_token), rows)
+        tok_valid = rel >= 0
+        pos = rel.clamp(min=0)
+        emb = self._emb["text_embedding.weight"][rows] + self._emb["text_pos_embedding.emb.weight"][pos]
+        if langs is not None and "lang_embedding.weight" in self._emb:
+            lg = langs.to(dev).long().reshape(-1)
+            if lg.numel() == 1:
+                lg = lg.expand(b)
+            emb = emb + self._emb["lang_embedding.weight"][lg][:, None, :]
+        emb = emb * tok_valid[..., None]                                # zero rows on the left pad
+        cond = conditional_latents.expand(b, -1, -1) if single_cond else conditional_latents
+        # [pad][cond][text]: roll the cond block to sit right after the pad
+        out = torch.zeros(b, target_len, self.model_dim, dtype=torch.float32, device=dev)
+        col = torch.arange(target_len, device=dev)[None, :]
+        is_cond = (col >= padding[:, None]) & (col < padding[:, None] + n_cond)
+        cond_idx = (col - padding[:, None]).clamp(0, n_cond - 1)
+        out = torch.where(is_cond[..., None], torch.gather(cond, 1, cond_idx[..., None].expand(-1, -1, self.model_dim)), out)
+        is_text = col >= padding[:, None] + n_cond
+        text_idx = (col - n_cond).clamp(0, L + 1).expand(b, -1)
+        out = torch.where(is_text[..., None], torch.gather(emb, 1, text_idx[..., None].expand(-1, -1, self.model_dim)), out)
+        attention_mask = torch.ones(b, target_len + 1, dtype=torch.long, device=dev)
+        attention_mask[:, :target_len] = (col >= padding[:, None]).long()
+        fake_inputs = torch.ones(b, target_len + 1, dtype=torch.long, device=dev)
+        fake_inputs[:, -1] = self.start_mel_token
+        return fake_inputs, out, attention_mask
+
+    def conds_latent(self, campplus_embedding: torch.Tensor, emo_vec: torch.Tensor) -> torch.Tensor:
+        """spk_emb_proj(style) + emo_vec, then two zero tokens (model_v2.py:754-755,768)."""
+        dev = self.device
+        spk = F.linear(campplus_embedding.to(dev, torch.float32), self._emb["spk_emb_proj.weight"],
+                       self._emb["spk_emb_proj.bias"])
+        spk = spk.unsqueeze(0) if spk.ndim != 3 else spk
+        emo_vec = emo_vec.to(dev, torch.float32)
+        return torch.cat((spk + emo_vec.unsqueeze(1), torch.zeros(spk.size(0), 2, spk.size(2), device=dev)), 1), spk
+
+    # ---- generation ----------------------------------------------------------------------------------------------
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def generate(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int, do_sample=False,
+                 num_beams=1, top_p=1.0, top_k=50, temperature=1.0, repetition_penalty=1.0, length_penalty=1.0,
+                 uniforms: Optional[torch.Tensor] = None, seed: int = 0, **unused) -> torch.Tensor:
+        """`GPT2InferenceModel.generate` for greedy / multinomial sampling.  inputs_embeds (B,s,D) = the cached prefix;
+        attention_mask (B,s+1).  Returns generated ids (B, n) (what `output[:, trunc_index:]` is in the reference)."""
+        if not self._loaded:
+            raise RuntimeError("UnifiedVoice: load_state_dict() first")
+        if num_beams != 1:
+            raise NotImplementedError("num_beams > 1: beam-sample is not on the device loop yet (use num_beams=1)")
+        dev = self.device
+        B, s, D = inputs_embeds.shape
+        start = (self._emb["mel_embedding.weight"][self.start_mel_token] + self._emb["mel_pos_embedding.emb.weight"][0])
+        x = torch.cat([inputs_embeds.to(dev, torch.float32), start.expand(B, 1, D)], dim=1).contiguous()
+        S = s + 1
+        pad = (attention_mask[:, :S] == 0).sum(dim=1).to(torch.int32).contiguous()
+        gp = _lib.GenParams()
+        gp.do_sample, gp.num_beams, gp.top_k = int(bool(do_sample)), 1, int(top_k or 0)
+        gp.min_tokens_to_keep, gp.max_new_tokens = 1, int(max_new_tokens)
+        gp.pos_offset = 2 if self.kv_cache else 1
+        gp.top_p, gp.temperature = float(top_p), float(temperature)
+        gp.repetition_penalty = float(repetition_penalty if repetition_penalty is not None else 1.0)
+        gp.length_penalty, gp.seed = float(length_penalty), int(seed)
+        L = _lib.lib()
+        Tmax = S + int(max_new_tokens)
+        need = L.itts_gpt_workspace_bytes(self._h, B, S, Tmax)
+        ws = self._workspace(need)
+        codes = torch.empty(B, int(max_new_tokens), dtype=torch.int64, device=dev)
+        n_steps = C.c_int32(0)
+        pen = (C.c_int32 * 2)(1, self.start_mel_token)          # fake prefix ids (all ones) + start_mel
+        u = None
+        if uniforms is not None:
+            u = uniforms.to(dev, torch.float64).contiguous()
+            if u.shape[0] < max_new_tokens or u.shape[1] != B:
+                raise ValueError("uniforms must be (>= max_new_tokens, B)")
+        rc = L.itts_gpt_generate(self._h, _lib.ptr(x), _lib.ptr(pad), B, S, C.byref(gp), pen, 2, _lib.ptr(u),
+                                 _lib.ptr(codes), C.byref(n_steps), _lib.ptr(ws), ws.numel(), int(self.use_graph),
+                                 _lib.stream_ptr())
+        _lib.check(rc, "itts_gpt_generate")
+        pm, dm, st = C.c_float(0), C.c_float(0), C.c_int32(0)
+        L.itts_gpt_last_timing(self._h, C.byref(pm), C.byref(dm), C.byref(st))
+        self.last_timing = dict(prefill_ms=pm.value, decode_ms=dm.value, steps=st.value)
+        # HF stops right after the step at which every row has emitted EOS
+        is_stop = codes == self.stop_mel_token
+        first = torch.where(is_stop.any(1), is_stop.int().argmax(1) + 1, torch.full((B,), codes.shape[1], device=dev))
+        n = int(min(int(first.max().item()), n_steps.value))
+        return codes[:, :n]
+
+    def inference_speech(self, speech_condition, text_inputs, langs=None, emo_speech_condition=None, cond_lengths=None,
+                         emo_cond_lengths=None, emo_vec=None, use_speed=False, campplus_embedding=None, wav=None,
+                         input_tokens=None, num_return_sequences=1, max_generate_length=None, typical_sampling=False,
+                         typical_mass=.9, conds_latent=None, uniforms=None, **hf_generate_kwargs):
+        """model_v2.py:716-825 (campplus conditioning).  Returns (codes, speech_conditioning_latent)."""
+        if input_tokens is not None or num_return_sequences != 1:
+            raise NotImplementedError("input_tokens / num_return_sequences > 1 are not used by the v2.5 pipeline")
+        if typical_sampling:
+            raise NotImplementedError("typical_sampling is not on the device path")
+        if conds_latent is None:
+            if campplus_embedding is None:
+                raise ValueError("campplus mode requires campplus_embedding or wav")
+            if emo_vec is None:
+                raise NotImplementedError("emo_vec=None needs the Conformer/Perceiver emotion encoder (PyTorch side): "
+                                          "compute it with merge_emovec / get_emovec and pass emo_vec=")
+            conds_latent, spk_lat = self.conds_latent(campplus_embedding, emo_vec)
+        else:
+            spk_lat = conds_latent[:, :1]
+        input_ids, inputs_embeds, attention_mask = self.prepare_gpt_inputs(conds_latent, text_inputs, langs)
+        max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
+        hf = dict(hf_generate_kwargs)
+        hf.pop("logits_processor", None)
+        codes = self.generate(inputs_embeds, attention_mask, max_new, uniforms=uniforms, **hf)
+        return codes, spk_lat
+
+    # ---- teacher-forced latent pass (model_v2.py:596-646) ----------------------------------------------------------
+    def forward_latent(self, conds: torch.Tensor, text_inputs: torch.Tensor, text_lengths: torch.Tensor,
+                       mel_codes: torch.Tensor, mel_codes_lengths: torch.Tensor) -> torch.Tensor:
+        dev = self.device
+        text = text_inputs.to(dev).long().clone()
+        mel = mel_codes.to(dev).long().clone()
+        tl, ml = text_lengths.to(dev), mel_codes_lengths.to(dev)
+        text = torch.where(torch.arange(text.shape[1], device=dev)[None] >= tl[:, None],
+                           torch.full_like(text, self.stop_text_token), text)
+        mel = torch.where(torch.arange(mel.shape[1], device=dev)[None] >= ml[:, None],
+                          torch.full_like(mel, self.stop_mel_token), mel)
+        text = F.pad(F.pad(text, (0, 1), value=self.stop_text_token), (1, 0), value=self.start_text_token)
+        mel = F.pad(F.pad(mel, (0, 1), value=self.stop_mel_token), (1, 0), value=self.start_mel_token)
+        te = self._emb["text_embedding.weight"][text] + self._emb["text_pos_embedding.emb.weight"][: text.shape[1]]
+        me = self._emb["mel_embedding.weight"][mel] + self._emb["mel_pos_embedding.emb.weight"][: mel.shape[1]]
+        x = torch.cat([conds.to(dev, torch.float32), te, me], dim=1).contiguous()
+        B, S, D = x.shape
+        L = _lib.lib()
+        ws = self._workspace(L.itts_gpt_workspace_bytes(self._h, B, S, S))
+        out = torch.empty_like(x)
+        _lib.check(L.itts_gpt_forward_latent(self._h, _lib.ptr(x), B, S, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                             _lib.stream_ptr()), "itts_gpt_forward_latent")
+        enc = out[:, conds.shape[1]:]
+        return enc[:, -mel.shape[1]:][:, :-2]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.lib().itts_gpt_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def pack_gemm_weight(w_kn: torch.Tensor, precision: int, transposed: bool = False) -> torch.Tensor:
+    w = w_kn.detach().to("cpu", torch.float32).contiguous()
+    K, N = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    L = _lib.lib()
+    out = torch.empty(L.itts_packed_gemm_bytes(K, N, precision), dtype=torch.uint8)
+    _lib.check(L.itts_pack_gemm_weight(_lib.ptr(w), K, N, int(transposed), precision, _lib.ptr(out)), "itts_pack_gemm_weight")
+    return out
+
+
+def gemm(a: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], N: int, precision: int,
+         prefill_tiles: bool = False) -> torch.Tensor:
+    M, K = a.shape
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().itts_gemm_forward(_lib.ptr(a.contiguous()), _lib.ptr(w_packed), _lib.ptr(bias), _lib.ptr(out),
+                                            M, N, K, precision, int(prefill_tiles), 0, _lib.stream_ptr()),
+               "itts_gemm_forward")
+    return out
+
+
+def layernorm(x, g, b, g2=None, b2=None, eps=1e-5):
+    rows, D = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().itts_layernorm_forward(_lib.ptr(x.contiguous()), _lib.ptr(g), _lib.ptr(b), _lib.ptr(g2),
+                                                 _lib.ptr(b2), _lib.ptr(out), rows, D, float(eps), _lib.stream_ptr()),
+               "itts_layernorm_forward")
+    return out
