@@ -93,6 +93,14 @@ size_t itts_bigvgan_workspace_bytes(const itts_bigvgan* h, int B, int T);
 int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32_t* lens, const float* spk, float* wav, int B,
                          int T, void* workspace, size_t workspace_bytes, void* stream);
 
+/* measurement hooks (no reference counterpart: the reference only has unsynchronised perf_counter stage timers,
+ *   indextts/infer_v2_5.py:744-746,871-876).  With profiling enabled every kernel launch of the forward is bracketed
+ *   by HIP events on the launch stream; profile_read returns, for the LAST forward and per kernel class
+ *   {0: Conv1d MFMA, 1: ConvTranspose1d MFMA, 2: anti-aliased activation, 3: conv_post}, the summed GPU ms, launch
+ *   count, algorithmic FLOPs and algorithmic tensor bytes (arrays of 4 doubles). */
+int itts_bigvgan_set_profiling(itts_bigvgan* h, int enable);
+int itts_bigvgan_profile_read(itts_bigvgan* h, double* ms, double* launches, double* flops, double* bytes);
+
 /* ------------------------------------------------------------------------------------------------------------
  * GPT speech-token decoder
  * ---------------------------------------------------------------------------------------------------------- */

@@ -196,6 +196,16 @@ class BigVGAN:
 
     __call__ = forward
 
+    def set_profiling(self, enable: bool):
+        _lib.check(_lib.lib().itts_bigvgan_set_profiling(self._h, int(enable)), "itts_bigvgan_set_profiling")
+
+    def profile(self):
+        """Per-kernel-class totals of the last forward (HIP events on the launch stream)."""
+        arr = [(C.c_double * 4)() for _ in range(4)]
+        _lib.check(_lib.lib().itts_bigvgan_profile_read(self._h, *arr), "itts_bigvgan_profile_read")
+        names = ("conv1d_mfma", "conv_transpose1d_mfma", "aa_activation", "conv_post")
+        return {n: dict(ms=arr[0][i], launches=int(arr[1][i]), flops=arr[2][i], bytes=arr[3][i]) for i, n in enumerate(names)}
+
     def __del__(self):
         try:
             if getattr(self, "_h", None) and self._h.value:

@@ -168,6 +168,36 @@ struct itts_bigvgan {
     bool finalized = false;
     std::vector<float*> owned;
     int total_up = 1;
+    // optional per-launch HIP-event profiling (itts_bigvgan_set_profiling)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct Rec { int cls; double flops; double bytes; };
+    std::vector<Rec> recs;      // one per launch of the last forward; events 2i, 2i+1
+    hipStream_t prof_stream = nullptr;
+};
+
+// profiling classes
+enum { PC_CONV = 0, PC_CONVT = 1, PC_ACT = 2, PC_POST = 3, PC_COUNT = 4 };
+
+struct ProfScope {
+    itts_bigvgan* h;
+    hipStream_t st;
+    bool on;
+    size_t idx;
+    ProfScope(itts_bigvgan* h_, hipStream_t st_, int cls, double flops, double bytes) : h(h_), st(st_), on(h_->profiling), idx(0) {
+        if (!on) return;
+        idx = h->recs.size();
+        h->recs.push_back({cls, flops, bytes});
+        while (h->ev_pool.size() < 2 * (idx + 1)) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+            h->ev_pool.push_back(e);
+        }
+        (void)hipEventRecord(h->ev_pool[2 * idx], st);
+    }
+    ~ProfScope() {
+        if (on) (void)hipEventRecord(h->ev_pool[2 * idx + 1], st);
+    }
 };
 
 static int upload(itts_bigvgan* h, const float* host, size_t n, DevBuf* dst) {
@@ -235,6 +265,7 @@ extern "C" int itts_bigvgan_create(const itts_bigvgan_config* cfg, itts_bigvgan*
 extern "C" void itts_bigvgan_destroy(itts_bigvgan* h) {
     if (!h) return;
     for (float* p : h->owned) (void)hipFree(p);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -512,16 +543,22 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
             }
     }
 
+    h->recs.clear();
+    h->prof_stream = st;
+    auto conv_flops = [&](int Cin, int Cout, int k, int t) { return 2.0 * Cin * Cout * k * (double)t * B; };
+    auto tensor_bytes = [&](int C, int t) { return 4.0 * C * (double)t * B; };
     // conv_pre (bigvgan.py:362; v1 models.py:224-226)
+    { ProfScope ps(h, st, PC_CONV, conv_flops(c.in_channels, c.upsample_initial_channel, 7, T), tensor_bytes(c.in_channels + c.upsample_initial_channel, T));
     rc = conv1d_impl(x, h->conv_pre.w.p, h->conv_pre.b.p, cond0, nullptr, P, B, c.in_channels, c.upsample_initial_channel, T,
-                     7, 1, lens, 1, 0, 1.f, st);
+                     7, 1, lens, 1, 0, 1.f, st); }
     if (rc) return rc;
 
     int t_cur = T, mult = 1;
     for (int i = 0; i < c.num_upsamples; ++i) {
         const int Cin = c.upsample_initial_channel >> i, ch = stage_channels(c, i);
         const int u = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
-        rc = convT_impl(P, h->ups[i].w.p, h->ups[i].b.p, cond_up[i], X, B, Cin, ch, t_cur, k, u, lens, mult, st);
+        { ProfScope ps(h, st, PC_CONVT, conv_flops(Cin, ch, k / u, t_cur * u), tensor_bytes(Cin, t_cur) + tensor_bytes(ch, t_cur * u));
+          rc = convT_impl(P, h->ups[i].w.p, h->ups[i].b.p, cond_up[i], X, B, Cin, ch, t_cur, k, u, lens, mult, st); }
         if (rc) return rc;
         t_cur *= u;
         mult *= u;
@@ -534,22 +571,27 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
                 const ActL& a2 = h->acts[(size_t)n * 2 * ND + 2 * d + 1];
                 const ConvL& c1 = h->convs1[(size_t)n * ND + d];
                 const ConvL& c2 = h->convs2[(size_t)n * ND + d];
-                rc = launch_aa_act(cur, T1, a1.alpha.p, a1.beta.p, a1.fu.p, a1.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st);
+                { ProfScope ps(h, st, PC_ACT, 0, tensor_bytes(2 * ch, t_cur));
+                  rc = launch_aa_act(cur, T1, a1.alpha.p, a1.beta.p, a1.fu.p, a1.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st); }
                 if (rc) return rc;
-                rc = conv1d_impl(T1, c1.w.p, c1.b.p, nullptr, nullptr, T2, B, ch, ch, t_cur, kk, c.resblock_dilations[j][d], lens, mult, 0, 1.f, st);
+                { ProfScope ps(h, st, PC_CONV, conv_flops(ch, ch, kk, t_cur), tensor_bytes(2 * ch, t_cur));
+                  rc = conv1d_impl(T1, c1.w.p, c1.b.p, nullptr, nullptr, T2, B, ch, ch, t_cur, kk, c.resblock_dilations[j][d], lens, mult, 0, 1.f, st); }
                 if (rc) return rc;
-                rc = launch_aa_act(T2, T1, a2.alpha.p, a2.beta.p, a2.fu.p, a2.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st);
+                { ProfScope ps(h, st, PC_ACT, 0, tensor_bytes(2 * ch, t_cur));
+                  rc = launch_aa_act(T2, T1, a2.alpha.p, a2.beta.p, a2.fu.p, a2.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st); }
                 if (rc) return rc;
                 if (d < ND - 1) {
                     float* nxt = (cur == RA) ? RB : RA;
-                    rc = conv1d_impl(T1, c2.w.p, c2.b.p, nullptr, cur, nxt, B, ch, ch, t_cur, kk, 1, lens, mult, 0, 1.f, st);
+                    { ProfScope ps(h, st, PC_CONV, conv_flops(ch, ch, kk, t_cur), tensor_bytes(3 * ch, t_cur));
+                      rc = conv1d_impl(T1, c2.w.p, c2.b.p, nullptr, cur, nxt, B, ch, ch, t_cur, kk, 1, lens, mult, 0, 1.f, st); }
                     if (rc) return rc;
                     cur = nxt;
                 } else {
                     // block output r_j = conv2(..) + cur, folded into the MRF sum: xs = r_0; xs += r_1; ...; /num_kernels
                     int mode = (j == 0) ? 0 : 1;
                     if (j == c.num_kernels - 1) mode = (c.num_kernels == 1) ? 0 : 2;
-                    rc = conv1d_impl(T1, c2.w.p, c2.b.p, nullptr, cur, XS, B, ch, ch, t_cur, kk, 1, lens, mult, mode, (float)c.num_kernels, st);
+                    { ProfScope ps(h, st, PC_CONV, conv_flops(ch, ch, kk, t_cur), tensor_bytes((mode ? 4 : 3) * ch, t_cur));
+                      rc = conv1d_impl(T1, c2.w.p, c2.b.p, nullptr, cur, XS, B, ch, ch, t_cur, kk, 1, lens, mult, mode, (float)c.num_kernels, st); }
                     if (rc) return rc;
                 }
             }
@@ -557,9 +599,36 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
         float* tmp = P; P = XS; XS = tmp;
     }
     const int ch = stage_channels(c, c.num_upsamples - 1);
-    rc = launch_aa_act(P, T1, h->act_post.alpha.p, h->act_post.beta.p, h->act_post.fu.p, h->act_post.fd.p, B, ch, t_cur, lens, mult,
-                       c.snake_logscale, st);
+    { ProfScope ps(h, st, PC_ACT, 0, tensor_bytes(2 * ch, t_cur));
+      rc = launch_aa_act(P, T1, h->act_post.alpha.p, h->act_post.beta.p, h->act_post.fu.p, h->act_post.fd.p, B, ch, t_cur, lens, mult,
+                         c.snake_logscale, st); }
     if (rc) return rc;
+    ProfScope ps(h, st, PC_POST, 2.0 * ch * 7 * (double)t_cur * B, tensor_bytes(ch + 1, t_cur));
     return launch_conv_post(T1, wav, h->post_w.p, c.use_bias_at_final ? h->post_b.p : nullptr, B, ch, t_cur, 7, lens, mult,
                             c.use_tanh_at_final, st);
+}
+
+// ---- HIP-event profiling of the forward pass ------------------------------------------------------------------
+extern "C" int itts_bigvgan_set_profiling(itts_bigvgan* h, int enable) {
+    if (!h) { itts_set_error("set_profiling: null"); return ITTS_ERR_ARG; }
+    h->profiling = enable != 0;
+    h->recs.clear();
+    return ITTS_OK;
+}
+
+// Totals of the LAST forward per kernel class (0 Conv1d MFMA, 1 ConvTranspose1d MFMA phases, 2 anti-aliased
+// activation, 3 conv_post): GPU milliseconds between the events bracketing each launch (recorded on the stream the
+// kernels ran on), launch count, algorithmic FLOPs and algorithmic tensor bytes.  Synchronises that stream.
+extern "C" int itts_bigvgan_profile_read(itts_bigvgan* h, double* ms, double* launches, double* flops, double* bytes) {
+    if (!h || !ms || !launches || !flops || !bytes) { itts_set_error("profile_read: null"); return ITTS_ERR_ARG; }
+    for (int i = 0; i < PC_COUNT; ++i) ms[i] = launches[i] = flops[i] = bytes[i] = 0;
+    if (h->recs.empty()) return ITTS_OK;
+    HIP_TRY(hipStreamSynchronize(h->prof_stream));
+    for (size_t i = 0; i < h->recs.size(); ++i) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
+        const auto& r = h->recs[i];
+        ms[r.cls] += t; launches[r.cls] += 1; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes;
+    }
+    return ITTS_OK;
 }
