@@ -33,6 +33,30 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask and cgroup CPU quota, not the host's os.cpu_count()
+    (spawning one OpenMP thread per HOST core inside a quota-limited container stalls for minutes)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel):
     """Reference CPU path restated (oracle/), timed on this box's host cores on a bounded sample.
 
@@ -41,8 +65,9 @@ def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel):
     """
     from oracle import bigvgan_oracle as BO
     from oracle import gpt_oracle as GO
-    cores = os.cpu_count() or 1
+    cores = min(usable_cores(), max(1, torch.get_num_threads()))     # never above torch's own default
     torch.set_num_threads(cores)
+    log(f"[bench] cpu_baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
     cfg = GO.GPTConfig(layers=gpt_cfg["layers"], model_dim=gpt_cfg["model_dim"], heads=gpt_cfg["heads"],
                        max_text_tokens=gpt_cfg["max_text_tokens"], max_mel_tokens=gpt_cfg["max_mel_tokens"],
                        number_text_tokens=gpt_cfg["number_text_tokens"])
@@ -168,8 +193,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         one_step(False)
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"[bench] warmup step {i}: {time.perf_counter() - tw:.2f}s")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -225,11 +254,14 @@ def main():
                          "avg_launch_ms": conv["ms"] / max(1, conv["launches"])},
             "stages": stages,
         }
+        log("[bench] GPU result:", json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline", "stages")}))
         if not args.no_cpu_baseline and world == 1:
+            t_cpu = time.perf_counter()
             try:
                 out["cpu_baseline"] = cpu_baseline(gsd, gcfg, bsd, bh, n_text, n_gen, t_mel)
             except Exception as e:      # never lose the GPU line because the baseline leg failed
                 out["cpu_baseline"] = {"error": repr(e)}
+            log(f"[bench] cpu_baseline leg took {time.perf_counter() - t_cpu:.1f}s")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
