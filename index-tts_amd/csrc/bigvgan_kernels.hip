@@ -131,17 +131,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int lane_row = lane >> 5;          // which of the 2 input channels of a K-step
     const int lane_col = lane & 31;
 
+    // x-tile staging is split (issue-early / write-late): the global loads of chunk c+1 are issued into registers
+    // before the MFMA loop of chunk c and written to LDS after it, so their HBM/L2 latency hides under the MFMAs.
+    constexpr int NCOL = LDW / 64;             // 64-lane column groups per row (covers BN + halo)
+    float stage[CI_CHUNK / 4][NCOL];
+    // Rows are fetched through a buffer descriptor per row (base = row start, size = the row's valid length):
+    // the hardware bounds check returns 0 for t < 0 (offset wraps to a huge unsigned) and t >= len, and for rows past
+    // the channel count (size 0) -- no per-lane guard in the code, so hipcc emits straight back-to-back loads (a
+    // guarded load becomes a branch + vmcnt(0) per element and serialises the tile fetch).
+    const int w_u = __builtin_amdgcn_readfirstlane(w);
+    auto stage_load = [&](int ci0s) {
+        const int cnt = min(CI_CHUNK, a.Cin - ci0s);
+#pragma unroll
+        for (int rr = 0; rr < CI_CHUNK / 4; ++rr) {
+            const int r = w_u + 4 * rr;
+            const bool row_ok = r < cnt;
+            const float* xr = xb + (size_t)(ci0s + (row_ok ? r : 0)) * a.Tin;
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xr), 0, row_ok ? len_in * 4 : 0, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NCOL; ++i) {
+                const int t = m0 + min_off + lane + 64 * i;
+                stage[rr][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, t * 4, 0, 0));
+            }
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < CI_CHUNK / 4; ++rr)
+#pragma unroll
+            for (int i = 0; i < NCOL; ++i) xs[(w + 4 * rr) * LDW + lane + 64 * i] = stage[rr][i];
+    };
+    stage_load(0);
+
     for (int ci0 = 0; ci0 < a.Cin; ci0 += CI_CHUNK) {
         const int ci_cnt = min(CI_CHUNK, a.Cin - ci0);
         __syncthreads();   // previous chunk fully consumed
-        for (int r = w; r < ci_cnt; r += 4) {
-            const float* xr = xb + (size_t)(ci0 + r) * a.Tin;
-            for (int c = lane; c < W; c += 64) {
-                const int t = m0 + min_off + c;
-                xs[r * LDW + c] = (t >= 0 && t < len_in) ? xr[t] : 0.f;
-            }
-        }
+        stage_write();
         __syncthreads();
+        if (ci0 + CI_CHUNK < a.Cin) stage_load(ci0 + CI_CHUNK);
 
         const int cp4n = ci_cnt >> 3;
         const int nit = a.k * cp4n;
@@ -183,26 +211,65 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     }
 
     // epilogue: C/D layout col(N) = lane&31, row(M) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Branch-free: residual / accumulate reads and the stores go through one buffer descriptor per batch row
+    // ([C_out][T_out] of row b); an invalid element gets an out-of-range offset, for which the hardware returns 0 on
+    // loads and drops stores.  (Per-element `if (valid) { load; ...; store }` compiles to a branch + vmcnt(0) per
+    // element, i.e. 64 serialised memory round trips per lane per tile.)
+    const int plane_bytes = a.Cout * a.Tout * 4;
+    const __amdgpu_buffer_rsrc_t yrs =
+        __builtin_amdgcn_make_buffer_rsrc(a.y + (size_t)b * a.Cout * a.Tout, 0, plane_bytes, 0x00020000);
+    const float* resb = a.res ? a.res + (size_t)b * a.Cout * a.Tout : a.y;
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resb), 0, plane_bytes, 0x00020000);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int m = m0 + (wn * NT + nt) * 32 + lane_col;
-            const int n = m * a.ostride + a.ooff;
-            const bool n_ok = (m < m_count) && (n >= 0) && (n < len_out);
+        for (int hf = 0; hf < 2; ++hf) {          // 8 accumulator rows at a time keeps the register footprint small
+            int corow[8];
+            float badd[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_row;
-                if (n_ok && co < a.Cout) {
-                    float v = acc[mt][nt][r];
-                    if (a.bias) v += a.bias[co];
-                    if (a.bias_b) v += a.bias_b[(size_t)b * a.Cout + co];
-                    const size_t o = ((size_t)b * a.Cout + co) * a.Tout + n;
-                    if (a.res) v += a.res[o];
-                    if (a.acc_mode == 1) v = a.y[o] + v;
-                    else if (a.acc_mode == 2) v = (a.y[o] + v) / a.div;
-                    a.y[o] = v;
+            for (int q = 0; q < 8; ++q) {
+                const int r = hf * 8 + q;
+                corow[q] = co0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lane_row;
+                badd[q] = 0.f;
+            }
+            if (a.bias) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) badd[q] = a.bias[corow[q] < a.Cout ? corow[q] : a.Cout - 1];
+            }
+            if (a.bias_b) {
+                const float* bb = a.bias_b + (size_t)b * a.Cout;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) badd[q] += bb[corow[q] < a.Cout ? corow[q] : a.Cout - 1];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int m = m0 + (wn * NT + nt) * 32 + lane_col;
+                const int n = m * a.ostride + a.ooff;
+                const bool n_ok = (m < m_count) && (n >= 0) && (n < len_out);
+                unsigned voff[8];
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bool ok = n_ok && corow[q] < a.Cout;
+                    voff[q] = ok ? (unsigned)(corow[q] * a.Tout + n) * 4u : 0xFFFFFFF0u;
+                    v[q] = acc[mt][nt][hf * 8 + q] + badd[q];
                 }
+                if (a.res) {
+                    float rv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, voff[q], 0, 0));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += rv[q];
+                }
+                if (a.acc_mode != 0) {
+                    float yo[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) yo[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, voff[q], 0, 0));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = a.acc_mode == 1 ? yo[q] + v[q] : (yo[q] + v[q]) / a.div;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), yrs, voff[q], 0, 0);
             }
         }
     }
@@ -281,6 +348,8 @@ static int launch_conv_cfg(const ConvArgs& a, int B, int m_total, hipStream_t st
 int launch_conv(const ConvArgs& a, int B, hipStream_t st) {
     if (B <= 0) return ITTS_OK;
     if (a.Cin % 8 != 0) { itts_set_error("conv: C_in=%d must be a multiple of 8", a.Cin); return ITTS_ERR_ARG; }
+    if ((long long)a.Cout * a.Tout >= (1ll << 29)) { itts_set_error("conv: C_out*T_out = %lld exceeds the 2 GiB per-row plane limit", (long long)a.Cout * a.Tout); return ITTS_ERR_ARG; }
+    if ((long long)a.Tin >= (1ll << 29)) { itts_set_error("conv: T too large"); return ITTS_ERR_ARG; }
     const int span = (a.k - 1) * (a.tap_step < 0 ? -a.tap_step : a.tap_step);
     if (span > CONV_HALO) { itts_set_error("conv: tap span %d exceeds halo %d", span, CONV_HALO); return ITTS_ERR_ARG; }
     const int m_total = a.Tin + a.m_extra;

@@ -32,18 +32,28 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
     float* xr = a.x + in_r * D;
     float v[NE];
     const bool upd = (a.partial != nullptr) || (a.bias_prev != nullptr);
+    // phases of independent, unconditional loads (each phase under one wave-uniform branch) so they are issued
+    // back-to-back; a dependent per-element "load, add, store" chain costs one memory round trip per element
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int idx = lane + 64 * i;
-        float val = xr[idx];
-        if (a.partial) {
-            float p = 0.f;
-            for (int s = 0; s < a.nsplit; ++s) p += a.partial[((size_t)s * a.rows + r) * D + idx];
-            val += p;
+    for (int i = 0; i < NE; ++i) v[i] = xr[lane + 64 * i];
+    if (a.partial) {       // nsplit == 4 (checked on the host)
+        const size_t ps = (size_t)a.rows * D;
+        const float* pp = a.partial + (size_t)r * D + lane;
+        float p0[NE], p1[NE], p2[NE], p3[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            p0[i] = pp[64 * i]; p1[i] = pp[ps + 64 * i]; p2[i] = pp[2 * ps + 64 * i]; p3[i] = pp[3 * ps + 64 * i];
         }
-        if (a.bias_prev) val += a.bias_prev[idx];
-        if (upd) xr[idx] = val;
-        v[i] = val;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] += (p0[i] + p1[i]) + (p2[i] + p3[i]);
+    }
+    if (a.bias_prev) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] += a.bias_prev[lane + 64 * i];
+    }
+    if (upd) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) xr[lane + 64 * i] = v[i];
     }
     const float invD = 1.0f / (float)D;
     float s = 0.f;
@@ -100,6 +110,7 @@ static int launch_ln_t(const LnArgs& a, hipStream_t st) {
 int launch_ln(const LnArgs& a, int prec, hipStream_t st) {
     if (a.rows <= 0) return ITTS_OK;
     if (a.D % 64) { itts_set_error("layernorm: D %% 64 != 0"); return ITTS_ERR_ARG; }
+    if (a.partial && a.nsplit != 4) { itts_set_error("layernorm: fused split-K reduce expects 4 slices"); return ITTS_ERR_ARG; }
     return prec == PREC_BF16 ? launch_ln_t<true>(a, st) : launch_ln_t<false>(a, st);
 }
 
@@ -153,7 +164,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, int mbase, int 
 }
 
 template <bool BF16, int MT, int NT, bool KSPLIT>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ? 2 : 4))) void gemm_kernel(GemmArgs a) {
     constexpr int KB = BF16 ? 32 : 16;
     constexpr int ESZ = BF16 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) float red[];   // KSPLIT: [4][MT*NT][64] f32x4
@@ -190,13 +201,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         wp[nt] = (const uint4*)a.Wp + (size_t)t * nkb * 64 + lane;
     }
 
-#pragma unroll 2
-    for (int kb = kb_start; kb < kb_hi; kb += kb_step) {
-        uint4 af[MT], bfr[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = *(const uint4*)(arow[mt] + (size_t)kb * KB * ESZ);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bfr[nt] = wp[nt][(size_t)kb * 64];
+    auto mfma_step = [&](const uint4 (&af)[MT], const uint4 (&bfr)[NT]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -211,6 +216,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[mt].w), __uint_as_float(bfr[nt].w), acc[mt][nt], 0, 0, 0);
                 }
             }
+    };
+
+    if constexpr (KSPLIT) {
+        // Decode (weight streaming, one block-wave on the chip): a wave's whole K range is only ~10 k-blocks, so the
+        // loop is latency-, not bandwidth-bound unless every HBM load of the range is in flight at once.  Issue all
+        // PF weight-fragment loads (and the matching L2-resident activation fragments) before the first MFMA; k-blocks
+        // past the range are clamped to a valid address and their B fragment zeroed, so the code is branch-free.
+        constexpr int PF = 10;
+        for (int kb0 = kb_start; kb0 < kb_hi; kb0 += PF * kb_step) {
+            uint4 bq[PF][NT], aq[PF][MT];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int kbi = kb0 + i * kb_step;
+                const bool ok = kbi < kb_hi;
+                const int kbc = ok ? kbi : kb0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    uint4 v = wp[nt][(size_t)kbc * 64];
+                    if (!ok) v = uint4{0u, 0u, 0u, 0u};
+                    bq[i][nt] = v;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int kbi = kb0 + i * kb_step;
+                const int kbc = kbi < kb_hi ? kbi : kb0;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) aq[i][mt] = *(const uint4*)(arow[mt] + (size_t)kbc * KB * ESZ);
+            }
+#pragma unroll
+            for (int i = 0; i < PF; ++i) mfma_step(aq[i], bq[i]);
+        }
+    } else {
+#pragma unroll 2
+        for (int kb = kb_start; kb < kb_hi; kb += kb_step) {
+            uint4 af[MT], bfr[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *(const uint4*)(arow[mt] + (size_t)kb * KB * ESZ);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[nt] = wp[nt][(size_t)kb * 64];
+            mfma_step(af, bfr);
+        }
     }
 
     if constexpr (KSPLIT) {
