@@ -196,6 +196,40 @@ class BigVGAN:
 
     __call__ = forward
 
+    # ---- streaming / chunked synthesis (BASELINE.json configs[4]: long-form, "streaming BigVGAN overlap-add") ----------
+    # One-sided receptive field of the generator in mel frames: conv_pre 3 + sum over stages of the AMP-block reach
+    # (96 samples at the stage rate for k=11, d=(1,3,5)) / cumulative upsampling + upsamplers.
+    def receptive_field_frames(self) -> int:
+        h = self.h
+        kmax = max(h["resblock_kernel_sizes"])
+        reach = 0
+        for d in max(h["resblock_dilation_sizes"], key=lambda ds: sum(ds)):
+            reach += 6 + (kmax - 1) // 2 * d + 6 + (kmax - 1) // 2
+        frames, rate = 3.0, 1
+        for u, k in zip(h["upsample_rates"], h["upsample_kernel_sizes"]):
+            frames += (k / u) / rate              # transposed-conv taps reach k/u input samples
+            rate *= u
+            frames += reach / rate
+        frames += (6 + 3) / rate                  # activation_post + conv_post
+        return int(frames) + 2
+
+    def stream(self, mel: torch.Tensor, chunk_frames: int = 256, halo_frames: Optional[int] = None):
+        """Yield the waveform of `mel` (B, C, T) chunk by chunk.  Each chunk is synthesised with `halo_frames` of real
+        context on both sides and the halo output is discarded (overlap-save), so the concatenation equals the
+        one-shot `forward(mel)` -- unlike the reference's TensorRT streaming path, which re-synthesises overlapping
+        code chunks and Hann-crossfades them (backends/trt/pipeline/streaming.py:57-68,140-172)."""
+        halo = self.receptive_field_frames() if halo_frames is None else int(halo_frames)
+        T = mel.shape[-1]
+        up = self.total_up
+        for t0 in range(0, T, chunk_frames):
+            t1 = min(T, t0 + chunk_frames)
+            a, b = max(0, t0 - halo), min(T, t1 + halo)
+            w = self.forward(mel[..., a:b].contiguous())
+            yield w[..., (t0 - a) * up: (t0 - a) * up + (t1 - t0) * up]
+
+    def forward_chunked(self, mel: torch.Tensor, chunk_frames: int = 256, halo_frames: Optional[int] = None) -> torch.Tensor:
+        return torch.cat(list(self.stream(mel, chunk_frames, halo_frames)), dim=-1)
+
     def set_profiling(self, enable: bool):
         _lib.check(_lib.lib().itts_bigvgan_set_profiling(self._h, int(enable)), "itts_bigvgan_set_profiling")
 

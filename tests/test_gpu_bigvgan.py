@@ -183,3 +183,22 @@ def test_full_size_batching_invariance(bv):
     solo = m(mel[1:2].to(DEV))
     assert torch.equal(both[1:2], solo)
     assert float(both.abs().max()) <= 1.0 and rms(both) > 0.05
+
+
+def test_streaming_equals_one_shot(bv):
+    """configs[4] (long-form, chunked vocoding): overlap-save chunks with a receptive-field halo reproduce the one-shot
+    waveform (gate 1e-4 RMS; observed ~1e-7), including chunk sizes that do not divide T and a too-small halo failing."""
+    h = dict(O.V2_HPARAMS, upsample_initial_channel=512)
+    sd = O.synth_weights(h, seed=21)
+    m = _model(bv, h, sd)
+    g = torch.Generator().manual_seed(4)
+    mel = (torch.randn(1, 80, 333, generator=g) * 2 - 4).to(DEV)
+    full = m(mel)
+    rf = m.receptive_field_frames()
+    assert 20 <= rf <= 64
+    for chunk in (64, 100, 333):
+        st = m.forward_chunked(mel, chunk_frames=chunk)
+        assert st.shape == full.shape
+        assert rms(st - full) <= 1e-6, (chunk, rms(st - full))
+    bad = m.forward_chunked(mel, chunk_frames=64, halo_frames=2)
+    assert rms(bad - full) > 1e-4          # the halo is what makes it exact
