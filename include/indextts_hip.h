@@ -100,6 +100,8 @@ int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32_t* lens, c
  *   count, algorithmic FLOPs and algorithmic tensor bytes (arrays of 4 doubles). */
 int itts_bigvgan_set_profiling(itts_bigvgan* h, int enable);
 int itts_bigvgan_profile_read(itts_bigvgan* h, double* ms, double* launches, double* flops, double* bytes);
+/* per-launch records of the last forward, launch order: out[4*i..] = {class, ms, flops, bytes}; returns the count */
+int itts_bigvgan_profile_records(itts_bigvgan* h, double* out, int max_records);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GPT speech-token decoder

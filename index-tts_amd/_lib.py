@@ -59,6 +59,7 @@ SIGNATURES = {
     "itts_bigvgan_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "itts_bigvgan_set_profiling": (C.c_int, [vp, C.c_int]),
     "itts_bigvgan_profile_read": (C.c_int, [vp, vp, vp, vp, vp]),
+    "itts_bigvgan_profile_records": (C.c_int, [vp, vp, C.c_int]),
     "itts_packed_gemm_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "itts_pack_gemm_weight": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "itts_gpt_create": (C.c_int, [C.POINTER(GPTConfig), C.POINTER(vp)]),

@@ -233,6 +233,14 @@ class BigVGAN:
     def set_profiling(self, enable: bool):
         _lib.check(_lib.lib().itts_bigvgan_set_profiling(self._h, int(enable)), "itts_bigvgan_set_profiling")
 
+    def profile_records(self):
+        """Per-launch (class, ms, flops, bytes) of the last forward, in launch order."""
+        buf = (C.c_double * (4 * 1024))()
+        n = _lib.lib().itts_bigvgan_profile_records(self._h, buf, 1024)
+        if n < 0:
+            _lib.check(1, "itts_bigvgan_profile_records")
+        return [(int(buf[4 * i]), buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]) for i in range(min(n, 1024))]
+
     def profile(self):
         """Per-kernel-class totals of the last forward (HIP events on the launch stream)."""
         arr = [(C.c_double * 4)() for _ in range(4)]

@@ -619,6 +619,21 @@ extern "C" int itts_bigvgan_set_profiling(itts_bigvgan* h, int enable) {
 // Totals of the LAST forward per kernel class (0 Conv1d MFMA, 1 ConvTranspose1d MFMA phases, 2 anti-aliased
 // activation, 3 conv_post): GPU milliseconds between the events bracketing each launch (recorded on the stream the
 // kernels ran on), launch count, algorithmic FLOPs and algorithmic tensor bytes.  Synchronises that stream.
+// Per-launch records of the LAST forward, in launch order: out[4*i + {0,1,2,3}] = {class, ms, flops, bytes}.
+// Returns the number of launches (<= max_records written).  Synchronises the launch stream.
+extern "C" int itts_bigvgan_profile_records(itts_bigvgan* h, double* out, int max_records) {
+    if (!h || !out) { itts_set_error("profile_records: null"); return -1; }
+    if (h->recs.empty()) return 0;
+    if (hipStreamSynchronize(h->prof_stream) != hipSuccess) return -1;
+    int n = 0;
+    for (size_t i = 0; i < h->recs.size() && n < max_records; ++i, ++n) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]);
+        out[4 * n + 0] = h->recs[i].cls; out[4 * n + 1] = t; out[4 * n + 2] = h->recs[i].flops; out[4 * n + 3] = h->recs[i].bytes;
+    }
+    return (int)h->recs.size();
+}
+
 extern "C" int itts_bigvgan_profile_read(itts_bigvgan* h, double* ms, double* launches, double* flops, double* bytes) {
     if (!h || !ms || !launches || !flops || !bytes) { itts_set_error("profile_read: null"); return ITTS_ERR_ARG; }
     for (int i = 0; i < PC_COUNT; ++i) ms[i] = launches[i] = flops[i] = bytes[i] = 0;

@@ -164,7 +164,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, int mbase, int 
 }
 
 template <bool BF16, int MT, int NT, bool KSPLIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ? 2 : 4))) void gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ? 1 : 4))) void gemm_kernel(GemmArgs a) {
     constexpr int KB = BF16 ? 32 : 16;
     constexpr int ESZ = BF16 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) float red[];   // KSPLIT: [4][MT*NT][64] f32x4
@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) aq[i][mt] = *(const uint4*)(arow[mt] + (size_t)kbc * KB * ESZ);
             }
+            // keep the scheduler from sinking the loads between the MFMAs (it would re-serialise them behind
+            // vmcnt(0) waits to save registers): every load above is issued before the first MFMA below
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < PF; ++i) mfma_step(aq[i], bq[i]);
         }
