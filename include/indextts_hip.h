@@ -162,6 +162,22 @@ int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const int32_t* pa
                       const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids,
                       const double* uniforms, int64_t* codes_out, int32_t* n_steps_out, void* workspace,
                       size_t workspace_bytes, int use_graph, void* stream);
+/* replaces: the same generate() call in beam mode, num_beams > 1 (the reference default is 3-beam beam-sample,
+ *   indextts/infer_v2_5.py:732-740) -> vendored GenerationMixin._beam_search (transformers_generation_utils.py:3325-3609),
+ *   BeamSearchScorer.process (3rd-party; mirror indextts/gpt/transformers_beam_search.py:215-305,930-1013) and
+ *   _reorder_cache (model_v2.py:200-213, done here as a per-position row map instead of copying the KV cache).
+ * prefix_embeds / pad_lens are given per SEQUENCE row (n_utts*num_beams rows, beams of one utterance adjacent, i.e.
+ *   repeat_interleave as _expand_inputs_for_generation does).  uniforms: optional f64 [max_new][n_utts][2*num_beams].
+ * Outputs (device): per step the chosen token and parent row of every sequence row (hist_*: [max_new][n_utts*num_beams]
+ *   int32), the running beam scores, the finished-hypothesis records hyps_out [n_utts][4]{f32 score, i32 step, i32 row,
+ *   i32 pad}, their count and the per-utterance done flags; BeamSearchScorer.finalize (:320-408) is a host-side walk over
+ *   these (index-tts_amd/gpt.py).  Max 4 beams. */
+size_t itts_gpt_beam_workspace_bytes(const itts_gpt* h, int n_utts, int num_beams, int S, int Tmax);
+int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int n_utts, int num_beams,
+                           int S, const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids,
+                           const double* uniforms, int32_t* hist_tok_out, int32_t* hist_par_out, float* beam_scores_out,
+                           float* hyps_out, int32_t* n_hyps_out, uint8_t* done_out, int32_t* n_steps_out,
+                           void* workspace, size_t workspace_bytes, int use_graph, void* stream);
 /* HIP-event timings of the last itts_gpt_generate call on its internal stream */
 int itts_gpt_last_timing(const itts_gpt* h, float* prefill_ms, float* decode_ms, int32_t* steps);
 

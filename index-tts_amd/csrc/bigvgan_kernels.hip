@@ -354,7 +354,12 @@ int launch_conv(const ConvArgs& a, int B, hipStream_t st) {
     if (span > CONV_HALO) { itts_set_error("conv: tap span %d exceeds halo %d", span, CONV_HALO); return ITTS_ERR_ARG; }
     const int m_total = a.Tin + a.m_extra;
     const int n_cosub = (a.Cout + 31) / 32;
-    if (n_cosub >= 4) return launch_conv_cfg<2, 2, 2, 2>(a, B, m_total, st);
+    // pick the co-tile (128 or 96 rows) that wastes the fewest MFMA rows: C_out = 192 is 2 x 96, not 1.5 x 128
+    if (n_cosub >= 4) {
+        const int waste128 = ceil_div(n_cosub, 4) * 4 - n_cosub, waste96 = ceil_div(n_cosub, 3) * 3 - n_cosub;
+        if (waste96 < waste128) return launch_conv_cfg<1, 4, 3, 2>(a, B, m_total, st);
+        return launch_conv_cfg<2, 2, 2, 2>(a, B, m_total, st);
+    }
     if (n_cosub == 3) return launch_conv_cfg<1, 4, 3, 2>(a, B, m_total, st);
     if (n_cosub == 2) return launch_conv_cfg<1, 4, 2, 2>(a, B, m_total, st);
     return launch_conv_cfg<1, 4, 1, 2>(a, B, m_total, st);

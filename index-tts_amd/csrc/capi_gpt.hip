@@ -214,11 +214,17 @@ struct GptWs {
     int* state;         // [0] step, [1] pos
     int* pad;           // [nseq]
     int* pen_ids;       // [16]
+    // beam search (nb > 1)
+    unsigned char* seen2;    // second seen buffer
+    int* row_map[2];         // [nseq][Tmax]
+    float* beam_scores; float* next_scores; int* next_tokens; int* next_indices;   // [nseq]
+    BeamHyp* hyps; int* n_hyps; float* worst; unsigned char* done;                 // per utterance
+    int* hist_tok; int* hist_par;                                                   // [max_new][nseq]
     size_t total;
     size_t layer_cache_bytes;
 };
 
-static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tmax) {
+static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tmax, int nb = 1) {
     GptWs w;
     const size_t esz = c.precision == PREC_BF16 ? 2 : 4;
     const size_t D = c.model_dim, rows = (size_t)nseq * S;
@@ -240,6 +246,23 @@ static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tm
     w.state = (int*)take(64);
     w.pad = (int*)take((size_t)nseq * 4);
     w.pen_ids = (int*)take(64);
+    w.seen2 = nullptr; w.row_map[0] = w.row_map[1] = nullptr;
+    if (nb > 1) {
+        const int B = nseq / nb, max_new = Tmax - S;
+        w.seen2 = (unsigned char*)take((size_t)nseq * c.vocab);
+        w.row_map[0] = (int*)take((size_t)nseq * Tmax * 4);
+        w.row_map[1] = (int*)take((size_t)nseq * Tmax * 4);
+        w.beam_scores = (float*)take((size_t)nseq * 4);
+        w.next_scores = (float*)take((size_t)nseq * 4);
+        w.next_tokens = (int*)take((size_t)nseq * 4);
+        w.next_indices = (int*)take((size_t)nseq * 4);
+        w.hyps = (BeamHyp*)take((size_t)B * BEAM_MAX * sizeof(BeamHyp));
+        w.n_hyps = (int*)take((size_t)B * 4);
+        w.worst = (float*)take((size_t)B * 4);
+        w.done = (unsigned char*)take((size_t)B);
+        w.hist_tok = (int*)take((size_t)max_new * nseq * 4);
+        w.hist_par = (int*)take((size_t)max_new * nseq * 4);
+    }
     w.total = off + 256;
     return w;
 }
@@ -247,6 +270,10 @@ static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tm
 extern "C" size_t itts_gpt_workspace_bytes(const itts_gpt* h, int nseq, int S, int Tmax) {
     if (!h || nseq <= 0 || S <= 0 || Tmax < S) return 0;
     return carve(h->cfg, nullptr, nseq, S, Tmax).total;
+}
+extern "C" size_t itts_gpt_beam_workspace_bytes(const itts_gpt* h, int n_utts, int num_beams, int S, int Tmax) {
+    if (!h || n_utts <= 0 || num_beams < 2 || num_beams > BEAM_MAX || S <= 0 || Tmax <= S) return 0;
+    return carve(h->cfg, nullptr, n_utts * num_beams, S, Tmax, num_beams).total;
 }
 
 // ---- small state kernels ---------------------------------------------------------------------------------------
@@ -267,7 +294,7 @@ __global__ void mark_seen_kernel(unsigned char* seen, const int* ids, int n_ids,
 // rows = nseq*S new positions (S = 1 for a decode step).  prefill: direct residual epilogues + big-tile GEMMs;
 // decode: split-K partials reduced inside the next LayerNorm kernel.
 static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bool prefill, const int* pos_ptr, const int* pad,
-                      bool* pending, hipStream_t st) {
+                      bool* pending, hipStream_t st, bool beam = false) {
     const itts_gpt_config& c = h->cfg;
     const int D = c.model_dim, prec = c.precision, rows = nseq * S;
     int rc;
@@ -288,7 +315,8 @@ static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bo
         if ((rc = launch_gemm(g, prec, prefill, st))) return rc;
 
         AttnArgs at{};
-        at.qbuf = w.qbuf; at.kcache = g.kcache; at.vcache = g.vcache; at.pad = pad; at.row_map = nullptr; at.pos_ptr = pos_ptr;
+        at.qbuf = w.qbuf; at.kcache = g.kcache; at.vcache = g.vcache; at.pad = pad; at.pos_ptr = pos_ptr;
+        at.row_map = beam ? w.row_map[0] : nullptr; at.row_map_alt = beam ? w.row_map[1] : nullptr; at.step_ptr = beam ? w.state : nullptr;
         at.out = w.attn; at.nseq = nseq; at.H = c.heads; at.nq = S; at.Tmax = Tmax; at.D = D;
         if ((rc = launch_attention(at, prec, st))) return rc;
 
@@ -460,6 +488,156 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
         }
     }
     HIP_TRY(hipEventRecord(h->ev_t2, st));
+    HIP_TRY(hipEventRecord(h->ev_out, st));
+    HIP_TRY(hipStreamWaitEvent(cs, h->ev_out, 0));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (exec) (void)hipGraphExecDestroy(exec);
+    (void)hipEventElapsedTime(&h->last_prefill_ms, h->ev_t0, h->ev_t1);
+    (void)hipEventElapsedTime(&h->last_decode_ms, h->ev_t1, h->ev_t2);
+    h->last_steps = steps;
+    *n_steps_out = steps;
+    return ITTS_OK;
+}
+
+// ---- beam search / beam-sample ------------------------------------------------------------------------------------
+__global__ void beam_init_kernel(int* row_map0, float* beam_scores, float* worst, int* n_hyps, unsigned char* done, int nseq, int nb,
+                                 int Tmax) {
+    const int i = blockIdx.x;
+    for (int t = threadIdx.x; t < Tmax; t += blockDim.x) row_map0[(size_t)i * Tmax + t] = i;
+    if (threadIdx.x == 0) {
+        beam_scores[i] = (i % nb == 0) ? 0.f : -1e9f;             // generation_utils.py:3408-3410
+        if (i % nb == 0) { worst[i / nb] = 1e9f; n_hyps[i / nb] = 0; done[i / nb] = 0; }
+    }
+}
+
+static BeamArgs make_beam(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, int B, int nb, int S, int Tmax, const double* uniforms) {
+    const itts_gpt_config& c = h->cfg;
+    BeamArgs a{};
+    a.logits = w.logits; a.seen[0] = w.seen; a.seen[1] = w.seen2; a.row_map[0] = w.row_map[0]; a.row_map[1] = w.row_map[1];
+    a.beam_scores = w.beam_scores; a.next_scores = w.next_scores; a.next_tokens = w.next_tokens; a.next_indices = w.next_indices;
+    a.hyps = w.hyps; a.n_hyps = w.n_hyps; a.worst = w.worst; a.done = w.done; a.hist_tok = w.hist_tok; a.hist_par = w.hist_par;
+    a.step_ptr = w.state; a.uniforms = uniforms; a.seed = gp.seed; a.B = B; a.nb = nb; a.V = c.vocab; a.max_new = gp.max_new_tokens;
+    a.Tmax = Tmax; a.S = S; a.do_sample = gp.do_sample; a.top_k = gp.top_k;
+    a.min_keep = gp.min_tokens_to_keep < 1 ? 1 : gp.min_tokens_to_keep;
+    a.top_p = gp.top_p; a.temperature = gp.temperature; a.rep_penalty = gp.repetition_penalty; a.length_penalty = gp.length_penalty;
+    a.stop_token = c.stop_mel_token; a.mel_emb = h->mel_emb; a.mel_pos = h->mel_pos; a.x_next = w.x; a.D = c.model_dim;
+    a.pos_offset = gp.pos_offset; a.n_mel_pos = c.n_mel_pos;
+    return a;
+}
+
+static int decode_step_beam(itts_gpt* h, const GptWs& w, const BeamArgs& ba, int nseq, int Tmax, hipStream_t st) {
+    bool pending = false;
+    int rc = run_layers(h, w, nseq, 1, Tmax, false, w.state + 1, w.pad, &pending, st, true);
+    if (rc) return rc;
+    if ((rc = run_head(h, w, nseq, 1, 0, pending, st))) return rc;
+    if ((rc = launch_beam_step(ba, st))) return rc;
+    if ((rc = launch_beam_apply(ba, st))) return rc;
+    return launch_advance(w.state, w.state + 1, st);
+}
+
+extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int n_utts, int num_beams,
+                                      int S, const itts_gen_params* gpp, const int32_t* penalty_ids, int n_penalty_ids,
+                                      const double* uniforms, int32_t* hist_tok_out, int32_t* hist_par_out, float* beam_scores_out,
+                                      float* hyps_out, int32_t* n_hyps_out, uint8_t* done_out, int32_t* n_steps_out,
+                                      void* workspace, size_t workspace_bytes, int use_graph, void* caller_stream) {
+    if (!h || !prefix_embeds || !gpp || !hist_tok_out || !hist_par_out || !beam_scores_out || !hyps_out || !n_hyps_out || !done_out ||
+        !n_steps_out || !workspace) { itts_set_error("gpt_generate_beam: null pointer"); return ITTS_ERR_ARG; }
+    if (!h->finalized) { itts_set_error("gpt_generate_beam: call itts_gpt_finalize first"); return ITTS_ERR_STATE; }
+    const itts_gpt_config& c = h->cfg;
+    const itts_gen_params gp = *gpp;
+    const int nb = num_beams, B = n_utts, nseq = B * nb;
+    if (B <= 0 || nb < 2 || nb > BEAM_MAX || S <= 0 || gp.max_new_tokens <= 0) { itts_set_error("gpt_generate_beam: bad sizes"); return ITTS_ERR_ARG; }
+    if (gp.max_new_tokens + gp.pos_offset > c.n_mel_pos + 1) { itts_set_error("gpt_generate_beam: max_new_tokens exceeds the mel position table"); return ITTS_ERR_ARG; }
+    if (n_penalty_ids < 0 || n_penalty_ids > 16) { itts_set_error("gpt_generate_beam: at most 16 initial penalty ids"); return ITTS_ERR_ARG; }
+    const int Tmax = S + gp.max_new_tokens;
+    const GptWs w0 = carve(c, nullptr, nseq, S, Tmax, nb);
+    if (workspace_bytes < w0.total) { itts_set_error("gpt_generate_beam: workspace too small (%zu < %zu)", workspace_bytes, w0.total); return ITTS_ERR_ARG; }
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const GptWs w = carve(c, base, nseq, S, Tmax, nb);
+    hipStream_t st = h->stream, cs = (hipStream_t)caller_stream;
+    int rc;
+    if (h->fin_cap < nseq) {
+        if (h->host_fin) (void)hipHostFree(h->host_fin);
+        HIP_TRY(hipHostMalloc((void**)&h->host_fin, (size_t)nseq, hipHostMallocDefault));
+        h->fin_cap = nseq;
+    }
+    HIP_TRY(hipEventRecord(h->ev_in, cs));
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_in, 0));
+    HIP_TRY(hipMemsetAsync(w.seen, 0, (size_t)nseq * c.vocab, st));
+    HIP_TRY(hipMemsetAsync(w.seen2, 0, (size_t)nseq * c.vocab, st));
+    HIP_TRY(hipMemsetAsync(w.hist_tok, 0, (size_t)gp.max_new_tokens * nseq * 4, st));
+    HIP_TRY(hipMemsetAsync(w.hist_par, 0, (size_t)gp.max_new_tokens * nseq * 4, st));
+    HIP_TRY(hipMemsetAsync(w.hyps, 0, (size_t)B * BEAM_MAX * sizeof(BeamHyp), st));
+    if (pad_lens) HIP_TRY(hipMemcpyAsync(w.pad, pad_lens, (size_t)nseq * 4, hipMemcpyDeviceToDevice, st));
+    else HIP_TRY(hipMemsetAsync(w.pad, 0, (size_t)nseq * 4, st));
+    if (n_penalty_ids > 0) {
+        HIP_TRY(hipMemcpyAsync(w.pen_ids, penalty_ids, (size_t)n_penalty_ids * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(mark_seen_kernel, dim3(nseq), dim3(64), 0, st, w.seen, w.pen_ids, n_penalty_ids, c.vocab);
+    }
+    hipLaunchKernelGGL(beam_init_kernel, dim3(nseq), dim3(256), 0, st, w.row_map[0], w.beam_scores, w.worst, w.n_hyps, w.done, nseq, nb, Tmax);
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 0, 0);
+    HIP_TRY(hipMemcpyAsync(w.x, prefix_embeds, (size_t)nseq * S * c.model_dim * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+
+    HIP_TRY(hipEventRecord(h->ev_t0, st));
+    bool pending = false;
+    rc = run_layers(h, w, nseq, S, Tmax, true, w.state + 1, w.pad, &pending, st, true);
+    if (rc) return rc;
+    if ((rc = run_head(h, w, nseq, S, S - 1, pending, st))) return rc;
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 0, S);
+    const BeamArgs ba = make_beam(h, w, gp, B, nb, S, Tmax, uniforms);
+    if ((rc = launch_beam_step(ba, st))) return rc;
+    if ((rc = launch_beam_apply(ba, st))) return rc;
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 1, S);
+    HIP_TRY(hipEventRecord(h->ev_t1, st));
+
+    int steps = 1;
+    hipGraphExec_t exec = nullptr;
+    bool graph_ok = false;
+    if (use_graph && gp.max_new_tokens > 1) {
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            rc = decode_step_beam(h, w, ba, nseq, Tmax, st);
+            e = hipStreamEndCapture(st, &graph);
+            if (rc == ITTS_OK && e == hipSuccess && graph) {
+                e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                graph_ok = (e == hipSuccess && exec);
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        if (!graph_ok) {
+            (void)hipGetLastError();
+            itts_set_error("gpt_generate_beam: hipGraph capture failed (%s); rerun with use_graph=0", hipGetErrorString(e));
+            return ITTS_ERR_HIP;
+        }
+    }
+    // the reference loop stops when every utterance is done (checked right after the scorer) or at max_length
+    auto all_done = [&](bool* out) -> int {
+        HIP_TRY(hipMemcpyAsync(h->host_fin, w.done, B, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool all = true;
+        for (int i = 0; i < B; ++i) all = all && h->host_fin[i];
+        *out = all;
+        return ITTS_OK;
+    };
+    bool fin = false;
+    if ((rc = all_done(&fin))) return rc;
+    while (!fin && steps < gp.max_new_tokens) {
+        if (graph_ok) { HIP_TRY(hipGraphLaunch(exec, st)); }
+        else if ((rc = decode_step_beam(h, w, ba, nseq, Tmax, st))) return rc;
+        ++steps;
+        // finished utterances are frozen on the device (their block returns early), so a late check only costs idle
+        // steps; the host reports min(steps, the step at which the last utterance finished) like the reference loop
+        if (steps % 4 == 0 && (rc = all_done(&fin))) return rc;
+    }
+    HIP_TRY(hipEventRecord(h->ev_t2, st));
+    HIP_TRY(hipMemcpyAsync(hist_tok_out, w.hist_tok, (size_t)gp.max_new_tokens * nseq * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(hist_par_out, w.hist_par, (size_t)gp.max_new_tokens * nseq * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(beam_scores_out, w.beam_scores, (size_t)nseq * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(hyps_out, w.hyps, (size_t)B * BEAM_MAX * sizeof(BeamHyp), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(n_hyps_out, w.n_hyps, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(done_out, w.done, (size_t)B, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipEventRecord(h->ev_out, st));
     HIP_TRY(hipStreamWaitEvent(cs, h->ev_out, 0));
     HIP_TRY(hipStreamSynchronize(st));

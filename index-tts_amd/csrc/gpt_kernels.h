@@ -44,6 +44,8 @@ struct AttnArgs {
     const void* kcache; const void* vcache;   // [nseq][H][Tmax][64] cache dtype
     const int* pad;          // [nseq] first valid key (left padding), or null
     const int* row_map;      // [nseq][Tmax] physical row holding position t of sequence b (beam indirection) or null
+    const int* row_map_alt;  // second buffer: the map in use is (*step_ptr & 1) ? row_map_alt : row_map
+    const int* step_ptr;
     const int* pos_ptr;      // cache index of query 0
     void* out;               // [nseq*nq][D] act dtype
     int nseq, H, nq, Tmax, D;
@@ -68,3 +70,29 @@ struct SampleArgs {
 };
 int launch_sample(const SampleArgs& a, hipStream_t st);
 int launch_advance(int* step_ptr, int* pos_ptr, hipStream_t st);
+
+// ---- beam search / beam-sample step (GenerationMixin._beam_search + BeamSearchScorer.process) ------------------
+#define BEAM_MAX 4
+struct BeamHyp { float score; int step; int row; int pad; };
+struct BeamArgs {
+    const float* logits;          // [B*nb][V]
+    unsigned char* seen[2];       // [B*nb][V], parity = step & 1 (read), 1 - parity (written by apply)
+    int* row_map[2];              // [B*nb][Tmax]
+    float* beam_scores;           // [B*nb]
+    float* next_scores; int* next_tokens; int* next_indices;   // [B*nb]
+    BeamHyp* hyps;                // [B][BEAM_MAX]
+    int* n_hyps;                  // [B]
+    float* worst;                 // [B]
+    unsigned char* done;          // [B]
+    int* hist_tok; int* hist_par; // [max_new][B*nb]
+    const int* step_ptr;
+    const double* uniforms;       // [max_new][B][2*nb] or null
+    unsigned long long seed;
+    int B, nb, V, max_new, Tmax, S;
+    int do_sample, top_k, min_keep;
+    float top_p, temperature, rep_penalty, length_penalty;
+    int stop_token;
+    const float* mel_emb; const float* mel_pos; float* x_next; int D; int pos_offset; int n_mel_pos;
+};
+int launch_beam_step(const BeamArgs& a, hipStream_t st);
+int launch_beam_apply(const BeamArgs& a, hipStream_t st);

@@ -340,6 +340,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int first = a.pad ? a.pad[b] : 0;
     const int sub = lane % LPK, grp = lane / LPK;
     const size_t qrow = (size_t)b * a.nq + qi;
+    const int* rmap = a.row_map;
+    if (rmap && a.row_map_alt && a.step_ptr && (*a.step_ptr & 1)) rmap = a.row_map_alt;
 
     float q[DPL];
 #pragma unroll
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         const int t = t0 + grp;
         const bool ok = t <= last;
         const int tc = ok ? t : last;
-        const int prow = a.row_map ? a.row_map[(size_t)b * a.Tmax + tc] : b;
+        const int prow = rmap ? rmap[(size_t)b * a.Tmax + tc] : b;
         const size_t off = (((size_t)prow * a.H + h) * a.Tmax + tc) * 64 + sub * DPL;
         float kf[DPL], vf[DPL];
         if constexpr (BF16) {
@@ -624,6 +626,279 @@ __global__ void advance_kernel(int* step_ptr, int* pos_ptr) {
 
 int launch_advance(int* step_ptr, int* pos_ptr, hipStream_t st) {
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, step_ptr, pos_ptr);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// ================================================================================================================
+// Beam search / beam-sample: one block per utterance.
+//   per beam: log_softmax -> repetition penalty (on log-probs) -> [temperature -> top-k -> top-p]  (processors act on
+//   log-probs here, generation_utils.py:3475-3479) -> + beam score; union over beams; 2*nb candidates by multinomial
+//   without replacement (inverse CDF over the flattened beam-major index, one uniform per draw) or top-2*nb; sorted by
+//   score; BeamSearchScorer.process (transformers_beam_search.py:215-305) incl. hypothesis heap and the
+//   early_stopping=False done rule (:979-996).
+// ================================================================================================================
+#define BEAM_CAP 64            // survivors kept per beam after top-k (top_k <= 64)
+
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
+    extern __shared__ float sl[];                        // [V] processed log-probs of the current beam
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_mask, s_kk, s_count;
+    __shared__ float red[4];
+    __shared__ float s_m, s_lse;
+    __shared__ int ci[BEAM_CAP];
+    __shared__ float cv[BEAM_CAP];
+    __shared__ int ui[BEAM_MAX * BEAM_CAP];              // union: flat index beam*V + token
+    __shared__ float uv[BEAM_MAX * BEAM_CAP];
+    __shared__ int s_un;
+    const int b = blockIdx.x, tid = threadIdx.x, V = a.V, nb = a.nb;
+    const int step = *a.step_ptr;
+    const int par = step & 1;
+    if (a.done[b]) {                                     // :255-264 finished utterance: pad tokens, score 0
+        if (tid < nb) {
+            a.next_scores[b * nb + tid] = 0.f;
+            a.next_tokens[b * nb + tid] = a.stop_token;
+            a.next_indices[b * nb + tid] = b * nb + tid;
+        }
+        return;
+    }
+    if (tid == 0) s_un = 0;
+    const bool pen = a.rep_penalty != 1.0f;
+    const bool temp = a.do_sample && a.temperature != 1.0f;
+    const int ksel_raw = a.do_sample ? max(a.top_k, a.min_keep) : 2 * nb;
+    const int ksel = ksel_raw < V ? ksel_raw : V;
+    for (int j = 0; j < nb; ++j) {
+        const int row = b * nb + j;
+        const float* lg = a.logits + (size_t)row * V;
+        const unsigned char* seen = a.seen[par] + (size_t)row * V;
+        // log_softmax
+        float mx = -INFINITY;
+        for (int i = tid; i < V; i += 256) { const float x = lg[i]; sl[i] = x; mx = fmaxf(mx, x); }
+        mx = wave_max(mx);
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        if (tid == 0) s_m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        const float m = s_m;
+        float se = 0.f;
+        for (int i = tid; i < V; i += 256) se += expf(sl[i] - m);
+        se = wave_sum(se);
+        if ((tid & 63) == 0) red[tid >> 6] = se;
+        __syncthreads();
+        if (tid == 0) { s_lse = logf((red[0] + red[1]) + (red[2] + red[3])); s_prefix = 0; s_mask = 0; s_kk = (unsigned)ksel; s_count = 0; }
+        __syncthreads();
+        const float lse = s_lse;
+        for (int i = tid; i < V; i += 256) {
+            float x = (sl[i] - m) - lse;
+            if (pen && seen[i]) x = x < 0.f ? x * a.rep_penalty : x / a.rep_penalty;
+            if (temp) x = x / a.temperature;
+            sl[i] = x;
+        }
+        __syncthreads();
+        // top-ksel threshold (radix select)
+        for (int pass = 3; pass >= 0; --pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix, mask = s_mask;
+            const int shift = pass * 8;
+            for (int i = tid; i < V; i += 256) {
+                const uint32_t key = f2key(sl[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned cum = 0, kk = s_kk;
+                int bsel = 0;
+                for (int bb = 255; bb >= 0; --bb) {
+                    if (cum + hist[bb] >= kk) { bsel = bb; break; }
+                    cum += hist[bb];
+                }
+                s_prefix = prefix | ((unsigned)bsel << shift);
+                s_mask = mask | (255u << shift);
+                s_kk = kk - cum;
+            }
+            __syncthreads();
+        }
+        const uint32_t kth = s_prefix;
+        for (int i = tid; i < V; i += 256) {
+            if (f2key(sl[i]) >= kth) {
+                const unsigned slot = atomicAdd(&s_count, 1u);
+                if (slot < BEAM_CAP) { ci[slot] = i; cv[slot] = sl[i]; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int n = (int)(s_count < BEAM_CAP ? s_count : BEAM_CAP);
+            for (int i = 1; i < n; ++i) {                 // ascending by (value, index)
+                const float v = cv[i];
+                const int ix = ci[i];
+                int q = i - 1;
+                while (q >= 0 && (cv[q] > v || (cv[q] == v && ci[q] > ix))) { cv[q + 1] = cv[q]; ci[q + 1] = ci[q]; --q; }
+                cv[q + 1] = v; ci[q + 1] = ix;
+            }
+            int lo = 0;
+            if (a.do_sample && a.top_p < 1.0f) {
+                const float mxv = cv[n - 1];
+                float sum = 0.f;
+                for (int i = 0; i < n; ++i) sum += expf(cv[i] - mxv);
+                const float thr = (float)(1.0 - (double)a.top_p);
+                double cum = 0.0;
+                const int keep = a.min_keep < 1 ? 1 : a.min_keep;
+                for (int i = 0; i < n - keep; ++i) {
+                    cum += (double)(expf(cv[i] - mxv) / sum);
+                    if ((float)cum <= thr) lo = i + 1; else break;
+                }
+            }
+            const float bs = a.beam_scores[row];
+            int un = s_un;
+            for (int i = lo; i < n; ++i) { ui[un] = j * V + ci[i]; uv[un] = cv[i] + bs; ++un; }
+            s_un = un;
+        }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    // ---- candidate selection over the union (thread 0; <= nb*64 entries) ----
+    int un = s_un;
+    const int ncand = 2 * nb;
+    int ctok[2 * BEAM_MAX], cidx[2 * BEAM_MAX];
+    float csc[2 * BEAM_MAX];
+    int nc = 0;
+    for (int i = 1; i < un; ++i) {                        // sort union by flat index (vocabulary order of the flattened row)
+        const float v = uv[i];
+        const int ix = ui[i];
+        int q = i - 1;
+        while (q >= 0 && ui[q] > ix) { uv[q + 1] = uv[q]; ui[q + 1] = ui[q]; --q; }
+        uv[q + 1] = v; ui[q + 1] = ix;
+    }
+    if (a.do_sample) {
+        float mxv = -INFINITY;
+        for (int i = 0; i < un; ++i) mxv = fmaxf(mxv, uv[i]);
+        float sum = 0.f;
+        for (int i = 0; i < un; ++i) sum += expf(uv[i] - mxv);
+        // probabilities in cv-like scratch: reuse hist as float storage is unsafe; recompute on the fly
+        bool taken[BEAM_MAX * BEAM_CAP];
+        for (int i = 0; i < un; ++i) taken[i] = false;
+        for (int d = 0; d < ncand && d < un; ++d) {
+            double total = 0.0;
+            for (int i = 0; i < un; ++i) if (!taken[i]) total += (double)(expf(uv[i] - mxv) / sum);
+            const double u = a.uniforms ? a.uniforms[((size_t)step * a.B + b) * ncand + d]
+                                        : rng_uniform(a.seed, (unsigned long long)step * 8 + d, (unsigned long long)b);
+            const double tgt = u * total;
+            double cum = 0.0;
+            int pick = -1, lastfree = -1;
+            for (int i = 0; i < un; ++i) {
+                if (taken[i]) continue;
+                lastfree = i;
+                cum += (double)(expf(uv[i] - mxv) / sum);
+                if (cum > tgt) { pick = i; break; }
+            }
+            if (pick < 0) pick = lastfree;
+            taken[pick] = true;
+            ctok[nc] = ui[pick] % V; cidx[nc] = ui[pick] / V; csc[nc] = uv[pick]; ++nc;
+        }
+    } else {
+        bool taken[BEAM_MAX * BEAM_CAP];
+        for (int i = 0; i < un; ++i) taken[i] = false;
+        for (int d = 0; d < ncand && d < un; ++d) {       // top-2nb by score, ties -> lower flat index
+            int best = -1;
+            for (int i = 0; i < un; ++i)
+                if (!taken[i] && (best < 0 || uv[i] > uv[best])) best = i;
+            taken[best] = true;
+            ctok[nc] = ui[best] % V; cidx[nc] = ui[best] / V; csc[nc] = uv[best]; ++nc;
+        }
+    }
+    for (int i = 1; i < nc; ++i) {                        // sort candidates by score, descending (stable)
+        const float v = csc[i];
+        const int t = ctok[i], x = cidx[i];
+        int q = i - 1;
+        while (q >= 0 && csc[q] < v) { csc[q + 1] = csc[q]; ctok[q + 1] = ctok[q]; cidx[q + 1] = cidx[q]; --q; }
+        csc[q + 1] = v; ctok[q + 1] = t; cidx[q + 1] = x;
+    }
+    // ---- BeamSearchScorer.process ----
+    const int gen_len = step + 1;                          // cur_len - decoder_prompt_len
+    BeamHyp* hy = a.hyps + (size_t)b * BEAM_MAX;
+    int nh = a.n_hyps[b];
+    float worst = a.worst[b];
+    int filled = 0;
+    for (int rank = 0; rank < nc && filled < nb; ++rank) {
+        if (ctok[rank] == a.stop_token) {
+            if (rank >= nb) continue;
+            const float sc = csc[rank] / powf((float)gen_len, a.length_penalty);
+            if (nh < nb || sc > worst) {                  // BeamHypotheses.add (:955-976)
+                BeamHyp nhyp{sc, step, b * nb + cidx[rank], 0};
+                if (nh < nb) {
+                    hy[nh++] = nhyp;
+                    worst = fminf(sc, worst);
+                } else {
+                    int wi = 0;                           // replace the worst, new worst = second worst of the old+new set
+                    for (int q = 1; q < nh; ++q) if (hy[q].score < hy[wi].score) wi = q;
+                    hy[wi] = nhyp;
+                    float w2 = hy[0].score;
+                    for (int q = 1; q < nh; ++q) w2 = fminf(w2, hy[q].score);
+                    worst = w2;
+                }
+            }
+        } else {
+            a.next_scores[b * nb + filled] = csc[rank];
+            a.next_tokens[b * nb + filled] = ctok[rank];
+            a.next_indices[b * nb + filled] = b * nb + cidx[rank];
+            ++filled;
+        }
+    }
+    for (; filled < nb; ++filled) {                       // cannot happen with >= nb non-EOS candidates; keep state sane
+        a.next_scores[b * nb + filled] = -1e9f;
+        a.next_tokens[b * nb + filled] = a.stop_token;
+        a.next_indices[b * nb + filled] = b * nb;
+    }
+    a.n_hyps[b] = nh;
+    a.worst[b] = worst;
+    if (nh >= nb) {                                       // is_done, early_stopping=False (:979-996)
+        const float highest = csc[0] / powf((float)gen_len, a.length_penalty);
+        if (worst >= highest) a.done[b] = 1;
+    }
+}
+
+// one block per sequence row: inherit the chosen parent's history (seen set, KV row map), record the step
+__global__ __launch_bounds__(256) void beam_apply_kernel(BeamArgs a) {
+    const int i = blockIdx.x, tid = threadIdx.x, V = a.V;
+    const int step = *a.step_ptr;
+    const int par = step & 1;
+    const int src = a.next_indices[i], tok = a.next_tokens[i];
+    const unsigned char* so = a.seen[par] + (size_t)src * V;
+    unsigned char* sn = a.seen[1 - par] + (size_t)i * V;
+    for (int k = tid; k < V; k += 256) sn[k] = so[k];
+    const int npos = a.S + step;                           // cache index of this token's K/V in the next forward
+    const int* mo = a.row_map[par] + (size_t)src * a.Tmax;
+    int* mn = a.row_map[1 - par] + (size_t)i * a.Tmax;
+    for (int t = tid; t < npos && t < a.Tmax; t += 256) mn[t] = mo[t];
+    __syncthreads();
+    if (tid == 0) {
+        if (tok >= 0 && tok < V) sn[tok] = 1;
+        if (npos < a.Tmax) mn[npos] = i;
+        a.hist_tok[(size_t)step * a.B * a.nb + i] = tok;
+        a.hist_par[(size_t)step * a.B * a.nb + i] = src;
+        a.beam_scores[i] = a.next_scores[i];
+    }
+    int p = step + a.pos_offset;
+    p = p < a.n_mel_pos ? p : a.n_mel_pos - 1;
+    const int tk = (tok >= 0 && tok < V) ? tok : 0;
+    for (int d = tid; d < a.D; d += 256)
+        a.x_next[(size_t)i * a.D + d] = a.mel_emb[(size_t)tk * a.D + d] + a.mel_pos[(size_t)p * a.D + d];
+}
+
+int launch_beam_step(const BeamArgs& a, hipStream_t st) {
+    if (a.nb < 2 || a.nb > BEAM_MAX) { itts_set_error("beam: num_beams must be 2..%d", BEAM_MAX); return ITTS_ERR_ARG; }
+    if (a.do_sample && (a.top_k <= 0 || max(a.top_k, a.min_keep) > BEAM_CAP)) {
+        itts_set_error("beam-sample: top_k must be in 1..%d on the device path (got %d)", BEAM_CAP, a.top_k);
+        return ITTS_ERR_ARG;
+    }
+    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(256), (size_t)a.V * sizeof(float), st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+int launch_beam_apply(const BeamArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(beam_apply_kernel, dim3(a.B * a.nb), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }

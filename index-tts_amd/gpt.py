@@ -171,7 +171,8 @@ class UnifiedVoice:
         if not self._loaded:
             raise RuntimeError("UnifiedVoice: load_state_dict() first")
         if num_beams != 1:
-            raise NotImplementedError("num_beams > 1: beam-sample is not on the device loop yet (use num_beams=1)")
+            return self._generate_beam(inputs_embeds, attention_mask, max_new_tokens, do_sample, num_beams, top_p, top_k,
+                                       temperature, repetition_penalty, length_penalty, uniforms, seed)
         dev = self.device
         B, s, D = inputs_embeds.shape
         start = (self._emb["mel_embedding.weight"][self.start_mel_token] + self._emb["mel_pos_embedding.emb.weight"][0])
@@ -209,6 +210,94 @@ class UnifiedVoice:
         first = torch.where(is_stop.any(1), is_stop.int().argmax(1) + 1, torch.full((B,), codes.shape[1], device=dev))
         n = int(min(int(first.max().item()), n_steps.value))
         return codes[:, :n]
+
+    # ---- beam search / beam-sample (num_beams > 1; the reference default is 3-beam beam-sample) ------------------------
+    def _generate_beam(self, inputs_embeds, attention_mask, max_new_tokens, do_sample, num_beams, top_p, top_k, temperature,
+                       repetition_penalty, length_penalty, uniforms, seed) -> torch.Tensor:
+        dev = self.device
+        nb = int(num_beams)
+        B, s, D = inputs_embeds.shape
+        start = (self._emb["mel_embedding.weight"][self.start_mel_token] + self._emb["mel_pos_embedding.emb.weight"][0])
+        x = torch.cat([inputs_embeds.to(dev, torch.float32), start.expand(B, 1, D)], dim=1)
+        x = x.repeat_interleave(nb, dim=0).contiguous()               # _expand_inputs_for_generation: beams adjacent
+        S = s + 1
+        pad = (attention_mask[:, :S] == 0).sum(dim=1).to(torch.int32).repeat_interleave(nb).contiguous()
+        nseq, max_new = B * nb, int(max_new_tokens)
+        gp = _lib.GenParams()
+        gp.do_sample, gp.num_beams, gp.top_k = int(bool(do_sample)), nb, int(top_k or 0)
+        gp.min_tokens_to_keep, gp.max_new_tokens = 2, max_new        # one eos id -> keep eos + 1 (generation_utils.py:1023-1029)
+        gp.pos_offset = 2 if self.kv_cache else 1
+        gp.top_p, gp.temperature = float(top_p), float(temperature)
+        gp.repetition_penalty = float(repetition_penalty if repetition_penalty is not None else 1.0)
+        gp.length_penalty, gp.seed = float(length_penalty), int(seed)
+        L = _lib.lib()
+        Tmax = S + max_new
+        ws = self._workspace(L.itts_gpt_beam_workspace_bytes(self._h, B, nb, S, Tmax))
+        hist_tok = torch.empty(max_new, nseq, dtype=torch.int32, device=dev)
+        hist_par = torch.empty(max_new, nseq, dtype=torch.int32, device=dev)
+        beam_scores = torch.empty(nseq, dtype=torch.float32, device=dev)
+        hyps = torch.empty(B, 4, 4, dtype=torch.float32, device=dev)          # {f32 score, i32 step, i32 row, pad}
+        n_hyps = torch.empty(B, dtype=torch.int32, device=dev)
+        done = torch.empty(B, dtype=torch.uint8, device=dev)
+        n_steps = C.c_int32(0)
+        pen = (C.c_int32 * 2)(1, self.start_mel_token)
+        u = None
+        if uniforms is not None:
+            u = uniforms.to(dev, torch.float64).contiguous()
+            if u.dim() != 3 or u.shape[0] < max_new or u.shape[1] != B or u.shape[2] != 2 * nb:
+                raise ValueError("uniforms must be (>= max_new_tokens, B, 2*num_beams)")
+            u = u[:max_new].contiguous()
+        rc = L.itts_gpt_generate_beam(self._h, _lib.ptr(x), _lib.ptr(pad), B, nb, S, C.byref(gp), pen, 2, _lib.ptr(u),
+                                      _lib.ptr(hist_tok), _lib.ptr(hist_par), _lib.ptr(beam_scores), _lib.ptr(hyps),
+                                      _lib.ptr(n_hyps), _lib.ptr(done), C.byref(n_steps), _lib.ptr(ws), ws.numel(),
+                                      int(self.use_graph), _lib.stream_ptr())
+        _lib.check(rc, "itts_gpt_generate_beam")
+        pm, dm, st = C.c_float(0), C.c_float(0), C.c_int32(0)
+        L.itts_gpt_last_timing(self._h, C.byref(pm), C.byref(dm), C.byref(st))
+        self.last_timing = dict(prefill_ms=pm.value, decode_ms=dm.value, steps=st.value)
+        # ---- BeamSearchScorer.finalize (transformers_beam_search.py:320-408) on the host ----
+        ht, hp = hist_tok.cpu().numpy(), hist_par.cpu().numpy()
+        bs = beam_scores.cpu().numpy()
+        hy_f = hyps.cpu()
+        hy_i = hy_f.view(torch.int32).numpy()
+        hy_s = hy_f.numpy()
+        nh, dn = n_hyps.cpu().numpy(), done.cpu().numpy()
+        steps_run = int(n_steps.value)
+        # the reference loop ends at the first step after which every utterance is done (or at max_length)
+        if dn.all():
+            last = max(int(hy_i[b, q, 1]) for b in range(B) for q in range(int(nh[b])))
+            steps_run = min(steps_run, last + 1)
+
+        def seq_of(row: int, upto: int):
+            toks = []
+            r = row
+            for sidx in range(upto, -1, -1):
+                toks.append(int(ht[sidx, r]))
+                r = int(hp[sidx, r])
+            return toks[::-1]
+
+        stop = self.stop_mel_token
+        best = []
+        for b in range(B):
+            heap = [(float(hy_s[b, q, 0]), seq_of(int(hy_i[b, q, 2]), int(hy_i[b, q, 1]) - 1) if int(hy_i[b, q, 1]) > 0 else [])
+                    for q in range(int(nh[b]))]
+            if not dn[b]:
+                worst = min([h0[0] for h0 in heap], default=1e9) if len(heap) >= nb else 1e9
+                for j in range(nb):                         # open beams join the heap with generated_len = steps
+                    row = b * nb + j
+                    sc = float(bs[row]) / (steps_run ** float(length_penalty))
+                    if len(heap) < nb or sc > worst:
+                        heap.append((sc, seq_of(row, steps_run - 1)))
+                        if len(heap) > nb:
+                            heap.remove(min(heap, key=lambda t: t[0]))
+                        worst = min(t[0] for t in heap)
+            best.append(sorted(heap, key=lambda t: t[0])[-1][1])
+        lens = [len(t) for t in best]
+        sent_max = min(max(lens) + 1, max_new)
+        out = torch.full((B, sent_max), stop, dtype=torch.int64)
+        for b, t in enumerate(best):
+            out[b, : len(t)] = torch.tensor(t[:sent_max], dtype=torch.int64)
+        return out.to(dev)
 
     def inference_speech(self, speech_condition, text_inputs, langs=None, emo_speech_condition=None, cond_lengths=None,
                          emo_cond_lengths=None, emo_vec=None, use_speed=False, campplus_embedding=None, wav=None,

@@ -74,7 +74,9 @@ def run_case(m, z, cfg, sd):
     g = z["gen"]
     kw = dict(do_sample=bool(g[0]), num_beams=int(g[1]), top_p=float(g[2]), top_k=int(g[3]), temperature=float(g[4]),
               repetition_penalty=float(g[5]), length_penalty=float(g[6]))
-    u = torch.from_numpy(z["uniforms"])[..., 0]
+    u = torch.from_numpy(z["uniforms"])
+    if kw["num_beams"] == 1:
+        u = u[..., 0]
     m.post_init_gpt2_config(kv_cache=bool(z["kv_cache"]))
     codes, _ = m.inference_speech(None, torch.from_numpy(z["text"]), langs=torch.from_numpy(z["langs"]),
                                   emo_vec=torch.from_numpy(z["emo_vec"]), campplus_embedding=torch.from_numpy(z["style"]),
@@ -87,6 +89,21 @@ def run_case(m, z, cfg, sd):
 def test_codes_bit_exact_vs_reference_golden(golden_dir, tag, use_graph):
     """f32 engine mode: ids identical to the ids the REFERENCE's own generate() produced (ragged left-padded batch,
     EOS at ragged steps, repetition penalty 10, kv-cache position quirk / no-kv rule, top-k/top-p sampling)."""
+    z, cfg, sd = load_case(golden_dir, tag)
+    m = engine(cfg, sd, "fp32")
+    m.use_graph = use_graph
+    codes = run_case(m, z, cfg, sd)
+    assert codes.shape == z["codes"].shape, (codes.shape, z["codes"].shape)
+    if not np.array_equal(codes, z["codes"]):
+        bad = np.argwhere(codes != z["codes"])
+        pytest.fail(f"first divergence at (row, step) = {bad[0].tolist()}: got {codes[tuple(bad[0])]} want {z['codes'][tuple(bad[0])]}")
+
+
+@pytest.mark.parametrize("tag", ["beam", "beam_sample"])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_beam_codes_bit_exact_vs_reference_golden(golden_dir, tag, use_graph):
+    """Beam search and 3-beam beam-sample (the reference DEFAULT mode, infer_v2_5.py:732-740): device beam step +
+    scorer + KV row map + host finalize reproduce the ids of the reference's own _beam_search/BeamSearchScorer."""
     z, cfg, sd = load_case(golden_dir, tag)
     m = engine(cfg, sd, "fp32")
     m.use_graph = use_graph
