@@ -1,0 +1,355 @@
+"""`IndexTTS2` (v2.5) pipeline class with the reference's constructor / `infer()` / `infer_generator()` signatures,
+with the two hot stages re-routed to the HIP engine.
+
+Reference mirrored: `indextts/infer_v2_5.py::IndexTTS2` (`__init__` :77-279, `infer` :506-567, `infer_generator`
+:570-899).  What changes behind the API:
+  * `self.gpt` is `indextts_amd.gpt.UnifiedVoice` (decode on the HIP engine), `self.bigvgan` is
+    `indextts_amd.bigvgan.BigVGAN`;
+  * all text segments of one call are decoded as ONE left-padded GPT batch and vocoded as ONE ragged BigVGAN batch
+    (the reference loops segment by segment, `:749`); per-segment results are unchanged (padding invariance is a tested
+    property), and `infer_batch()` extends the same to many utterances;
+  * everything that is NOT on the hot path -- audio loading, w2v-bert features, CAMPPlus, the emotion Conformer/Perceiver,
+    text normalisation + tokenizer, semantic codec, s2mel length regulator + CFM -- stays on the reference's PyTorch
+    modules, reached through a `frontend` object.  `ReferenceFrontend` builds them from the reference package + checkpoint
+    directory (needs the reference's `indextts` package, torchaudio, librosa, ... -- none exist in the build/bench
+    images, so that class is exercised only where they do); tests inject a stub with the same methods.
+There is no silent fallback: a missing frontend dependency raises at construction.
+"""
+import os
+import time
+import warnings
+import wave
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+PCM16_MAX = 32767.0
+
+
+def save_pcm_wav(path: str, wav: torch.Tensor, sampling_rate: int):
+    """16-bit PCM WAV writer for a PCM-scale (+-32767) waveform (C, T) -- `indextts/utils/common.py:38-58` semantics
+    (normalise by 32767, clamp to [-1, 1], encode PCM_S16) without the torchaudio dependency."""
+    w = (wav.detach().to("cpu", torch.float32) / PCM16_MAX).clamp_(-1.0, 1.0)
+    pcm = torch.round(w * PCM16_MAX).to(torch.int16).numpy()
+    if pcm.ndim == 1:
+        pcm = pcm[None, :]
+    with wave.open(path, "wb") as f:
+        f.setnchannels(pcm.shape[0])
+        f.setsampwidth(2)
+        f.setframerate(int(sampling_rate))
+        f.writeframes(np.ascontiguousarray(pcm.T).tobytes())
+
+
+class Frontend:
+    """Everything outside the hot path, as the pipeline consumes it.  Shapes follow the reference."""
+
+    def speaker_bundle(self, spk_audio_prompt) -> Dict[str, torch.Tensor]:
+        """-> {style (1,192), spk_cond_emb (1,T,1024), ref_mel (1,80,Tm), prompt_condition (1,Tm,512)}  (:620-667)"""
+        raise NotImplementedError
+
+    def emo_cond(self, emo_audio_prompt) -> torch.Tensor:            # (:682-697)
+        raise NotImplementedError
+
+    def merge_emovec(self, spk_cond_emb, emo_cond_emb, alpha: float) -> torch.Tensor:   # gpt.merge_emovec (:759-765)
+        raise NotImplementedError
+
+    def emo_vector_mix(self, emo_vector, style, use_random: bool):  # (:669-680) -> (emovec_mat (1,D), weight_sum)
+        raise NotImplementedError
+
+    def text_segments(self, text: str, lang: str, max_text_tokens_per_segment: int, text_normalization: bool,
+                      capacity: int) -> List[torch.Tensor]:
+        """normalise, split (split_text_by_tokens :427-464), tokenize `<|lang|> seg`, append the stop id (:699-727)."""
+        raise NotImplementedError
+
+    def lang_id(self, lang: str) -> int:
+        raise NotImplementedError
+
+    def codes_to_mel(self, codes: torch.Tensor, code_lens: torch.Tensor, bundle, duration_factor: float):
+        """semantic_codec.decode -> length_regulator -> cfm.inference -> drop prompt frames (:830-846).
+        -> mel (B, 80, Tmax) f32 and lens (B,) frames."""
+        raise NotImplementedError
+
+
+class IndexTTS2:
+    def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", use_bf16=False, device=None,
+                 use_cuda_kernel=None, use_deepspeed=False, use_accel=False, use_torch_compile=False, use_qwen_emo=False,
+                 *, frontend: Optional[Frontend] = None, gpt=None, bigvgan=None, cfg: Optional[dict] = None):
+        if device is not None:
+            self.device = device
+        elif torch.cuda.is_available():
+            self.device = "cuda:0"
+        else:
+            raise RuntimeError("IndexTTS2 (HIP engine) needs a GPU: there is no CPU path")
+        self.use_bf16 = bool(use_bf16)
+        self.use_cuda_kernel = True            # the HIP kernels are the only implementation
+        self.model_dir = model_dir
+        self.dtype = torch.bfloat16 if self.use_bf16 else None
+        if cfg is None:
+            import yaml
+            with open(cfg_path) as f:
+                cfg = yaml.safe_load(f)
+        self.cfg = cfg
+        gcfg = dict(cfg["gpt"])
+        self.stop_mel_token = gcfg.get("stop_mel_token", 8193)
+        self.model_version = cfg.get("version", None)
+        self.gr_progress = None
+        self.qwen_emo = None
+        if use_qwen_emo:
+            raise NotImplementedError("QwenEmotion (text -> emotion vector) is a prompt-side LLM; run it with the reference "
+                                      "package and pass emo_vector= instead")
+        if gpt is None:
+            from .gpt import UnifiedVoice
+            gpt = UnifiedVoice(**gcfg, spk_cond_mode="campplus", precision="bf16" if self.use_bf16 else "fp32",
+                               device=self.device)
+            ck = torch.load(os.path.join(model_dir, cfg["gpt_checkpoint"]), map_location="cpu")
+            gpt.load_state_dict(ck["model"] if "model" in ck else ck)
+            gpt.post_init_gpt2_config(use_deepspeed=False, kv_cache=True, half=self.use_bf16)
+        self.gpt = gpt
+        if bigvgan is None:
+            from .bigvgan import BigVGAN
+            bigvgan = BigVGAN.from_pretrained(os.path.join(model_dir, "hf_cache", "bigvgan")).to(self.device)
+        self.bigvgan = bigvgan
+        if frontend is None:
+            frontend = ReferenceFrontend(cfg, model_dir, self.device, self.gpt)
+        self.frontend = frontend
+        self.tokenizer = getattr(frontend, "tokenizer", None)
+        # reference cache attributes (:269-279)
+        self.cache_spk_cond = None
+        self.cache_s2mel_style = None
+        self.cache_s2mel_prompt = None
+        self.cache_spk_audio_prompt = None
+        self.cache_emo_cond = None
+        self.cache_emo_audio_prompt = None
+        self.cache_mel = None
+        self._bundle = None
+        self.last_timing = {}
+
+    # ---- helpers mirrored from the reference ---------------------------------------------------------------------
+    def _set_gr_progress(self, value, desc):
+        if self.gr_progress is not None:
+            self.gr_progress(value, desc=desc)
+
+    def interval_silence(self, wavs, sampling_rate=22050, interval_silence=200):
+        if not wavs or interval_silence <= 0:
+            return wavs
+        return torch.zeros(wavs[0].size(0), int(sampling_rate * interval_silence / 1000.0))
+
+    def insert_interval_silence(self, wavs, sampling_rate=22050, interval_silence=200):
+        if not wavs or interval_silence <= 0:
+            return wavs
+        sil = torch.zeros(wavs[0].size(0), int(sampling_rate * interval_silence / 1000.0))
+        out = []
+        for i, w in enumerate(wavs):
+            out.append(w)
+            if i < len(wavs) - 1:
+                out.append(sil)
+        return out
+
+    def trim_codes(self, codes: torch.Tensor):
+        """Stop-token trim (:809-821): per row the length up to the first stop token, batch cut to the longest."""
+        lens = []
+        for code in codes:
+            hit = (code == self.stop_mel_token).nonzero(as_tuple=False)
+            lens.append(int(hit[0, 0]) if hit.numel() > 0 else int(code.numel()))
+        mx = max(lens) if lens else 0
+        return codes[:, :mx], torch.tensor(lens, dtype=torch.long, device=codes.device)
+
+    # ---- conditioning --------------------------------------------------------------------------------------------
+    def _speaker(self, spk_audio_prompt):
+        if self._bundle is None or self.cache_spk_audio_prompt != spk_audio_prompt:
+            self._bundle = self.frontend.speaker_bundle(spk_audio_prompt)
+            self.cache_spk_audio_prompt = spk_audio_prompt
+            self.cache_spk_cond = self._bundle["spk_cond_emb"]
+            self.cache_s2mel_style = self._bundle["style"]
+            self.cache_s2mel_prompt = self._bundle["prompt_condition"]
+            self.cache_mel = self._bundle["ref_mel"]
+        return self._bundle
+
+    def _emotion(self, emo_audio_prompt):
+        if self.cache_emo_cond is None or self.cache_emo_audio_prompt != emo_audio_prompt:
+            self.cache_emo_cond = self.frontend.emo_cond(emo_audio_prompt)
+            self.cache_emo_audio_prompt = emo_audio_prompt
+        return self.cache_emo_cond
+
+    def _emovec(self, bundle, emo_audio_prompt, emo_alpha, emo_vector, use_random):
+        emo_cond_emb = self._emotion(emo_audio_prompt)
+        emovec = self.frontend.merge_emovec(bundle["spk_cond_emb"], emo_cond_emb, emo_alpha)
+        if emo_vector is not None:
+            emovec_mat, wsum = self.frontend.emo_vector_mix(emo_vector, bundle["style"], use_random)
+            emovec = emovec_mat + (1 - wsum) * emovec                 # (:767-769)
+        return emovec
+
+    # ---- API -------------------------------------------------------------------------------------------------------
+    def infer(self, spk_audio_prompt, text, output_path, lang, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None,
+              use_emo_text=False, emo_text=None, use_random=False, interval_silence=200, verbose=False,
+              max_text_tokens_per_segment=120, stream_return=False, more_segment_before=0, duration_factor=1.0,
+              text_normalization=True, **generation_kwargs):
+        gen = self.infer_generator(spk_audio_prompt, text, output_path, lang, emo_audio_prompt, emo_alpha, emo_vector,
+                                   use_emo_text, emo_text, use_random, interval_silence, verbose,
+                                   max_text_tokens_per_segment, stream_return, more_segment_before, duration_factor,
+                                   text_normalization, **generation_kwargs)
+        if stream_return:
+            return gen
+        try:
+            return list(gen)[0]
+        except IndexError:
+            return None
+
+    def infer_generator(self, spk_audio_prompt, text, output_path, lang, emo_audio_prompt=None, emo_alpha=1.0,
+                        emo_vector=None, use_emo_text=False, emo_text=None, use_random=False, interval_silence=200,
+                        verbose=False, max_text_tokens_per_segment=120, stream_return=False, quick_streaming_tokens=0,
+                        duration_factor=1.0, text_normalization=True, **generation_kwargs):
+        start_time = time.perf_counter()
+        self._set_gr_progress(0, "starting inference...")
+        if use_emo_text:
+            raise RuntimeError("use_emo_text=True requires QwenEmotion, but it was not loaded at init "
+                               "(use_qwen_emo=False). Re-construct IndexTTS2 with use_qwen_emo=True.")
+        if emo_vector is not None:
+            emo_audio_prompt = None
+            scale = max(0.0, min(1.0, emo_alpha))
+            if scale != 1.0:
+                emo_vector = [int(x * scale * 10000) / 10000 for x in emo_vector]
+        if emo_audio_prompt is None:
+            emo_audio_prompt, emo_alpha = spk_audio_prompt, 1.0
+        bundle = self._speaker(spk_audio_prompt)
+        emovec = self._emovec(bundle, emo_audio_prompt, emo_alpha, emo_vector, use_random)
+        self._set_gr_progress(0.1, "text processing...")
+        capacity = self.gpt.n_text_pos
+        segments = self.frontend.text_segments(text, lang, max_text_tokens_per_segment, text_normalization, capacity)
+        if not segments:
+            return
+        sr = 22050
+        wavs = self._synthesize(segments, [self.frontend.lang_id(lang)] * len(segments), bundle, emovec, duration_factor,
+                                generation_kwargs, max_text_tokens_per_segment)
+        silence = None
+        if stream_return:
+            for w in wavs:
+                yield w
+                if silence is None:
+                    silence = self.interval_silence(wavs, sampling_rate=sr, interval_silence=interval_silence)
+                yield silence
+        end_time = time.perf_counter()
+        self._set_gr_progress(0.9, "saving audio...")
+        wav = torch.cat(self.insert_interval_silence(wavs, sampling_rate=sr, interval_silence=interval_silence), dim=1)
+        wav_length = wav.shape[-1] / sr
+        t = self.last_timing
+        print(f">> gpt_gen_time: {t.get('gpt', 0):.2f} seconds")
+        print(f">> s2mel_time: {t.get('s2mel', 0):.2f} seconds")
+        print(f">> bigvgan_time: {t.get('bigvgan', 0):.2f} seconds")
+        print(f">> Total inference time: {end_time - start_time:.2f} seconds")
+        print(f">> Generated audio length: {wav_length:.2f} seconds")
+        print(f">> RTF: {(end_time - start_time) / max(wav_length, 1e-9):.4f}")
+        if output_path:
+            if os.path.isfile(output_path):
+                os.remove(output_path)
+            if os.path.dirname(output_path) != "":
+                os.makedirs(os.path.dirname(output_path), exist_ok=True)
+            save_pcm_wav(output_path, wav, sr)
+            if stream_return:
+                return
+            yield output_path
+        else:
+            if stream_return:
+                return
+            yield (sr, wav.type(torch.int16).numpy().T)
+
+    def infer_batch(self, spk_audio_prompt, texts: Sequence[str], lang, emo_audio_prompt=None, emo_alpha=1.0,
+                    interval_silence=200, max_text_tokens_per_segment=120, duration_factor=1.0, text_normalization=True,
+                    **generation_kwargs):
+        """New capability (BASELINE.json configs[1,2]): many utterances of one speaker in one pass.  Every segment of
+        every utterance is a row of one GPT batch / one ragged BigVGAN batch.  Returns a list of (22050, int16 (T,1))."""
+        if emo_audio_prompt is None:
+            emo_audio_prompt, emo_alpha = spk_audio_prompt, 1.0
+        bundle = self._speaker(spk_audio_prompt)
+        emovec = self._emovec(bundle, emo_audio_prompt, emo_alpha, None, False)
+        capacity = self.gpt.n_text_pos
+        seg_tokens, owner = [], []
+        for u, text in enumerate(texts):
+            segs = self.frontend.text_segments(text, lang, max_text_tokens_per_segment, text_normalization, capacity)
+            seg_tokens += segs
+            owner += [u] * len(segs)
+        if not seg_tokens:
+            return [None] * len(texts)
+        wavs = self._synthesize(seg_tokens, [self.frontend.lang_id(lang)] * len(seg_tokens), bundle, emovec,
+                                duration_factor, generation_kwargs, max_text_tokens_per_segment)
+        out = []
+        for u in range(len(texts)):
+            mine = [w for w, o in zip(wavs, owner) if o == u]
+            if not mine:
+                out.append(None)
+                continue
+            wav = torch.cat(self.insert_interval_silence(mine, 22050, interval_silence), dim=1)
+            out.append((22050, wav.type(torch.int16).numpy().T))
+        return out
+
+    # ---- the hot path: one GPT batch, one ragged vocoder batch -------------------------------------------------------
+    def _synthesize(self, segment_tokens: List[torch.Tensor], lang_ids: List[int], bundle, emovec, duration_factor,
+                    generation_kwargs, max_text_tokens_per_segment) -> List[torch.Tensor]:
+        gk = dict(generation_kwargs)
+        gk.pop("do_sample", None)                       # popped and ignored by the reference too (:732,781)
+        top_p, top_k = gk.pop("top_p", 0.8), gk.pop("top_k", 30)
+        temperature = gk.pop("temperature", 0.8)
+        length_penalty = gk.pop("length_penalty", 0.0)
+        num_beams = gk.pop("num_beams", 3)
+        repetition_penalty = gk.pop("repetition_penalty", 10.0)
+        max_mel_tokens = gk.pop("max_mel_tokens", 1500)
+        dev = self.device
+        L = max(int(t.numel()) for t in segment_tokens)
+        text = torch.full((len(segment_tokens), L), 1, dtype=torch.int32)      # stop_text_token right padding (:726)
+        for i, t in enumerate(segment_tokens):
+            text[i, : t.numel()] = t.reshape(-1).to(torch.int32)
+        langs = torch.tensor(lang_ids, dtype=torch.long)
+        t0 = time.perf_counter()
+        codes, _ = self.gpt.inference_speech(bundle["spk_cond_emb"], text.to(dev), langs.to(dev), emo_vec=emovec,
+                                             campplus_embedding=bundle["style"], do_sample=True, top_p=top_p, top_k=top_k,
+                                             temperature=temperature, num_return_sequences=1, length_penalty=length_penalty,
+                                             num_beams=num_beams, repetition_penalty=repetition_penalty,
+                                             max_generate_length=max_mel_tokens, **gk)
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        t1 = time.perf_counter()
+        if codes.shape[1] > 0 and (codes[:, -1] != self.stop_mel_token).any():
+            warnings.warn(f"WARN: generation stopped due to exceeding `max_mel_tokens` ({max_mel_tokens}). "
+                          f"Consider reducing `max_text_tokens_per_segment`({max_text_tokens_per_segment}) or increasing "
+                          f"`max_mel_tokens`.", category=RuntimeWarning)
+        codes, code_lens = self.trim_codes(codes)
+        mel, mel_lens = self.frontend.codes_to_mel(codes, code_lens, bundle, duration_factor)
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        t2 = time.perf_counter()
+        wav = self.bigvgan(mel.float(), lens=mel_lens)                      # (B, 1, Tmax*256), rows bounded at own length
+        wav = torch.clamp(PCM16_MAX * wav, -PCM16_MAX, PCM16_MAX)           # (:855)
+        up = self.bigvgan.total_up
+        out = [wav[i, :, : int(mel_lens[i]) * up].cpu() for i in range(wav.shape[0])]
+        t3 = time.perf_counter()
+        self.last_timing = dict(gpt=t1 - t0, s2mel=t2 - t1, bigvgan=t3 - t2)
+        return out
+
+
+class ReferenceFrontend(Frontend):
+    """Prompt / text / s2mel stages on the reference's own PyTorch modules (lazy imports; needs the reference package,
+    its third-party dependencies and the checkpoint directory).  Mirrors `indextts/infer_v2_5.py:169-266` (loading) and
+    the call sequences cited per method."""
+
+    def __init__(self, cfg, model_dir, device, gpt_engine):
+        try:
+            import librosa  # noqa: F401
+            import torchaudio  # noqa: F401
+            from indextts.gpt.model_v2 import UnifiedVoice as RefUnifiedVoice
+            from indextts.s2mel.modules.commons import MyModel, load_checkpoint2
+            from indextts.s2mel.modules.audio import mel_spectrogram
+            from indextts.s2mel.modules.campplus.DTDNN import CAMPPlus
+            from indextts.codec.models import EnhancedCodec
+            from indextts.utils.tokenizer import lang_to_token, get_tokenizer
+            from indextts.utils.front import TextNormalizer
+            from transformers import SeamlessM4TFeatureExtractor, Wav2Vec2BertModel
+        except Exception as e:                                   # loud: there is no fallback
+            raise RuntimeError("ReferenceFrontend needs the reference `indextts` package and its prompt-side dependencies "
+                               f"(torchaudio, librosa, ...): {e!r}.  Inject frontend= instead.") from e
+        self._mods = dict(RefUnifiedVoice=RefUnifiedVoice, MyModel=MyModel, load_checkpoint2=load_checkpoint2,
+                          mel_spectrogram=mel_spectrogram, CAMPPlus=CAMPPlus, EnhancedCodec=EnhancedCodec,
+                          lang_to_token=lang_to_token, get_tokenizer=get_tokenizer, TextNormalizer=TextNormalizer,
+                          SeamlessM4TFeatureExtractor=SeamlessM4TFeatureExtractor, Wav2Vec2BertModel=Wav2Vec2BertModel)
+        self.cfg, self.model_dir, self.device = cfg, model_dir, device
+        raise NotImplementedError(
+            "ReferenceFrontend wiring is exercised only where the reference package + checkpoints exist; "
+            "this build image has neither (SURVEY.md header).  See INTEGRATION.md for the call sequence; inject frontend=.")

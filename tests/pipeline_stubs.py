@@ -1,0 +1,58 @@
+"""Stub frontend for the IndexTTS2 pipeline tests: deterministic tiny stand-ins for the PyTorch-side stages
+(the reference tests inject a fake backend the same way: cli_tests/test_cli_v2_batch.py:574-599)."""
+import torch
+
+from indextts_amd.infer_v2_5 import Frontend
+
+
+class StubFrontend(Frontend):
+    def __init__(self, model_dim, n_text=200, device="cpu", n_mels=80):
+        self.D, self.n_text, self.device, self.n_mels = model_dim, n_text, device, n_mels
+        g = torch.Generator().manual_seed(0)
+        self.style = torch.randn(1, 192, generator=g)
+        self.emo = torch.randn(1, model_dim, generator=g) * 0.1
+        self.codebook = torch.randn(8194, n_mels, generator=g)
+        self.calls = []
+
+    def speaker_bundle(self, spk_audio_prompt):
+        self.calls.append(("speaker", spk_audio_prompt))
+        return dict(style=self.style.to(self.device), spk_cond_emb=torch.zeros(1, 4, 1024, device=self.device),
+                    ref_mel=torch.zeros(1, self.n_mels, 5, device=self.device),
+                    prompt_condition=torch.zeros(1, 5, 512, device=self.device))
+
+    def emo_cond(self, emo_audio_prompt):
+        self.calls.append(("emo", emo_audio_prompt))
+        return torch.zeros(1, 4, 1024, device=self.device)
+
+    def merge_emovec(self, spk_cond_emb, emo_cond_emb, alpha):
+        return (self.emo * float(alpha)).to(self.device)
+
+    def emo_vector_mix(self, emo_vector, style, use_random):
+        w = torch.tensor(emo_vector, dtype=torch.float32)
+        return torch.ones(1, self.D, device=self.device) * float(w.sum()) * 0.01, float(w.sum())
+
+    def text_segments(self, text, lang, max_text_tokens_per_segment, text_normalization, capacity):
+        # one segment per sentence; token = 2 + (ord % (n_text-2)); trailing stop id like F.pad(..., value=1)
+        segs = [s for s in text.split(".") if s.strip()]
+        out = []
+        for s in segs:
+            ids = [2 + (ord(ch) % (self.n_text - 2)) for ch in s.strip()][: max_text_tokens_per_segment]
+            out.append(torch.tensor(ids + [1], dtype=torch.int32))
+        return out
+
+    def lang_id(self, lang):
+        return 3
+
+    def codes_to_mel(self, codes, code_lens, bundle, duration_factor):
+        # "s2mel": 2 frames per code from a fixed codebook (keeps mel length proportional to code length)
+        B = codes.shape[0]
+        lens = (code_lens * 2 * duration_factor).long().clamp(min=1)
+        T = int(lens.max())
+        mel = torch.zeros(B, self.n_mels, T, device=codes.device)
+        cb = self.codebook.to(codes.device)
+        for b in range(B):
+            n = int(code_lens[b])
+            if n > 0:
+                m = cb[codes[b, :n].clamp(0, 8193)].repeat_interleave(2, dim=0)[: int(lens[b])]
+                mel[b, :, : m.shape[0]] = m.t() - 4.0
+        return mel, lens.to(torch.int32)

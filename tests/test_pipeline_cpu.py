@@ -1,0 +1,100 @@
+"""CPU control-flow tests of the IndexTTS2 boundary class with fake engines (no GPU): segment batching, stop-token trim,
+silence insertion, return formats, WAV writer."""
+import os
+import wave
+
+import numpy as np
+import torch
+
+from indextts_amd.infer_v2_5 import IndexTTS2, save_pcm_wav
+from tests.pipeline_stubs import StubFrontend
+
+
+class FakeGPT:
+    n_text_pos = 42
+
+    def __init__(self):
+        self.calls = []
+
+    def inference_speech(self, cond, text, langs, **kw):
+        self.calls.append((text.clone(), kw))
+        B = text.shape[0]
+        codes = torch.full((B, 9), 8193, dtype=torch.long)
+        for b in range(B):
+            n = 3 + int((text[b] != 1).sum()) % 5          # 3..7 codes then stop tokens
+            codes[b, :n] = torch.arange(10 * b, 10 * b + n)
+        return codes, None
+
+
+class FakeVoc:
+    total_up = 256
+
+    def __call__(self, mel, lens=None):
+        B, _, T = mel.shape
+        w = torch.zeros(B, 1, T * 256)
+        for b in range(B):
+            w[b, :, : int(lens[b]) * 256] = 0.5 + 0.01 * b
+        return w
+
+
+def make(tmp=None):
+    fe = StubFrontend(64)
+    tts = IndexTTS2(cfg={"gpt": {"stop_mel_token": 8193}}, device="cpu", frontend=fe, gpt=FakeGPT(), bigvgan=FakeVoc())
+    return tts, fe
+
+
+def test_infer_batches_segments_and_returns_gradio_tuple():
+    tts, fe = make()
+    sr, wav = tts.infer("spk.wav", "hello there. how are you. fine", None, "en", num_beams=1, top_k=1)
+    assert sr == 22050 and wav.dtype == np.int16 and wav.ndim == 2 and wav.shape[1] == 1
+    assert len(tts.gpt.calls) == 1 and tts.gpt.calls[0][0].shape[0] == 3            # one GPT batch for 3 segments
+    kw = tts.gpt.calls[0][1]
+    assert kw["do_sample"] is True and kw["num_beams"] == 1 and kw["top_k"] == 1 and kw["repetition_penalty"] == 10.0
+    assert kw["max_generate_length"] == 1500 and kw["length_penalty"] == 0.0 and kw["temperature"] == 0.8
+    sil = int(22050 * 0.2)
+    text = tts.gpt.calls[0][0]
+    n_codes = [3 + int((text[b] != 1).sum()) % 5 for b in range(3)]
+    expect = sum(2 * n * 256 for n in n_codes) + 2 * sil
+    assert wav.shape[0] == expect
+    assert abs(int(wav[10, 0]) - int(0.5 * 32767)) <= 1                              # clamp(32767*wav) scaling
+    # speaker conditioning cached by path (:620)
+    tts.infer("spk.wav", "again", None, "en")
+    assert [c for c in fe.calls if c[0] == "speaker"] == [("speaker", "spk.wav")]
+    tts.infer("other.wav", "again", None, "en")
+    assert len([c for c in fe.calls if c[0] == "speaker"]) == 2
+
+
+def test_infer_writes_wav_and_stream_return(tmp_path):
+    tts, _ = make()
+    out = str(tmp_path / "sub" / "o.wav")
+    assert tts.infer("spk.wav", "one. two", out, "en") == out
+    with wave.open(out) as f:
+        assert f.getframerate() == 22050 and f.getsampwidth() == 2 and f.getnchannels() == 1 and f.getnframes() > 0
+    chunks = list(tts.infer("spk.wav", "one. two", None, "en", stream_return=True))
+    assert len(chunks) == 4 and chunks[1].shape[1] == int(22050 * 0.2)               # wav, silence, wav, silence
+    assert tts.infer("spk.wav", " . ", None, "en") is None                             # empty text -> None (:566-567)
+
+
+def test_infer_batch_groups_utterances():
+    tts, _ = make()
+    res = tts.infer_batch("spk.wav", ["a. b", "c", "d. e. f"], "en", num_beams=1)
+    assert len(res) == 3 and all(r[0] == 22050 for r in res)
+    assert tts.gpt.calls[-1][0].shape[0] == 6
+
+
+def test_trim_codes_and_emo_vector_path():
+    tts, _ = make()
+    codes = torch.tensor([[5, 6, 8193, 8193], [7, 8, 9, 10], [8193, 1, 2, 3]])
+    c, lens = tts.trim_codes(codes)
+    assert lens.tolist() == [2, 4, 0] and c.shape == (3, 4)
+    tts.infer("spk.wav", "x", None, "en", emo_vector=[0.5, 0, 0, 0, 0, 0, 0, 0], emo_alpha=0.5)
+
+
+def test_save_pcm_wav_roundtrip(tmp_path):
+    """tests/test_audio_save.py of the reference pins the 16-bit PCM writer semantics."""
+    wav = torch.tensor([[0.0, 32767.0, -32767.0, 16383.5, 40000.0]])
+    p = str(tmp_path / "x.wav")
+    save_pcm_wav(p, wav, 22050)
+    with wave.open(p) as f:
+        data = np.frombuffer(f.readframes(5), dtype=np.int16)
+    assert data.tolist()[:3] == [0, 32767, -32767] and data[4] == 32767 and abs(int(data[3]) - 16384) <= 1
