@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
                 const int kbc = ok ? kbi : kb0;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    uint4 v = wp[nt][(size_t)kbc * 64];
+                    uint4 v = (a.ablate & 2) ? uint4{1u, 2u, 3u, 4u} : wp[nt][(size_t)kbc * 64];
                     if (!ok) v = uint4{0u, 0u, 0u, 0u};
                     bq[i][nt] = v;
                 }
@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
                 const int kbi = kb0 + i * kb_step;
                 const int kbc = kbi < kb_hi ? kbi : kb0;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) aq[i][mt] = *(const uint4*)(arow[mt] + (size_t)kbc * KB * ESZ);
+                for (int mt = 0; mt < MT; ++mt)
+                    aq[i][mt] = (a.ablate & 1) ? uint4{5u, 6u, 7u, 8u} : *(const uint4*)(arow[mt] + (size_t)kbc * KB * ESZ);
             }
             // keep the scheduler from sinking the loads between the MFMAs (it would re-serialise them behind
             // vmcnt(0) waits to save registers): every load above is issued before the first MFMA below
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
                 s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
             }
             const int mt = tile / NT, nt = tile - mt * NT;
+            if ((a.ablate & 4) && s[0] != 12345.678f) continue;
             if ((nt0 + nt) < ntiles) gemm_epilogue<BF16>(a, m0 + mt * 16, (nt0 + nt) * 16, lane, z, s);
         }
     } else {
@@ -461,6 +463,36 @@ __device__ __forceinline__ double rng_uniform(unsigned long long seed, unsigned 
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// Radix-select bucket pick by one wave: hist[256] counts, find the highest byte value b with
+// count(bins > b) < kk <= count(bins >= b); returns b and writes the count of strictly higher bins to *above.
+__device__ __forceinline__ int pick_bucket_wave(const unsigned* hist, unsigned kk, int lane, unsigned* above) {
+    const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    unsigned suf = h0 + h1 + h2 + h3;                    // becomes the inclusive suffix sum over lanes >= lane
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += v;
+    }
+    const unsigned long long m = __ballot(suf >= kk);    // lanes whose suffix reaches kk; the highest one holds the bucket
+    const int sel = 63 - __builtin_clzll(m | 1ull);
+    unsigned higher = __shfl_down(suf, 1, 64);
+    if (lane == 63) higher = 0;                          // count in lanes strictly above
+    int b = 0;
+    unsigned ab = 0;
+    if (lane == sel) {
+        unsigned cum = higher;
+        if (cum + h3 >= kk) { b = 4 * lane + 3; ab = cum; }
+        else { cum += h3;
+            if (cum + h2 >= kk) { b = 4 * lane + 2; ab = cum; }
+            else { cum += h2;
+                if (cum + h1 >= kk) { b = 4 * lane + 1; ab = cum; }
+                else { cum += h1; b = 4 * lane; ab = cum; } } }
+    }
+    b = __shfl(b, sel, 64);
+    *above = __shfl(ab, sel, 64);
+    return b;
+}
+
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     extern __shared__ float sl[];                    // [V] processed scores
     __shared__ unsigned hist[256];
@@ -518,16 +550,14 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned cum = 0, kk = s_kk;
-                int bsel = 0;
-                for (int bb = 255; bb >= 0; --bb) {
-                    if (cum + hist[bb] >= kk) { bsel = bb; break; }
-                    cum += hist[bb];
+            if (tid < 64) {
+                unsigned above;
+                const int bsel = pick_bucket_wave(hist, s_kk, tid, &above);
+                if (tid == 0) {
+                    s_prefix = prefix | ((unsigned)bsel << shift);
+                    s_mask = mask | (255u << shift);
+                    s_kk = s_kk - above;
                 }
-                s_prefix = prefix | ((unsigned)bsel << shift);
-                s_mask = mask | (255u << shift);
-                s_kk = kk - cum;
             }
             __syncthreads();
         }
@@ -539,18 +569,23 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             }
         }
         __syncthreads();
+        {   // parallel rank sort of the survivors, ascending by (value, index), and their exponentials
+            const int n = (int)(s_count < SAMPLE_CAP ? s_count : SAMPLE_CAP);
+            float myv = 0.f; int myi = 0, rank = 0;
+            if (tid < n) {
+                myv = cand_v[tid]; myi = cand_i[tid];
+                for (int j = 0; j < n; ++j) {
+                    const float vj = cand_v[j]; const int ij = cand_i[j];
+                    rank += (vj < myv || (vj == myv && ij < myi)) ? 1 : 0;
+                }
+            }
+            __syncthreads();
+            if (tid < n) { cand_v[rank] = myv; cand_i[rank] = myi; }
+            __syncthreads();
+        }
         if (tid == 0) {
             int n = (int)(s_count < SAMPLE_CAP ? s_count : SAMPLE_CAP);
-            // sort ascending by (value, index)
-            for (int i = 1; i < n; ++i) {
-                const float v = cand_v[i];
-                const int ix = cand_i[i];
-                int j = i - 1;
-                while (j >= 0 && (cand_v[j] > v || (cand_v[j] == v && cand_i[j] > ix))) {
-                    cand_v[j + 1] = cand_v[j]; cand_i[j + 1] = cand_i[j]; --j;
-                }
-                cand_v[j + 1] = v; cand_i[j + 1] = ix;
-            }
+            // (sorted ascending by (value, index) above)
             int lo = 0;                                   // first kept element after top-p
             if (a.top_p < 1.0f) {
                 const float mx = cand_v[n - 1];
