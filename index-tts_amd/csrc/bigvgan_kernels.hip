@@ -16,6 +16,7 @@
 //   * Every kernel takes per-row lengths so a ragged batch gives the B=1 result for each row: zero padding for
 //     convs, replicate padding for the activation at the row's OWN end (ragged batches).
 #include "bigvgan_kernels.h"
+#include <stdlib.h>
 
 #define AA_TILE 1024
 
@@ -78,6 +79,102 @@ __global__ __launch_bounds__(256) void aa_act_kernel(const float* __restrict__ x
 #pragma unroll
         for (int j = 0; j < 12; ++j) acc = fmaf(fds[j], vs[2 * i + j + 1], acc);
         yr[t0 + i] = acc;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// Register-tiled version of the same activation (the one launched): each thread owns 4 outputs = 8 consecutive
+// 2x-rate samples; it reads its 10 input samples from LDS once (instead of 6 per 2x-rate sample), keeps the 8
+// snake values in registers, shares them through LDS, and reads only the 11 neighbour values it does not own.
+// LDS traffic per output drops from ~27 to ~7 dwords.  sin: two-term Cody-Waite reduction by 2*pi followed by the
+// hardware v_sin_f32 (FAST_SIN, absolute error vs sinf measured in tests/test_gpu_bigvgan.py) or libm sinf.
+// --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sin_reduced(float x) {
+    const float inv2pi = 0.15915494309189535f;
+    const float k = rintf(x * inv2pi);
+    float r = fmaf(-k, 6.2831855f, x);            // 2*pi rounded to f32
+    r = fmaf(-k, -1.7484555e-7f, r);              // 2*pi - f32(2*pi)
+    return __builtin_amdgcn_sinf(r * inv2pi);     // v_sin_f32: sin(2*pi*arg), arg in [-0.5, 0.5]
+}
+
+template <bool FAST_SIN>
+__global__ __launch_bounds__(256) void aa_act_kernel_v2(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                        const float* __restrict__ fu, const float* __restrict__ fd,
+                                                        int C, int T, const int* __restrict__ lens, int len_mult,
+                                                        int logscale) {
+    __shared__ __attribute__((aligned(16))) float xs[AA_TILE + 16];
+    __shared__ __attribute__((aligned(16))) float vs[2 * AA_TILE + 32];
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int t0 = blockIdx.x * AA_TILE;
+    const int len = lens ? min(lens[b] * len_mult, T) : T;
+    if (t0 >= len) return;
+    const int tid = threadIdx.x;
+    const float* xr = x + ((size_t)b * C + c) * T;
+    float* yr = y + ((size_t)b * C + c) * T;
+    float fus[12], fds[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { fus[j] = 2.0f * fu[j]; fds[j] = fd[j]; }     // fold the x2 up-sampling gain
+    float a_e = alpha[c], b_e = beta[c];
+    if (logscale) { a_e = expf(a_e); b_e = expf(b_e); }
+    const float inv_b = 1.0f / (b_e + 1e-9f);
+    const int n_out = min(AA_TILE, len - t0);
+    // x window: xs[i] = x[clamp(t0 - 6 + i)], i in [0, AA_TILE + 12)   (always fill the whole window: clamped reads)
+    for (int i = tid; i < AA_TILE + 12; i += 256) {
+        int t = t0 - 6 + i;
+        t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
+        xs[i] = xr[t];
+    }
+    __syncthreads();
+    // 2x-rate window: vs[vi] <-> i = 2*t0 - 6 + vi.  Thread owns vi = 8*tid .. 8*tid+7; threads 0..1 also the 12-entry tail.
+    auto snake8 = [&](int vb, float* v) {
+        float xw[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) xw[j] = xs[(vb >> 1) + j];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {            // q = q0 + p ; xw[p + 3] = x[q]
+            float ue = 0.f, uo = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                ue = fmaf(fus[1 + 2 * j], xw[p + 5 - j], ue);     // x[q + 2 - j]
+                uo = fmaf(fus[2 * j], xw[p + 6 - j], uo);         // x[q + 3 - j]
+            }
+            const float se = FAST_SIN ? sin_reduced(ue * a_e) : sinf(ue * a_e);
+            const float so = FAST_SIN ? sin_reduced(uo * a_e) : sinf(uo * a_e);
+            v[2 * p] = fmaf(inv_b * se, se, ue);
+            v[2 * p + 1] = fmaf(inv_b * so, so, uo);
+        }
+    };
+    float v[8];
+    snake8(8 * tid, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vs[8 * tid + j] = v[j];
+    if (tid < 2) {                               // tail: vi = 2048 .. 2063 (only the first 12 are used)
+        float vt[8];
+        snake8(2 * AA_TILE + 8 * tid, vt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vs[2 * AA_TILE + 8 * tid + j] = vt[j];
+    }
+    __syncthreads();
+    // replicate padding at the 2x rate (5 left / 6 right): entries outside [0, 2*len-1] take the edge value
+    if (t0 == 0 && tid < 6) vs[tid] = vs[6];
+    const int vi_end = (2 * len - 1) - (2 * t0 - 6);          // window index of the last real 2x-rate sample
+    if (vi_end < 2 * AA_TILE + 12 - 1) {
+        const int vi = vi_end + 1 + tid;
+        if (tid < 8 && vi < 2 * AA_TILE + 16) vs[vi] = vs[vi_end];
+    }
+    __syncthreads();
+    // outputs 4*tid .. 4*tid+3: y[t] = sum_j fd[j] * vs[2*(t - t0) + j + 1]
+    float vw[19];
+#pragma unroll
+    for (int j = 0; j < 19; ++j) vw[j] = vs[8 * tid + j];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = 4 * tid + p;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc = fmaf(fds[j], vw[2 * p + j + 1], acc);
+        if (i < n_out) yr[t0 + i] = acc;
     }
 }
 
@@ -330,7 +427,10 @@ int launch_aa_act(const float* x, float* y, const float* alpha, const float* bet
                   int B, int C, int T, const int* lens, int len_mult, int logscale, hipStream_t st) {
     if (B <= 0 || C <= 0 || T <= 0) return ITTS_OK;
     dim3 grid(ceil_div(T, AA_TILE), C, B);
-    hipLaunchKernelGGL(aa_act_kernel, grid, dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
+    static const int mode = [] { const char* e = getenv("ITTS_AA_ACT"); return e ? atoi(e) : 2; }();   // 0 v1, 1 v2 + sinf, 2 v2 + v_sin
+    if (mode == 0) hipLaunchKernelGGL(aa_act_kernel, grid, dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
+    else if (mode == 1) hipLaunchKernelGGL(aa_act_kernel_v2<false>, grid, dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
+    else hipLaunchKernelGGL(aa_act_kernel_v2<true>, grid, dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }

@@ -694,7 +694,7 @@ extern "C" int itts_gemm_forward(const void* A, const void* Wp, const float* bia
     GemmArgs g{};
     g.A = A; g.lda = K; g.Wp = Wp; g.bias = bias; g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.D = N;
     g.epi = EPI_STORE_F32; g.out_f32 = out; g.ldo = N;
-    g.ablate = gelu;      // diagnostics: ablation mask (tools/gemm_ablate.py); 0 in every product call
+    (void)gelu;
     return launch_gemm(g, precision, prefill_tiles != 0, (hipStream_t)stream);
 }
 

@@ -35,7 +35,6 @@ struct GemmArgs {
     // EPI_QKV: n < D -> qbuf[m][n]; D <= n < 2D -> K cache; else V cache, at cache position *pos_ptr + (m % S)
     float* qbuf; void* kcache; void* vcache;
     const int* pos_ptr; int S, H, Tmax, D;
-    int ablate;                      // diagnostics only: 1 skip A loads, 2 skip W loads, 4 skip the epilogue
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);
 

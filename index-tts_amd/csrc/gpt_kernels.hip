@@ -17,6 +17,7 @@
 #include "gpt_kernels.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));   // native vector (HIP's uint4 struct defeats SROA in loops)
 
 // ================================================================================================================
 // LayerNorm (+ fused split-K reduce, bias, residual write-back, optional second LayerNorm)
@@ -192,16 +193,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
         m = m < a.M ? m : a.M - 1;
         arow[mt] = (const char*)a.A + ((size_t)m * a.lda + (lane >> 4) * (KB / 4)) * ESZ;
     }
-    const uint4* wp[NT];
+    const v4u* wp[NT];
     bool nt_ok[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         nt_ok[nt] = (nt0 + nt) < ntiles;
         const int t = nt_ok[nt] ? nt0 + nt : ntiles - 1;
-        wp[nt] = (const uint4*)a.Wp + (size_t)t * nkb * 64 + lane;
+        wp[nt] = (const v4u*)a.Wp + (size_t)t * nkb * 64 + lane;
     }
 
-    auto mfma_step = [&](const uint4 (&af)[MT], const uint4 (&bfr)[NT]) {
+    auto mfma_step = [&](const v4u (&af)[MT], const v4u (&bfr)[NT]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -219,45 +220,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
     };
 
     if constexpr (KSPLIT) {
-        // Decode (weight streaming, one block-wave on the chip): a wave's whole K range is only ~10 k-blocks, so the
-        // loop is latency-, not bandwidth-bound unless every HBM load of the range is in flight at once.  Issue all
-        // PF weight-fragment loads (and the matching L2-resident activation fragments) before the first MFMA; k-blocks
-        // past the range are clamped to a valid address and their B fragment zeroed, so the code is branch-free.
-        constexpr int PF = 10;
-        for (int kb0 = kb_start; kb0 < kb_hi; kb0 += PF * kb_step) {
-            uint4 bq[PF][NT], aq[PF][MT];
+        // Decode (weight streaming).  Measured with ablations (tools/gemm_ablate.py): the HBM weight stream is NOT
+        // the bottleneck at M = 64, the activation operand is -- fragment-shaped loads (16 rows x 64 B per wave
+        // instruction) straight from L2 cost 4-17 us per GEMM.  So the block stages its activation slab through LDS
+        // in full 1280-byte row segments (coalesced 16 B per lane, 8 full lines per wave instruction), 20 k-blocks
+        // (one 1280-byte segment per row) at a time, and the waves read their A fragments with ds_read_b128
+        // (row stride padded by 16 B: the 16 rows of a fragment hit 16 distinct 4-bank groups).  All weight fragments of
+        // a 40-k-block super-chunk are issued up front so the HBM latency overlaps the staging.
+        constexpr int CH = 20;                        // k-blocks per staged chunk: CH * 64 B = 1280 B per row
+        constexpr int ROWB = CH * 64 + 16;            // padded LDS row stride in bytes
+        constexpr int ROWS = MT * 16;
+        constexpr int NLD = ROWS * (CH * 4) / 256;    // 16-byte pieces per thread per chunk (5 * MT)
+        char* lds_a = (char*)red + (size_t)4 * MT * NT * 64 * 16;     // behind the reduction scratch
+        const char* abase = (const char*)a.A;
+        const size_t lda_b = (size_t)a.lda * ESZ;
+        auto load_b5 = [&](int cb, v4u (&bq)[5][NT]) {       // this wave's 5 k-blocks of the chunk starting at cb
 #pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                const int kbi = kb0 + i * kb_step;
+            for (int i = 0; i < 5; ++i) {
+                const int kbi = cb + w + 4 * i;
                 const bool ok = kbi < kb_hi;
-                const int kbc = ok ? kbi : kb0;
+                const int kbc = ok ? kbi : kb_lo;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    uint4 v = (a.ablate & 2) ? uint4{1u, 2u, 3u, 4u} : wp[nt][(size_t)kbc * 64];
-                    if (!ok) v = uint4{0u, 0u, 0u, 0u};
+                    v4u v = wp[nt][(size_t)kbc * 64];
+                    if (!ok) v = v4u{0u, 0u, 0u, 0u};
                     bq[i][nt] = v;
                 }
             }
+        };
+        auto stage = [&](int cb) {                    // activation rows [m0, m0 + ROWS) x k-blocks [cb, cb + CH) -> LDS
+            v4u st[NLD];
 #pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                const int kbi = kb0 + i * kb_step;
-                const int kbc = kbi < kb_hi ? kbi : kb0;
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = threadIdx.x + 256 * i;
+                const int row = idx / (CH * 4), piece = idx - row * (CH * 4);
+                int m = m0 + row;
+                m = m < a.M ? m : a.M - 1;
+                long long kbyte = ((long long)cb * KB) * ESZ + piece * 16;          // byte offset within the row
+                const long long kmax = (long long)a.K * ESZ - 16;
+                kbyte = kbyte < kmax ? kbyte : kmax;                                 // tail chunk: clamp (unused k)
+                st[i] = *(const v4u*)(abase + (size_t)m * lda_b + kbyte);
+            }
+            __syncthreads();                          // previous chunk's fragments consumed
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = threadIdx.x + 256 * i;
+                const int row = idx / (CH * 4), piece = idx - row * (CH * 4);
+                *(v4u*)(lds_a + row * ROWB + piece * 16) = st[i];
+            }
+            __syncthreads();
+        };
+        auto compute = [&](const v4u (&bq)[5][NT]) {
+#pragma unroll
+            for (int i5 = 0; i5 < 5; ++i5) {
+                const int kl = w + 4 * i5;            // k-block within the chunk
+                v4u af[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    aq[i][mt] = (a.ablate & 1) ? uint4{5u, 6u, 7u, 8u} : *(const uint4*)(arow[mt] + (size_t)kbc * KB * ESZ);
+                    af[mt] = *(const v4u*)(lds_a + (mt * 16 + (lane & 15)) * ROWB + kl * 64 + (lane >> 4) * 16);
+                mfma_step(af, bq[i5]);
             }
-            // keep the scheduler from sinking the loads between the MFMAs (it would re-serialise them behind
-            // vmcnt(0) waits to save registers): every load above is issued before the first MFMA below
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < PF; ++i) mfma_step(aq[i], bq[i]);
+        };
+#pragma unroll 1
+        for (int sc0 = kb_lo; sc0 < kb_hi; sc0 += 2 * CH) {
+            v4u bq0[5][NT], bq1[5][NT];
+            load_b5(sc0, bq0);                        // HBM weight stream of the first half: in flight during staging
+            stage(sc0);
+            __builtin_amdgcn_sched_barrier(0);        // keep the second half's loads below the staging (register budget)
+            load_b5(sc0 + CH, bq1);                   // second half: in flight during the first half's MFMAs + staging
+            compute(bq0);
+            if (sc0 + CH < kb_hi) {                   // block-uniform
+                stage(sc0 + CH);
+                compute(bq1);
+            }
         }
     } else {
 #pragma unroll 2
         for (int kb = kb_start; kb < kb_hi; kb += kb_step) {
-            uint4 af[MT], bfr[NT];
+            v4u af[MT], bfr[NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = *(const uint4*)(arow[mt] + (size_t)kb * KB * ESZ);
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *(const v4u*)(arow[mt] + (size_t)kb * KB * ESZ);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bfr[nt] = wp[nt][(size_t)kb * 64];
             mfma_step(af, bfr);
@@ -279,7 +321,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
                 s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
             }
             const int mt = tile / NT, nt = tile - mt * NT;
-            if ((a.ablate & 4) && s[0] != 12345.678f) continue;
             if ((nt0 + nt) < ntiles) gemm_epilogue<BF16>(a, m0 + mt * 16, (nt0 + nt) * 16, lane, z, s);
         }
     } else {
@@ -296,7 +337,7 @@ static int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
     const int ntiles = (a.N + 15) / 16;
     const int per_block = KSPLIT ? NT : 4 * NT;
     dim3 grid(ceil_div(ntiles, per_block), ceil_div(a.M, MT * 16), a.nsplit);
-    const size_t lds = KSPLIT ? (size_t)4 * MT * NT * 64 * 16 : 0;
+    const size_t lds = KSPLIT ? (size_t)4 * MT * NT * 64 * 16 + (size_t)MT * 16 * (20 * 64 + 16) : 0;
     hipLaunchKernelGGL((gemm_kernel<BF16, MT, NT, KSPLIT>), grid, dim3(256), lds, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
