@@ -97,16 +97,17 @@ __device__ __forceinline__ float sin_reduced(float x) {
     return __builtin_amdgcn_sinf(r * inv2pi);     // v_sin_f32: sin(2*pi*arg), arg in [-0.5, 0.5]
 }
 
-template <bool FAST_SIN>
+template <int OPT, bool FAST_SIN>     // OPT = outputs per thread (4 or 8); tile = 256 * OPT outputs per block
 __global__ __launch_bounds__(256) void aa_act_kernel_v2(const float* __restrict__ x, float* __restrict__ y,
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
                                                         const float* __restrict__ fu, const float* __restrict__ fd,
                                                         int C, int T, const int* __restrict__ lens, int len_mult,
                                                         int logscale) {
-    __shared__ __attribute__((aligned(16))) float xs[AA_TILE + 16];
-    __shared__ __attribute__((aligned(16))) float vs[2 * AA_TILE + 32];
+    constexpr int TILE = 256 * OPT;
+    __shared__ __attribute__((aligned(16))) float xs[TILE + 16];
+    __shared__ __attribute__((aligned(16))) float vs[2 * TILE + 32];
     const int b = blockIdx.z, c = blockIdx.y;
-    const int t0 = blockIdx.x * AA_TILE;
+    const int t0 = blockIdx.x * TILE;
     const int len = lens ? min(lens[b] * len_mult, T) : T;
     if (t0 >= len) return;
     const int tid = threadIdx.x;
@@ -118,15 +119,20 @@ __global__ __launch_bounds__(256) void aa_act_kernel_v2(const float* __restrict_
     float a_e = alpha[c], b_e = beta[c];
     if (logscale) { a_e = expf(a_e); b_e = expf(b_e); }
     const float inv_b = 1.0f / (b_e + 1e-9f);
-    const int n_out = min(AA_TILE, len - t0);
-    // x window: xs[i] = x[clamp(t0 - 6 + i)], i in [0, AA_TILE + 12)   (always fill the whole window: clamped reads)
-    for (int i = tid; i < AA_TILE + 12; i += 256) {
-        int t = t0 - 6 + i;
+    const int n_out = min(TILE, len - t0);
+    // x window: xs[i] = x[clamp(t0 - 6 + i)], i in [0, TILE + 12): unconditional clamped loads, all in flight at once
+    float xl[OPT + 1];
+#pragma unroll
+    for (int k = 0; k < OPT + 1; ++k) {
+        int t = t0 - 6 + tid + 256 * k;
         t = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
-        xs[i] = xr[t];
+        xl[k] = xr[t];
     }
+#pragma unroll
+    for (int k = 0; k < OPT + 1; ++k)
+        if (tid + 256 * k < TILE + 12) xs[tid + 256 * k] = xl[k];
     __syncthreads();
-    // 2x-rate window: vs[vi] <-> i = 2*t0 - 6 + vi.  Thread owns vi = 8*tid .. 8*tid+7; threads 0..1 also the 12-entry tail.
+    // 2x-rate window: vs[vi] <-> i = 2*t0 - 6 + vi.  Thread owns vi = 2*OPT*tid .. +2*OPT-1; threads 0..1 also the tail.
     auto snake8 = [&](int vb, float* v) {
         float xw[10];
 #pragma unroll
@@ -145,36 +151,43 @@ __global__ __launch_bounds__(256) void aa_act_kernel_v2(const float* __restrict_
             v[2 * p + 1] = fmaf(inv_b * so, so, uo);
         }
     };
-    float v[8];
-    snake8(8 * tid, v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) vs[8 * tid + j] = v[j];
-    if (tid < 2) {                               // tail: vi = 2048 .. 2063 (only the first 12 are used)
+    for (int g = 0; g < OPT / 4; ++g) {
+        float v[8];
+        const int vb = 2 * OPT * tid + 8 * g;
+        snake8(vb, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vs[vb + j] = v[j];
+    }
+    if (tid < 2) {                               // tail: vi = 2*TILE .. 2*TILE+15 (only the first 12 are used)
         float vt[8];
-        snake8(2 * AA_TILE + 8 * tid, vt);
+        snake8(2 * TILE + 8 * tid, vt);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vs[2 * AA_TILE + 8 * tid + j] = vt[j];
+        for (int j = 0; j < 8; ++j) vs[2 * TILE + 8 * tid + j] = vt[j];
     }
     __syncthreads();
     // replicate padding at the 2x rate (5 left / 6 right): entries outside [0, 2*len-1] take the edge value
     if (t0 == 0 && tid < 6) vs[tid] = vs[6];
     const int vi_end = (2 * len - 1) - (2 * t0 - 6);          // window index of the last real 2x-rate sample
-    if (vi_end < 2 * AA_TILE + 12 - 1) {
+    if (vi_end < 2 * TILE + 12 - 1) {
         const int vi = vi_end + 1 + tid;
-        if (tid < 8 && vi < 2 * AA_TILE + 16) vs[vi] = vs[vi_end];
+        if (tid < 8 && vi < 2 * TILE + 16) vs[vi] = vs[vi_end];
     }
     __syncthreads();
-    // outputs 4*tid .. 4*tid+3: y[t] = sum_j fd[j] * vs[2*(t - t0) + j + 1]
-    float vw[19];
+    // outputs OPT*tid .. OPT*tid+OPT-1: y[t] = sum_j fd[j] * vs[2*(t - t0) + j + 1]
 #pragma unroll
-    for (int j = 0; j < 19; ++j) vw[j] = vs[8 * tid + j];
+    for (int g = 0; g < OPT / 4; ++g) {
+        float vw[19];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int i = 4 * tid + p;
-        float acc = 0.f;
+        for (int j = 0; j < 19; ++j) vw[j] = vs[2 * (OPT * tid + 4 * g) + j];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) acc = fmaf(fds[j], vw[2 * p + j + 1], acc);
-        if (i < n_out) yr[t0 + i] = acc;
+        for (int p = 0; p < 4; ++p) {
+            const int i = OPT * tid + 4 * g + p;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) acc = fmaf(fds[j], vw[2 * p + j + 1], acc);
+            if (i < n_out) yr[t0 + i] = acc;
+        }
     }
 }
 
@@ -426,11 +439,13 @@ __global__ __launch_bounds__(256) void cond_bias_kernel(const float* __restrict_
 int launch_aa_act(const float* x, float* y, const float* alpha, const float* beta, const float* fu, const float* fd,
                   int B, int C, int T, const int* lens, int len_mult, int logscale, hipStream_t st) {
     if (B <= 0 || C <= 0 || T <= 0) return ITTS_OK;
-    dim3 grid(ceil_div(T, AA_TILE), C, B);
-    static const int mode = [] { const char* e = getenv("ITTS_AA_ACT"); return e ? atoi(e) : 2; }();   // 0 v1, 1 v2 + sinf, 2 v2 + v_sin
-    if (mode == 0) hipLaunchKernelGGL(aa_act_kernel, grid, dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
-    else if (mode == 1) hipLaunchKernelGGL(aa_act_kernel_v2<false>, grid, dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
-    else hipLaunchKernelGGL(aa_act_kernel_v2<true>, grid, dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
+    // ITTS_AA_ACT: 0 = v1 (LDS per tap, libm sinf), 1 = register-tiled + sinf, 2 = register-tiled + reduced v_sin (4/thread),
+    //              3 = same with 8 outputs per thread (default: twice the bytes in flight per block)
+    static const int mode = [] { const char* e = getenv("ITTS_AA_ACT"); return e ? atoi(e) : 3; }();
+    if (mode == 0) hipLaunchKernelGGL(aa_act_kernel, dim3(ceil_div(T, AA_TILE), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
+    else if (mode == 1) hipLaunchKernelGGL((aa_act_kernel_v2<4, false>), dim3(ceil_div(T, 1024), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
+    else if (mode == 2) hipLaunchKernelGGL((aa_act_kernel_v2<4, true>), dim3(ceil_div(T, 1024), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
+    else hipLaunchKernelGGL((aa_act_kernel_v2<8, true>), dim3(ceil_div(T, 2048), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }

@@ -219,8 +219,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
             }
     };
 
-    if constexpr (KSPLIT) {
-        // Decode (weight streaming).  Measured with ablations (tools/gemm_ablate.py): the HBM weight stream is NOT
+    if constexpr (KSPLIT && MT < 4) {
+        // Decode with <= 32 rows: activation fragments straight from L2 (the slab is small), every load of the wave's
+        // K range issued before the first MFMA (sched_barrier keeps hipcc from re-serialising them behind vmcnt(0)).
+        constexpr int PF = 10;
+        for (int kb0 = kb_start; kb0 < kb_hi; kb0 += PF * kb_step) {
+            v4u bq[PF][NT], aq[PF][MT];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int kbi = kb0 + i * kb_step;
+                const bool ok = kbi < kb_hi;
+                const int kbc = ok ? kbi : kb0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    v4u v = *(const v4u*)(wp[nt] + (size_t)kbc * 64);
+                    if (!ok) v = v4u{0u, 0u, 0u, 0u};
+                    bq[i][nt] = v;
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) aq[i][mt] = *(const v4u*)(arow[mt] + (size_t)kbc * KB * ESZ);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < PF; ++i) mfma_step(aq[i], bq[i]);
+        }
+    } else if constexpr (KSPLIT) {
+        // Decode (weight streaming), 64 rows.  Measured with ablations (tools/gemm_ablate.py): the HBM weight stream is NOT
         // the bottleneck at M = 64, the activation operand is -- fragment-shaped loads (16 rows x 64 B per wave
         // instruction) straight from L2 cost 4-17 us per GEMM.  So the block stages its activation slab through LDS
         // in full 1280-byte row segments (coalesced 16 B per lane, 8 full lines per wave instruction), 20 k-blocks
@@ -337,7 +361,7 @@ static int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
     const int ntiles = (a.N + 15) / 16;
     const int per_block = KSPLIT ? NT : 4 * NT;
     dim3 grid(ceil_div(ntiles, per_block), ceil_div(a.M, MT * 16), a.nsplit);
-    const size_t lds = KSPLIT ? (size_t)4 * MT * NT * 64 * 16 + (size_t)MT * 16 * (20 * 64 + 16) : 0;
+    const size_t lds = KSPLIT ? (size_t)4 * MT * NT * 64 * 16 + (MT >= 4 ? (size_t)MT * 16 * (20 * 64 + 16) : 0) : 0;
     hipLaunchKernelGGL((gemm_kernel<BF16, MT, NT, KSPLIT>), grid, dim3(256), lds, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
