@@ -15,6 +15,7 @@ struct ConvArgs {
     int k, tap_base, tap_step, ostride, ooff, m_extra;
     int acc_mode;          // 0 store, 1 y += v, 2 y = (y + v) / div
     float div;
+    int B, n_mt, n_co;     // filled by the launcher: batch rows, time tiles, co tiles (XCD-aware 1-D grid)
 };
 
 int launch_aa_act(const float* x, float* y, const float* alpha, const float* beta, const float* fu, const float* fd,

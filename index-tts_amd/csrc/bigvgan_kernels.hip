@@ -214,9 +214,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WN, wn = w % WN;
-    const int b = blockIdx.y;
-    const int m0 = blockIdx.x * BN;
-    const int co0 = blockIdx.z * BM;
+    // XCD-aware 1-D block mapping: the dispatcher places block L on XCD L % 8 (observed, used for speed only).  All
+    // co-tiles of one (batch row, time tile) get consecutive slots of the SAME XCD, so the x tile they share is fetched
+    // from HBM once and then served by that XCD's L2 (with co-tile as the slowest grid axis it was re-streamed from HBM
+    // once per co-tile: measured FETCH_SIZE 6x the tensor).
+    const int L = blockIdx.x;
+    const int xcd = L & 7, slot = L >> 3;
+    const int tile = (slot / a.n_co) * 8 + xcd;
+    if (tile >= a.n_mt * a.B) return;
+    const int b = tile / a.n_mt;
+    const int m0 = (tile - b * a.n_mt) * BN;
+    const int co0 = (slot % a.n_co) * BM;
     const int len_in = a.lens ? min(a.lens[b] * a.len_mult_in, a.Tin) : a.Tin;
     const int len_out = a.lens ? min(a.lens[b] * a.len_mult_out, a.Tout) : a.Tout;
     const int m_count = len_in + a.m_extra;
@@ -274,49 +282,86 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     };
     stage_load(0);
 
-    for (int ci0 = 0; ci0 < a.Cin; ci0 += CI_CHUNK) {
-        const int ci_cnt = min(CI_CHUNK, a.Cin - ci0);
-        __syncthreads();   // previous chunk fully consumed
-        stage_write();
-        __syncthreads();
-        if (ci0 + CI_CHUNK < a.Cin) stage_load(ci0 + CI_CHUNK);
-
-        const int cp4n = ci_cnt >> 3;
-        const int nit = a.k * cp4n;
-        f32x4 afr[MT], afr_next[MT];
-        auto load_a = [&](int it, f32x4* dst) {
-            const int j = it / cp4n, cp4 = it - j * cp4n;
+    // Weight (A) fragments: one tap = CP4 x MT float4 per lane, fetched ONE TAP AHEAD (4 K-groups = 64 MFMAs ~ 1.7 us).
+    // vmcnt retires in order, so a fragment load issued behind the 24 staging loads of the next x tile would stall on
+    // their HBM latency; issuing the next tap's fragments first and the staging loads second keeps every wait on data
+    // that was requested at least one tap earlier.  Loads are unconditional (clamped index + select) -> straight-line.
+    constexpr int CP4 = CI_CHUNK / 8;
+    f32x4 a_cur[CP4][MT], a_nxt[CP4][MT];
+    const int nchunks = (a.Cin + CI_CHUNK - 1) / CI_CHUNK;
+    const int G = nchunks * a.k;                       // stream of (chunk, tap) steps
+    // packed weights through a buffer descriptor: fragments of padded channel groups / co sub-tiles get an out-of-range
+    // offset and read as 0 in hardware (a `cond ? load : 0` select is compiled to a branch + vmcnt(0) per load)
+    const unsigned wpk_bytes = (unsigned)n_cosub * a.k * cin8 * 64u * 16u;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wpk), 0, (int)wpk_bytes, 0x00020000);
+    auto load_tap = [&](int g, f32x4 (&dst)[CP4][MT]) {
+        const int c = g / a.k, j = g - c * a.k;
+        const int cbase = c * CI_CHUNK;
+        const int cp4n = min(CI_CHUNK, a.Cin - cbase) >> 3;
+#pragma unroll
+        for (int cp4 = 0; cp4 < CP4; ++cp4) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int co_sub = (co0 >> 5) + wm * MT + mt;
-                if (co_sub < n_cosub) {
-                    const f32x4* p = reinterpret_cast<const f32x4*>(a.wpk) +
-                                     ((size_t)(co_sub * a.k + j) * cin8 + ((ci0 >> 3) + cp4)) * 64 + lane;
-                    dst[mt] = *p;
-                } else {
-                    dst[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                const bool ok = (cp4 < cp4n) && (co_sub < n_cosub);            // wave-uniform
+                const unsigned off = ok ? ((unsigned)((co_sub * a.k + j) * cin8 + ((cbase >> 3) + cp4)) * 64u + lane) * 16u
+                                        : 0xFFFFFFF0u;
+                dst[cp4][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
             }
-        };
-        load_a(0, afr);
-        for (int it = 0; it < nit; ++it) {
-            if (it + 1 < nit) load_a(it + 1, afr_next);
-            const int j = it / cp4n, cp4 = it - j * cp4n;
-            const int colb = wn * NT * 32 + lane_col + (a.tap_base + j * a.tap_step - min_off);
-            const float* xrow = xs + (cp4 * 8 + lane_row) * LDW + colb;
+        }
+    };
+    auto compute_tap = [&](int j) {
+        const int colb = wn * NT * 32 + lane_col + (a.tap_base + j * a.tap_step - min_off);
+        const float* xcol = xs + lane_row * LDW + colb;
+        // B fragments (LDS) are read one K-group ahead of the MFMAs that consume them
+        float bcur[4][NT], bnxt[4][NT];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float bfr[NT];
+        for (int sidx = 0; sidx < 4; ++sidx)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bfr[nt] = xrow[s * 2 * LDW + nt * 32];
+            for (int nt = 0; nt < NT; ++nt) bcur[sidx][nt] = xcol[(2 * sidx) * LDW + nt * 32];
+#pragma unroll
+        for (int cp4 = 0; cp4 < CP4; ++cp4) {
+            if (cp4 + 1 < CP4) {
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bnxt[sidx][nt] = xcol[((cp4 + 1) * 8 + 2 * sidx) * LDW + nt * 32];
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[mt][s], bfr[nt], acc[mt][nt], 0, 0, 0);
-            }
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cp4][mt][sidx], bcur[sidx][nt], acc[mt][nt], 0, 0, 0);
+            if (cp4 + 1 < CP4) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) afr[mt] = afr_next[mt];
+                for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bcur[sidx][nt] = bnxt[sidx][nt];
+            }
+        }
+#pragma unroll
+        for (int cp4 = 0; cp4 < CP4; ++cp4)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a_cur[cp4][mt] = a_nxt[cp4][mt];
+    };
+    load_tap(0, a_cur);
+    int g = 0;
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += CI_CHUNK) {
+        __syncthreads();   // previous chunk fully consumed
+        stage_write();
+        __syncthreads();
+        // Tap 0 is straight-line: every load below is issued unconditionally (the last step re-fetches its own tap, a
+        // chunk past the end gets zero-size descriptors) so the compiler knows the exact number of loads in flight and
+        // can wait with counted vmcnt(N) instead of draining the queue.
+        load_tap(g + 1 < G ? g + 1 : G - 1, a_nxt);    // next tap's weights first ...
+        stage_load(ci0 + CI_CHUNK);                     // ... then the next x tile (behind them in vmcnt order)
+        compute_tap(0);
+        ++g;
+        for (int j = 1; j < a.k; ++j, ++g) {
+            load_tap(g + 1 < G ? g + 1 : G - 1, a_nxt);
+            compute_tap(j);
         }
     }
 
@@ -440,8 +485,9 @@ int launch_aa_act(const float* x, float* y, const float* alpha, const float* bet
                   int B, int C, int T, const int* lens, int len_mult, int logscale, hipStream_t st) {
     if (B <= 0 || C <= 0 || T <= 0) return ITTS_OK;
     // ITTS_AA_ACT: 0 = v1 (LDS per tap, libm sinf), 1 = register-tiled + sinf, 2 = register-tiled + reduced v_sin (4/thread),
-    //              3 = same with 8 outputs per thread (default: twice the bytes in flight per block)
-    static const int mode = [] { const char* e = getenv("ITTS_AA_ACT"); return e ? atoi(e) : 3; }();
+    //              3 = same with 8 outputs per thread.  Measured (B=16, T=1926): 4.17 / 5.4 / 3.66 / 4.98 ms per 6 launches
+    //              -> default 2.
+    static const int mode = [] { const char* e = getenv("ITTS_AA_ACT"); return e ? atoi(e) : 2; }();
     if (mode == 0) hipLaunchKernelGGL(aa_act_kernel, dim3(ceil_div(T, AA_TILE), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
     else if (mode == 1) hipLaunchKernelGGL((aa_act_kernel_v2<4, false>), dim3(ceil_div(T, 1024), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
     else if (mode == 2) hipLaunchKernelGGL((aa_act_kernel_v2<4, true>), dim3(ceil_div(T, 1024), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
@@ -454,8 +500,14 @@ template <int WM, int WN, int MT, int NT>
 static int launch_conv_cfg(const ConvArgs& a, int B, int m_total, hipStream_t st) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     const size_t lds = (size_t)CI_CHUNK * (BN + CONV_HALO) * sizeof(float);
-    dim3 grid(ceil_div(m_total, BN), B, ceil_div(a.Cout, BM));
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, MT, NT>), grid, dim3(256), lds, st, a);
+    ConvArgs a2 = a;
+    a2.B = B;
+    a2.n_mt = ceil_div(m_total, BN);
+    a2.n_co = ceil_div(a.Cout, BM);
+    const long long tiles8 = ((long long)a2.n_mt * B + 7) / 8 * 8;
+    const long long nblocks = tiles8 * a2.n_co;
+    if (nblocks > 2147483647ll) { itts_set_error("conv: grid too large"); return ITTS_ERR_ARG; }
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, MT, NT>), dim3((unsigned)nblocks), dim3(256), lds, st, a2);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
