@@ -521,15 +521,20 @@ int launch_conv(const ConvArgs& a, int B, hipStream_t st) {
     if (span > CONV_HALO) { itts_set_error("conv: tap span %d exceeds halo %d", span, CONV_HALO); return ITTS_ERR_ARG; }
     const int m_total = a.Tin + a.m_extra;
     const int n_cosub = (a.Cout + 31) / 32;
-    // pick the co-tile (128 or 96 rows) that wastes the fewest MFMA rows: C_out = 192 is 2 x 96, not 1.5 x 128
-    if (n_cosub >= 4) {
-        const int waste128 = ceil_div(n_cosub, 4) * 4 - n_cosub, waste96 = ceil_div(n_cosub, 3) * 3 - n_cosub;
-        if (waste96 < waste128) return launch_conv_cfg<1, 4, 3, 2>(a, B, m_total, st);
-        return launch_conv_cfg<2, 2, 2, 2>(a, B, m_total, st);
+    // co-tile choice: fewest wasted MFMA rows first, then the config with the better occupancy.  ITTS_CONV_BM (32/64/96/128)
+    // forces a tile height for experiments.
+    static const int force_bm = [] { const char* e = getenv("ITTS_CONV_BM"); return e ? atoi(e) : 0; }();
+    auto waste = [&](int sub) { return ceil_div(n_cosub, sub) * sub - n_cosub; };
+    int bm_sub = 4;                                   // co sub-tiles (32 rows each) per block
+    if (force_bm) bm_sub = force_bm / 32;
+    else if (n_cosub <= 3) bm_sub = n_cosub;
+    else if (waste(3) < waste(4)) bm_sub = (waste(2) == 0) ? 2 : 3;      // e.g. C_out = 192: 3 x 64 rather than 2 x 96 (occupancy 2 vs 1)
+    switch (bm_sub) {
+        case 1: return launch_conv_cfg<1, 4, 1, 2>(a, B, m_total, st);
+        case 2: return launch_conv_cfg<1, 4, 2, 2>(a, B, m_total, st);
+        case 3: return launch_conv_cfg<1, 4, 3, 2>(a, B, m_total, st);
+        default: return launch_conv_cfg<2, 2, 2, 2>(a, B, m_total, st);
     }
-    if (n_cosub == 3) return launch_conv_cfg<1, 4, 3, 2>(a, B, m_total, st);
-    if (n_cosub == 2) return launch_conv_cfg<1, 4, 2, 2>(a, B, m_total, st);
-    return launch_conv_cfg<1, 4, 1, 2>(a, B, m_total, st);
 }
 
 int launch_conv_post(const float* x, float* y, const float* w, const float* bias, int B, int Cin, int T, int k,
