@@ -60,8 +60,10 @@ def usable_cores() -> int:
 def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel):
     """Reference CPU path restated (oracle/), timed on this box's host cores on a bounded sample.
 
-    GPT: 1 utterance, `n_text` text tokens, prefill + 12 greedy decode steps (fp32, kv-cache) on the full-size stack.
-    BigVGAN: 1 utterance x 48 mel frames (fp32).  Scaled to audio-seconds/second for an utterance of `n_gen` tokens.
+    GPT: 1 utterance, `n_text` text tokens, prefill + 120 greedy decode steps (fp32, kv-cache) on the full-size stack.
+    BigVGAN: 1 utterance x 480 mel frames (fp32).  About 15-25 s of CPU work; scaled to audio-seconds/second for an
+    utterance of `n_gen` tokens / `t_mel` frames (decode cost per token grows with context; the sample covers the first
+    120 of `n_gen` positions, which favours the CPU).
     """
     from oracle import bigvgan_oracle as BO
     from oracle import gpt_oracle as GO
@@ -74,7 +76,7 @@ def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel):
     g = torch.Generator().manual_seed(7)
     text = torch.randint(2, cfg.number_text_tokens, (1, n_text), generator=g)
     conds = torch.randn(1, 3, cfg.model_dim, generator=g) * 0.1
-    steps = 12
+    steps = 120
     with torch.no_grad():
         fake, embeds, mask = GO.prepare_gpt_inputs(gpt_sd, cfg, conds, text, torch.tensor([3]))
         model = GO.InferenceModel(gpt_sd, cfg, kv_cache=True)
@@ -90,7 +92,7 @@ def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel):
             mask = torch.cat([mask, mask.new_ones(1, 1)], 1)
             logits, past = model.forward(ids, mask, past)
         t_tok = (time.perf_counter() - t0) / steps
-        frames = 48
+        frames = 480
         mel = torch.randn(1, bv_h["num_mels"], frames, generator=g) * 2 - 4
         BO.bigvgan_forward(bv_sd, mel[:, :, :8], bv_h)      # warm
         t0 = time.perf_counter()
@@ -213,8 +215,16 @@ def main():
     audio_per_step = world * B * (t_mel * HOP) / SR
     value = audio_per_step * args.steps / elapsed
     if rank == 0:
-        conv = prof_acc.get("conv1d_mfma", dict(ms=1e-9, launches=1, flops=0.0))
+        conv = prof_acc.get("conv1d_mfma", dict(ms=1e-9, launches=1, flops=0.0, bytes=0.0))
         achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+        # HBM traffic of the same kernel: PMC counters cannot be read from inside this process, so the figure comes from
+        # the committed rocprofv3 --pmc summary of the same forward (tools/pmc_bench_traffic.sh), if it matches this shape.
+        traffic, traffic_src = None, None
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "conv_traffic.json")
+        if os.path.exists(tp):
+            tj = json.load(open(tp))
+            if tj.get("B") == B and tj.get("mel_frames") == t_mel:
+                traffic, traffic_src = tj["hbm_bytes_per_conv_dispatch"], "profiles/conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         D, L, V = gcfg["model_dim"], gcfg["layers"], gcfg["number_mel_codes"]
         esz = 2 if args.precision == "bf16" else 4
         n_dec = max(1, gpt_t["steps"] - args.steps)                # decode steps (first token comes from prefill)
@@ -249,7 +259,8 @@ def main():
                        "use_hipgraph": not args.no_graph},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (BigVGAN Conv1d implicit GEMM, v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
                          "launches_per_step": conv["launches"] // max(1, args.steps),
                          "avg_launch_ms": conv["ms"] / max(1, conv["launches"])},
             "stages": stages,

@@ -521,14 +521,13 @@ int launch_conv(const ConvArgs& a, int B, hipStream_t st) {
     if (span > CONV_HALO) { itts_set_error("conv: tap span %d exceeds halo %d", span, CONV_HALO); return ITTS_ERR_ARG; }
     const int m_total = a.Tin + a.m_extra;
     const int n_cosub = (a.Cout + 31) / 32;
-    // co-tile choice: fewest wasted MFMA rows first, then the config with the better occupancy.  ITTS_CONV_BM (32/64/96/128)
-    // forces a tile height for experiments.
+    // co-tile choice (measured, profiles/r01_conv_tiles.txt): the 32-row tile <1,4,1,2> runs at 3 waves/SIMD (146 regs) and
+    // beats the taller tiles (occupancy 2 or 1) up to C_out = 384; from 768 channels the 128-row tile's 4x weight reuse wins.
+    // ITTS_CONV_BM (32/64/96/128) forces a tile height for experiments.
     static const int force_bm = [] { const char* e = getenv("ITTS_CONV_BM"); return e ? atoi(e) : 0; }();
-    auto waste = [&](int sub) { return ceil_div(n_cosub, sub) * sub - n_cosub; };
     int bm_sub = 4;                                   // co sub-tiles (32 rows each) per block
     if (force_bm) bm_sub = force_bm / 32;
-    else if (n_cosub <= 3) bm_sub = n_cosub;
-    else if (waste(3) < waste(4)) bm_sub = (waste(2) == 0) ? 2 : 3;      // e.g. C_out = 192: 3 x 64 rather than 2 x 96 (occupancy 2 vs 1)
+    else if (n_cosub <= 12) bm_sub = 1;
     switch (bm_sub) {
         case 1: return launch_conv_cfg<1, 4, 1, 2>(a, B, m_total, st);
         case 2: return launch_conv_cfg<1, 4, 2, 2>(a, B, m_total, st);

@@ -38,7 +38,11 @@ gu, _log = ref_shim.load_ref_generation_utils()
 
 from transformers import GPT2Config, GPT2Model, GenerationConfig, LogitsProcessorList  # noqa: E402
 from transformers.cache_utils import DynamicCache  # noqa: E402
-from transformers.generation.logits_process import TypicalLogitsWarper as HFTypical  # noqa: E402
+import importlib.util  # noqa: E402
+_sp = importlib.util.spec_from_file_location("ref_typical_sampling", os.path.join(ref_shim.REF, "indextts/utils/typical_sampling.py"))
+_ref_typical = importlib.util.module_from_spec(_sp)
+_sp.loader.exec_module(_ref_typical)                       # the reference's own TypicalLogitsWarper (typical_sampling.py:4-30)
+HFTypical = _ref_typical.TypicalLogitsWarper
 from transformers.modeling_outputs import CausalLMOutputWithCrossAttentions  # noqa: E402
 
 from oracle import gpt_oracle as G  # noqa: E402
@@ -231,9 +235,23 @@ def main():
                              repetition_penalty=10.0, length_penalty=0.0), True, 1.5),
         "greedy_mid": (dict(layers=4, model_dim=256, heads=4), 26, 4, 16, [16, 12, 9, 16],
                        dict(do_sample=False, num_beams=1, repetition_penalty=10.0), True, 2.5),
+        # typical sampling (model_v2.py:794-799 -> indextts/utils/typical_sampling.py) in the three loop modes
+        "typical_sample": (dict(layers=2, model_dim=128, heads=2), 27, 3, 9, [9, 6, 8],
+                           dict(do_sample=True, num_beams=1, top_p=0.8, top_k=30, temperature=0.8, repetition_penalty=10.0,
+                                typical_sampling=True, typical_mass=0.9), True, 1.9),
+        "typical_greedy": (dict(layers=2, model_dim=128, heads=2), 28, 3, 9, [9, 4, 7],
+                           dict(do_sample=False, num_beams=1, repetition_penalty=10.0, typical_sampling=True,
+                                typical_mass=0.2), True, 2.2),
+        "typical_beam_sample": (dict(layers=2, model_dim=128, heads=2), 29, 2, 9, [9, 6],
+                                dict(do_sample=True, num_beams=3, top_p=0.8, top_k=30, temperature=0.8,
+                                     repetition_penalty=10.0, length_penalty=0.0, typical_sampling=True,
+                                     typical_mass=0.5), True, 1.5),
     }
+    only = sys.argv[1] if len(sys.argv) > 1 else None          # substring filter: regenerate a subset of the cases
     max_gen = 28
     for tag, (ck, seed, B, L, lens, gk, kv, eos_bias) in cases.items():
+        if only and only not in tag:
+            continue
         cfg = G.GPTConfig(max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200, **ck)
         sd = G.synth_weights(cfg, seed=seed)
         sd["mel_head.bias"][cfg.stop_mel_token] += eos_bias          # make EOS reachable at ragged steps
@@ -267,7 +285,8 @@ def main():
                           cfg.number_text_tokens]),
             gen=np.array([int(gk.get("do_sample", False)), nb, gk.get("top_p", 1.0), gk.get("top_k", 0),
                           gk.get("temperature", 1.0), gk.get("repetition_penalty", 1.0),
-                          gk.get("length_penalty", 1.0)], dtype=np.float64))
+                          gk.get("length_penalty", 1.0), int(gk.get("typical_sampling", False)),
+                          gk.get("typical_mass", 0.9)], dtype=np.float64))
 
         if tag == "greedy":
             # teacher-forced latent pass (UnifiedVoice.forward, model_v2.py:596-646) on the generated codes
