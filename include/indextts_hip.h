@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 1
+#define ITTS_ABI_VERSION 2
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -120,13 +120,16 @@ typedef struct {
 
 typedef struct {
     int32_t do_sample;                  /* 0: argmax (HF greedy), 1: multinomial after the warpers */
-    int32_t num_beams;                  /* 1 (beam search is handled by the host-side scorer) */
+    int32_t num_beams;                  /* 1 for itts_gpt_generate, 2..4 for itts_gpt_generate_beam */
     int32_t top_k;                      /* 1..64 when do_sample */
     int32_t min_tokens_to_keep;         /* 1 (2 under beams) */
     int32_t max_new_tokens;             /* max_generate_length */
     int32_t pos_offset;                 /* 2: HF kv-cache position rule (k-th token at mel position k+1, 1-based k);
                                            1: kv_cache=False rule (positions 0..n-1), model_v2.py:145-161 */
     float top_p, temperature, repetition_penalty, length_penalty;
+    float typical_mass;                 /* 0: off; else typical_sampling=True with this typical_mass in (0,1)
+                                           (model_v2.py:794-799, indextts/utils/typical_sampling.py:4-30) */
+    int32_t reserved;                   /* must be 0 */
     uint64_t seed;                      /* device RNG seed when no uniform stream is supplied */
 } itts_gen_params;
 

@@ -31,11 +31,15 @@ class GPTConfig(C.Structure):
                 ("stop_mel_token", C.c_int32), ("ln_eps", C.c_float)]
 
 
+ABI_VERSION = 2          # include/indextts_hip.h ITTS_ABI_VERSION
+
+
 class GenParams(C.Structure):
     _fields_ = [("do_sample", C.c_int32), ("num_beams", C.c_int32), ("top_k", C.c_int32),
                 ("min_tokens_to_keep", C.c_int32), ("max_new_tokens", C.c_int32), ("pos_offset", C.c_int32),
                 ("top_p", C.c_float), ("temperature", C.c_float), ("repetition_penalty", C.c_float),
-                ("length_penalty", C.c_float), ("seed", C.c_uint64)]
+                ("length_penalty", C.c_float), ("typical_mass", C.c_float), ("reserved", C.c_int32),
+                ("seed", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/indextts_hip.h declares must appear here
@@ -98,7 +102,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.itts_abi_version() != 1:
+        if L.itts_abi_version() != ABI_VERSION:
             raise HipEngineError("libindextts_hip.so ABI version mismatch")
         _lib = L
     return _lib

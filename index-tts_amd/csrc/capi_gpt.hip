@@ -370,6 +370,7 @@ static SampleArgs make_sample(itts_gpt* h, const GptWs& w, const itts_gen_params
     s.uniforms = uniforms; s.seed = gp.seed; s.B = nseq; s.V = c.vocab; s.max_new = gp.max_new_tokens;
     s.do_sample = gp.do_sample; s.top_k = gp.top_k; s.min_keep = gp.min_tokens_to_keep < 1 ? 1 : gp.min_tokens_to_keep;
     s.top_p = gp.top_p; s.temperature = gp.temperature; s.rep_penalty = gp.repetition_penalty;
+    s.typical_mass = gp.typical_mass;
     s.stop_token = c.stop_mel_token; s.mel_emb = h->mel_emb; s.mel_pos = h->mel_pos; s.x_next = w.x; s.D = c.model_dim;
     s.pos_offset = gp.pos_offset; s.n_mel_pos = c.n_mel_pos;
     return s;
@@ -520,6 +521,7 @@ static BeamArgs make_beam(itts_gpt* h, const GptWs& w, const itts_gen_params& gp
     a.Tmax = Tmax; a.S = S; a.do_sample = gp.do_sample; a.top_k = gp.top_k;
     a.min_keep = gp.min_tokens_to_keep < 1 ? 1 : gp.min_tokens_to_keep;
     a.top_p = gp.top_p; a.temperature = gp.temperature; a.rep_penalty = gp.repetition_penalty; a.length_penalty = gp.length_penalty;
+    a.typical_mass = gp.typical_mass;
     a.stop_token = c.stop_mel_token; a.mel_emb = h->mel_emb; a.mel_pos = h->mel_pos; a.x_next = w.x; a.D = c.model_dim;
     a.pos_offset = gp.pos_offset; a.n_mel_pos = c.n_mel_pos;
     return a;

@@ -64,6 +64,7 @@ struct SampleArgs {
     int B, V, max_new;
     int do_sample, top_k, min_keep;
     float top_p, temperature, rep_penalty;
+    float typical_mass;      // 0 = off, else TypicalLogitsWarper(mass) between the repetition penalty and the warpers
     int stop_token;
     // next-step embedding: x_next[b] = mel_emb[tok] + mel_pos[step + pos_offset]
     const float* mel_emb; const float* mel_pos; float* x_next; int D; int pos_offset; int n_mel_pos;
@@ -91,6 +92,7 @@ struct BeamArgs {
     int B, nb, V, max_new, Tmax, S;
     int do_sample, top_k, min_keep;
     float top_p, temperature, rep_penalty, length_penalty;
+    float typical_mass;
     int stop_token;
     const float* mel_emb; const float* mel_pos; float* x_next; int D; int pos_offset; int n_mel_pos;
 };

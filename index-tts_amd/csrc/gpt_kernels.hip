@@ -558,6 +558,96 @@ __device__ __forceinline__ int pick_bucket_wave(const unsigned* hist, unsigned k
     return b;
 }
 
+// ---- TypicalLogitsWarper (indextts/utils/typical_sampling.py:9-30; appended after the repetition penalty by
+// UnifiedVoice.inference_speech, model_v2.py:794-799) on one LDS score row `sl[V]`; `q[V]` is scratch.
+//   s_i = | -log_softmax(x)_i - H |,  tokens ordered by ascending s, kept while the softmax mass of the tokens before
+//   them (f64 running sum rounded to f32, as torch.cumsum does on CPU) is < mass; everything with s above the crossing
+//   token's s becomes -inf; the `min_keep` smallest-s tokens always stay.
+// No sort: the crossing key is found by a bitwise search over the 32-bit key space (keys = bits of s >= 0), each probe a
+// fixed-order f64 block reduction of the mass below the candidate key -- deterministic, 32 probes.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ void typical_filter(float* sl, float* q, int V, float mass, int min_keep, int tid) {
+    __shared__ float tf_red[4];
+    __shared__ double td_red[4];
+    __shared__ unsigned tk_key[4];
+    __shared__ int tk_idx[4];
+    const int w = tid >> 6;
+    const bool lead = (tid & 63) == 0;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, sl[i]);
+    mx = wave_max(mx);
+    if (lead) tf_red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(tf_red[0], tf_red[1]), fmaxf(tf_red[2], tf_red[3]));
+    __syncthreads();
+    float se = 0.f;
+    for (int i = tid; i < V; i += 256) se += expf(sl[i] - mx);
+    se = wave_sum(se);
+    if (lead) tf_red[w] = se;
+    __syncthreads();
+    const float sum = (tf_red[0] + tf_red[1]) + (tf_red[2] + tf_red[3]);
+    const float lse = logf(sum);
+    __syncthreads();
+    float en = 0.f;
+    for (int i = tid; i < V; i += 256) {
+        const float nl = (sl[i] - mx) - lse;
+        const float t = nl * expf(nl);
+        if (t == t) en += t;                              // nansum
+        q[i] = expf(sl[i] - mx) / sum;
+    }
+    en = wave_sum(en);
+    if (lead) tf_red[w] = en;
+    __syncthreads();
+    const float ent = -((tf_red[0] + tf_red[1]) + (tf_red[2] + tf_red[3]));
+    auto key_of = [&](int i) -> unsigned { return __float_as_uint(fabsf((-((sl[i] - mx) - lse)) - ent)); };
+    unsigned T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = T | (1u << bit);
+        double m = 0.0;
+        for (int i = tid; i < V; i += 256)
+            if (key_of(i) < cand) m += (double)q[i];
+        m = wave_sum_f64(m);
+        __syncthreads();                                  // previous probe's readers are done with td_red
+        if (lead) td_red[w] = m;
+        __syncthreads();
+        const double tot = (td_red[0] + td_red[1]) + (td_red[2] + td_red[3]);
+        if ((float)tot < mass) T = cand;
+    }
+    // the min_keep (1 or 2) smallest (key, index) stay regardless; the smallest always passes key <= T
+    int keep2 = -1;
+    if (min_keep > 1) {
+        int first = -1;
+        for (int round = 0; round < 2; ++round) {
+            unsigned bk = 0xFFFFFFFFu; int bi = 0x7fffffff;
+            for (int i = tid; i < V; i += 256) {
+                if (i == first) continue;
+                const unsigned k = key_of(i);
+                if (k < bk || (k == bk && i < bi)) { bk = k; bi = i; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned ok = __shfl_xor(bk, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ok < bk || (ok == bk && oi < bi)) { bk = ok; bi = oi; }
+            }
+            __syncthreads();
+            if (lead) { tk_key[w] = bk; tk_idx[w] = bi; }
+            __syncthreads();
+            for (int ww = 0; ww < 4; ++ww)
+                if (tk_key[ww] < bk || (tk_key[ww] == bk && tk_idx[ww] < bi)) { bk = tk_key[ww]; bi = tk_idx[ww]; }
+            if (round == 0) first = bi; else keep2 = bi;
+        }
+    }
+    for (int i = tid; i < V; i += 256)
+        if (key_of(i) > T && i != keep2) sl[i] = -INFINITY;
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     extern __shared__ float sl[];                    // [V] processed scores
     __shared__ unsigned hist[256];
@@ -573,13 +663,21 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     unsigned char* seen = a.seen + (size_t)b * V;
     const bool pen = a.rep_penalty != 1.0f;
     const bool temp = a.do_sample && a.temperature != 1.0f;
+    const bool typical = a.typical_mass > 0.f;
     for (int i = tid; i < V; i += 256) {
         float x = lg[i];
         if (pen && seen[i]) x = x < 0.f ? x * a.rep_penalty : x / a.rep_penalty;
-        if (temp) x = x / a.temperature;
+        if (temp && !typical) x = x / a.temperature;
         sl[i] = x;
     }
     __syncthreads();
+    if (typical) {
+        typical_filter(sl, sl + V, V, a.typical_mass, a.min_keep, tid);
+        if (temp) {
+            for (int i = tid; i < V; i += 256) sl[i] = sl[i] / a.temperature;
+            __syncthreads();
+        }
+    }
 
     if (!a.do_sample) {
         float bv = -INFINITY;
@@ -628,7 +726,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         }
         const uint32_t kth = s_prefix;
         for (int i = tid; i < V; i += 256) {
-            if (f2key(sl[i]) >= kth) {
+            if (f2key(sl[i]) >= kth && sl[i] > -INFINITY) {   // masked (-inf) entries carry no probability
                 const unsigned slot = atomicAdd(&s_count, 1u);
                 if (slot < SAMPLE_CAP) { cand_i[slot] = i; cand_v[slot] = sl[i]; }
             }
@@ -714,7 +812,12 @@ int launch_sample(const SampleArgs& a, hipStream_t st) {
         itts_set_error("sampling: top_k must be in 1..64 on the device path (got %d)", a.top_k);
         return ITTS_ERR_ARG;
     }
-    hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), (size_t)a.V * sizeof(float), st, a);
+    if (a.typical_mass != 0.f && !(a.typical_mass > 0.f && a.typical_mass < 1.f)) {
+        itts_set_error("`typical_mass` has to be a float > 0 and < 1, but is %g", (double)a.typical_mass);
+        return ITTS_ERR_ARG;
+    }
+    const size_t lds = (size_t)a.V * sizeof(float) * (a.typical_mass > 0.f ? 2 : 1);
+    hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), lds, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
@@ -788,13 +891,21 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
         if (tid == 0) { s_lse = logf((red[0] + red[1]) + (red[2] + red[3])); s_prefix = 0; s_mask = 0; s_kk = (unsigned)ksel; s_count = 0; }
         __syncthreads();
         const float lse = s_lse;
+        const bool typical = a.typical_mass > 0.f;
         for (int i = tid; i < V; i += 256) {
             float x = (sl[i] - m) - lse;
             if (pen && seen[i]) x = x < 0.f ? x * a.rep_penalty : x / a.rep_penalty;
-            if (temp) x = x / a.temperature;
+            if (temp && !typical) x = x / a.temperature;
             sl[i] = x;
         }
         __syncthreads();
+        if (typical) {
+            typical_filter(sl, sl + V, V, a.typical_mass, a.min_keep, tid);
+            if (temp) {
+                for (int i = tid; i < V; i += 256) sl[i] = sl[i] / a.temperature;
+                __syncthreads();
+            }
+        }
         // top-ksel threshold (radix select)
         for (int pass = 3; pass >= 0; --pass) {
             hist[tid] = 0;
@@ -821,7 +932,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
         }
         const uint32_t kth = s_prefix;
         for (int i = tid; i < V; i += 256) {
-            if (f2key(sl[i]) >= kth) {
+            if (f2key(sl[i]) >= kth && sl[i] > -INFINITY) {
                 const unsigned slot = atomicAdd(&s_count, 1u);
                 if (slot < BEAM_CAP) { ci[slot] = i; cv[slot] = sl[i]; }
             }
@@ -992,7 +1103,12 @@ int launch_beam_step(const BeamArgs& a, hipStream_t st) {
         itts_set_error("beam-sample: top_k must be in 1..%d on the device path (got %d)", BEAM_CAP, a.top_k);
         return ITTS_ERR_ARG;
     }
-    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(256), (size_t)a.V * sizeof(float), st, a);
+    if (a.typical_mass != 0.f && !(a.typical_mass > 0.f && a.typical_mass < 1.f)) {
+        itts_set_error("`typical_mass` has to be a float > 0 and < 1, but is %g", (double)a.typical_mass);
+        return ITTS_ERR_ARG;
+    }
+    const size_t lds = (size_t)a.V * sizeof(float) * (a.typical_mass > 0.f ? 2 : 1);
+    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(256), lds, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }

@@ -20,13 +20,15 @@ from . import _lib
 
 
 class UnifiedVoice:
+    _ALLOW_ENCODER_CONDITIONING = False
+
     def __init__(self, layers=8, model_dim=512, heads=8, max_text_tokens=120, max_mel_tokens=250,
                  max_conditioning_inputs=1, mel_length_compression=1024, number_text_tokens=256, start_text_token=0,
                  stop_text_token=1, number_mel_codes=8194, start_mel_token=8192, stop_mel_token=8193,
                  train_solo_embeddings=False, use_mel_codes_as_input=True, checkpointing=True, types=1,
                  condition_num_latent=32, condition_type="perceiver", condition_module=None, emo_condition_module=None,
                  use_accel=False, spk_cond_mode="campplus", precision="bf16", device="cuda:0", **_unused):
-        if spk_cond_mode != "campplus":
+        if spk_cond_mode != "campplus" and not self._ALLOW_ENCODER_CONDITIONING:
             raise NotImplementedError("engine implements the v2.5 'campplus' conditioning path; v1/v2 conditioning "
                                       "encoders stay on PyTorch -- pass conds_latent= to inference_speech()")
         self.layers, self.model_dim, self.heads = layers, model_dim, heads
@@ -36,6 +38,7 @@ class UnifiedVoice:
         self.start_text_token, self.stop_text_token = start_text_token, stop_text_token
         self.start_mel_token, self.stop_mel_token = start_mel_token, stop_mel_token
         self.types = types
+        self.mel_length_compression = mel_length_compression
         self.spk_cond_mode = spk_cond_mode
         self.device = torch.device(device)
         self.precision = {"bf16": 1, "bfloat16": 1, "fp32": 0, "float32": 0, "f32": 0}[precision]
@@ -60,6 +63,8 @@ class UnifiedVoice:
                      "text_pos_embedding.emb.weight", "lang_embedding.weight", "spk_emb_proj.weight",
                      "spk_emb_proj.bias")
 
+    _OPTIONAL_HOST_TENSORS = ("lang_embedding.weight",)
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
         """Reference `gpt.pth` names (`strict=False` like indextts/utils/checkpoint.py:22-29); returns ignored keys."""
         L = _lib.lib()
@@ -78,7 +83,7 @@ class UnifiedVoice:
             elif name not in self._HOST_TENSORS:
                 ignored.append(name)
         _lib.check(L.itts_gpt_finalize(self._h), "itts_gpt_finalize")
-        missing = [n for n in self._HOST_TENSORS if n not in self._emb and n != "lang_embedding.weight"]
+        missing = [n for n in self._HOST_TENSORS if n not in self._emb and n not in self._OPTIONAL_HOST_TENSORS]
         if missing:
             raise _lib.HipEngineError(f"UnifiedVoice.load_state_dict: missing {missing}")
         self._loaded = True
@@ -165,14 +170,15 @@ class UnifiedVoice:
 
     def generate(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int, do_sample=False,
                  num_beams=1, top_p=1.0, top_k=50, temperature=1.0, repetition_penalty=1.0, length_penalty=1.0,
-                 uniforms: Optional[torch.Tensor] = None, seed: int = 0, **unused) -> torch.Tensor:
-        """`GPT2InferenceModel.generate` for greedy / multinomial sampling.  inputs_embeds (B,s,D) = the cached prefix;
+                 uniforms: Optional[torch.Tensor] = None, seed: int = 0, typical_mass: float = 0.0, **unused) -> torch.Tensor:
+        """`GPT2InferenceModel.generate` for greedy / multinomial sampling (typical_mass > 0: the reference's
+        TypicalLogitsWarper sits between the repetition penalty and the warpers, model_v2.py:794-799).  inputs_embeds (B,s,D) = the cached prefix;
         attention_mask (B,s+1).  Returns generated ids (B, n) (what `output[:, trunc_index:]` is in the reference)."""
         if not self._loaded:
             raise RuntimeError("UnifiedVoice: load_state_dict() first")
         if num_beams != 1:
             return self._generate_beam(inputs_embeds, attention_mask, max_new_tokens, do_sample, num_beams, top_p, top_k,
-                                       temperature, repetition_penalty, length_penalty, uniforms, seed)
+                                       temperature, repetition_penalty, length_penalty, uniforms, seed, typical_mass)
         dev = self.device
         B, s, D = inputs_embeds.shape
         start = (self._emb["mel_embedding.weight"][self.start_mel_token] + self._emb["mel_pos_embedding.emb.weight"][0])
@@ -186,6 +192,7 @@ class UnifiedVoice:
         gp.top_p, gp.temperature = float(top_p), float(temperature)
         gp.repetition_penalty = float(repetition_penalty if repetition_penalty is not None else 1.0)
         gp.length_penalty, gp.seed = float(length_penalty), int(seed)
+        gp.typical_mass = float(typical_mass)
         L = _lib.lib()
         Tmax = S + int(max_new_tokens)
         need = L.itts_gpt_workspace_bytes(self._h, B, S, Tmax)
@@ -213,7 +220,7 @@ class UnifiedVoice:
 
     # ---- beam search / beam-sample (num_beams > 1; the reference default is 3-beam beam-sample) ------------------------
     def _generate_beam(self, inputs_embeds, attention_mask, max_new_tokens, do_sample, num_beams, top_p, top_k, temperature,
-                       repetition_penalty, length_penalty, uniforms, seed) -> torch.Tensor:
+                       repetition_penalty, length_penalty, uniforms, seed, typical_mass=0.0) -> torch.Tensor:
         dev = self.device
         nb = int(num_beams)
         B, s, D = inputs_embeds.shape
@@ -230,6 +237,7 @@ class UnifiedVoice:
         gp.top_p, gp.temperature = float(top_p), float(temperature)
         gp.repetition_penalty = float(repetition_penalty if repetition_penalty is not None else 1.0)
         gp.length_penalty, gp.seed = float(length_penalty), int(seed)
+        gp.typical_mass = float(typical_mass)
         L = _lib.lib()
         Tmax = S + max_new
         ws = self._workspace(L.itts_gpt_beam_workspace_bytes(self._h, B, nb, S, Tmax))
@@ -306,8 +314,8 @@ class UnifiedVoice:
         """model_v2.py:716-825 (campplus conditioning).  Returns (codes, speech_conditioning_latent)."""
         if input_tokens is not None or num_return_sequences != 1:
             raise NotImplementedError("input_tokens / num_return_sequences > 1 are not used by the v2.5 pipeline")
-        if typical_sampling:
-            raise NotImplementedError("typical_sampling is not on the device path")
+        if typical_sampling and not (typical_mass > 0.0 and typical_mass < 1.0):           # model_v2.py:796-797
+            raise ValueError(f"`typical_mass` has to be a float > 0 and < 1, but is {typical_mass}")
         if conds_latent is None:
             if campplus_embedding is None:
                 raise ValueError("campplus mode requires campplus_embedding or wav")
@@ -321,7 +329,8 @@ class UnifiedVoice:
         max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
         hf = dict(hf_generate_kwargs)
         hf.pop("logits_processor", None)
-        codes = self.generate(inputs_embeds, attention_mask, max_new, uniforms=uniforms, **hf)
+        codes = self.generate(inputs_embeds, attention_mask, max_new, uniforms=uniforms,
+                              typical_mass=float(typical_mass) if typical_sampling else 0.0, **hf)
         return codes, spk_lat
 
     # ---- teacher-forced latent pass (model_v2.py:596-646) ----------------------------------------------------------
@@ -349,6 +358,27 @@ class UnifiedVoice:
         enc = out[:, conds.shape[1]:]
         return enc[:, -mel.shape[1]:][:, :-2]
 
+    def forward(self, speech_conditioning_latent, text_inputs, text_lengths, mel_codes, mel_codes_lengths,
+                emo_speech_conditioning_latent=None, cond_mel_lengths=None, emo_cond_mel_lengths=None, emo_vec=None,
+                use_speed=None, do_spk_cond=False):
+        """`UnifiedVoice.forward` of v2/v2.5 (model_v2.py:596-646; call site infer_v2.py:636-651): the teacher-forced
+        pass that returns the mel-position latents.  campplus conditioning: `speech_conditioning_latent` is the style
+        vector when `do_spk_cond` (projected here) or the projected (b,1,D) latent otherwise; `emo_vec` must be given
+        (the emotion Conformer/Perceiver is outside this path)."""
+        if emo_vec is None:
+            raise NotImplementedError("emo_vec=None needs the emotion encoder (PyTorch side); pass emo_vec=")
+        dev = self.device
+        spk = speech_conditioning_latent.to(dev, torch.float32)
+        if do_spk_cond:
+            spk = F.linear(spk, self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
+            if spk.ndim != 3:
+                spk = spk.unsqueeze(1)
+        conds = torch.cat((spk + emo_vec.to(dev, torch.float32).unsqueeze(1),
+                           torch.zeros(spk.size(0), 2, spk.size(2), device=dev)), 1)
+        return self.forward_latent(conds, text_inputs, text_lengths, mel_codes, mel_codes_lengths)
+
+    __call__ = forward
+
     def __del__(self):
         try:
             if getattr(self, "_h", None) and self._h.value:
@@ -356,6 +386,70 @@ class UnifiedVoice:
                 self._h = C.c_void_p()
         except Exception:
             pass
+
+
+class UnifiedVoiceV1(UnifiedVoice):
+    """IndexTTS-1 / 1.5 `UnifiedVoice` (indextts/gpt/model.py): the same GPT-2 stack and generate loop; conditioning is a
+    (b,32,D) latent from the Conformer+Perceiver encoder (`get_conditioning`, model.py:495-524), which stays on PyTorch:
+    set `conditioning_fn` (e.g. the reference module's bound `get_conditioning`) or pass `conds_latent=`.
+    No language embedding, `inference_speech` returns the codes only (model.py:660-716)."""
+    _ALLOW_ENCODER_CONDITIONING = True
+    _HOST_TENSORS = ("mel_embedding.weight", "mel_pos_embedding.emb.weight", "text_embedding.weight",
+                     "text_pos_embedding.emb.weight")
+    _OPTIONAL_HOST_TENSORS = ()
+
+    def __init__(self, *args, condition_type="conformer_perceiver", conditioning_fn=None, **kw):
+        kw.setdefault("spk_cond_mode", "encoder")
+        super().__init__(*args, condition_type=condition_type, **kw)
+        self.condition_type = condition_type
+        self.conditioning_fn = conditioning_fn
+
+    def get_conditioning(self, speech_conditioning_input, cond_mel_lengths=None):
+        if self.conditioning_fn is None:
+            raise NotImplementedError("v1 conditioning encoder (Conformer + Perceiver) is outside the engine: set "
+                                      "UnifiedVoiceV1.conditioning_fn or pass conds_latent=")
+        return self.conditioning_fn(speech_conditioning_input, cond_mel_lengths)
+
+    def prepare_gpt_inputs(self, conditional_latents, text_inputs):                      # model.py:597-659
+        return super().prepare_gpt_inputs(conditional_latents, text_inputs, None)
+
+    def inference_speech(self, speech_conditioning_mel, text_inputs, cond_mel_lengths=None, input_tokens=None,
+                         num_return_sequences=1, max_generate_length=None, typical_sampling=False, typical_mass=.9,
+                         conds_latent=None, uniforms=None, **hf_generate_kwargs):
+        if input_tokens is not None or num_return_sequences != 1:
+            raise NotImplementedError("input_tokens / num_return_sequences > 1 are not used by the v1 pipeline")
+        if typical_sampling and not (typical_mass > 0.0 and typical_mass < 1.0):
+            raise ValueError(f"`typical_mass` has to be a float > 0 and < 1, but is {typical_mass}")
+        if conds_latent is None:
+            if speech_conditioning_mel.ndim == 2:
+                speech_conditioning_mel = speech_conditioning_mel.unsqueeze(0)
+            if cond_mel_lengths is None:
+                cond_mel_lengths = torch.tensor([speech_conditioning_mel.shape[-1]], device=speech_conditioning_mel.device)
+            conds_latent = self.get_conditioning(speech_conditioning_mel, cond_mel_lengths)
+        input_ids, inputs_embeds, attention_mask = self.prepare_gpt_inputs(conds_latent, text_inputs)
+        max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
+        hf = dict(hf_generate_kwargs)
+        hf.pop("logits_processor", None)
+        return self.generate(inputs_embeds, attention_mask, max_new, uniforms=uniforms,
+                             typical_mass=float(typical_mass) if typical_sampling else 0.0, **hf)
+
+    def forward(self, speech_conditioning_latent, text_inputs, text_lengths, mel_codes, wav_lengths, cond_mel_lengths=None,
+                types=None, text_first=True, raw_mels=None, return_attentions=False, return_latent=False,
+                clip_inputs=False, conds_latent=None):
+        """model.py:526-590 with `return_latent=True` (the only use on the inference path, infer.py:449-454,638-643)."""
+        if not return_latent or not text_first or raw_mels is not None or return_attentions or clip_inputs:
+            raise NotImplementedError("only the return_latent=True, text_first inference form is on the engine path")
+        if conds_latent is None:
+            conds_latent = self.get_conditioning(speech_conditioning_latent, cond_mel_lengths)
+        if types is not None:
+            text_inputs = text_inputs * (1 + types).unsqueeze(-1)
+        wl = torch.as_tensor(wav_lengths)
+        mel_codes_lengths = torch.ceil(wl / self.mel_length_compression).long() + 1              # model.py:557
+        b = text_inputs.shape[0]
+        conds = conds_latent.expand(b, -1, -1) if conds_latent.shape[0] == 1 and b > 1 else conds_latent
+        return self.forward_latent(conds, text_inputs, torch.as_tensor(text_lengths), mel_codes, mel_codes_lengths)
+
+    __call__ = forward
 
 
 def pack_gemm_weight(w_kn: torch.Tensor, precision: int, transposed: bool = False) -> torch.Tensor:

@@ -573,3 +573,12 @@ def forward_latent(sd, cfg: GPTConfig, conds: torch.Tensor, text_inputs: torch.T
     enc = F.layer_norm(enc, (cfg.model_dim,), sd["final_norm.weight"], sd["final_norm.bias"], cfg.ln_eps)
     mel_lat = enc[:, -mel_in.shape[1]:]
     return mel_lat[:, :-2]
+
+
+def forward_latent_v1(sd, cfg: GPTConfig, conds: torch.Tensor, text_inputs: torch.Tensor, text_lengths: torch.Tensor,
+                      mel_codes: torch.Tensor, wav_lengths: torch.Tensor, mel_length_compression: int = 1024) -> torch.Tensor:
+    """IndexTTS-1/1.5 `UnifiedVoice.forward(..., return_latent=True)` (indextts/gpt/model.py:526-590): the same pass as
+    `forward_latent`, with the mel lengths derived from the waveform lengths, `ceil(wav/compression) + 1` (:557), and
+    `conds` = the (B, 32, D) output of get_conditioning."""
+    mel_lengths = torch.ceil(wav_lengths / mel_length_compression).long() + 1
+    return forward_latent(sd, cfg, conds, text_inputs, text_lengths, mel_codes, mel_lengths)

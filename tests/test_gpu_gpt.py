@@ -74,6 +74,8 @@ def run_case(m, z, cfg, sd):
     g = z["gen"]
     kw = dict(do_sample=bool(g[0]), num_beams=int(g[1]), top_p=float(g[2]), top_k=int(g[3]), temperature=float(g[4]),
               repetition_penalty=float(g[5]), length_penalty=float(g[6]))
+    if len(g) > 7 and int(g[7]):
+        kw.update(typical_sampling=True, typical_mass=float(g[8]))
     u = torch.from_numpy(z["uniforms"])
     if kw["num_beams"] == 1:
         u = u[..., 0]
@@ -84,7 +86,7 @@ def run_case(m, z, cfg, sd):
     return codes.cpu().numpy()
 
 
-@pytest.mark.parametrize("tag", ["greedy", "greedy_mid", "greedy_nokv", "sample"])
+@pytest.mark.parametrize("tag", ["greedy", "greedy_mid", "greedy_nokv", "sample", "typical_sample", "typical_greedy"])
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_codes_bit_exact_vs_reference_golden(golden_dir, tag, use_graph):
     """f32 engine mode: ids identical to the ids the REFERENCE's own generate() produced (ragged left-padded batch,
@@ -99,7 +101,7 @@ def test_codes_bit_exact_vs_reference_golden(golden_dir, tag, use_graph):
         pytest.fail(f"first divergence at (row, step) = {bad[0].tolist()}: got {codes[tuple(bad[0])]} want {z['codes'][tuple(bad[0])]}")
 
 
-@pytest.mark.parametrize("tag", ["beam", "beam_sample"])
+@pytest.mark.parametrize("tag", ["beam", "beam_sample", "typical_beam_sample"])
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_beam_codes_bit_exact_vs_reference_golden(golden_dir, tag, use_graph):
     """Beam search and 3-beam beam-sample (the reference DEFAULT mode, infer_v2_5.py:732-740): device beam step +

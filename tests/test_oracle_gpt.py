@@ -22,10 +22,12 @@ def gen_params(z):
     g = z["gen"]
     return G.GenParams(do_sample=bool(g[0]), num_beams=int(g[1]), top_p=float(g[2]), top_k=int(g[3]),
                        temperature=float(g[4]), repetition_penalty=float(g[5]), length_penalty=float(g[6]),
+                       typical_sampling=bool(len(g) > 7 and int(g[7])), typical_mass=float(g[8]) if len(g) > 8 else 0.9,
                        max_generate_length=int(z["max_gen"]))
 
 
-@pytest.mark.parametrize("tag", ["greedy", "greedy_nokv", "sample", "beam", "beam_sample", "greedy_mid"])
+@pytest.mark.parametrize("tag", ["greedy", "greedy_nokv", "sample", "beam", "beam_sample", "greedy_mid",
+                                 "typical_sample", "typical_greedy", "typical_beam_sample"])
 def test_codes_match_reference(golden_dir, tag):
     z, cfg, sd = load_case(golden_dir, tag)
     gp = gen_params(z)

@@ -49,6 +49,7 @@ from oracle import gpt_oracle as G  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 MODEL_V2 = "/root/reference/indextts/gpt/model_v2.py"
+MODEL_V1 = "/root/reference/indextts/gpt/model.py"
 
 LEGACY_GENCFG = {"return_legacy_cache", "forced_decoder_ids"}     # attributes 4.52's GenerationConfig had
 # transformers 4.52.1 GenerationConfig defaults (5.15 initialises every field to None)
@@ -113,9 +114,9 @@ class TransformerAdapter(nn.Module):
         return out
 
 
-def extract(names_top, methods_of=None, method_names=()):
-    """Pull class/function definitions (and selected methods of a class) out of model_v2.py as source."""
-    src = open(MODEL_V2).read()
+def extract(names_top, methods_of=None, method_names=(), path=None):
+    """Pull class/function definitions (and selected methods of a class) out of model_v2.py / model.py as source."""
+    src = open(path or MODEL_V2).read()
     tree = ast.parse(src)
     out = {}
     for node in tree.body:
@@ -129,23 +130,27 @@ def extract(names_top, methods_of=None, method_names=()):
     return out
 
 
-def build_reference(sd, cfg: G.GPTConfig, kv_cache=True):
+def build_reference(sd, cfg: G.GPTConfig, kv_cache=True, v1=False):
+    """v1=True: the IndexTTS-1/1.5 classes of indextts/gpt/model.py (no language embedding, 32-token conditioning
+    latent from get_conditioning -- stubbed to return the latent it is handed, the encoder is outside the hot path)."""
+    MODEL = MODEL_V1 if v1 else MODEL_V2
     ns = dict(torch=torch, nn=nn, F=F, functools=functools, GPT2PreTrainedModel=HarnessPreTrainedModel,
               CausalLMOutputWithCrossAttentions=CausalLMOutputWithCrossAttentions,
               LogitsProcessorList=LogitsProcessorList, TypicalLogitsWarper=HFTypical,
               get_device_map=None, assert_device_map=None)
     pieces = extract({"GPT2InferenceModel", "LearnedPositionEmbeddings", "null_position_embeddings"},
                      "UnifiedVoice", ("prepare_gpt_inputs", "inference_speech", "forward", "get_logits",
-                                      "set_text_padding", "set_mel_padding", "build_aligned_inputs_and_targets"))
+                                      "set_text_padding", "set_mel_padding", "build_aligned_inputs_and_targets"),
+                     path=MODEL)
     for name in ("null_position_embeddings", "LearnedPositionEmbeddings", "GPT2InferenceModel"):
-        exec(compile(pieces[name], MODEL_V2 + ":" + name, "exec"), ns)
+        exec(compile(pieces[name], MODEL + ":" + name, "exec"), ns)
 
     class RefUnifiedVoice(nn.Module):
         pass
 
     for name in ("prepare_gpt_inputs", "inference_speech", "forward", "get_logits", "set_text_padding",
                  "set_mel_padding", "build_aligned_inputs_and_targets"):
-        exec(compile(pieces[name], MODEL_V2 + ":" + name, "exec"), ns)
+        exec(compile(pieces[name], MODEL + ":" + name, "exec"), ns)
         setattr(RefUnifiedVoice, name, ns[name])
 
     D = cfg.model_dim
@@ -156,6 +161,9 @@ def build_reference(sd, cfg: G.GPTConfig, kv_cache=True):
     uv.max_mel_tokens, uv.max_text_tokens = cfg.max_mel_tokens, cfg.max_text_tokens
     uv.spk_cond_mode = "campplus"
     uv.accel_engine = None
+    uv.mel_length_compression = 1024
+    if v1:
+        uv.get_conditioning = lambda latent, lengths=None: latent        # (b, 32, D) handed in directly
     uv.spk_emb_proj = nn.Linear(192, D)
     uv.text_embedding = nn.Embedding(cfg.number_text_tokens * cfg.types + 1, D)
     uv.lang_embedding = nn.Embedding(cfg.n_langs, D)
@@ -308,6 +316,45 @@ def main():
                                 seed=np.int64(seed), eos_bias=np.float64(eos_bias),
                                 cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens,
                                               cfg.max_mel_tokens, cfg.number_text_tokens]))
+
+    if only is None or "v1" in only:
+        make_v1()
+
+
+def make_v1():
+    """BASELINE configs[0] shape in miniature: IndexTTS-1/1.5 `UnifiedVoice` (indextts/gpt/model.py), greedy decode with
+    kv_cache=False (the reference's CPU setting, infer.py:99-101), 32-token conditioning latent, then the teacher-forced
+    latent pass `self.gpt(..., return_latent=True)` (infer.py:638-643) on the generated codes."""
+    seed, B, L, lens, max_gen, eos_bias = 33, 2, 9, [9, 6], 24, 1.7
+    cfg = G.GPTConfig(layers=2, model_dim=128, heads=2, max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200)
+    sd = G.synth_weights(cfg, seed=seed)
+    sd["mel_head.bias"][cfg.stop_mel_token] += eos_bias
+    g = torch.Generator().manual_seed(seed + 100)
+    text = ragged_text(g, B, L, cfg.number_text_tokens, lens)
+    conds = torch.randn(1, 32, cfg.model_dim, generator=g) * 0.3
+    gk = dict(do_sample=False, num_beams=1, repetition_penalty=10.0)
+    uv = build_reference(sd, cfg, kv_cache=False, v1=True)
+    with torch.no_grad():
+        codes = uv.inference_speech(conds, text, cond_mel_lengths=torch.tensor([7]), max_generate_length=max_gen, **gk)
+        oc = G.inference_speech(sd, cfg, conds, text, None, G.GenParams(max_generate_length=max_gen, **gk), kv_cache=False)
+    same = codes.shape == oc.shape and bool((codes == oc).all())
+    eos_at = [(int((r == cfg.stop_mel_token).nonzero()[0]) if (r == cfg.stop_mel_token).any() else -1) for r in codes]
+    print(f"v1_greedy_nokv: ref codes {tuple(codes.shape)} eos_at={eos_at} oracle==reference: {same}")
+    code_lens = torch.tensor([(e if e >= 0 else codes.shape[1]) for e in eos_at])
+    code_lens[1] = min(int(code_lens[1]), 12)              # ragged lengths for set_mel_padding (model.py:439-451)
+    mel_codes = codes[:, : int(code_lens.max())].clone()
+    tl = torch.tensor(lens)
+    with torch.no_grad():
+        lat_ref = uv.forward(conds.repeat(B, 1, 1), text.clone(), tl, mel_codes.clone(), code_lens * uv.mel_length_compression,
+                             cond_mel_lengths=torch.tensor([7]), return_latent=True, clip_inputs=False)
+        lat_o = G.forward_latent_v1(sd, cfg, conds.repeat(B, 1, 1), text, tl, mel_codes, code_lens * 1024)
+    print(f"  v1 latent pass: ref {tuple(lat_ref.shape)} oracle max|d| = {(lat_ref - lat_o).abs().max().item():.3e}")
+    np.savez_compressed(os.path.join(GOLD, "gpt_v1.npz"), text=text.numpy(), text_lens=tl.numpy(), conds=conds.numpy(),
+                        codes=codes.numpy(), code_lens=code_lens.numpy(), mel_codes=mel_codes.numpy(),
+                        latent=lat_ref.numpy().astype(np.float32), seed=np.int64(seed), eos_bias=np.float64(eos_bias),
+                        max_gen=np.int64(max_gen),
+                        cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens, cfg.max_mel_tokens,
+                                      cfg.number_text_tokens]))
 
 
 if __name__ == "__main__":
