@@ -56,3 +56,46 @@ class StubFrontend(Frontend):
                 m = cb[codes[b, :n].clamp(0, 8193)].repeat_interleave(2, dim=0)[: int(lens[b])]
                 mel[b, :, : m.shape[0]] = m.t() - 4.0
         return mel, lens.to(torch.int32)
+
+
+class StubTokenizerV1:
+    """Whitespace 'tokenizer' with the TextTokenizer methods the v1 pipeline calls (indextts/utils/front.py)."""
+
+    def __init__(self, n_text=200):
+        self.n_text = n_text
+
+    def tokenize(self, text):
+        return text.split()
+
+    def split_segments(self, tokens, max_text_tokens_per_segment=120):
+        segs, cur = [], []
+        for t in tokens:
+            cur.append(t.rstrip("."))
+            if t.endswith(".") or len(cur) >= max_text_tokens_per_segment:
+                segs.append(cur)
+                cur = []
+        if cur:
+            segs.append(cur)
+        return segs
+
+    def convert_tokens_to_ids(self, sent):
+        return [2 + (sum(map(ord, t)) % (self.n_text - 2)) for t in sent]
+
+
+class StubFrontendV1:
+    """cond mel + conditioning latent stand-ins for the v1 pipeline (indextts/infer.py)."""
+
+    def __init__(self, model_dim, device="cpu", n_text=200):
+        g = torch.Generator().manual_seed(3)
+        self.mel = torch.randn(1, 100, 37, generator=g)
+        self.latent = torch.randn(1, 32, model_dim, generator=g) * 0.3
+        self.device = device
+        self.tokenizer = StubTokenizerV1(n_text)
+        self.calls = []
+
+    def cond_mel(self, audio_prompt, truncate_seconds=None):
+        self.calls.append(("cond_mel", audio_prompt, truncate_seconds))
+        return self.mel.to(self.device)
+
+    def conditioning(self, cond_mel, cond_mel_lengths):
+        return self.latent.to(self.device)

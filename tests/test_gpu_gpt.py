@@ -159,6 +159,46 @@ def test_latent_pass_vs_reference_golden(golden_dir):
     np.testing.assert_allclose(lat, z["latent"], rtol=0, atol=5e-5)
 
 
+def test_v1_decode_and_latent_vs_reference_golden(golden_dir):
+    """IndexTTS-1/1.5 mirror (`UnifiedVoiceV1`, reference indextts/gpt/model.py): BASELINE configs[0] in miniature --
+    greedy, kv_cache=False position rule, 32-token conditioning latent, then `gpt(..., return_latent=True)`."""
+    from indextts_amd import gpt
+    z = np.load(os.path.join(golden_dir, "gpt_v1.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]),
+                      max_mel_tokens=int(c[4]), number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))
+    sd["mel_head.bias"][cfg.stop_mel_token] += float(z["eos_bias"])
+    m = gpt.UnifiedVoiceV1(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
+                           max_mel_tokens=cfg.max_mel_tokens, number_text_tokens=cfg.number_text_tokens,
+                           precision="fp32", device=DEV)
+    m.load_state_dict(sd)
+    m.post_init_gpt2_config(kv_cache=False)
+    conds, text = torch.from_numpy(z["conds"]), torch.from_numpy(z["text"])
+    m.conditioning_fn = lambda mel, lengths=None: conds.to(DEV)          # stands in for Conformer + Perceiver
+    codes = m.inference_speech(torch.zeros(1, 100, 7), text, cond_mel_lengths=torch.tensor([7]),
+                               max_generate_length=int(z["max_gen"]), do_sample=False, num_beams=1, repetition_penalty=10.0)
+    assert np.array_equal(codes.cpu().numpy(), z["codes"])
+    B = text.shape[0]
+    lat = m(conds.repeat(B, 1, 1), text, torch.from_numpy(z["text_lens"]), torch.from_numpy(z["mel_codes"]),
+            torch.from_numpy(z["code_lens"]) * m.mel_length_compression, cond_mel_lengths=torch.tensor([7]),
+            return_latent=True, clip_inputs=False, conds_latent=conds.repeat(B, 1, 1))
+    assert lat.shape == z["latent"].shape
+    np.testing.assert_allclose(lat.cpu().numpy(), z["latent"], rtol=0, atol=5e-5)
+    with pytest.raises(NotImplementedError):
+        m.conditioning_fn = None
+        m.inference_speech(torch.zeros(1, 100, 7), text)
+
+
+def test_typical_mass_validation():
+    from indextts_amd import gpt
+    cfg = G.GPTConfig(layers=1, model_dim=128, heads=2, max_text_tokens=20, max_mel_tokens=30, number_text_tokens=50)
+    m = engine(cfg, G.synth_weights(cfg, seed=3), "fp32")
+    with pytest.raises(ValueError):
+        m.inference_speech(None, torch.randint(2, 50, (1, 5)), emo_vec=torch.zeros(1, 128), campplus_embedding=torch.zeros(1, 192),
+                           typical_sampling=True, typical_mass=1.5, max_generate_length=3)
+
+
 def test_full_size_greedy_vs_oracle():
     """IndexTTS-2.5 sized stack (24 x 1280, 20 heads), B=3 ragged, 10 steps: ids identical to the CPU oracle."""
     cfg = G.GPTConfig(max_text_tokens=120, max_mel_tokens=200)

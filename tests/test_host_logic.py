@@ -114,3 +114,45 @@ def test_prepare_gpt_inputs_matches_oracle():
     fo, eo, mo = G.prepare_gpt_inputs(sd, cfg, condsB, text, langs[:1])
     fm, em, mm = m.prepare_gpt_inputs(condsB, text, langs[:1])
     assert torch.equal(mo, mm) and torch.allclose(eo, em, atol=1e-6)
+
+
+# ---- v1 pipeline helpers vs the reference's own functions (fixture: tools/make_golden_host.py) ----------------------
+def _v1_shell(version=None):
+    from indextts_amd.infer import IndexTTS
+    t = IndexTTS.__new__(IndexTTS)                       # helpers need no engine / GPU
+    t.stop_mel_token = 8193
+    t.cfg = {"gpt": {"stop_text_token": 1, "start_text_token": 0}}
+    t.model_version = version
+    return t
+
+
+def _host_golden(golden_dir):
+    import json
+    import os
+    with open(os.path.join(golden_dir, "host_v1.json")) as f:
+        return json.load(f)
+
+
+def test_v1_remove_long_silence_matches_reference(golden_dir):
+    import torch
+    t = _v1_shell()
+    for case in _host_golden(golden_dir)["silence"]:
+        codes, lens = t.remove_long_silence(torch.tensor(case["codes"], dtype=torch.long), silent_token=52, max_consecutive=30)
+        assert codes.tolist() == case["out"]
+        assert lens.tolist() == case["lens"]
+
+
+def test_v1_bucket_segments_matches_reference(golden_dir):
+    t = _v1_shell()
+    for case in _host_golden(golden_dir)["buckets"]:
+        segs = [["t"] * n for n in case["lens"]]
+        res = t.bucket_segments(segs, bucket_max_size=case["bucket_max_size"])
+        assert [[it["idx"] for it in b] for b in res] == case["out"], case
+
+
+def test_v1_pad_tokens_cat_matches_reference(golden_dir):
+    import torch
+    for case in _host_golden(golden_dir)["pad"]:
+        t = _v1_shell(case["version"])
+        res = t.pad_tokens_cat([torch.tensor(x) for x in case["tokens"]])
+        assert res.tolist() == case["out"]

@@ -103,3 +103,22 @@ def test_processors_vs_installed_hf():
         mine = G.process_scores(scores.clone(), ids, G.GenParams(do_sample=True, num_beams=nb))
         assert torch.equal(torch.isinf(ref), torch.isinf(mine))
         assert torch.allclose(ref[~torch.isinf(ref)], mine[~torch.isinf(mine)], atol=0, rtol=0)
+
+
+def test_v1_codes_and_latent_match_reference(golden_dir):
+    """IndexTTS-1/1.5 classes (indextts/gpt/model.py): greedy kv_cache=False decode + return_latent pass, fixture minted by
+    running the reference's own v1 inference_speech / forward (tools/make_golden_gpt.py make_v1)."""
+    z = np.load(os.path.join(golden_dir, "gpt_v1.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]),
+                      max_mel_tokens=int(c[4]), number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))
+    sd["mel_head.bias"][cfg.stop_mel_token] += float(z["eos_bias"])
+    conds, text = torch.from_numpy(z["conds"]), torch.from_numpy(z["text"])
+    gp = G.GenParams(do_sample=False, num_beams=1, repetition_penalty=10.0, max_generate_length=int(z["max_gen"]))
+    with torch.no_grad():
+        codes = G.inference_speech(sd, cfg, conds, text, None, gp, kv_cache=False)
+        lat = G.forward_latent_v1(sd, cfg, conds.repeat(text.shape[0], 1, 1), text, torch.from_numpy(z["text_lens"]),
+                                  torch.from_numpy(z["mel_codes"]), torch.from_numpy(z["code_lens"]) * 1024)
+    assert np.array_equal(codes.numpy(), z["codes"])
+    np.testing.assert_allclose(lat.numpy(), z["latent"], rtol=0, atol=5e-6)
