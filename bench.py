@@ -26,6 +26,7 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
 SR, HOP = 22050, 256
 
 
@@ -231,8 +232,13 @@ def main():
         ms_tok = gpt_t["decode_ms"] / n_dec
         ctx_avg = (n_text + 6) + n_gen / 2.0
         bytes_step = (12 * D * D * L + D * V) * esz + B * 2 * L * D * ctx_avg * esz
+        s_pre = n_text + 6                                         # 3 cond + text + start/stop text + start mel
+        prefill_flops = 2.0 * (12 * D * D * L) * B * s_pre + 4.0 * L * D * s_pre * s_pre * B / 2 + 2.0 * D * V * B
+        prefill_tflops = prefill_flops / (gpt_t["prefill_ms"] / args.steps * 1e-3) / 1e12
         stages = {
             "gpt_prefill_ms_per_step": gpt_t["prefill_ms"] / args.steps,
+            "gpt_prefill_tflops": prefill_tflops,          # whole prefill pass (GEMMs + attention + LayerNorms) per wall time
+            "gpt_prefill_mfma_frac": prefill_tflops / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
             "gpt_decode_ms_per_step": gpt_t["decode_ms"] / args.steps,
             "gpt_decode_ms_per_token": ms_tok,
             "gpt_decode_algorithmic_GBps": bytes_step / (ms_tok * 1e-3) / 1e9,

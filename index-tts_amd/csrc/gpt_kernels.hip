@@ -356,6 +356,166 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
     }
 }
 
+// ================================================================================================================
+// Prefill / teacher-forced GEMM, bf16: C[M,N] = A[M,K] * W on v_mfma_f32_16x16x32_bf16.
+//   block tile 128 x 128, BK = 64, 4 waves as 2 (M) x 2 (N), each 64 x 64 = 4 x 4 MFMA tiles (64 accumulator registers);
+//   both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction), two LDS buffers:
+//   tile t+1 is in flight while tile t feeds the MFMAs; one barrier per K tile.
+//   A image: 16 chunks of [8 rows][128 B]; a chunk is filled by ONE instruction reading 8 full 128-byte lines, the 16-byte
+//   pieces of a row XOR-permuted by (row16 >> 1) on the SOURCE side (the LDS destination of an LDS-DMA is lane-linear) so
+//   the 16 rows of a fragment read hit 16 distinct 16-byte bank slots.  W is already stored in fragment order
+//   ([N/16][K/32][64 lanes][16 B]): a chunk is one contiguous KiB and its ds_read_b128 is lane-linear.
+//   Block -> tile map: XCD-aware (consecutive tiles of one XCD's share) and grouped 8 m-tiles x all n-tiles so the
+//   blocks resident on an XCD reuse A rows and W columns out of that XCD's L2.
+// ================================================================================================================
+#define PF_BM 128
+#define PF_BN 128
+#define PF_BK 64
+#define PF_GM 8
+
+template <int EPI>
+__device__ __forceinline__ void pf_epilogue(const GemmArgs& a, int mbase, int nbase, int lane, f32x4 v) {
+    const int n = nbase + (lane & 15);
+    if (n >= a.N) return;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+    int which = 0, c = n;
+    if constexpr (EPI == EPI_QKV) { which = n / a.D; c = n - which * a.D; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = mbase + (lane >> 4) * 4 + r;
+        if (m >= a.M) continue;
+        const float val = v[r] + bias;
+        if constexpr (EPI == EPI_STORE_F32) a.out_f32[(size_t)m * a.ldo + n] = val;
+        else if constexpr (EPI == EPI_RESIDUAL) a.out_f32[(size_t)m * a.ldo + n] += val;
+        else if constexpr (EPI == EPI_GELU_ACT) ((u16*)a.out_act)[(size_t)m * a.ldo + n] = f32_to_bf16(gelu_new_f(val));
+        else {                                                   // EPI_QKV
+            if (which == 0) {
+                a.qbuf[(size_t)m * a.D + c] = val;
+            } else {
+                const int b = m / a.S, si = m - b * a.S;
+                const int pos = *a.pos_ptr + si;
+                const size_t o = (((size_t)b * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
+                ((u16*)(which == 1 ? a.kcache : a.vcache))[o] = f32_to_bf16(val);
+            }
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB | W 16 KiB]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int n_mt = (a.M + PF_BM - 1) / PF_BM, n_nt = (a.N + PF_BN - 1) / PF_BN;
+    const int total = n_mt * n_nt, per = (total + 7) >> 3;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= total) return;
+    const int g = t / (PF_GM * n_nt), first_m = g * PF_GM;
+    const int gm = (n_mt - first_m) < PF_GM ? (n_mt - first_m) : PF_GM;
+    const int r = t - g * PF_GM * n_nt;
+    const int bn = r / gm, bm = first_m + (r - bn * gm);
+    const int m0 = bm * PF_BM, nt0 = bn * (PF_BN / 16);
+    const int nkb = a.K >> 5, nk = a.K / PF_BK;
+    const int ntiles = (a.N + 15) >> 4;
+
+    // staging sources of this lane: 4 A chunks (rows) and 4 W chunks per wave per K tile
+    const char* asrc[4];
+    const char* bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = w * 4 + i;                               // A chunk: tile rows c*8 .. c*8+7
+        const int row_t = c * 8 + (lane >> 3), row16 = row_t & 15;
+        const int piece = (lane & 7) ^ ((row16 >> 1) & 7);
+        int m = m0 + row_t;
+        m = m < a.M ? m : a.M - 1;
+        asrc[i] = (const char*)a.A + ((size_t)m * a.lda + piece * 8) * 2;
+        const int nblk = w * 2 + (i >> 1), kb = i & 1;          // W chunk (n-block, k-block of the pair)
+        int nt = nt0 + nblk;
+        nt = nt < ntiles ? nt : ntiles - 1;
+        bsrc[i] = (const char*)a.Wp + ((size_t)nt * nkb + kb) * 1024 + lane * 16;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = pf_sm + buf * 32768;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)kt * (PF_BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(base + (w * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (size_t)kt * 2048),
+                                             (__attribute__((address_space(3))) void*)(base + 16384 + ((w * 2 + (i >> 1)) * 2 + (i & 1)) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes inside a buffer)
+    const int row16 = lane & 15, kg = lane >> 4;
+    int a_off[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int pos = (s2 * 4 + kg) ^ ((row16 >> 1) & 7);
+        a_off[s2] = (row16 >> 3) * 1024 + ((row16 & 7) * 8 + pos) * 16;
+    }
+    const int a_wave = wr * 4 * 2048;                           // 4 m-blocks of 2 chunks each
+    const int b_wave = 16384 + wc * 4 * 2048 + lane * 16;
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* base = pf_sm + (kt & 1) * 32768;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            v4u af[4], bfr[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const v4u*)(base + a_wave + mt * 2048 + a_off[s2]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bfr[nt] = *(const v4u*)(base + b_wave + (nt * 2 + s2) * 1024);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[mt]),
+                                                                          __builtin_bit_cast(bf16x8_t, bfr[nt]), acc[mt][nt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int ntile = nt0 + wc * 4 + nt;
+            if (ntile < ntiles) pf_epilogue<EPI>(a, m0 + wr * 64 + mt * 16, ntile * 16, lane, acc[mt][nt]);
+        }
+}
+
+template <int EPI>
+static int launch_gemm_prefill_e(const GemmArgs& a, hipStream_t st) {
+    const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
+    const int per = ceil_div(n_mt * n_nt, 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_prefill_kernel<EPI>, dim3(per * 8), dim3(256), 65536, st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
+    switch (a.epi) {
+        case EPI_STORE_F32: return launch_gemm_prefill_e<EPI_STORE_F32>(a, st);
+        case EPI_RESIDUAL: return launch_gemm_prefill_e<EPI_RESIDUAL>(a, st);
+        case EPI_GELU_ACT: return launch_gemm_prefill_e<EPI_GELU_ACT>(a, st);
+        case EPI_QKV: return launch_gemm_prefill_e<EPI_QKV>(a, st);
+        default: itts_set_error("gemm prefill: unsupported epilogue %d", a.epi); return ITTS_ERR_ARG;
+    }
+}
+
 template <bool BF16, int MT, int NT, bool KSPLIT>
 static int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
     const int ntiles = (a.N + 15) / 16;
@@ -369,7 +529,12 @@ static int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
 
 template <bool BF16>
 static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
-    if (prefill) return launch_gemm_cfg<BF16, 8, 2, false>(a, st);
+    if (prefill) {
+        // bf16, K a multiple of the 64-deep K tile, 16-byte aligned rows: the LDS-DMA tile kernel; else the direct-load one
+        static const bool old_path = [] { const char* e = getenv("ITTS_PREFILL_GEMM"); return e && atoi(e) == 0; }();
+        if (BF16 && !old_path && a.K % PF_BK == 0 && a.lda % 8 == 0 && a.nsplit == 1 && a.epi != EPI_PARTIAL) return launch_gemm_prefill(a, st);
+        return launch_gemm_cfg<BF16, 8, 2, false>(a, st);
+    }
     if (a.M <= 16) return launch_gemm_cfg<BF16, 1, 1, true>(a, st);
     if (a.M <= 32) return launch_gemm_cfg<BF16, 2, 1, true>(a, st);
     return launch_gemm_cfg<BF16, 4, 1, true>(a, st);

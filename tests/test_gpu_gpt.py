@@ -190,6 +190,23 @@ def test_v1_decode_and_latent_vs_reference_golden(golden_dir):
         m.inference_speech(torch.zeros(1, 100, 7), text)
 
 
+def test_prefill_gemm_kernels_agree():
+    """bf16 prefill: the LDS-DMA 128x128 tile kernel and the direct-load kernel issue the same MFMA on the same fragments
+    in the same K order, so the teacher-forced latents and the decoded ids must be BITWISE equal between the two."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prefill_probe.py")
+    outs = []
+    for v in ("0", "1"):
+        env = dict(os.environ, ITTS_PREFILL_GEMM=v)
+        r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1]
+        outs.append(line)
+    assert float(outs[0].split()[2]) > 1e-3          # the latents are not trivially zero
+    assert outs[0] == outs[1], outs
+
+
 def test_typical_mass_validation():
     from indextts_amd import gpt
     cfg = G.GPTConfig(layers=1, model_dim=128, heads=2, max_text_tokens=20, max_mel_tokens=30, number_text_tokens=50)
