@@ -23,8 +23,113 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));   // native vector
 // LayerNorm (+ fused split-K reduce, bias, residual write-back, optional second LayerNorm)
 // one wave per row, NE = D/64 elements per lane kept in registers
 // ================================================================================================================
-template <int NE, bool OUT_BF16>
+// Every operand of a row (x, the 4 split-K partials, the previous GEMM's bias, both affine pairs) is fetched in ONE
+// phase of 16-byte loads issued back to back: the kernel is a latency chain (launch -> loads -> 2-4 wave reductions ->
+// stores), so each extra dependent load phase costs a full L2/HBM round trip.  Which operands exist is a template
+// parameter (FLAGS) -- a runtime branch around a group of loads makes hipcc wait for the previous group first.
+//   lane holds elements 4*lane + 256*i + {0..3}, i < NV = D/256.
+enum { LN_PARTIAL = 1, LN_BIAS = 2, LN_SECOND = 4 };
+
+template <int NV, bool OUT_BF16, int FLAGS>
 __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + w;
+    if (r >= a.rows) return;
+    const int D = a.D;
+    const size_t in_r = (size_t)r * a.in_row_mul + a.in_row_add;
+    float* xr = a.x + in_r * D;
+    f32x4 v[NV], p0[NV], p1[NV], p2[NV], p3[NV], bp[NV], g1[NV], b1[NV], g2[NV], b2[NV];
+    const size_t ps = (size_t)a.rows * D;
+    const float* pp = a.partial + (size_t)r * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int e = 4 * lane + 256 * i;
+        v[i] = *(const f32x4*)(xr + e);
+        if constexpr (FLAGS & LN_PARTIAL) {
+            p0[i] = *(const f32x4*)(pp + e); p1[i] = *(const f32x4*)(pp + ps + e);
+            p2[i] = *(const f32x4*)(pp + 2 * ps + e); p3[i] = *(const f32x4*)(pp + 3 * ps + e);
+        }
+        if constexpr (FLAGS & LN_BIAS) bp[i] = *(const f32x4*)(a.bias_prev + e);
+        g1[i] = *(const f32x4*)(a.g1 + e);
+        b1[i] = *(const f32x4*)(a.b1 + e);
+        if constexpr (FLAGS & LN_SECOND) { g2[i] = *(const f32x4*)(a.g2 + e); b2[i] = *(const f32x4*)(a.b2 + e); }
+    }
+    __builtin_amdgcn_sched_barrier(0);          // keep hipcc from sinking the affine loads below the reductions
+    if constexpr (FLAGS & LN_PARTIAL) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] += (p0[i][j] + p1[i][j]) + (p2[i][j] + p3[i][j]);
+    }
+    if constexpr (FLAGS & LN_BIAS) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] += bp[i][j];
+    }
+    if constexpr (FLAGS & (LN_PARTIAL | LN_BIAS)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *(f32x4*)(xr + 4 * lane + 256 * i) = v[i];
+    }
+    const float invD = 1.0f / (float)D;
+    auto normalise = [&](const f32x4 (&g)[NV], const f32x4 (&bb)[NV]) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        const float mean = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * invD + a.eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * g[i][j] + bb[i][j];
+    };
+    normalise(g1, b1);
+    if constexpr (FLAGS & LN_SECOND) normalise(g2, b2);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const size_t o = (size_t)r * D + 4 * lane + 256 * i;
+        if (OUT_BF16 && !a.out_f32) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v[i][0]) | ((uint32_t)f32_to_bf16(v[i][1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v[i][2]) | ((uint32_t)f32_to_bf16(v[i][3]) << 16);
+            *(uint2*)((u16*)a.out + o) = pk;
+        } else {
+            *(f32x4*)((float*)a.out + o) = v[i];
+        }
+    }
+}
+
+template <int NV, bool OUT_BF16>
+static void launch_ln_flags(const LnArgs& a, dim3 grid, hipStream_t st) {
+    const int flags = (a.partial ? LN_PARTIAL : 0) | (a.bias_prev ? LN_BIAS : 0) | (a.g2 ? LN_SECOND : 0);
+#define LN_F(F) case F: hipLaunchKernelGGL((ln_kernel<NV, OUT_BF16, F>), grid, dim3(256), 0, st, a); break;
+    switch (flags) { LN_F(0) LN_F(1) LN_F(2) LN_F(3) LN_F(4) LN_F(5) LN_F(6) LN_F(7) }
+#undef LN_F
+}
+
+template <bool OUT_BF16>
+static int launch_ln_t(const LnArgs& a, hipStream_t st) {
+    dim3 grid(ceil_div(a.rows, 4));
+#define LN_CASE(NV) case NV: launch_ln_flags<NV, OUT_BF16>(a, grid, st); break;
+    switch (a.D / 256) {
+        LN_CASE(1) LN_CASE(2) LN_CASE(3) LN_CASE(4) LN_CASE(5) LN_CASE(6) LN_CASE(8)
+        default:
+            itts_set_error("layernorm: model_dim %d unsupported (need 256 * {1,2,3,4,5,6,8})", a.D);
+            return ITTS_ERR_ARG;
+    }
+#undef LN_CASE
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// model_dim not a multiple of 256 (small test models): one 4-byte element per lane per step, loads in phases
+template <int NE, bool OUT_BF16>
+__global__ __launch_bounds__(256) void ln_small_kernel(LnArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + w;
     if (r >= a.rows) return;
@@ -94,9 +199,9 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
 }
 
 template <bool OUT_BF16>
-static int launch_ln_t(const LnArgs& a, hipStream_t st) {
+static int launch_ln_small_t(const LnArgs& a, hipStream_t st) {
     dim3 grid(ceil_div(a.rows, 4));
-#define LN_CASE(NE) case NE: hipLaunchKernelGGL((ln_kernel<NE, OUT_BF16>), grid, dim3(256), 0, st, a); break;
+#define LN_CASE(NE) case NE: hipLaunchKernelGGL((ln_small_kernel<NE, OUT_BF16>), grid, dim3(256), 0, st, a); break;
     switch (a.D / 64) {
         LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(12) LN_CASE(16) LN_CASE(20) LN_CASE(24) LN_CASE(32)
         default:
@@ -110,7 +215,10 @@ static int launch_ln_t(const LnArgs& a, hipStream_t st) {
 
 int launch_ln(const LnArgs& a, int prec, hipStream_t st) {
     if (a.rows <= 0) return ITTS_OK;
-    if (a.D % 64) { itts_set_error("layernorm: D %% 64 != 0"); return ITTS_ERR_ARG; }
+    if (a.D % 256) {      // smaller test models: the scalar-load variant
+        if (a.D % 64) { itts_set_error("layernorm: D %% 64 != 0"); return ITTS_ERR_ARG; }
+        return prec == PREC_BF16 ? launch_ln_small_t<true>(a, st) : launch_ln_small_t<false>(a, st);
+    }
     if (a.partial && a.nsplit != 4) { itts_set_error("layernorm: fused split-K reduce expects 4 slices"); return ITTS_ERR_ARG; }
     return prec == PREC_BF16 ? launch_ln_t<true>(a, st) : launch_ln_t<false>(a, st);
 }
@@ -266,7 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
                 const int kbc = ok ? kbi : kb_lo;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    v4u v = wp[nt][(size_t)kbc * 64];
+                    v4u v = *(const v4u*)(wp[nt] + (size_t)kbc * 64);
                     if (!ok) v = v4u{0u, 0u, 0u, 0u};
                     bq[i][nt] = v;
                 }
