@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     __shared__ int red_i[4];
     __shared__ int s_tok;
     __shared__ int cand_i[SAMPLE_CAP];
-    __shared__ float cand_v[SAMPLE_CAP];
+    __shared__ float cand_v[SAMPLE_CAP], cand_e[SAMPLE_CAP];
     const int b = blockIdx.x, tid = threadIdx.x, V = a.V;
     const int step = *a.step_ptr;
     const float* lg = a.logits + (size_t)b * V;
@@ -1019,45 +1019,53 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             if (tid < n) { cand_v[rank] = myv; cand_i[rank] = myi; }
             __syncthreads();
         }
-        if (tid == 0) {
-            int n = (int)(s_count < SAMPLE_CAP ? s_count : SAMPLE_CAP);
-            // (sorted ascending by (value, index) above)
-            int lo = 0;                                   // first kept element after top-p
-            if (a.top_p < 1.0f) {
-                const float mx = cand_v[n - 1];
-                float sum = 0.f;
-                for (int i = 0; i < n; ++i) sum += expf(cand_v[i] - mx);
-                const float thr = (float)(1.0 - (double)a.top_p);
-                double cum = 0.0;
-                const int keep = a.min_keep < 1 ? 1 : a.min_keep;
-                for (int i = 0; i < n - keep; ++i) {
-                    cum += (double)(expf(cand_v[i] - mx) / sum);
-                    if ((float)cum <= thr) lo = i + 1; else break;
+        {   // exponentials in parallel; the float / double sums below keep the sequential ascending order
+            const int n = (int)(s_count < SAMPLE_CAP ? s_count : SAMPLE_CAP);
+            if (tid < n) cand_e[tid] = expf(cand_v[tid] - cand_v[n - 1]);
+            __syncthreads();
+            if (tid == 0) {
+                int lo = 0;                                   // first kept element after top-p
+                if (a.top_p < 1.0f) {
+                    float sum = 0.f;
+                    for (int i = 0; i < n; ++i) sum += cand_e[i];
+                    const float thr = (float)(1.0 - (double)a.top_p);
+                    double cum = 0.0;
+                    const int keep = a.min_keep < 1 ? 1 : a.min_keep;
+                    for (int i = 0; i < n - keep; ++i) {
+                        cum += (double)(cand_e[i] / sum);
+                        if ((float)cum <= thr) lo = i + 1; else break;
+                    }
                 }
+                float sum = 0.f;                              // renormalised softmax over the kept set
+                for (int i = lo; i < n; ++i) sum += cand_e[i];
+                red_v[0] = sum;
+                red_i[0] = lo;
             }
-            // renormalised softmax over the kept set, inverse CDF in vocabulary order
-            const float mx = cand_v[n - 1];
-            float sum = 0.f;
-            for (int i = lo; i < n; ++i) sum += expf(cand_v[i] - mx);
-            for (int i = lo; i < n; ++i) cand_v[i] = expf(cand_v[i] - mx) / sum;
-            for (int i = lo + 1; i < n; ++i) {            // sort kept by index
-                const float v = cand_v[i];
-                const int ix = cand_i[i];
-                int j = i - 1;
-                while (j >= lo && cand_i[j] > ix) { cand_v[j + 1] = cand_v[j]; cand_i[j + 1] = cand_i[j]; --j; }
-                cand_v[j + 1] = v; cand_i[j + 1] = ix;
+            __syncthreads();
+            const int lo = red_i[0];
+            const float sum = red_v[0];
+            // kept set in vocabulary order: parallel rank sort on the (unique) token index
+            float myp = 0.f; int myi = 0, rank = 0;
+            if (tid >= lo && tid < n) {
+                myp = cand_e[tid] / sum; myi = cand_i[tid];
+                for (int q = lo; q < n; ++q) rank += (cand_i[q] < myi) ? 1 : 0;
             }
-            double total = 0.0;
-            for (int i = lo; i < n; ++i) total += (double)cand_v[i];
-            const double u = a.uniforms ? a.uniforms[(size_t)step * a.B + b] : rng_uniform(a.seed, (unsigned long long)step, (unsigned long long)b);
-            const double tgt = u * total;
-            double cum = 0.0;
-            int pick = cand_i[n - 1];
-            for (int i = lo; i < n; ++i) {
-                cum += (double)cand_v[i];
-                if (cum > tgt) { pick = cand_i[i]; break; }
+            __syncthreads();
+            if (tid >= lo && tid < n) { cand_v[lo + rank] = myp; cand_i[lo + rank] = myi; }
+            __syncthreads();
+            if (tid == 0) {
+                double total = 0.0;
+                for (int i = lo; i < n; ++i) total += (double)cand_v[i];
+                const double u = a.uniforms ? a.uniforms[(size_t)step * a.B + b] : rng_uniform(a.seed, (unsigned long long)step, (unsigned long long)b);
+                const double tgt = u * total;
+                double cum = 0.0;
+                int pick = cand_i[n - 1];
+                for (int i = lo; i < n; ++i) {
+                    cum += (double)cand_v[i];
+                    if (cum > tgt) { pick = cand_i[i]; break; }
+                }
+                s_tok = pick;
             }
-            s_tok = pick;
         }
     }
     __syncthreads();
@@ -1126,7 +1134,9 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
     __shared__ float cv[BEAM_CAP];
     __shared__ int ui[BEAM_MAX * BEAM_CAP];              // union: flat index beam*V + token
     __shared__ float uv[BEAM_MAX * BEAM_CAP];
-    __shared__ int s_un;
+    __shared__ float ue[BEAM_MAX * BEAM_CAP];            // exp(uv - max) of the union / scratch exponentials per beam
+    __shared__ int s_un, s_lo;
+    __shared__ float s_mxv;
     const int b = blockIdx.x, tid = threadIdx.x, V = a.V, nb = a.nb;
     const int step = *a.step_ptr;
     const int par = step & 1;
@@ -1211,84 +1221,103 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            int n = (int)(s_count < BEAM_CAP ? s_count : BEAM_CAP);
-            for (int i = 1; i < n; ++i) {                 // ascending by (value, index)
-                const float v = cv[i];
-                const int ix = ci[i];
-                int q = i - 1;
-                while (q >= 0 && (cv[q] > v || (cv[q] == v && ci[q] > ix))) { cv[q + 1] = cv[q]; ci[q + 1] = ci[q]; --q; }
-                cv[q + 1] = v; ci[q + 1] = ix;
-            }
-            int lo = 0;
-            if (a.do_sample && a.top_p < 1.0f) {
-                const float mxv = cv[n - 1];
-                float sum = 0.f;
-                for (int i = 0; i < n; ++i) sum += expf(cv[i] - mxv);
-                const float thr = (float)(1.0 - (double)a.top_p);
-                double cum = 0.0;
-                const int keep = a.min_keep < 1 ? 1 : a.min_keep;
-                for (int i = 0; i < n - keep; ++i) {
-                    cum += (double)(expf(cv[i] - mxv) / sum);
-                    if ((float)cum <= thr) lo = i + 1; else break;
+        {   // ascending by (value, index): parallel rank sort (same order as a stable insertion sort on that key)
+            const int n = (int)(s_count < BEAM_CAP ? s_count : BEAM_CAP);
+            float myv = 0.f; int myi = 0, rank = 0;
+            if (tid < n) {
+                myv = cv[tid]; myi = ci[tid];
+                for (int q = 0; q < n; ++q) {
+                    const float vq = cv[q]; const int iq = ci[q];
+                    rank += (vq < myv || (vq == myv && iq < myi)) ? 1 : 0;
                 }
             }
+            __syncthreads();
+            if (tid < n) { cv[rank] = myv; ci[rank] = myi; }
+            __syncthreads();
+            if (tid < n) ue[tid] = expf(cv[tid] - cv[n - 1]);
+            __syncthreads();
+            if (tid == 0) {
+                int lo = 0;
+                if (a.do_sample && a.top_p < 1.0f) {
+                    float sum = 0.f;
+                    for (int i = 0; i < n; ++i) sum += ue[i];
+                    const float thr = (float)(1.0 - (double)a.top_p);
+                    double cum = 0.0;
+                    const int keep = a.min_keep < 1 ? 1 : a.min_keep;
+                    for (int i = 0; i < n - keep; ++i) {
+                        cum += (double)(ue[i] / sum);
+                        if ((float)cum <= thr) lo = i + 1; else break;
+                    }
+                }
+                s_lo = lo;
+            }
+            __syncthreads();
+            const int lo = s_lo, un0 = s_un;
             const float bs = a.beam_scores[row];
-            int un = s_un;
-            for (int i = lo; i < n; ++i) { ui[un] = j * V + ci[i]; uv[un] = cv[i] + bs; ++un; }
-            s_un = un;
+            if (tid >= lo && tid < n) { ui[un0 + tid - lo] = j * V + ci[tid]; uv[un0 + tid - lo] = cv[tid] + bs; }
+            __syncthreads();
+            if (tid == 0) s_un = un0 + (n - lo);
+            __syncthreads();
+        }
+    }
+    // ---- the union in vocabulary order of the flattened (beam-major) row: parallel rank sort on the unique flat index ----
+    const int un = s_un;
+    {
+        float myv = 0.f; int myi = 0, rank = 0;
+        if (tid < un) {
+            myv = uv[tid]; myi = ui[tid];
+            for (int q = 0; q < un; ++q) rank += (ui[q] < myi) ? 1 : 0;
         }
         __syncthreads();
+        if (tid < un) { uv[rank] = myv; ui[rank] = myi; }
+        __syncthreads();
+        if (a.do_sample) {
+            if (tid == 0) {
+                float mxv = -INFINITY;
+                for (int i = 0; i < un; ++i) mxv = fmaxf(mxv, uv[i]);
+                s_mxv = mxv;
+            }
+            __syncthreads();
+            if (tid < un) ue[tid] = expf(uv[tid] - s_mxv);
+            __syncthreads();
+        }
     }
     if (tid != 0) return;
     // ---- candidate selection over the union (thread 0; <= nb*64 entries) ----
-    int un = s_un;
     const int ncand = 2 * nb;
     int ctok[2 * BEAM_MAX], cidx[2 * BEAM_MAX];
     float csc[2 * BEAM_MAX];
     int nc = 0;
-    for (int i = 1; i < un; ++i) {                        // sort union by flat index (vocabulary order of the flattened row)
-        const float v = uv[i];
-        const int ix = ui[i];
-        int q = i - 1;
-        while (q >= 0 && ui[q] > ix) { uv[q + 1] = uv[q]; ui[q + 1] = ui[q]; --q; }
-        uv[q + 1] = v; ui[q + 1] = ix;
-    }
     if (a.do_sample) {
-        float mxv = -INFINITY;
-        for (int i = 0; i < un; ++i) mxv = fmaxf(mxv, uv[i]);
         float sum = 0.f;
-        for (int i = 0; i < un; ++i) sum += expf(uv[i] - mxv);
-        // probabilities in cv-like scratch: reuse hist as float storage is unsafe; recompute on the fly
-        bool taken[BEAM_MAX * BEAM_CAP];
-        for (int i = 0; i < un; ++i) taken[i] = false;
+        for (int i = 0; i < un; ++i) sum += ue[i];
+        for (int i = 0; i < un; ++i) ue[i] = ue[i] / sum;          // probabilities; a drawn entry is zeroed
         for (int d = 0; d < ncand && d < un; ++d) {
             double total = 0.0;
-            for (int i = 0; i < un; ++i) if (!taken[i]) total += (double)(expf(uv[i] - mxv) / sum);
+            for (int i = 0; i < un; ++i) total += (double)ue[i];
             const double u = a.uniforms ? a.uniforms[((size_t)step * a.B + b) * ncand + d]
                                         : rng_uniform(a.seed, (unsigned long long)step * 8 + d, (unsigned long long)b);
             const double tgt = u * total;
             double cum = 0.0;
             int pick = -1, lastfree = -1;
             for (int i = 0; i < un; ++i) {
-                if (taken[i]) continue;
+                if (ui[i] < 0) continue;                              // already drawn
                 lastfree = i;
-                cum += (double)(expf(uv[i] - mxv) / sum);
+                cum += (double)ue[i];
                 if (cum > tgt) { pick = i; break; }
             }
             if (pick < 0) pick = lastfree;
-            taken[pick] = true;
             ctok[nc] = ui[pick] % V; cidx[nc] = ui[pick] / V; csc[nc] = uv[pick]; ++nc;
+            ui[pick] = -1 - ui[pick];
+            ue[pick] = 0.f;
         }
     } else {
-        bool taken[BEAM_MAX * BEAM_CAP];
-        for (int i = 0; i < un; ++i) taken[i] = false;
         for (int d = 0; d < ncand && d < un; ++d) {       // top-2nb by score, ties -> lower flat index
             int best = -1;
             for (int i = 0; i < un; ++i)
-                if (!taken[i] && (best < 0 || uv[i] > uv[best])) best = i;
-            taken[best] = true;
+                if (ui[i] >= 0 && (best < 0 || uv[i] > uv[best])) best = i;
             ctok[nc] = ui[best] % V; cidx[nc] = ui[best] / V; csc[nc] = uv[best]; ++nc;
+            ui[best] = -1 - ui[best];                     // taken
         }
     }
     for (int i = 1; i < nc; ++i) {                        // sort candidates by score, descending (stable)

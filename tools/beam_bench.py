@@ -16,7 +16,8 @@ text = torch.randint(2, 12000, (B, 128), generator=g).cuda()
 langs = torch.full((B,), 3, dtype=torch.long).cuda()
 style = torch.randn(1, 192, generator=g).cuda()
 emo = (torch.randn(1, 1280, generator=g) * 0.1).cuda()
-for nb, samp, typ in ((1, True, False), (3, True, False), (3, False, False), (1, True, True), (3, True, True)):
+MODES = ((1, True, False), (3, True, False), (3, False, False), (1, True, True), (3, True, True))
+for nb, samp, typ in MODES[: int(os.environ.get("ITTS_BEAM_BENCH_MODES", len(MODES)))]:
     kw = dict(do_sample=samp, top_p=0.8, top_k=30, temperature=0.8, num_beams=nb, repetition_penalty=10.0,
               length_penalty=0.0, typical_sampling=typ, typical_mass=0.9)
     for rep in range(2):
