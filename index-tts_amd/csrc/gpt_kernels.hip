@@ -624,6 +624,152 @@ static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
     }
 }
 
+// ================================================================================================================
+// Decode GEMM, bf16, 33..64 activation rows per block (B = 64 utterances; 64-row slices of the beam batch).
+//   Same decomposition as gemm_kernel<true,4,1,true> -- one 16-column n-tile per block, the block's K slice (<= 1280)
+//   split over the 4 waves by k-block (w, w+4, ...), LDS reduce, shared epilogue -- but the activation slab no longer
+//   goes global -> registers -> ds_write in two serial phases: the whole [64 rows][<=1280 k] slab (<= 160 KiB) is DMA'd
+//   into LDS with global_load_lds_dwordx4 in ONE burst issued together with the wave's weight fragments, so every byte
+//   the block needs is in flight before the first wait.  A image as in the prefill kernel: 1 KiB chunks of
+//   [8 rows][128 B], 16-byte pieces XOR-permuted on the source side (bank-conflict-free fragment reads).
+//   Accumulation order per output is unchanged -> bitwise equal to the register-staged kernel.
+// ================================================================================================================
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_decode64_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];     // [kp][8 row groups][1 KiB]; reused for the reduction
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nkb = a.K >> 5;
+    const int z = blockIdx.z;
+    const int kb_lo = (int)((long long)z * nkb / a.nsplit);
+    const int kb_hi = (int)((long long)(z + 1) * nkb / a.nsplit);
+    const int kps = (kb_hi - kb_lo + 1) >> 1;                      // 128-byte k-pairs in the slice (<= 20)
+    const int ntiles = (a.N + 15) >> 4;
+    const int nt0 = blockIdx.x * NT;                               // NT n-tiles (16 columns each) per block
+    const int m0 = blockIdx.y * 64;
+
+    // weight fragments of this wave's k-blocks: straight to registers, all issued now
+    v4u bq[10][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = (nt0 + j) < ntiles ? nt0 + j : ntiles - 1;
+        const v4u* wp = (const v4u*)a.Wp + (size_t)t * nkb * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int kbi = kb_lo + w + 4 * i;
+            const bool ok = kbi < kb_hi;
+            v4u v = wp[(size_t)(ok ? kbi : kb_lo) * 64];
+            if (!ok) v = v4u{0u, 0u, 0u, 0u};
+            bq[i][j] = v;
+        }
+    }
+    // activation slab: chunk c = kp * 8 + rg; wave w DMAs k-pairs [5w, 5w + 5) of all 8 row groups
+    {
+        const char* arow[8];
+#pragma unroll
+        for (int rg = 0; rg < 8; ++rg) {
+            const int row = rg * 8 + (lane >> 3), row16 = row & 15;
+            const int piece = (lane & 7) ^ ((row16 >> 1) & 7);
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            arow[rg] = (const char*)a.A + ((size_t)m * a.lda + (size_t)kb_lo * 32 + piece * 8) * 2;
+        }
+        const long long kmax = ((long long)a.K - (long long)kb_lo * 32) * 2 - 128;    // last full 128-byte piece of a row
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int kp = w * 5 + j;
+            if (kp < kps) {                                        // wave-uniform
+                long long koff = (long long)kp * 128;
+                koff = koff < kmax ? koff : kmax;                  // odd k-block count: the tail pair re-reads in-range bytes
+#pragma unroll
+                for (int rg = 0; rg < 8; ++rg)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(arow[rg] + koff),
+                                                     (__attribute__((address_space(3))) void*)(dsm + (kp * 8 + rg) * 1024), 16, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int row16 = lane & 15, kg = lane >> 4;
+    const int a_lane = (row16 >> 3) * 1024 + (row16 & 7) * 128;
+    const int sw = (row16 >> 1) & 7;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const int kl = w + 4 * i;                                  // k-block inside the slice
+        if (kb_lo + kl < kb_hi) {                                  // wave-uniform
+            const int kp = kl >> 1, pos = (((kl & 1) << 2) + kg) ^ sw;
+            const char* base = dsm + kp * 8192 + a_lane + pos * 16;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const v4u af = *(const v4u*)(base + mt * 2048);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bq[i][j]),
+                                                                         acc[mt][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                               // every wave is done with the slab: reuse it
+    f32x4* r4 = (f32x4*)dsm;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) r4[((size_t)w * (4 * NT) + mt * NT + j) * 64 + lane] = acc[mt][j];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        const int tile = w * NT + q;                               // 4 * NT output tiles, NT per wave
+        f32x4 s = r4[(size_t)tile * 64 + lane];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            const f32x4 o = r4[((size_t)ww * (4 * NT) + tile) * 64 + lane];
+            s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+        }
+        const int mt = tile / NT, j = tile - mt * NT;
+        if (nt0 + j < ntiles) gemm_epilogue<true>(a, m0 + mt * 16, (nt0 + j) * 16, lane, z, s);
+    }
+}
+
+
+
+template <int NT>
+static int launch_gemm_decode64_nt(const GemmArgs& a, int ntiles, size_t lds, hipStream_t st) {
+    static int attr_state = 0;                                     // 0 unknown, 1 ok, -1 the device refuses 160 KiB of LDS
+    if (attr_state == 0) {
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm_decode64_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attr_state = (e == hipSuccess) ? 1 : -1;
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
+    if (attr_state < 0) return -1;
+    hipLaunchKernelGGL(gemm_decode64_kernel<NT>, dim3(ceil_div(ntiles, NT), ceil_div(a.M, 64), a.nsplit), dim3(256), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// n-tiles per block: the slab is 160 KiB of LDS, i.e. ONE block per CU, so a grid above 256 blocks runs in rounds; take the
+// smallest NT (1, 2, 4) that fits the launch into a single round (more columns per block also amortise the slab DMA).
+static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
+    const int ntiles = (a.N + 15) / 16;
+    const int slice_kb = ceil_div(a.K / 32, a.nsplit);
+    size_t lds = (size_t)((slice_kb + 1) / 2) * 8192;
+    const int other = ceil_div(a.M, 64) * a.nsplit;
+    static const int force_nt = [] { const char* e = getenv("ITTS_DECODE_NT"); return e ? atoi(e) : 0; }();
+    int nt = 1;
+    if (force_nt) nt = force_nt;
+    else if (ntiles * other > 256) nt = (ceil_div(ntiles, 2) * other > 256) ? 4 : 2;
+    if (lds < (size_t)nt * 16384) lds = (size_t)nt * 16384;        // reduction scratch: 4 waves x 4*NT tiles x 1 KiB
+    switch (nt) {
+        case 1: return launch_gemm_decode64_nt<1>(a, ntiles, lds, st);
+        case 2: return launch_gemm_decode64_nt<2>(a, ntiles, lds, st);
+        default: return launch_gemm_decode64_nt<4>(a, ntiles, lds, st);
+    }
+}
+
 template <bool BF16, int MT, int NT, bool KSPLIT>
 static int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
     const int ntiles = (a.N + 15) / 16;
@@ -645,6 +791,15 @@ static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
     }
     if (a.M <= 16) return launch_gemm_cfg<BF16, 1, 1, true>(a, st);
     if (a.M <= 32) return launch_gemm_cfg<BF16, 2, 1, true>(a, st);
+    if constexpr (BF16) {
+        // 33+ rows: LDS-DMA slab kernel when the K slice fits the 160 KiB image (ITTS_DECODE_GEMM=0: register-staged kernel)
+        static const bool old_path = [] { const char* e = getenv("ITTS_DECODE_GEMM"); return e && atoi(e) == 0; }();
+        const int slice_kb = ceil_div(a.K / 32, a.nsplit);
+        if (!old_path && slice_kb <= 40 && a.lda % 8 == 0 && a.K % 64 == 0) {
+            const int rc = launch_gemm_decode64(a, st);
+            if (rc >= 0) return rc;
+        }
+    }
     return launch_gemm_cfg<BF16, 4, 1, true>(a, st);
 }
 

@@ -11,20 +11,24 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from indextts_amd import gpt  # noqa: E402
 from oracle import gpt_oracle as G  # noqa: E402  (seeded synthetic weights only)
 
-cfg = G.GPTConfig(layers=3, model_dim=256, heads=4, max_text_tokens=60, max_mel_tokens=80, number_text_tokens=200)
+BIG = os.environ.get("PROBE_BIG") == "1"       # full-width stack (K = 1280 / 5120 slices) and 40 rows: the 33..64-row decode GEMM
+cfg = (G.GPTConfig(layers=2, model_dim=1280, heads=20, max_text_tokens=60, max_mel_tokens=80, number_text_tokens=200) if BIG
+       else G.GPTConfig(layers=3, model_dim=256, heads=4, max_text_tokens=60, max_mel_tokens=80, number_text_tokens=200))
 sd = G.synth_weights(cfg, seed=77)
 m = gpt.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
                      max_mel_tokens=cfg.max_mel_tokens, number_text_tokens=cfg.number_text_tokens, precision="bf16",
                      device="cuda:0")
 m.load_state_dict(sd)
 g = torch.Generator().manual_seed(5)
-B = 5
+B = 40 if BIG else 5
 text = torch.randint(2, 200, (B, 37), generator=g)
 text[1, 20:] = 1
 text[3, 9:] = 1
-tl = torch.tensor([37, 20, 37, 9, 37])
+tl = torch.full((B,), 37)
+tl[1], tl[3] = 20, 9
 mel = torch.randint(0, 8192, (B, 61), generator=g)
-ml = torch.tensor([61, 40, 13, 61, 2])
+ml = torch.full((B,), 61)
+ml[1], ml[2], ml[4] = 40, 13, 2
 style = torch.randn(1, 192, generator=g)
 emo = torch.randn(1, cfg.model_dim, generator=g) * 0.1
 conds, _ = m.conds_latent(style, emo)
