@@ -33,7 +33,7 @@ enum { LN_PARTIAL = 1, LN_BIAS = 2, LN_SECOND = 4 };
 template <int NV, bool OUT_BF16, int FLAGS>
 __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + w;
+    const int r = blockIdx.x * (int)(blockDim.x >> 6) + w;
     if (r >= a.rows) return;
     const int D = a.D;
     const size_t in_r = (size_t)r * a.in_row_mul + a.in_row_add;
@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
 template <int NV, bool OUT_BF16>
 static void launch_ln_flags(const LnArgs& a, dim3 grid, hipStream_t st) {
     const int flags = (a.partial ? LN_PARTIAL : 0) | (a.bias_prev ? LN_BIAS : 0) | (a.g2 ? LN_SECOND : 0);
-#define LN_F(F) case F: hipLaunchKernelGGL((ln_kernel<NV, OUT_BF16, F>), grid, dim3(256), 0, st, a); break;
+    // decode (a few dozen rows): one wave per block so the rows spread over as many CUs as there are rows
+    const int wpb = a.rows <= 256 ? 1 : 4;
+    grid = dim3(ceil_div(a.rows, wpb));
+#define LN_F(F) case F: hipLaunchKernelGGL((ln_kernel<NV, OUT_BF16, F>), grid, dim3(64 * wpb), 0, st, a); break;
     switch (flags) { LN_F(0) LN_F(1) LN_F(2) LN_F(3) LN_F(4) LN_F(5) LN_F(6) LN_F(7) }
 #undef LN_F
 }
