@@ -97,6 +97,11 @@ def lib():
             raise HipEngineError(
                 f"{LIB_PATH} is missing: build it with `python index-tts_amd/build.py` (hipcc, gfx950). "
                 "The engine has no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64.  The engine must share THAT runtime instance (device
+        # pointers, streams and events cross the boundary): importing torch first makes the loader bind the library's
+        # libamdhip64.so.7 dependency to the copy torch already mapped.  Loaded the other way round the process ends up with
+        # two HSA runtimes and the second one sees no device.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
