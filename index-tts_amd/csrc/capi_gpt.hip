@@ -220,6 +220,7 @@ struct GptWs {
     float* beam_scores; float* next_scores; int* next_tokens; int* next_indices;   // [nseq]
     BeamHyp* hyps; int* n_hyps; float* worst; unsigned char* done;                 // per utterance
     int* hist_tok; int* hist_par;                                                   // [max_new][nseq]
+    int* surv_idx; float* surv_val; int* surv_n;                                    // [nseq][64], [nseq]
     size_t total;
     size_t layer_cache_bytes;
 };
@@ -262,6 +263,9 @@ static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tm
         w.done = (unsigned char*)take((size_t)B);
         w.hist_tok = (int*)take((size_t)max_new * nseq * 4);
         w.hist_par = (int*)take((size_t)max_new * nseq * 4);
+        w.surv_idx = (int*)take((size_t)nseq * 64 * 4);
+        w.surv_val = (float*)take((size_t)nseq * 64 * 4);
+        w.surv_n = (int*)take((size_t)nseq * 4);
     }
     w.total = off + 256;
     return w;
@@ -517,6 +521,7 @@ static BeamArgs make_beam(itts_gpt* h, const GptWs& w, const itts_gen_params& gp
     a.logits = w.logits; a.seen[0] = w.seen; a.seen[1] = w.seen2; a.row_map[0] = w.row_map[0]; a.row_map[1] = w.row_map[1];
     a.beam_scores = w.beam_scores; a.next_scores = w.next_scores; a.next_tokens = w.next_tokens; a.next_indices = w.next_indices;
     a.hyps = w.hyps; a.n_hyps = w.n_hyps; a.worst = w.worst; a.done = w.done; a.hist_tok = w.hist_tok; a.hist_par = w.hist_par;
+    a.surv_idx = w.surv_idx; a.surv_val = w.surv_val; a.surv_n = w.surv_n;
     a.step_ptr = w.state; a.uniforms = uniforms; a.seed = gp.seed; a.B = B; a.nb = nb; a.V = c.vocab; a.max_new = gp.max_new_tokens;
     a.Tmax = Tmax; a.S = S; a.do_sample = gp.do_sample; a.top_k = gp.top_k;
     a.min_keep = gp.min_tokens_to_keep < 1 ? 1 : gp.min_tokens_to_keep;

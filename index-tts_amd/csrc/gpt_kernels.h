@@ -81,6 +81,7 @@ struct BeamArgs {
     int* row_map[2];              // [B*nb][Tmax]
     float* beam_scores;           // [B*nb]
     float* next_scores; int* next_tokens; int* next_indices;   // [B*nb]
+    int* surv_idx; float* surv_val; int* surv_n;                // [B*nb][64], [B*nb]: per-row survivors (phase 1 -> phase 2)
     BeamHyp* hyps;                // [B][BEAM_MAX]
     int* n_hyps;                  // [B]
     float* worst;                 // [B]

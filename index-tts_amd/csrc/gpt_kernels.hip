@@ -1282,37 +1282,28 @@ int launch_advance(int* step_ptr, int* pos_ptr, hipStream_t st) {
 // ================================================================================================================
 #define BEAM_CAP 64            // survivors kept per beam after top-k (top_k <= 64)
 
-__global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
-    extern __shared__ float sl[];                        // [V] processed log-probs of the current beam
+// Phase 1, one block per sequence row (utterance x beam): processed log-probs of the row -> its survivors (token, score +
+// beam score) in vocabulary-independent order (ascending by (value, index)), written to surv_*[row][BEAM_CAP].
+__global__ __launch_bounds__(256) void beam_rows_kernel(BeamArgs a) {
+    extern __shared__ float sl[];                        // [V] processed log-probs (+ [V] scratch with typical sampling)
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_mask, s_kk, s_count;
     __shared__ float red[4];
     __shared__ float s_m, s_lse;
     __shared__ int ci[BEAM_CAP];
     __shared__ float cv[BEAM_CAP];
-    __shared__ int ui[BEAM_MAX * BEAM_CAP];              // union: flat index beam*V + token
-    __shared__ float uv[BEAM_MAX * BEAM_CAP];
-    __shared__ float ue[BEAM_MAX * BEAM_CAP];            // exp(uv - max) of the union / scratch exponentials per beam
-    __shared__ int s_un, s_lo;
-    __shared__ float s_mxv;
-    const int b = blockIdx.x, tid = threadIdx.x, V = a.V, nb = a.nb;
+    __shared__ float ue[BEAM_CAP];
+    __shared__ int s_lo;
+    const int row = blockIdx.x, tid = threadIdx.x, V = a.V, nb = a.nb;
+    const int b = row / nb, j = row - b * nb;
     const int step = *a.step_ptr;
     const int par = step & 1;
-    if (a.done[b]) {                                     // :255-264 finished utterance: pad tokens, score 0
-        if (tid < nb) {
-            a.next_scores[b * nb + tid] = 0.f;
-            a.next_tokens[b * nb + tid] = a.stop_token;
-            a.next_indices[b * nb + tid] = b * nb + tid;
-        }
-        return;
-    }
-    if (tid == 0) s_un = 0;
+    if (a.done[b]) { if (tid == 0) a.surv_n[row] = 0; return; }
     const bool pen = a.rep_penalty != 1.0f;
     const bool temp = a.do_sample && a.temperature != 1.0f;
     const int ksel_raw = a.do_sample ? max(a.top_k, a.min_keep) : 2 * nb;
     const int ksel = ksel_raw < V ? ksel_raw : V;
-    for (int j = 0; j < nb; ++j) {
-        const int row = b * nb + j;
+    {
         const float* lg = a.logits + (size_t)row * V;
         const unsigned char* seen = a.seen[par] + (size_t)row * V;
         // log_softmax
@@ -1410,16 +1401,41 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
                 s_lo = lo;
             }
             __syncthreads();
-            const int lo = s_lo, un0 = s_un;
+            const int lo = s_lo;
             const float bs = a.beam_scores[row];
-            if (tid >= lo && tid < n) { ui[un0 + tid - lo] = j * V + ci[tid]; uv[un0 + tid - lo] = cv[tid] + bs; }
-            __syncthreads();
-            if (tid == 0) s_un = un0 + (n - lo);
-            __syncthreads();
+            if (tid >= lo && tid < n) {
+                a.surv_idx[(size_t)row * BEAM_CAP + tid - lo] = j * V + ci[tid];
+                a.surv_val[(size_t)row * BEAM_CAP + tid - lo] = cv[tid] + bs;
+            }
+            if (tid == 0) a.surv_n[row] = n - lo;
         }
     }
+}
+
+// Phase 2, one block per utterance: union of its beams' survivors, candidate draw / top, scorer.
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
+    __shared__ int ui[BEAM_MAX * BEAM_CAP];              // union: flat index beam*V + token
+    __shared__ float uv[BEAM_MAX * BEAM_CAP];
+    __shared__ float ue[BEAM_MAX * BEAM_CAP];            // exp(uv - max) of the union
+    __shared__ float s_mxv;
+    const int b = blockIdx.x, tid = threadIdx.x, V = a.V, nb = a.nb;
+    const int step = *a.step_ptr;
+    if (a.done[b]) {                                     // :255-264 finished utterance: pad tokens, score 0
+        if (tid < nb) {
+            a.next_scores[b * nb + tid] = 0.f;
+            a.next_tokens[b * nb + tid] = a.stop_token;
+            a.next_indices[b * nb + tid] = b * nb + tid;
+        }
+        return;
+    }
+    int un = 0;
+    for (int j = 0; j < nb; ++j) {                       // beams in order, each beam's survivors in its own order
+        const int row = b * nb + j, n = a.surv_n[row];
+        if (tid < n) { ui[un + tid] = a.surv_idx[(size_t)row * BEAM_CAP + tid]; uv[un + tid] = a.surv_val[(size_t)row * BEAM_CAP + tid]; }
+        un += n;
+    }
+    __syncthreads();
     // ---- the union in vocabulary order of the flattened (beam-major) row: parallel rank sort on the unique flat index ----
-    const int un = s_un;
     {
         float myv = 0.f; int myi = 0, rank = 0;
         if (tid < un) {
@@ -1568,7 +1584,8 @@ int launch_beam_step(const BeamArgs& a, hipStream_t st) {
         return ITTS_ERR_ARG;
     }
     const size_t lds = (size_t)a.V * sizeof(float) * (a.typical_mass > 0.f ? 2 : 1);
-    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(beam_rows_kernel, dim3(a.B * a.nb), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
