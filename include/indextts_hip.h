@@ -170,7 +170,9 @@ int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const int32_t* pa
  *   BeamSearchScorer.process (3rd-party; mirror indextts/gpt/transformers_beam_search.py:215-305,930-1013) and
  *   _reorder_cache (model_v2.py:200-213, done here as a per-position row map instead of copying the KV cache).
  * prefix_embeds / pad_lens are given per SEQUENCE row (n_utts*num_beams rows, beams of one utterance adjacent, i.e.
- *   repeat_interleave as _expand_inputs_for_generation does).  uniforms: optional f64 [max_new][n_utts][2*num_beams].
+ *   repeat_interleave as _expand_inputs_for_generation does); the beams of an utterance must therefore carry identical
+ *   prefix rows -- the engine prefills row n*num_beams of each utterance once and all its beams read that prompt K/V
+ *   through the row map.  uniforms: optional f64 [max_new][n_utts][2*num_beams].
  * Outputs (device): per step the chosen token and parent row of every sequence row (hist_*: [max_new][n_utts*num_beams]
  *   int32), the running beam scores, the finished-hypothesis records hyps_out [n_utts][4]{f32 score, i32 step, i32 row,
  *   i32 pad}, their count and the per-utterance done flags; BeamSearchScorer.finalize (:320-408) is a host-side walk over

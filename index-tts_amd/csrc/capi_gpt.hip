@@ -298,7 +298,7 @@ __global__ void mark_seen_kernel(unsigned char* seen, const int* ids, int n_ids,
 // rows = nseq*S new positions (S = 1 for a decode step).  prefill: direct residual epilogues + big-tile GEMMs;
 // decode: split-K partials reduced inside the next LayerNorm kernel.
 static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bool prefill, const int* pos_ptr, const int* pad,
-                      bool* pending, hipStream_t st, bool beam = false) {
+                      bool* pending, hipStream_t st, bool beam = false, int seq_mul = 1) {
     const itts_gpt_config& c = h->cfg;
     const int D = c.model_dim, prec = c.precision, rows = nseq * S;
     int rc;
@@ -315,13 +315,13 @@ static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bo
         GemmArgs g{};
         g.A = w.hbuf; g.lda = D; g.Wp = L.w_qkv; g.bias = L.b_qkv; g.M = rows; g.N = 3 * D; g.K = D; g.nsplit = 1; g.epi = EPI_QKV;
         g.qbuf = w.qbuf; g.kcache = w.kc + w.layer_cache_bytes * l; g.vcache = w.vc + w.layer_cache_bytes * l;
-        g.pos_ptr = pos_ptr; g.S = S; g.H = c.heads; g.Tmax = Tmax; g.D = D;
+        g.pos_ptr = pos_ptr; g.S = S; g.H = c.heads; g.Tmax = Tmax; g.D = D; g.seq_mul = seq_mul;
         if ((rc = launch_gemm(g, prec, prefill, st))) return rc;
 
         AttnArgs at{};
         at.qbuf = w.qbuf; at.kcache = g.kcache; at.vcache = g.vcache; at.pad = pad; at.pos_ptr = pos_ptr;
         at.row_map = beam ? w.row_map[0] : nullptr; at.row_map_alt = beam ? w.row_map[1] : nullptr; at.step_ptr = beam ? w.state : nullptr;
-        at.out = w.attn; at.nseq = nseq; at.H = c.heads; at.nq = S; at.Tmax = Tmax; at.D = D;
+        at.out = w.attn; at.nseq = nseq; at.H = c.heads; at.nq = S; at.Tmax = Tmax; at.D = D; at.seq_mul = seq_mul;
         if ((rc = launch_attention(at, prec, st))) return rc;
 
         GemmArgs p{};
@@ -505,10 +505,12 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
 }
 
 // ---- beam search / beam-sample ------------------------------------------------------------------------------------
+// The beams of an utterance share ONE copy of the prompt's K/V (cache row b*nb, written by a prefill over the B unique
+// prompts): prompt positions map there, generated positions to the row's own cache row.
 __global__ void beam_init_kernel(int* row_map0, float* beam_scores, float* worst, int* n_hyps, unsigned char* done, int nseq, int nb,
-                                 int Tmax) {
+                                 int Tmax, int S) {
     const int i = blockIdx.x;
-    for (int t = threadIdx.x; t < Tmax; t += blockDim.x) row_map0[(size_t)i * Tmax + t] = i;
+    for (int t = threadIdx.x; t < Tmax; t += blockDim.x) row_map0[(size_t)i * Tmax + t] = t < S ? (i / nb) * nb : i;
     if (threadIdx.x == 0) {
         beam_scores[i] = (i % nb == 0) ? 0.f : -1e9f;             // generation_utils.py:3408-3410
         if (i % nb == 0) { worst[i / nb] = 1e9f; n_hyps[i / nb] = 0; done[i / nb] = 0; }
@@ -581,19 +583,23 @@ extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, c
         HIP_TRY(hipMemcpyAsync(w.pen_ids, penalty_ids, (size_t)n_penalty_ids * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(mark_seen_kernel, dim3(nseq), dim3(64), 0, st, w.seen, w.pen_ids, n_penalty_ids, c.vocab);
     }
-    hipLaunchKernelGGL(beam_init_kernel, dim3(nseq), dim3(256), 0, st, w.row_map[0], w.beam_scores, w.worst, w.n_hyps, w.done, nseq, nb, Tmax);
+    hipLaunchKernelGGL(beam_init_kernel, dim3(nseq), dim3(256), 0, st, w.row_map[0], w.beam_scores, w.worst, w.n_hyps, w.done, nseq, nb, Tmax, S);
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 0, 0);
-    HIP_TRY(hipMemcpyAsync(w.x, prefix_embeds, (size_t)nseq * S * c.model_dim * 4, hipMemcpyDeviceToDevice, st));
+    // the nb rows of an utterance carry the same prompt (repeat_interleave): prefill the B unique prompts only
+    const size_t row_bytes = (size_t)S * c.model_dim * 4;
+    HIP_TRY(hipMemcpy2DAsync(w.x, row_bytes, prefix_embeds, row_bytes * nb, row_bytes, B, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipGetLastError());
 
     HIP_TRY(hipEventRecord(h->ev_t0, st));
     bool pending = false;
-    rc = run_layers(h, w, nseq, S, Tmax, true, w.state + 1, w.pad, &pending, st, true);
+    rc = run_layers(h, w, B, S, Tmax, true, w.state + 1, w.pad, &pending, st, false, nb);
     if (rc) return rc;
-    if ((rc = run_head(h, w, nseq, S, S - 1, pending, st))) return rc;
+    if ((rc = run_head(h, w, B, S, S - 1, pending, st))) return rc;
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 0, S);
     const BeamArgs ba = make_beam(h, w, gp, B, nb, S, Tmax, uniforms);
-    if ((rc = launch_beam_step(ba, st))) return rc;
+    BeamArgs ba0 = ba;
+    ba0.logits_shared = 1;                       // one logits row per utterance after the shared prefill
+    if ((rc = launch_beam_step(ba0, st))) return rc;
     if ((rc = launch_beam_apply(ba, st))) return rc;
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 1, S);
     HIP_TRY(hipEventRecord(h->ev_t1, st));

@@ -35,6 +35,7 @@ struct GemmArgs {
     // EPI_QKV: n < D -> qbuf[m][n]; D <= n < 2D -> K cache; else V cache, at cache position *pos_ptr + (m % S)
     float* qbuf; void* kcache; void* vcache;
     const int* pos_ptr; int S, H, Tmax, D;
+    int seq_mul;                     // EPI_QKV: cache row of sequence b is b * seq_mul (0/1 = identity); beam prefill writes only row b*nb
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);
 
@@ -49,6 +50,7 @@ struct AttnArgs {
     const int* pos_ptr;      // cache index of query 0
     void* out;               // [nseq*nq][D] act dtype
     int nseq, H, nq, Tmax, D;
+    int seq_mul;             // sequence b reads cache row / pad entry b * seq_mul when no row map is given (0/1 = identity)
 };
 int launch_attention(const AttnArgs& a, int prec, hipStream_t st);
 
@@ -88,6 +90,7 @@ struct BeamArgs {
     unsigned char* done;          // [B]
     int* hist_tok; int* hist_par; // [max_new][B*nb]
     const int* step_ptr;
+    int logits_shared;            // 1: logits hold ONE row per utterance (first step after the shared-prompt prefill)
     const double* uniforms;       // [max_new][B][2*nb] or null
     unsigned long long seed;
     int B, nb, V, max_new, Tmax, S;

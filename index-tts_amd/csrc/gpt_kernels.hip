@@ -264,7 +264,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, int mbase, int 
                     a.qbuf[(size_t)m * a.D + c] = val;
                 } else {
                     const int pos = *a.pos_ptr + si;
-                    const size_t o = (((size_t)b * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
+                    const size_t o = (((size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1) * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
                     void* cache = which == 1 ? a.kcache : a.vcache;
                     if (BF16) ((u16*)cache)[o] = f32_to_bf16(val);
                     else ((float*)cache)[o] = val;
@@ -505,7 +505,7 @@ __device__ __forceinline__ void pf_epilogue(const GemmArgs& a, int mbase, int nb
             } else {
                 const int b = m / a.S, si = m - b * a.S;
                 const int pos = *a.pos_ptr + si;
-                const size_t o = (((size_t)b * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
+                const size_t o = (((size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1) * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
                 ((u16*)(which == 1 ? a.kcache : a.vcache))[o] = f32_to_bf16(val);
             }
         }
@@ -835,7 +835,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
     const int qi = blockIdx.y;
     const int last = *a.pos_ptr + qi;
-    const int first = a.pad ? a.pad[b] : 0;
+    const int sm = a.seq_mul > 1 ? a.seq_mul : 1;
+    const int first = a.pad ? a.pad[b * sm] : 0;
     const int sub = lane % LPK, grp = lane / LPK;
     const size_t qrow = (size_t)b * a.nq + qi;
     const int* rmap = a.row_map;
@@ -853,7 +854,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         const int t = t0 + grp;
         const bool ok = t <= last;
         const int tc = ok ? t : last;
-        const int prow = rmap ? rmap[(size_t)b * a.Tmax + tc] : b;
+        const int prow = rmap ? rmap[(size_t)b * a.Tmax + tc] : b * sm;
         const size_t off = (((size_t)prow * a.H + h) * a.Tmax + tc) * 64 + sub * DPL;
         float kf[DPL], vf[DPL];
         if constexpr (BF16) {
@@ -1304,7 +1305,7 @@ __global__ __launch_bounds__(256) void beam_rows_kernel(BeamArgs a) {
     const int ksel_raw = a.do_sample ? max(a.top_k, a.min_keep) : 2 * nb;
     const int ksel = ksel_raw < V ? ksel_raw : V;
     {
-        const float* lg = a.logits + (size_t)row * V;
+        const float* lg = a.logits + (size_t)(a.logits_shared ? b : row) * V;
         const unsigned char* seen = a.seen[par] + (size_t)row * V;
         // log_softmax
         float mx = -INFINITY;
