@@ -93,6 +93,21 @@ size_t itts_bigvgan_workspace_bytes(const itts_bigvgan* h, int B, int T);
 int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32_t* lens, const float* spk, float* wav, int B,
                          int T, void* workspace, size_t workspace_bytes, void* stream);
 
+/* replaces: the vocoder stage of the reference's streaming pipeline (backends/trt/pipeline/streaming.py:57-68,140-172:
+ *   overlapping chunks re-synthesised and Hann-crossfaded) by an exact overlap-save stream: one utterance, mel frames
+ *   [in_channels][n_frames] (row stride ld_mel floats, device) pushed in chunks of at most chunk_frames; each push writes
+ *   the samples that became final to wav_out (capacity (chunk_frames + halo_frames) * prod(upsample_rates) floats) and
+ *   their count to *n_samples_out.  Output trails the input by halo_frames until the push with is_last != 0.  The
+ *   concatenation equals itts_bigvgan_forward over the whole mel when halo_frames covers the receptive field (43 frames
+ *   for the 22 kHz v2 generator).  spk: v1 speaker embedding [cond_dim] or NULL. */
+typedef struct itts_bigvgan_stream itts_bigvgan_stream;
+int itts_bigvgan_stream_open(itts_bigvgan* h, int chunk_frames, int halo_frames, itts_bigvgan_stream** out);
+size_t itts_bigvgan_stream_workspace_bytes(const itts_bigvgan_stream* s);
+int itts_bigvgan_stream_push(itts_bigvgan_stream* s, const float* mel, int ld_mel, int n_frames, int is_last,
+                             const float* spk, float* wav_out, int32_t* n_samples_out, void* workspace,
+                             size_t workspace_bytes, void* stream);
+void itts_bigvgan_stream_close(itts_bigvgan_stream* s);
+
 /* measurement hooks (no reference counterpart: the reference only has unsynchronised perf_counter stage timers,
  *   indextts/infer_v2_5.py:744-746,871-876).  With profiling enabled every kernel launch of the forward is bracketed
  *   by HIP events on the launch stream; profile_read returns, for the LAST forward and per kernel class

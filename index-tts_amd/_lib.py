@@ -61,6 +61,10 @@ SIGNATURES = {
     "itts_bigvgan_destroy": (None, [vp]),
     "itts_bigvgan_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int]),
     "itts_bigvgan_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "itts_bigvgan_stream_open": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)]),
+    "itts_bigvgan_stream_workspace_bytes": (C.c_size_t, [vp]),
+    "itts_bigvgan_stream_push": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_int32), vp, C.c_size_t, vp]),
+    "itts_bigvgan_stream_close": (None, [vp]),
     "itts_bigvgan_set_profiling": (C.c_int, [vp, C.c_int]),
     "itts_bigvgan_profile_read": (C.c_int, [vp, vp, vp, vp, vp]),
     "itts_bigvgan_profile_records": (C.c_int, [vp, vp, C.c_int]),

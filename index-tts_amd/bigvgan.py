@@ -227,6 +227,11 @@ class BigVGAN:
             w = self.forward(mel[..., a:b].contiguous())
             yield w[..., (t0 - a) * up: (t0 - a) * up + (t1 - t0) * up]
 
+    def open_stream(self, chunk_frames: int = 256, halo_frames: Optional[int] = None) -> "BigVGANStream":
+        """Push-style streaming for one utterance (`itts_bigvgan_stream_*`): feed mel chunks as they arrive, get the
+        samples that became final; output trails the input by the halo until `push(..., last=True)`."""
+        return BigVGANStream(self, chunk_frames, self.receptive_field_frames() if halo_frames is None else int(halo_frames))
+
     def forward_chunked(self, mel: torch.Tensor, chunk_frames: int = 256, halo_frames: Optional[int] = None) -> torch.Tensor:
         return torch.cat(list(self.stream(mel, chunk_frames, halo_frames)), dim=-1)
 
@@ -253,6 +258,43 @@ class BigVGAN:
             if getattr(self, "_h", None) and self._h.value:
                 _lib.lib().itts_bigvgan_destroy(self._h)
                 self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+class BigVGANStream:
+    def __init__(self, model: BigVGAN, chunk_frames: int, halo_frames: int):
+        if model.cond_dim > 0:
+            raise NotImplementedError("streaming is wired for the v2 generator (no speaker conditioning)")
+        self.model, self.chunk, self.halo = model, int(chunk_frames), int(halo_frames)
+        self._s = C.c_void_p()
+        _lib.check(_lib.lib().itts_bigvgan_stream_open(model._h, self.chunk, self.halo, C.byref(self._s)), "itts_bigvgan_stream_open")
+        self._ws = None
+
+    def push(self, mel_chunk: torch.Tensor, last: bool = False) -> torch.Tensor:
+        """mel_chunk (C, n) or (1, C, n) with n <= chunk_frames (n = 0 allowed with last=True) -> (1, 1, samples)."""
+        n_new = int(mel_chunk.shape[-1])
+        x = mel_chunk.reshape(self.model.in_channels, n_new).float().contiguous()
+        if not x.is_cuda:
+            raise _lib.HipEngineError("BigVGANStream needs a CUDA/HIP tensor")
+        L = _lib.lib()
+        if self._ws is None:
+            self._ws = torch.empty(L.itts_bigvgan_stream_workspace_bytes(self._s), dtype=torch.uint8, device=x.device)
+        out = torch.empty((self.chunk + self.halo) * self.model.total_up, dtype=torch.float32, device=x.device)
+        n = C.c_int32(0)
+        _lib.check(L.itts_bigvgan_stream_push(self._s, _lib.ptr(x) if n_new else None, max(1, n_new), n_new,
+                                              int(last), None, _lib.ptr(out), C.byref(n), _lib.ptr(self._ws), self._ws.numel(),
+                                              _lib.stream_ptr()), "itts_bigvgan_stream_push")
+        return out[: n.value].reshape(1, 1, -1)
+
+    def close(self):
+        if self._s and self._s.value:
+            _lib.lib().itts_bigvgan_stream_close(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

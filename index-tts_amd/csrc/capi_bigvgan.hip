@@ -647,3 +647,96 @@ extern "C" int itts_bigvgan_profile_read(itts_bigvgan* h, double* ms, double* la
     }
     return ITTS_OK;
 }
+
+
+// ================================================================================================================
+// Streaming vocoder (BASELINE configs[4]): one utterance, mel frames pushed in chunks, waveform emitted as soon as it is
+// final.  Exact overlap-save: a chunk is synthesised together with `halo` frames of real context on both sides (the
+// generator's receptive field) and only the centre is emitted, so the concatenated output equals the one-shot forward --
+// the reference's streaming path (backends/trt/pipeline/streaming.py:57-172) re-synthesises overlapping chunks and
+// Hann-crossfades them instead.  Output lags the input by `halo` frames until the last push.
+// ================================================================================================================
+struct itts_bigvgan_stream {
+    itts_bigvgan* h;
+    int chunk, halo, cap;        // cap = frames the context buffer holds
+    int received, emitted;       // absolute frame counters
+    int base;                    // absolute index of ctx column 0
+    float* ctx;                  // [C][cap] the frames [base, received)
+    float* xwin;                 // [C][cap] contiguous window handed to the forward
+    float* wwin;                 // [cap * total_up]
+};
+
+extern "C" int itts_bigvgan_stream_open(itts_bigvgan* h, int chunk_frames, int halo_frames, itts_bigvgan_stream** out) {
+    if (!h || !out) { itts_set_error("bigvgan_stream_open: null pointer"); return ITTS_ERR_ARG; }
+    if (!h->finalized) { itts_set_error("bigvgan_stream_open: call itts_bigvgan_finalize first"); return ITTS_ERR_STATE; }
+    if (chunk_frames <= 0 || halo_frames < 0) { itts_set_error("bigvgan_stream_open: bad chunk/halo"); return ITTS_ERR_ARG; }
+    auto* s = new itts_bigvgan_stream();
+    s->h = h; s->chunk = chunk_frames; s->halo = halo_frames; s->cap = 2 * chunk_frames + 2 * halo_frames;
+    s->received = s->emitted = s->base = 0;
+    s->ctx = s->xwin = s->wwin = nullptr;
+    const size_t C = (size_t)h->cfg.in_channels;
+    hipError_t e = hipMalloc((void**)&s->ctx, C * s->cap * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->xwin, C * s->cap * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&s->wwin, (size_t)s->cap * h->total_up * sizeof(float));
+    if (e != hipSuccess) {
+        itts_set_error("bigvgan_stream_open: hipMalloc -> %s", hipGetErrorString(e));
+        if (s->ctx) (void)hipFree(s->ctx);
+        if (s->xwin) (void)hipFree(s->xwin);
+        delete s;
+        return ITTS_ERR_HIP;
+    }
+    *out = s;
+    return ITTS_OK;
+}
+
+extern "C" void itts_bigvgan_stream_close(itts_bigvgan_stream* s) {
+    if (!s) return;
+    (void)hipFree(s->ctx); (void)hipFree(s->xwin); (void)hipFree(s->wwin);
+    delete s;
+}
+
+extern "C" size_t itts_bigvgan_stream_workspace_bytes(const itts_bigvgan_stream* s) {
+    return s ? itts_bigvgan_workspace_bytes(s->h, 1, s->cap) : 0;
+}
+
+extern "C" int itts_bigvgan_stream_push(itts_bigvgan_stream* s, const float* mel, int ld_mel, int n_frames, int is_last,
+                                        const float* spk, float* wav_out, int32_t* n_samples_out, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    if (!s || !wav_out || !n_samples_out || !workspace || (n_frames > 0 && !mel)) { itts_set_error("bigvgan_stream_push: null pointer"); return ITTS_ERR_ARG; }
+    if (n_frames < 0 || n_frames > s->chunk || (n_frames > 0 && ld_mel < n_frames)) { itts_set_error("bigvgan_stream_push: n_frames %d outside 0..%d", n_frames, s->chunk); return ITTS_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int C = s->h->cfg.in_channels, up = s->h->total_up;
+    *n_samples_out = 0;
+    if (n_frames > 0) {                                      // append [C][n_frames] at column received - base
+        const int col = s->received - s->base;
+        HIP_TRY(hipMemcpy2DAsync(s->ctx + col, (size_t)s->cap * 4, mel, (size_t)ld_mel * 4, (size_t)n_frames * 4, C,
+                                 hipMemcpyDeviceToDevice, st));
+        s->received += n_frames;
+    }
+    const int emit_to = is_last ? s->received : s->received - s->halo;     // frames whose right context is complete
+    if (emit_to <= s->emitted) return ITTS_OK;
+    const int w0 = (s->emitted - s->halo) > s->base ? (s->emitted - s->halo) : s->base;   // window [w0, w1)
+    const int w1 = (emit_to + s->halo) < s->received ? (emit_to + s->halo) : s->received;
+    const int Tw = w1 - w0;
+    HIP_TRY(hipMemcpy2DAsync(s->xwin, (size_t)Tw * 4, s->ctx + (w0 - s->base), (size_t)s->cap * 4, (size_t)Tw * 4, C,
+                             hipMemcpyDeviceToDevice, st));
+    int rc = itts_bigvgan_forward(s->h, s->xwin, nullptr, spk, s->wwin, 1, Tw, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    const int n_out = (emit_to - s->emitted) * up;
+    HIP_TRY(hipMemcpyAsync(wav_out, s->wwin + (size_t)(s->emitted - w0) * up, (size_t)n_out * 4, hipMemcpyDeviceToDevice, st));
+    *n_samples_out = n_out;
+    s->emitted = emit_to;
+    // keep [emitted - halo, received): slide the context to column 0 (through xwin: source and destination overlap)
+    const int nb = (s->emitted - s->halo) > s->base ? (s->emitted - s->halo) : s->base;
+    if (nb > s->base) {
+        const int keep = s->received - nb;
+        if (keep > 0) {
+            HIP_TRY(hipMemcpy2DAsync(s->xwin, (size_t)keep * 4, s->ctx + (nb - s->base), (size_t)s->cap * 4, (size_t)keep * 4, C,
+                                     hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpy2DAsync(s->ctx, (size_t)s->cap * 4, s->xwin, (size_t)keep * 4, (size_t)keep * 4, C,
+                                     hipMemcpyDeviceToDevice, st));
+        }
+        s->base = nb;
+    }
+    return ITTS_OK;
+}
