@@ -628,7 +628,7 @@ static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
 }
 
 // ================================================================================================================
-// Decode GEMM, bf16, 33..64 activation rows per block (B = 64 utterances; 64-row slices of the beam batch).
+// Decode GEMM, bf16, 16 / 32 / 64 activation rows per block (MT m-tiles; 64-row slices of larger batches).
 //   Same decomposition as gemm_kernel<true,4,1,true> -- one 16-column n-tile per block, the block's K slice (<= 1280)
 //   split over the 4 waves by k-block (w, w+4, ...), LDS reduce, shared epilogue -- but the activation slab no longer
 //   goes global -> registers -> ds_write in two serial phases: the whole [64 rows][<=1280 k] slab (<= 160 KiB) is DMA'd
@@ -637,8 +637,8 @@ static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
 //   [8 rows][128 B], 16-byte pieces XOR-permuted on the source side (bank-conflict-free fragment reads).
 //   Accumulation order per output is unchanged -> bitwise equal to the register-staged kernel.
 // ================================================================================================================
-template <int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_decode64_kernel(GemmArgs a) {
+template <int NT, int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MT == 4 ? 1 : 4))) void gemm_decode64_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];     // [kp][8 row groups][1 KiB]; reused for the reduction
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nkb = a.K >> 5;
@@ -648,7 +648,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int kps = (kb_hi - kb_lo + 1) >> 1;                      // 128-byte k-pairs in the slice (<= 20)
     const int ntiles = (a.N + 15) >> 4;
     const int nt0 = blockIdx.x * NT;                               // NT n-tiles (16 columns each) per block
-    const int m0 = blockIdx.y * 64;
+    constexpr int RG = 2 * MT;                                     // 8-row groups of the slab (MT m-tiles of 16 rows)
+    const int m0 = blockIdx.y * (16 * MT);
 
     // weight fragments of this wave's k-blocks: straight to registers, all issued now
     v4u bq[10][NT];
@@ -667,9 +668,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // activation slab: chunk c = kp * 8 + rg; wave w DMAs k-pairs [5w, 5w + 5) of all 8 row groups
     {
-        const char* arow[8];
+        const char* arow[RG];
 #pragma unroll
-        for (int rg = 0; rg < 8; ++rg) {
+        for (int rg = 0; rg < RG; ++rg) {
             const int row = rg * 8 + (lane >> 3), row16 = row & 15;
             const int piece = (lane & 7) ^ ((row16 >> 1) & 7);
             int m = m0 + row;
@@ -684,18 +685,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 long long koff = (long long)kp * 128;
                 koff = koff < kmax ? koff : kmax;                  // odd k-block count: the tail pair re-reads in-range bytes
 #pragma unroll
-                for (int rg = 0; rg < 8; ++rg)
+                for (int rg = 0; rg < RG; ++rg)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(arow[rg] + koff),
-                                                     (__attribute__((address_space(3))) void*)(dsm + (kp * 8 + rg) * 1024), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(dsm + (kp * RG + rg) * 1024), 16, 0, 0);
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    f32x4 acc[4][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int row16 = lane & 15, kg = lane >> 4;
@@ -706,9 +707,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int kl = w + 4 * i;                                  // k-block inside the slice
         if (kb_lo + kl < kb_hi) {                                  // wave-uniform
             const int kp = kl >> 1, pos = (((kl & 1) << 2) + kg) ^ sw;
-            const char* base = dsm + kp * 8192 + a_lane + pos * 16;
+            const char* base = dsm + kp * (RG * 1024) + a_lane + pos * 16;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const v4u af = *(const v4u*)(base + mt * 2048);
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
@@ -720,17 +721,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();                                               // every wave is done with the slab: reuse it
     f32x4* r4 = (f32x4*)dsm;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) r4[((size_t)w * (4 * NT) + mt * NT + j) * 64 + lane] = acc[mt][j];
+        for (int j = 0; j < NT; ++j) r4[((size_t)w * (MT * NT) + mt * NT + j) * 64 + lane] = acc[mt][j];
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        const int tile = w * NT + q;                               // 4 * NT output tiles, NT per wave
+    for (int tile = w; tile < MT * NT; tile += 4) {                // MT * NT output tiles over the 4 waves
         f32x4 s = r4[(size_t)tile * 64 + lane];
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) {
-            const f32x4 o = r4[((size_t)ww * (4 * NT) + tile) * 64 + lane];
+            const f32x4 o = r4[((size_t)ww * (MT * NT) + tile) * 64 + lane];
             s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
         }
         const int mt = tile / NT, j = tile - mt * NT;
@@ -740,16 +739,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 
 
-template <int NT>
+template <int NT, int MT>
 static int launch_gemm_decode64_nt(const GemmArgs& a, int ntiles, size_t lds, hipStream_t st) {
-    static int attr_state = 0;                                     // 0 unknown, 1 ok, -1 the device refuses 160 KiB of LDS
+    static int attr_state = 0;                                     // 0 unknown, 1 ok, -1 the device refuses the LDS size
     if (attr_state == 0) {
-        const hipError_t e = hipFuncSetAttribute((const void*)gemm_decode64_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm_decode64_kernel<NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 40960 * MT);
         attr_state = (e == hipSuccess) ? 1 : -1;
         if (e != hipSuccess) (void)hipGetLastError();
     }
     if (attr_state < 0) return -1;
-    hipLaunchKernelGGL(gemm_decode64_kernel<NT>, dim3(ceil_div(ntiles, NT), ceil_div(a.M, 64), a.nsplit), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((gemm_decode64_kernel<NT, MT>), dim3(ceil_div(ntiles, NT), ceil_div(a.M, 16 * MT), a.nsplit), dim3(256), lds, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
@@ -759,6 +758,12 @@ static int launch_gemm_decode64_nt(const GemmArgs& a, int ntiles, size_t lds, hi
 static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
     const int ntiles = (a.N + 15) / 16;
     const int slice_kb = ceil_div(a.K / 32, a.nsplit);
+    if (a.M <= 32) {                                               // 16 / 32 rows: 40 / 80 KiB slabs, several blocks per CU
+        const int mt = a.M <= 16 ? 1 : 2;
+        size_t l2 = (size_t)((slice_kb + 1) / 2) * 2048 * mt;
+        if (l2 < (size_t)mt * 4096) l2 = (size_t)mt * 4096;
+        return mt == 1 ? launch_gemm_decode64_nt<1, 1>(a, ntiles, l2, st) : launch_gemm_decode64_nt<1, 2>(a, ntiles, l2, st);
+    }
     size_t lds = (size_t)((slice_kb + 1) / 2) * 8192;
     const int other = ceil_div(a.M, 64) * a.nsplit;
     static const int force_nt = [] { const char* e = getenv("ITTS_DECODE_NT"); return e ? atoi(e) : 0; }();
@@ -767,9 +772,9 @@ static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
     else if (ntiles * other > 256) nt = (ceil_div(ntiles, 2) * other > 256) ? 4 : 2;
     if (lds < (size_t)nt * 16384) lds = (size_t)nt * 16384;        // reduction scratch: 4 waves x 4*NT tiles x 1 KiB
     switch (nt) {
-        case 1: return launch_gemm_decode64_nt<1>(a, ntiles, lds, st);
-        case 2: return launch_gemm_decode64_nt<2>(a, ntiles, lds, st);
-        default: return launch_gemm_decode64_nt<4>(a, ntiles, lds, st);
+        case 1: return launch_gemm_decode64_nt<1, 4>(a, ntiles, lds, st);
+        case 2: return launch_gemm_decode64_nt<2, 4>(a, ntiles, lds, st);
+        default: return launch_gemm_decode64_nt<4, 4>(a, ntiles, lds, st);
     }
 }
 
@@ -792,17 +797,16 @@ static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
         if (BF16 && !old_path && a.K % PF_BK == 0 && a.lda % 8 == 0 && a.nsplit == 1 && a.epi != EPI_PARTIAL) return launch_gemm_prefill(a, st);
         return launch_gemm_cfg<BF16, 8, 2, false>(a, st);
     }
-    if (a.M <= 16) return launch_gemm_cfg<BF16, 1, 1, true>(a, st);
-    if (a.M <= 32) return launch_gemm_cfg<BF16, 2, 1, true>(a, st);
     if constexpr (BF16) {
-        // 33+ rows: LDS-DMA slab kernel when the K slice fits the 160 KiB image (ITTS_DECODE_GEMM=0: register-staged kernel)
+        // bf16 decode: the LDS-DMA slab kernel whenever the K slice fits its image (ITTS_DECODE_GEMM=0: the register-path kernels)
         static const bool old_path = [] { const char* e = getenv("ITTS_DECODE_GEMM"); return e && atoi(e) == 0; }();
-        const int slice_kb = ceil_div(a.K / 32, a.nsplit);
-        if (!old_path && slice_kb <= 40 && a.lda % 8 == 0 && a.K % 64 == 0) {
+        if (!old_path && ceil_div(a.K / 32, a.nsplit) <= 40 && a.lda % 8 == 0 && a.K % 64 == 0) {
             const int rc = launch_gemm_decode64(a, st);
             if (rc >= 0) return rc;
         }
     }
+    if (a.M <= 16) return launch_gemm_cfg<BF16, 1, 1, true>(a, st);
+    if (a.M <= 32) return launch_gemm_cfg<BF16, 2, 1, true>(a, st);
     return launch_gemm_cfg<BF16, 4, 1, true>(a, st);
 }
 

@@ -208,18 +208,19 @@ def test_prefill_gemm_kernels_agree():
 
 
 def test_decode_gemm_kernels_agree():
-    """bf16 decode with 33..64 rows: the LDS-DMA slab kernel keeps the register-staged kernel's k-block split and reduction
-    order -> BITWISE equal latents/ids (full-width stack: K slices of 1280, split-K of the 5120-deep projection)."""
+    """bf16 decode: the LDS-DMA slab kernel keeps the register-path kernels' k-block split and reduction order -> BITWISE
+    equal latents/ids (full-width stack: K slices of 1280, split-K of the 5120-deep projection; and the 16-row slab)."""
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prefill_probe.py")
-    outs = []
-    for v in ("0", "1"):
-        env = dict(os.environ, ITTS_DECODE_GEMM=v, PROBE_BIG="1")
-        r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
-    assert outs[0] == outs[1], outs
+    for big in ("1", "0"):                 # 40 rows of the full-width stack (64-row slab), 5 rows of a small one (16-row slab)
+        outs = []
+        for v in ("0", "1"):
+            env = dict(os.environ, ITTS_DECODE_GEMM=v, PROBE_BIG=big)
+            r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+        assert outs[0] == outs[1], outs
 
 
 def test_typical_mass_validation():
