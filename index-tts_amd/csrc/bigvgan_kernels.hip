@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void aa_act_kernel_v2(const float* __restrict_
 
 
 template <int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((WM == 1 && MT == 1) ? 4 : 1, (WM == 1 && MT == 1) ? 4 : 8)))
+void conv_mfma_kernel(ConvArgs a) {
     constexpr int BM = WM * MT * 32;
     constexpr int BN = WN * NT * 32;
     constexpr int LDW = BN + CONV_HALO;
@@ -521,13 +522,12 @@ int launch_conv(const ConvArgs& a, int B, hipStream_t st) {
     if (span > CONV_HALO) { itts_set_error("conv: tap span %d exceeds halo %d", span, CONV_HALO); return ITTS_ERR_ARG; }
     const int m_total = a.Tin + a.m_extra;
     const int n_cosub = (a.Cout + 31) / 32;
-    // co-tile choice (measured, profiles/r01_conv_tiles.txt): the 32-row tile <1,4,1,2> runs at 3 waves/SIMD (146 regs) and
-    // beats the taller tiles (occupancy 2 or 1) up to C_out = 384; from 768 channels the 128-row tile's 4x weight reuse wins.
-    // ITTS_CONV_BM (32/64/96/128) forces a tile height for experiments.
+    // co-tile choice (measured, profiles/r01_conv_tiles.txt): the 32-row tile <1,4,1,2> fits 118 registers without spilling,
+    // i.e. 4 waves/SIMD with its 40 KiB x tile (4 blocks = the CU's 160 KiB of LDS), and beats or ties the taller tiles
+    // (occupancy 2 or 1) at every channel count of the generator.  ITTS_CONV_BM (32/64/96/128) forces a height for experiments.
     static const int force_bm = [] { const char* e = getenv("ITTS_CONV_BM"); return e ? atoi(e) : 0; }();
-    int bm_sub = 4;                                   // co sub-tiles (32 rows each) per block
-    if (force_bm) bm_sub = force_bm / 32;
-    else if (n_cosub <= 12) bm_sub = 1;
+    const int bm_sub = force_bm ? force_bm / 32 : 1;               // co sub-tiles (32 rows each) per block
+    (void)n_cosub;
     switch (bm_sub) {
         case 1: return launch_conv_cfg<1, 4, 1, 2>(a, B, m_total, st);
         case 2: return launch_conv_cfg<1, 4, 2, 2>(a, B, m_total, st);
