@@ -121,6 +121,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON of rank 0): native libraries (RCCL prints a version banner on init) and any
+    # stray print write to fd 1, so fd 1 is pointed at stderr for the run and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,7 +134,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ITTS_BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -279,7 +284,8 @@ def main():
             except Exception as e:      # never lose the GPU line because the baseline leg failed
                 out["cpu_baseline"] = {"error": repr(e)}
             log(f"[bench] cpu_baseline leg took {time.perf_counter() - t_cpu:.1f}s")
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
