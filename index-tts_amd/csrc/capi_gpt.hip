@@ -366,6 +366,12 @@ static int run_head(itts_gpt* h, const GptWs& w, int nseq, int mul, int add, boo
     return launch_gemm(g, prec, false, st);
 }
 
+// owns the instantiated decode-step graph for the duration of one generate call (error returns included)
+struct GraphExecGuard {
+    hipGraphExec_t e = nullptr;
+    ~GraphExecGuard() { if (e) (void)hipGraphExecDestroy(e); }
+};
+
 static SampleArgs make_sample(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, int nseq, long long* tokens,
                               const double* uniforms) {
     const itts_gpt_config& c = h->cfg;
@@ -459,7 +465,8 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
     // ---- decode loop ----
     int steps = 1;
     bool graph_ok = false;
-    hipGraphExec_t exec = nullptr;
+    GraphExecGuard guard;
+    hipGraphExec_t& exec = guard.e;
     if (use_graph && gp.max_new_tokens > 1) {
         // capture one decode step (all step-varying state lives in device memory)
         hipGraph_t graph = nullptr;
@@ -496,7 +503,6 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
     HIP_TRY(hipEventRecord(h->ev_out, st));
     HIP_TRY(hipStreamWaitEvent(cs, h->ev_out, 0));
     HIP_TRY(hipStreamSynchronize(st));
-    if (exec) (void)hipGraphExecDestroy(exec);
     (void)hipEventElapsedTime(&h->last_prefill_ms, h->ev_t0, h->ev_t1);
     (void)hipEventElapsedTime(&h->last_decode_ms, h->ev_t1, h->ev_t2);
     h->last_steps = steps;
@@ -605,7 +611,8 @@ extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, c
     HIP_TRY(hipEventRecord(h->ev_t1, st));
 
     int steps = 1;
-    hipGraphExec_t exec = nullptr;
+    GraphExecGuard guard;
+    hipGraphExec_t& exec = guard.e;
     bool graph_ok = false;
     if (use_graph && gp.max_new_tokens > 1) {
         hipGraph_t graph = nullptr;
@@ -654,7 +661,6 @@ extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, c
     HIP_TRY(hipEventRecord(h->ev_out, st));
     HIP_TRY(hipStreamWaitEvent(cs, h->ev_out, 0));
     HIP_TRY(hipStreamSynchronize(st));
-    if (exec) (void)hipGraphExecDestroy(exec);
     (void)hipEventElapsedTime(&h->last_prefill_ms, h->ev_t0, h->ev_t1);
     (void)hipEventElapsedTime(&h->last_decode_ms, h->ev_t1, h->ev_t2);
     h->last_steps = steps;
