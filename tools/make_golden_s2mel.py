@@ -1,0 +1,83 @@
+"""Mint tests/golden/s2mel_cfm.npz by running the REFERENCE's own CFM / DiT classes (indextts/s2mel/modules/flow_matching.py,
+diffusion_transformer.py, gpt_fast/model.py, wavenet.py) on CPU with the seeded weights of oracle.s2mel_oracle.synth_weights,
+and print the oracle-vs-reference agreement.  torchaudio / librosa / munch are stubbed (tools/ref_shim_s2mel.py): the
+flow-matching path never calls them."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, ".."))
+import ref_shim_s2mel as R  # noqa: E402
+
+R.install()
+from indextts.s2mel.modules.flow_matching import CFM  # noqa: E402
+
+from oracle import s2mel_oracle as S  # noqa: E402
+
+GOLD = os.path.join(HERE, "..", "tests", "golden")
+
+
+def reference(cfg: S.S2MelConfig, sd):
+    args = R.munchify(dict(
+        dit_type="DiT", reg_loss_type="l1",
+        DiT=dict(hidden_dim=cfg.hidden_dim, num_heads=cfg.num_heads, depth=cfg.depth, class_dropout_prob=0.1, block_size=8192,
+                 in_channels=cfg.in_channels, style_condition=True, final_layer_type="wavenet", target="mel",
+                 content_dim=cfg.content_dim, content_codebook_size=cfg.content_codebook_size, content_type="discrete",
+                 f0_condition=False, n_f0_bins=512, content_codebooks=1, is_causal=False, long_skip_connection=True,
+                 zero_prompt_speech_token=False, time_as_token=False, style_as_token=False, uvit_skip_connection=True,
+                 add_resblock_in_transformer=False),
+        wavenet=dict(hidden_dim=cfg.wavenet_hidden, num_layers=cfg.wavenet_layers, kernel_size=cfg.wavenet_kernel,
+                     dilation_rate=cfg.wavenet_dilation_rate, p_dropout=0.2, style_condition=True),
+        style_encoder=dict(dim=cfg.style_dim)))
+    m = CFM(args).eval()
+    ref_keys = [k for k in m.state_dict().keys() if not k.endswith("input_pos")]
+    ours = [n for n, _ in S.param_shapes(cfg)]
+    assert ref_keys == ours, (set(ref_keys) ^ set(ours))
+    for n, shp in S.param_shapes(cfg):
+        assert tuple(m.state_dict()[n].shape) == shp, (n, shp, tuple(m.state_dict()[n].shape))
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("input_pos") for k in missing), (missing, unexpected)
+    m.estimator.setup_caches(max_batch_size=2, max_seq_length=512)
+    return m
+
+
+def main():
+    cfg = S.S2MelConfig(hidden_dim=64, num_heads=2, depth=5, in_channels=80, content_dim=48, style_dim=24, wavenet_hidden=64,
+                        wavenet_layers=3, wavenet_kernel=5, wavenet_dilation_rate=2)
+    seed = 61
+    sd = S.synth_weights(cfg, seed)
+    m = reference(cfg, sd)
+    g = torch.Generator().manual_seed(seed + 1)
+    T, T_prompt, n_steps, cfg_rate = 57, 19, 4, 0.7
+    z = torch.randn(1, cfg.in_channels, T, generator=g)
+    prompt = torch.randn(1, cfg.in_channels, T_prompt, generator=g) * 0.5 - 1.0
+    mu = torch.randn(1, T, cfg.content_dim, generator=g)
+    style = torch.randn(1, cfg.style_dim, generator=g)
+    x_lens = torch.tensor([T - 6])                          # 6 padded frames: the key mask and the WaveNet mask bite
+    with torch.no_grad():
+        # one estimator call (CFG-stacked batch of 2) and the whole Euler solve, both from the reference classes
+        t = torch.tensor([0.35, 0.35])
+        px = torch.zeros(1, cfg.in_channels, T)
+        px[..., :T_prompt] = prompt
+        d_ref = m.estimator(torch.cat([z, z]), torch.cat([px, torch.zeros_like(px)]), x_lens, t,
+                            torch.cat([style, torch.zeros_like(style)]), torch.cat([mu, torch.zeros_like(mu)]))
+        d_o = S.dit_forward(sd, cfg, torch.cat([z, z]), torch.cat([px, torch.zeros_like(px)]), x_lens, t,
+                            torch.cat([style, torch.zeros_like(style)]), torch.cat([mu, torch.zeros_like(mu)]))
+        t_span = torch.linspace(0, 1, n_steps + 1)
+        y_ref = m.solve_euler(z.clone(), x_lens, prompt, mu.clone(), style, None, t_span, inference_cfg_rate=cfg_rate)
+        y_o = S.cfm_solve_euler(sd, cfg, z, x_lens, prompt, mu, style, n_steps, cfg_rate)
+    print(f"estimator: ref {tuple(d_ref.shape)} rms {d_ref.pow(2).mean().sqrt():.3f}  oracle max|d| = {(d_ref - d_o).abs().max():.3e}")
+    print(f"solve_euler ({n_steps} steps, cfg {cfg_rate}): ref rms {y_ref.pow(2).mean().sqrt():.3f}  oracle max|d| = {(y_ref - y_o).abs().max():.3e}")
+    np.savez_compressed(os.path.join(GOLD, "s2mel_cfm.npz"), z=z.numpy(), prompt=prompt.numpy(), mu=mu.numpy(), style=style.numpy(),
+                        x_lens=x_lens.numpy(), t=t.numpy(), estimator_out=d_ref.numpy(), euler_out=y_ref.numpy(),
+                        n_steps=np.int64(n_steps), cfg_rate=np.float64(cfg_rate), seed=np.int64(seed),
+                        cfg=np.array([cfg.hidden_dim, cfg.num_heads, cfg.depth, cfg.in_channels, cfg.content_dim, cfg.style_dim,
+                                      cfg.wavenet_hidden, cfg.wavenet_layers, cfg.wavenet_kernel, cfg.wavenet_dilation_rate]))
+
+
+if __name__ == "__main__":
+    main()
