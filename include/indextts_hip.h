@@ -191,7 +191,7 @@ int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const int32_t* pa
  * Outputs (device): per step the chosen token and parent row of every sequence row (hist_*: [max_new][n_utts*num_beams]
  *   int32), the running beam scores, the finished-hypothesis records hyps_out [n_utts][4]{f32 score, i32 step, i32 row,
  *   i32 pad}, their count and the per-utterance done flags; BeamSearchScorer.finalize (:320-408) is a host-side walk over
- *   these (index-tts_amd/gpt.py).  Max 4 beams. */
+ *   these (indextts_amd/gpt.py).  Max 4 beams. */
 size_t itts_gpt_beam_workspace_bytes(const itts_gpt* h, int n_utts, int num_beams, int S, int Tmax);
 int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int n_utts, int num_beams,
                            int S, const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids,

@@ -1,7 +1,2 @@
-"""Import shim: `import indextts_amd` resolves to the sources under ../index-tts_amd/."""
-import os as _os
-
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "index-tts_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
+"""MI355X-native IndexTTS hot-path engine (GPT speech-token decoder, s2mel flow-matching decoder, BigVGAN vocoder)."""
+__version__ = "0.2.0"

@@ -99,7 +99,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise HipEngineError(
-                f"{LIB_PATH} is missing: build it with `python index-tts_amd/build.py` (hipcc, gfx950). "
+                f"{LIB_PATH} is missing: build it with `python indextts_amd/build.py` (hipcc, gfx950). "
                 "The engine has no CPU fallback.")
         # PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64.  The engine must share THAT runtime instance (device
         # pointers, streams and events cross the boundary): importing torch first makes the loader bind the library's

@@ -1,4 +1,4 @@
-"""Build the gfx950 C-ABI library in-tree:  index-tts_amd/csrc/libindextts_hip.so
+"""Build the gfx950 C-ABI library in-tree:  indextts_amd/csrc/libindextts_hip.so
 
 `hipcc --offload-arch=gfx950` cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box
 with the gpurun snapshot.  Rebuilds only when a source is newer than the library.

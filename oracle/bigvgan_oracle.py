@@ -2,7 +2,7 @@
 
 This module is a plain fp32 CPU restatement of the reference vocoder arithmetic.
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
-import it; the product path (`index-tts_amd/`) never does.
+import it; the product path (`indextts_amd/`) never does.
 
 Pinning: `tests/golden/bigvgan_*.npz` were produced by importing the reference
 classes themselves (`tools/make_golden_bigvgan.py`, run in the build container

@@ -2,7 +2,7 @@
 
 Plain fp32 torch-on-CPU restatement of the reference decode path.  Only `tests/`,
 `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the
-product path (`index-tts_amd/`) never does.
+product path (`indextts_amd/`) never does.
 
 PINNING STATUS: PINNED by running the reference's own code in the build container.
   `tools/make_golden_gpt.py` executes, straight from /root/reference, the reference's

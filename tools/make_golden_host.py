@@ -1,6 +1,6 @@
 """Mint tests/golden/host_v1.json: inputs/outputs of the reference's OWN v1 pipeline helpers
 (`IndexTTS.remove_long_silence`, `bucket_segments`, `pad_tokens_cat`, indextts/infer.py:135-268), AST-extracted from
-/root/reference and run here on seeded inputs.  The host mirror (index-tts_amd/infer.py) is tested against this file."""
+/root/reference and run here on seeded inputs.  The host mirror (indextts_amd/infer.py) is tested against this file."""
 import ast
 import json
 import os
