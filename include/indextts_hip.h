@@ -6,6 +6,9 @@
  * the library never frees or retains them past the call, except the weights it copies at load time.
  * Every function returns 0 on success or an ITTS_ERR_* code; itts_last_error() gives the message.
  * Nothing throws across this boundary.  `stream` is a hipStream_t passed as void*.
+ * Devices: a model handle belongs to the HIP device that was current when its *_create ran (the analogue of
+ * `module.to(device)` in the reference, indextts/infer_v2_5.py:146,232); every call taking the handle switches to that
+ * device for its duration and rejects tensors that live on another one.
  */
 #ifndef INDEXTTS_HIP_H
 #define INDEXTTS_HIP_H
@@ -17,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 2
+#define ITTS_ABI_VERSION 3
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -39,8 +42,9 @@ int itts_aa_act_forward(const float* x, float* y, const float* alpha, const floa
 
 /* host-side weight packing into MFMA A-fragment order (pure CPU; no device needed).
  * conv1d: w [Cout][Cin][k] -> out[itts_packed_conv_floats(Cout, Cin, k)]
- * convT : w [Cin][Cout][k] (torch ConvTranspose1d layout), stride u: phase r in [0,u) -> 2-tap conv, out as above
- *         with k = 2 (requires k == 2*u). */
+ * convT : w [Cin][Cout][k] (torch ConvTranspose1d layout), stride u, padding (k-u)/2: phase r in [0,u) -> a (k/u)-tap
+ *         conv, out as above with k/u taps (requires k a multiple of u and k-u even: 8/4, 4/2 in BigVGAN-v2, also 4/4
+ *         as in the IndexTTS-1.5 vocoder config). */
 size_t itts_packed_conv_floats(int Cout, int Cin, int k);
 int itts_pack_conv1d_weight(const float* w, int Cout, int Cin, int k, float* out);
 int itts_pack_convT_weight(const float* w, int Cin, int Cout, int k, int u, int phase, float* out);
@@ -81,6 +85,7 @@ typedef struct itts_bigvgan itts_bigvgan;
  *   (indextts/s2mel/modules/bigvgan/bigvgan.py:266-358,388-492; v1 indextts/BigVGAN/models.py).
  * Tensors are given by their reference state-dict names (weight-norm already folded), host f32 pointers. */
 int itts_bigvgan_create(const itts_bigvgan_config* cfg, itts_bigvgan** out);
+int itts_bigvgan_device(const itts_bigvgan* h);   /* device index the handle is bound to */
 int itts_bigvgan_load_tensor(itts_bigvgan* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
 int itts_bigvgan_finalize(itts_bigvgan* h);       /* checks every required tensor arrived */
 void itts_bigvgan_destroy(itts_bigvgan* h);
@@ -160,6 +165,7 @@ int itts_pack_gemm_weight(const float* w, int K, int N, int transposed, int prec
  *   gpt.h.{i}.{ln_1,ln_2}.{weight,bias}, gpt.h.{i}.attn.{c_attn,c_proj}.{weight,bias}, gpt.h.{i}.mlp.{c_fc,c_proj}.*,
  *   gpt.ln_f.*, final_norm.*, mel_head.*, mel_embedding.weight, mel_pos_embedding.emb.weight (host f32 pointers). */
 int itts_gpt_create(const itts_gpt_config* cfg, itts_gpt** out);
+int itts_gpt_device(const itts_gpt* h);           /* device index the handle is bound to */
 int itts_gpt_load_tensor(itts_gpt* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
 int itts_gpt_finalize(itts_gpt* h);
 void itts_gpt_destroy(itts_gpt* h);

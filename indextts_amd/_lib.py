@@ -31,7 +31,7 @@ class GPTConfig(C.Structure):
                 ("stop_mel_token", C.c_int32), ("ln_eps", C.c_float)]
 
 
-ABI_VERSION = 2          # include/indextts_hip.h ITTS_ABI_VERSION
+ABI_VERSION = 3          # include/indextts_hip.h ITTS_ABI_VERSION
 
 
 class GenParams(C.Structure):
@@ -56,6 +56,7 @@ SIGNATURES = {
     "itts_conv_transpose1d_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, vp, C.c_int, vp]),
     "itts_bigvgan_create": (C.c_int, [C.POINTER(BigVGANConfig), C.POINTER(vp)]),
+    "itts_bigvgan_device": (C.c_int, [vp]),
     "itts_bigvgan_load_tensor": (C.c_int, [vp, C.c_char_p, vp, c_i64p, C.c_int]),
     "itts_bigvgan_finalize": (C.c_int, [vp]),
     "itts_bigvgan_destroy": (None, [vp]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "itts_packed_gemm_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "itts_pack_gemm_weight": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "itts_gpt_create": (C.c_int, [C.POINTER(GPTConfig), C.POINTER(vp)]),
+    "itts_gpt_device": (C.c_int, [vp]),
     "itts_gpt_load_tensor": (C.c_int, [vp, C.c_char_p, vp, c_i64p, C.c_int]),
     "itts_gpt_finalize": (C.c_int, [vp]),
     "itts_gpt_destroy": (None, [vp]),
@@ -130,6 +132,17 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """torch's current stream ON `device` (default: the current device) as a hipStream_t."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device(device):
+    """Context manager making `device` the current HIP device (handles are bound to the device current at *_create)."""
+    import contextlib
+    import torch
+    d = torch.device(device) if device is not None else None
+    if d is None or d.type != "cuda" or not torch.cuda.is_available():
+        return contextlib.nullcontext()
+    return torch.cuda.device(d)

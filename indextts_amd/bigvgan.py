@@ -49,7 +49,7 @@ class BigVGAN:
     """BigVGAN generator on the HIP engine.  `h` is the reference hparams mapping (config.json)."""
 
     def __init__(self, h, use_cuda_kernel: bool = False, cond_dim: int = 0, in_channels: Optional[int] = None,
-                 cond_in_each_up_layer: bool = True, speaker_encoder=None):
+                 cond_in_each_up_layer: bool = True, speaker_encoder=None, device=None):
         hp = dict(_V2_DEFAULTS)
         hp.update(dict(h))
         if str(hp.get("resblock", "1")) != "1":
@@ -90,23 +90,28 @@ class BigVGAN:
         self._cfg = cfg
         self.in_channels = cfg.in_channels
         self._h = C.c_void_p()
-        L = _lib.lib()
-        _lib.check(L.itts_bigvgan_create(C.byref(cfg), C.byref(self._h)), "itts_bigvgan_create")
         self._loaded = False
         self._ws = None
-        self.device = None
+        self._sd_host = None              # folded f32 CPU tensors, kept so .to(other_device) can rebuild the handle there
+        self.device = torch.device(device) if device is not None else None
+        self._create_handle()
 
-    # ---- checkpoint loading --------------------------------------------------------------------------------
-    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
-        """Reference state-dict names (SURVEY.md section 5); weight-norm is folded here."""
+    def _create_handle(self):
+        """(Re)create the C handle on `self.device` (or the current device): the handle's weights and events belong to the
+        device that is current at itts_bigvgan_create."""
         L = _lib.lib()
-        sd = fold_weight_norm({k: v for k, v in sd.items()})
+        if self._h.value:
+            L.itts_bigvgan_destroy(self._h)
+            self._h = C.c_void_p()
+        with _lib.on_device(self.device):
+            _lib.check(L.itts_bigvgan_create(C.byref(self._cfg), C.byref(self._h)), "itts_bigvgan_create")
+        self._loaded = False
+        self._ws = None
+
+    def _upload(self, strict: bool):
+        L = _lib.lib()
         skipped = []
-        for name, t in sd.items():
-            if name.startswith("speaker_encoder.") or name.endswith("num_batches_tracked") or name == "logit_scale":
-                skipped.append(name)
-                continue
-            t = t.detach().to("cpu", torch.float32).contiguous()
+        for name, t in self._sd_host.items():
             shape = (C.c_int64 * t.dim())(*t.shape)
             rc = L.itts_bigvgan_load_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim())
             if rc != 0:
@@ -116,6 +121,19 @@ class BigVGAN:
         _lib.check(L.itts_bigvgan_finalize(self._h), "itts_bigvgan_finalize")
         self._loaded = True
         return skipped
+
+    # ---- checkpoint loading --------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Reference state-dict names (SURVEY.md section 5); weight-norm is folded here."""
+        sd = fold_weight_norm({k: v for k, v in sd.items()})
+        skipped, host = [], {}
+        for name, t in sd.items():
+            if name.startswith("speaker_encoder.") or name.endswith("num_batches_tracked") or name == "logit_scale":
+                skipped.append(name)
+                continue
+            host[name] = t.detach().to("cpu", torch.float32).contiguous()
+        self._sd_host = host
+        return skipped + self._upload(strict)
 
     @classmethod
     def from_pretrained(cls, model_dir: str, use_cuda_kernel: bool = False, **kw):
@@ -134,7 +152,17 @@ class BigVGAN:
         return self
 
     def to(self, device):
-        self.device = torch.device(device)
+        """`module.to(device)` of the reference (infer_v2_5.py:232): binds the engine to `device`.  If the weights were
+        already uploaded to another GPU the handle is rebuilt on the new one from the retained host copy."""
+        d = torch.device(device)
+        if d.type != "cuda":
+            raise _lib.HipEngineError("BigVGAN (HIP engine) has no CPU path")
+        want = d.index if d.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", want)
+        if _lib.lib().itts_bigvgan_device(self._h) != want:
+            self._create_handle()
+            if self._sd_host is not None:
+                self._upload(strict=True)
         return self
 
     def float(self):
@@ -190,7 +218,7 @@ class BigVGAN:
                 raise ValueError("lens must have one entry per batch row")
         ws = self._workspace(B, T, x.device)
         rc = _lib.lib().itts_bigvgan_forward(self._h, _lib.ptr(x), _lib.ptr(lens_t), _lib.ptr(spk), _lib.ptr(wav), B, T,
-                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+                                             _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
         _lib.check(rc, "itts_bigvgan_forward")
         return (wav, None) if v1 else wav
 
@@ -284,7 +312,7 @@ class BigVGANStream:
         n = C.c_int32(0)
         _lib.check(L.itts_bigvgan_stream_push(self._s, _lib.ptr(x) if n_new else None, max(1, n_new), n_new,
                                               int(last), None, _lib.ptr(out), C.byref(n), _lib.ptr(self._ws), self._ws.numel(),
-                                              _lib.stream_ptr()), "itts_bigvgan_stream_push")
+                                              _lib.stream_ptr(x.device)), "itts_bigvgan_stream_push")
         return out[: n.value].reshape(1, 1, -1)
 
     def close(self):
@@ -312,10 +340,11 @@ def anti_alias_activation(x, up_filter, down_filter, alpha, beta, lens=None, log
     f = lambda t: t.detach().reshape(-1).to(dev, torch.float32).contiguous()
     a, b, fu, fd = f(alpha), f(beta), f(up_filter), f(down_filter)
     lens_t = None if lens is None else torch.as_tensor(lens, dtype=torch.int32, device=dev).contiguous()
-    _lib.check(_lib.lib().itts_aa_act_forward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(a), _lib.ptr(b), _lib.ptr(fu),
-                                              _lib.ptr(fd), B, Cc, T, _lib.ptr(lens_t), 1, int(logscale),
-                                              _lib.stream_ptr()), "itts_aa_act_forward")
-    return y
+    with _lib.on_device(x.device):
+        _lib.check(_lib.lib().itts_aa_act_forward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(a), _lib.ptr(b), _lib.ptr(fu),
+                                                  _lib.ptr(fd), B, Cc, T, _lib.ptr(lens_t), 1, int(logscale),
+                                                  _lib.stream_ptr(x.device)), "itts_aa_act_forward")
+        return y
 
 
 def pack_conv1d_weight(w: torch.Tensor) -> torch.Tensor:
@@ -331,7 +360,7 @@ def pack_convT_weight(w: torch.Tensor, u: int) -> torch.Tensor:
     w = w.detach().to("cpu", torch.float32).contiguous()
     Cin, Cout, k = w.shape
     L = _lib.lib()
-    per = L.itts_packed_conv_floats(Cout, Cin, 2)
+    per = L.itts_packed_conv_floats(Cout, Cin, k // u)      # k/u taps per phase
     out = torch.empty(per * u, dtype=torch.float32)
     for r in range(u):
         _lib.check(L.itts_pack_convT_weight(_lib.ptr(w), Cin, Cout, k, u, r, C.c_void_p(out.data_ptr() + 4 * per * r)),
@@ -344,10 +373,11 @@ def conv1d(x, w_packed, bias, Cout, k, dilation=1, res=None, lens=None, len_mult
     B, Cin, T = x.shape
     y = out if out is not None else torch.empty(B, Cout, T, dtype=torch.float32, device=x.device)
     lens_t = None if lens is None else torch.as_tensor(lens, dtype=torch.int32, device=x.device).contiguous()
-    _lib.check(_lib.lib().itts_conv1d_forward(_lib.ptr(x), _lib.ptr(w_packed), _lib.ptr(bias), None, _lib.ptr(res),
-                                              _lib.ptr(y), B, Cin, Cout, T, k, dilation, _lib.ptr(lens_t), len_mult,
-                                              acc_mode, float(div), _lib.stream_ptr()), "itts_conv1d_forward")
-    return y
+    with _lib.on_device(x.device):
+        _lib.check(_lib.lib().itts_conv1d_forward(_lib.ptr(x), _lib.ptr(w_packed), _lib.ptr(bias), None, _lib.ptr(res),
+                                                  _lib.ptr(y), B, Cin, Cout, T, k, dilation, _lib.ptr(lens_t), len_mult,
+                                                  acc_mode, float(div), _lib.stream_ptr(x.device)), "itts_conv1d_forward")
+        return y
 
 
 def conv_transpose1d(x, w_packed, bias, Cout, k, u, lens=None):
@@ -355,7 +385,8 @@ def conv_transpose1d(x, w_packed, bias, Cout, k, u, lens=None):
     B, Cin, T = x.shape
     y = torch.zeros(B, Cout, T * u, dtype=torch.float32, device=x.device)
     lens_t = None if lens is None else torch.as_tensor(lens, dtype=torch.int32, device=x.device).contiguous()
-    _lib.check(_lib.lib().itts_conv_transpose1d_forward(_lib.ptr(x), _lib.ptr(w_packed), _lib.ptr(bias), None,
-                                                        _lib.ptr(y), B, Cin, Cout, T, k, u, _lib.ptr(lens_t), 1,
-                                                        _lib.stream_ptr()), "itts_conv_transpose1d_forward")
-    return y
+    with _lib.on_device(x.device):
+        _lib.check(_lib.lib().itts_conv_transpose1d_forward(_lib.ptr(x), _lib.ptr(w_packed), _lib.ptr(bias), None,
+                                                            _lib.ptr(y), B, Cin, Cout, T, k, u, _lib.ptr(lens_t), 1,
+                                                            _lib.stream_ptr(x.device)), "itts_conv_transpose1d_forward")
+        return y

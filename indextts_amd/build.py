@@ -1,30 +1,45 @@
 """Build the gfx950 C-ABI library in-tree:  indextts_amd/csrc/libindextts_hip.so
 
 `hipcc --offload-arch=gfx950` cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box
-with the gpurun snapshot.  Rebuilds only when a source is newer than the library.
+with the gpurun snapshot.  Each .hip source is compiled to its own object (in parallel, only when the source or a
+header is newer than the object) and the objects are linked into the shared library.
 """
 import glob
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libindextts_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(p) > t for p in deps)
+
+
+def needs_build() -> bool:
+    return _stale(LIB, sources() + headers() + [os.path.abspath(__file__)])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -33,13 +48,30 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libindextts_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I", INCLUDE, "-o", LIB + ".tmp"]
-    cmd += sources()
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = headers() + [os.path.abspath(__file__)]
+
+    def compile_one(src):
+        obj = _obj(src)
+        if not force and not _stale(obj, [src] + hdrs):
+            return None
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {os.path.basename(src)}:\n" + r.stdout + r.stderr)
+        return obj
+
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + [_obj(s) for s in srcs]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

@@ -60,12 +60,13 @@ extern "C" int itts_pack_conv1d_weight(const float* w, int Cout, int Cin, int k,
 }
 
 extern "C" int itts_pack_convT_weight(const float* w, int Cin, int Cout, int k, int u, int phase, float* out) {
-    if (!w || !out || Cin % 8 || k != 2 * u || phase < 0 || phase >= u) {
-        itts_set_error("pack_convT: bad args Cin=%d Cout=%d k=%d u=%d phase=%d (need k == 2u)", Cin, Cout, k, u, phase);
+    if (!w || !out || Cin % 8 || u < 1 || k < u || k % u || ((k - u) & 1) || phase < 0 || phase >= u) {
+        itts_set_error("pack_convT: bad args Cin=%d Cout=%d k=%d u=%d phase=%d (need k a multiple of u with k-u even)", Cin, Cout, k, u, phase);
         return ITTS_ERR_ARG;
     }
-    // tap jj of phase r uses kernel index r + jj*u and reads x[m - jj]
-    pack_generic([&](int co, int ci, int jj) { return w[((size_t)ci * Cout + co) * k + phase + jj * u]; }, Cout, Cin, 2,
+    // k/u taps per phase: tap jj of phase r uses kernel index r + jj*u and reads x[m - jj]  (k == u: one tap, padding 0 --
+    // the 4/4 upsamplers of the v1.5 vocoder; k == 2u: two taps -- BigVGAN-v2)
+    pack_generic([&](int co, int ci, int jj) { return w[((size_t)ci * Cout + co) * k + phase + jj * u]; }, Cout, Cin, k / u,
                  out);
     return ITTS_OK;
 }
@@ -110,14 +111,14 @@ extern "C" int itts_conv1d_forward(const float* x, const float* wpk, const float
 
 static int convT_impl(const float* x, const float* wpk_phases, const float* bias, const float* bias_b, float* y, int B,
                       int Cin, int Cout, int Tin, int k, int u, const int* lens, int len_mult_in, hipStream_t st) {
-    const int p = (k - u) / 2;
-    const size_t per_phase = itts_packed_conv_floats(Cout, Cin, 2);
+    const int p = (k - u) / 2, ntaps = k / u;
+    const size_t per_phase = itts_packed_conv_floats(Cout, Cin, ntaps);
     for (int r = 0; r < u; ++r) {
         ConvArgs a;
         a.x = x; a.y = y; a.wpk = wpk_phases + per_phase * r; a.bias = bias; a.bias_b = bias_b; a.res = nullptr;
         a.lens = lens; a.len_mult_in = len_mult_in; a.len_mult_out = len_mult_in * u;
         a.Cin = Cin; a.Cout = Cout; a.Tin = Tin; a.Tout = Tin * u;
-        a.k = 2; a.tap_base = 0; a.tap_step = -1; a.ostride = u; a.ooff = r - p; a.m_extra = 1;
+        a.k = ntaps; a.tap_base = 0; a.tap_step = -1; a.ostride = u; a.ooff = r - p; a.m_extra = ntaps - 1;
         a.acc_mode = 0; a.div = 1.f;
         int rc = launch_conv(a, B, st);
         if (rc) return rc;
@@ -128,8 +129,8 @@ static int convT_impl(const float* x, const float* wpk_phases, const float* bias
 extern "C" int itts_conv_transpose1d_forward(const float* x, const float* wpk_phases, const float* bias,
                                              const float* bias_b, float* y, int B, int Cin, int Cout, int Tin, int k,
                                              int u, const int32_t* lens, int len_mult_in, void* stream) {
-    if (!x || !wpk_phases || !y || k != 2 * u || u < 1 || ((k - u) & 1)) {
-        itts_set_error("conv_transpose1d: need k == 2u and even k-u (k=%d u=%d)", k, u);
+    if (!x || !wpk_phases || !y || u < 1 || k < u || k % u || ((k - u) & 1)) {
+        itts_set_error("conv_transpose1d: need k a multiple of u with k-u even (k=%d u=%d)", k, u);
         return ITTS_ERR_ARG;
     }
     if (B <= 0 || Tin <= 0) return ITTS_OK;
@@ -174,6 +175,7 @@ struct itts_bigvgan {
     struct Rec { int cls; double flops; double bytes; };
     std::vector<Rec> recs;      // one per launch of the last forward; events 2i, 2i+1
     hipStream_t prof_stream = nullptr;
+    int device = -1;            // device current at itts_bigvgan_create: owns the weights and profiling events
 };
 
 // profiling classes
@@ -225,9 +227,9 @@ extern "C" int itts_bigvgan_create(const itts_bigvgan_config* cfg, itts_bigvgan*
         return ITTS_ERR_ARG;
     }
     for (int i = 0; i < c.num_upsamples; ++i) {
-        if (c.upsample_kernel_sizes[i] != 2 * c.upsample_rates[i]) {
-            itts_set_error("bigvgan_create: upsampler %d needs k == 2*stride (k=%d u=%d)", i, c.upsample_kernel_sizes[i],
-                           c.upsample_rates[i]);
+        const int uk = c.upsample_kernel_sizes[i], uu = c.upsample_rates[i];
+        if (uu < 1 || uk < uu || uk % uu || ((uk - uu) & 1)) {
+            itts_set_error("bigvgan_create: upsampler %d needs k a multiple of the stride with k-stride even (k=%d u=%d)", i, uk, uu);
             return ITTS_ERR_ARG;
         }
         if (stage_channels(c, i) < 1 || (c.upsample_initial_channel >> i) % 8) {
@@ -250,6 +252,7 @@ extern "C" int itts_bigvgan_create(const itts_bigvgan_config* cfg, itts_bigvgan*
     }
     itts_bigvgan* h = new itts_bigvgan();
     h->cfg = c;
+    h->device = itts_current_device();
     const int nres = c.num_upsamples * c.num_kernels;
     h->ups.resize(c.num_upsamples);
     h->conds.resize(c.num_upsamples);
@@ -262,8 +265,11 @@ extern "C" int itts_bigvgan_create(const itts_bigvgan_config* cfg, itts_bigvgan*
     return ITTS_OK;
 }
 
+extern "C" int itts_bigvgan_device(const itts_bigvgan* h) { return h ? h->device : -1; }
+
 extern "C" void itts_bigvgan_destroy(itts_bigvgan* h) {
     if (!h) return;
+    ItDevGuard dg(h->device);
     for (float* p : h->owned) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
@@ -328,6 +334,7 @@ static int load_act(itts_bigvgan* h, ActL* A, const char* what, const float* dat
 extern "C" int itts_bigvgan_load_tensor(itts_bigvgan* h, const char* name, const float* data, const int64_t* shape,
                                         int ndim) {
     if (!h || !name || !data || !shape || ndim < 1 || ndim > 3) { itts_set_error("load_tensor: bad args"); return ITTS_ERR_ARG; }
+    ItDevGuard dg(h->device);
     const itts_bigvgan_config& c = h->cfg;
     const char* s = name;
     int i, j, d;
@@ -349,7 +356,7 @@ extern "C" int itts_bigvgan_load_tensor(itts_bigvgan* h, const char* name, const
         ConvL* L = &h->ups[i];
         if (!strcmp(s, "weight")) {
             if (ndim != 3 || shape[0] != Cin || shape[1] != Cout || shape[2] != k) { itts_set_error("%s: shape mismatch", name); return ITTS_ERR_ARG; }
-            const size_t per = itts_packed_conv_floats(Cout, Cin, 2);
+            const size_t per = itts_packed_conv_floats(Cout, Cin, k / u);
             std::vector<float> pk(per * u);
             for (int r = 0; r < u; ++r) {
                 int rc = itts_pack_convT_weight(data, Cin, Cout, k, u, r, pk.data() + per * r);
@@ -432,6 +439,7 @@ static void default_filter12(float* f) {
 
 extern "C" int itts_bigvgan_finalize(itts_bigvgan* h) {
     if (!h) { itts_set_error("finalize: null"); return ITTS_ERR_ARG; }
+    ItDevGuard dg(h->device);
     const itts_bigvgan_config& c = h->cfg;
     std::string missing;
     auto need = [&](bool ok, const std::string& n) { if (!ok) missing += n + " "; };
@@ -506,6 +514,14 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
                                     int B, int T, void* workspace, size_t workspace_bytes, void* stream) {
     if (!h || !x || !wav || !workspace) { itts_set_error("bigvgan_forward: null pointer"); return ITTS_ERR_ARG; }
     if (!h->finalized) { itts_set_error("bigvgan_forward: call itts_bigvgan_finalize first"); return ITTS_ERR_STATE; }
+    ItDevGuard dg(h->device);
+    {
+        const int dx = itts_ptr_device(x), dw = itts_ptr_device(workspace);
+        if ((dx >= 0 && dx != h->device) || (dw >= 0 && dw != h->device)) {
+            itts_set_error("bigvgan_forward: tensors are on device %d/%d but the model was created on device %d", dx, dw, h->device);
+            return ITTS_ERR_ARG;
+        }
+    }
     if (B <= 0 || T <= 0) return ITTS_OK;
     if (B > 65535) { itts_set_error("bigvgan_forward: B must be <= 65535"); return ITTS_ERR_ARG; }
     const itts_bigvgan_config& c = h->cfg;
@@ -623,6 +639,7 @@ extern "C" int itts_bigvgan_set_profiling(itts_bigvgan* h, int enable) {
 // Returns the number of launches (<= max_records written).  Synchronises the launch stream.
 extern "C" int itts_bigvgan_profile_records(itts_bigvgan* h, double* out, int max_records) {
     if (!h || !out) { itts_set_error("profile_records: null"); return -1; }
+    ItDevGuard dg(h->device);
     if (h->recs.empty()) return 0;
     if (hipStreamSynchronize(h->prof_stream) != hipSuccess) return -1;
     int n = 0;
@@ -636,6 +653,7 @@ extern "C" int itts_bigvgan_profile_records(itts_bigvgan* h, double* out, int ma
 
 extern "C" int itts_bigvgan_profile_read(itts_bigvgan* h, double* ms, double* launches, double* flops, double* bytes) {
     if (!h || !ms || !launches || !flops || !bytes) { itts_set_error("profile_read: null"); return ITTS_ERR_ARG; }
+    ItDevGuard dg(h->device);
     for (int i = 0; i < PC_COUNT; ++i) ms[i] = launches[i] = flops[i] = bytes[i] = 0;
     if (h->recs.empty()) return ITTS_OK;
     HIP_TRY(hipStreamSynchronize(h->prof_stream));
@@ -670,6 +688,7 @@ extern "C" int itts_bigvgan_stream_open(itts_bigvgan* h, int chunk_frames, int h
     if (!h || !out) { itts_set_error("bigvgan_stream_open: null pointer"); return ITTS_ERR_ARG; }
     if (!h->finalized) { itts_set_error("bigvgan_stream_open: call itts_bigvgan_finalize first"); return ITTS_ERR_STATE; }
     if (chunk_frames <= 0 || halo_frames < 0) { itts_set_error("bigvgan_stream_open: bad chunk/halo"); return ITTS_ERR_ARG; }
+    ItDevGuard dg(h->device);
     auto* s = new itts_bigvgan_stream();
     s->h = h; s->chunk = chunk_frames; s->halo = halo_frames; s->cap = 2 * chunk_frames + 2 * halo_frames;
     s->received = s->emitted = s->base = 0;
@@ -691,6 +710,7 @@ extern "C" int itts_bigvgan_stream_open(itts_bigvgan* h, int chunk_frames, int h
 
 extern "C" void itts_bigvgan_stream_close(itts_bigvgan_stream* s) {
     if (!s) return;
+    ItDevGuard dg(s->h->device);
     (void)hipFree(s->ctx); (void)hipFree(s->xwin); (void)hipFree(s->wwin);
     delete s;
 }
@@ -704,6 +724,7 @@ extern "C" int itts_bigvgan_stream_push(itts_bigvgan_stream* s, const float* mel
                                         size_t workspace_bytes, void* stream) {
     if (!s || !wav_out || !n_samples_out || !workspace || (n_frames > 0 && !mel)) { itts_set_error("bigvgan_stream_push: null pointer"); return ITTS_ERR_ARG; }
     if (n_frames < 0 || n_frames > s->chunk || (n_frames > 0 && ld_mel < n_frames)) { itts_set_error("bigvgan_stream_push: n_frames %d outside 0..%d", n_frames, s->chunk); return ITTS_ERR_ARG; }
+    ItDevGuard dg(s->h->device);
     hipStream_t st = (hipStream_t)stream;
     const int C = s->h->cfg.in_channels, up = s->h->total_up;
     *n_samples_out = 0;

@@ -60,6 +60,7 @@ struct itts_gpt {
     int fin_cap = 0;
     float last_prefill_ms = 0, last_decode_ms = 0;
     int last_steps = 0;
+    int device = -1;                   // device current at itts_gpt_create: owns weights, stream, events
 };
 
 static int g_upload(itts_gpt* h, const void* host, size_t bytes, void** dst) {
@@ -83,13 +84,17 @@ extern "C" int itts_gpt_create(const itts_gpt_config* cfg, itts_gpt** out) {
     }
     itts_gpt* h = new itts_gpt();
     h->cfg = c;
+    h->device = itts_current_device();
     h->layers.resize(c.layers);
     *out = h;
     return ITTS_OK;
 }
 
+extern "C" int itts_gpt_device(const itts_gpt* h) { return h ? h->device : -1; }
+
 extern "C" void itts_gpt_destroy(itts_gpt* h) {
     if (!h) return;
+    ItDevGuard dg(h->device);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->host_flag) (void)hipHostFree(h->host_flag);
     if (h->host_fin) (void)hipHostFree(h->host_fin);
@@ -133,6 +138,7 @@ static int load_mat(itts_gpt* h, const float* data, const int64_t* shape, int nd
 // gpt.ln_f, final_norm, mel_head, mel_embedding.weight, mel_pos_embedding.emb.weight.  HF Conv1D weights are [in, out].
 extern "C" int itts_gpt_load_tensor(itts_gpt* h, const char* name, const float* data, const int64_t* shape, int ndim) {
     if (!h || !name || !data || !shape || ndim < 1 || ndim > 2) { itts_set_error("gpt_load_tensor: bad args"); return ITTS_ERR_ARG; }
+    ItDevGuard dg(h->device);
     const itts_gpt_config& c = h->cfg;
     const int D = c.model_dim;
     const char* s = name;
@@ -170,6 +176,7 @@ extern "C" int itts_gpt_load_tensor(itts_gpt* h, const char* name, const float* 
 
 extern "C" int itts_gpt_finalize(itts_gpt* h) {
     if (!h) { itts_set_error("gpt_finalize: null"); return ITTS_ERR_ARG; }
+    ItDevGuard dg(h->device);
     std::string missing;
     for (size_t i = 0; i < h->layers.size(); ++i) {
         const GLayer& L = h->layers[i];
@@ -193,6 +200,17 @@ extern "C" int itts_gpt_finalize(itts_gpt* h) {
         HIP_TRY(hipHostMalloc((void**)&h->host_flag, 64, hipHostMallocDefault));
     }
     h->finalized = true;
+    return ITTS_OK;
+}
+
+// caller tensors must live on the device that owns the engine (weights, stream): a mismatch would fault or go through
+// silent peer access
+static int check_same_device(const itts_gpt* h, const void* in, const void* ws, const char* who) {
+    const int di = itts_ptr_device(in), dw = itts_ptr_device(ws);
+    if ((di >= 0 && di != h->device) || (dw >= 0 && dw != h->device)) {
+        itts_set_error("%s: tensors are on device %d/%d but the engine was created on device %d", who, di, dw, h->device);
+        return ITTS_ERR_ARG;
+    }
     return ITTS_OK;
 }
 
@@ -403,6 +421,8 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
                                  size_t workspace_bytes, int use_graph, void* caller_stream) {
     if (!h || !prefix_embeds || !gpp || !codes_out || !n_steps_out || !workspace) { itts_set_error("gpt_generate: null pointer"); return ITTS_ERR_ARG; }
     if (!h->finalized) { itts_set_error("gpt_generate: call itts_gpt_finalize first"); return ITTS_ERR_STATE; }
+    ItDevGuard dg(h->device);
+    if (int rcd = check_same_device(h, prefix_embeds, workspace, "gpt_generate")) return rcd;
     const itts_gpt_config& c = h->cfg;
     const itts_gen_params gp = *gpp;
     if (nseq <= 0 || S <= 0 || gp.max_new_tokens <= 0) { itts_set_error("gpt_generate: nseq, S, max_new_tokens must be > 0"); return ITTS_ERR_ARG; }
@@ -558,6 +578,8 @@ extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, c
     if (!h || !prefix_embeds || !gpp || !hist_tok_out || !hist_par_out || !beam_scores_out || !hyps_out || !n_hyps_out || !done_out ||
         !n_steps_out || !workspace) { itts_set_error("gpt_generate_beam: null pointer"); return ITTS_ERR_ARG; }
     if (!h->finalized) { itts_set_error("gpt_generate_beam: call itts_gpt_finalize first"); return ITTS_ERR_STATE; }
+    ItDevGuard dg(h->device);
+    if (int rcd = check_same_device(h, prefix_embeds, workspace, "gpt_generate_beam")) return rcd;
     const itts_gpt_config& c = h->cfg;
     const itts_gen_params gp = *gpp;
     const int nb = num_beams, B = n_utts, nseq = B * nb;
@@ -682,6 +704,8 @@ extern "C" int itts_gpt_forward_latent(itts_gpt* h, const float* x, int nseq, in
                                        size_t workspace_bytes, void* caller_stream) {
     if (!h || !x || !out || !workspace) { itts_set_error("gpt_forward_latent: null pointer"); return ITTS_ERR_ARG; }
     if (!h->finalized) { itts_set_error("gpt_forward_latent: call itts_gpt_finalize first"); return ITTS_ERR_STATE; }
+    ItDevGuard dg(h->device);
+    if (int rcd = check_same_device(h, x, workspace, "gpt_forward_latent")) return rcd;
     const itts_gpt_config& c = h->cfg;
     if (nseq <= 0 || S <= 0 || S > 65535) { itts_set_error("gpt_forward_latent: bad shape"); return ITTS_ERR_ARG; }
     const GptWs w0 = carve(c, nullptr, nseq, S, S);

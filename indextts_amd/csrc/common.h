@@ -29,6 +29,33 @@ typedef unsigned short u16;
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Every object that owns device memory (weights, streams, events) records the device that was current when it was created;
+// each C-ABI entry point taking such a handle runs under this guard, so a caller whose current device differs (a process
+// driving several GPUs) neither allocates on nor launches to the wrong one.
+struct ItDevGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit ItDevGuard(int dev) {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        if (prev != dev && hipSetDevice(dev) == hipSuccess) switched = true;
+    }
+    ~ItDevGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    ItDevGuard(const ItDevGuard&) = delete;
+    ItDevGuard& operator=(const ItDevGuard&) = delete;
+};
+static inline int itts_current_device() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) { d = -1; (void)hipGetLastError(); }
+    return d;
+}
+// device that owns a device pointer, -1 if unknown (host pointer / query unsupported)
+static inline int itts_ptr_device(const void* p) {
+    hipPointerAttribute_t at;
+    if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return at.type == hipMemoryTypeDevice ? at.device : -1;
+}
+
 #ifdef __HIPCC__
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

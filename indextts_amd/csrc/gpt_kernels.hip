@@ -800,7 +800,9 @@ static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
     if constexpr (BF16) {
         // bf16 decode: the LDS-DMA slab kernel whenever the K slice fits its image (ITTS_DECODE_GEMM=0: the register-path kernels)
         static const bool old_path = [] { const char* e = getenv("ITTS_DECODE_GEMM"); return e && atoi(e) == 0; }();
-        if (!old_path && ceil_div(a.K / 32, a.nsplit) <= 40 && a.lda % 8 == 0 && a.K % 64 == 0) {
+        // every K slice must hold an EVEN number of 32-wide k-blocks: the slab is DMA'd in 128-byte k-pairs and a slice with
+        // an odd count would pair its last k-block with bytes of the neighbouring one (D = 128, 384, 640, ... with 4 slices)
+        if (!old_path && ceil_div(a.K / 32, a.nsplit) <= 40 && a.lda % 8 == 0 && (a.K / 32) % (2 * a.nsplit) == 0) {
             const int rc = launch_gemm_decode64(a, st);
             if (rc >= 0) return rc;
         }
@@ -1250,6 +1252,23 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     }
 }
 
+// The selection kernels keep the whole score row in LDS ([V] f32, twice that with typical sampling: 65.5 KB at the production
+// vocabulary of 8194, above the 64 KiB a kernel gets without asking).  Raise the kernel's dynamic-LDS limit once to what the
+// launch needs; the CU has 160 KiB.
+template <class K>
+static int ensure_dyn_lds(K kernel, size_t bytes, size_t* granted, const char* who) {
+    constexpr size_t kStatic = 8192;                    // static __shared__ of these kernels, rounded up
+    if (bytes + kStatic > 160 * 1024) {
+        itts_set_error("%s: vocabulary needs %zu bytes of LDS, above the 160 KiB of a CU", who, bytes);
+        return ITTS_ERR_ARG;
+    }
+    if (bytes > 48 * 1024 && bytes > *granted) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        *granted = bytes;
+    }
+    return ITTS_OK;
+}
+
 int launch_sample(const SampleArgs& a, hipStream_t st) {
     if (a.B <= 0) return ITTS_OK;
     if (a.do_sample && (a.top_k <= 0 || a.top_k > 64)) {
@@ -1261,6 +1280,8 @@ int launch_sample(const SampleArgs& a, hipStream_t st) {
         return ITTS_ERR_ARG;
     }
     const size_t lds = (size_t)a.V * sizeof(float) * (a.typical_mass > 0.f ? 2 : 1);
+    static size_t granted = 0;
+    if (int rc = ensure_dyn_lds(sample_kernel, lds, &granted, "sampling")) return rc;
     hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), lds, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
@@ -1589,6 +1610,8 @@ int launch_beam_step(const BeamArgs& a, hipStream_t st) {
         return ITTS_ERR_ARG;
     }
     const size_t lds = (size_t)a.V * sizeof(float) * (a.typical_mass > 0.f ? 2 : 1);
+    static size_t granted = 0;
+    if (int rc = ensure_dyn_lds(beam_rows_kernel, lds, &granted, "beam search")) return rc;
     hipLaunchKernelGGL(beam_rows_kernel, dim3(a.B * a.nb), dim3(256), lds, st, a);
     hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());

@@ -51,7 +51,8 @@ class UnifiedVoice:
         cfg.vocab, cfg.n_mel_pos, cfg.precision = number_mel_codes, self.n_mel_pos, self.precision
         cfg.start_mel_token, cfg.stop_mel_token, cfg.ln_eps = start_mel_token, stop_mel_token, 1e-5
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().itts_gpt_create(C.byref(cfg), C.byref(self._h)), "itts_gpt_create")
+        with _lib.on_device(self.device):          # the handle (weights, stream, events) is bound to the device current here
+            _lib.check(_lib.lib().itts_gpt_create(C.byref(cfg), C.byref(self._h)), "itts_gpt_create")
         self._emb: Dict[str, torch.Tensor] = {}
         self._loaded = False
         self._ws = None
@@ -99,6 +100,10 @@ class UnifiedVoice:
         return self
 
     def to(self, device):
+        """The engine lives on the device given at construction (`device=`); moving a loaded engine is not supported."""
+        d = torch.device(device)
+        if d.type == "cuda" and d.index is not None and self.device.index is not None and d.index != self.device.index:
+            raise _lib.HipEngineError(f"UnifiedVoice was built on {self.device}; construct it with device={device!r} instead")
         return self
 
     # ---- input assembly (model_v2.py:648-714) ------------------------------------------------------------------
@@ -207,7 +212,7 @@ class UnifiedVoice:
                 raise ValueError("uniforms must be (>= max_new_tokens, B)")
         rc = L.itts_gpt_generate(self._h, _lib.ptr(x), _lib.ptr(pad), B, S, C.byref(gp), pen, 2, _lib.ptr(u),
                                  _lib.ptr(codes), C.byref(n_steps), _lib.ptr(ws), ws.numel(), int(self.use_graph),
-                                 _lib.stream_ptr())
+                                 _lib.stream_ptr(self.device))
         _lib.check(rc, "itts_gpt_generate")
         pm, dm, st = C.c_float(0), C.c_float(0), C.c_int32(0)
         L.itts_gpt_last_timing(self._h, C.byref(pm), C.byref(dm), C.byref(st))
@@ -258,7 +263,7 @@ class UnifiedVoice:
         rc = L.itts_gpt_generate_beam(self._h, _lib.ptr(x), _lib.ptr(pad), B, nb, S, C.byref(gp), pen, 2, _lib.ptr(u),
                                       _lib.ptr(hist_tok), _lib.ptr(hist_par), _lib.ptr(beam_scores), _lib.ptr(hyps),
                                       _lib.ptr(n_hyps), _lib.ptr(done), C.byref(n_steps), _lib.ptr(ws), ws.numel(),
-                                      int(self.use_graph), _lib.stream_ptr())
+                                      int(self.use_graph), _lib.stream_ptr(self.device))
         _lib.check(rc, "itts_gpt_generate_beam")
         pm, dm, st = C.c_float(0), C.c_float(0), C.c_int32(0)
         L.itts_gpt_last_timing(self._h, C.byref(pm), C.byref(dm), C.byref(st))
@@ -354,7 +359,7 @@ class UnifiedVoice:
         ws = self._workspace(L.itts_gpt_workspace_bytes(self._h, B, S, S))
         out = torch.empty_like(x)
         _lib.check(L.itts_gpt_forward_latent(self._h, _lib.ptr(x), B, S, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                                             _lib.stream_ptr()), "itts_gpt_forward_latent")
+                                             _lib.stream_ptr(self.device)), "itts_gpt_forward_latent")
         enc = out[:, conds.shape[1]:]
         return enc[:, -mel.shape[1]:][:, :-2]
 
@@ -465,16 +470,18 @@ def gemm(a: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], 
          prefill_tiles: bool = False) -> torch.Tensor:
     M, K = a.shape
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    _lib.check(_lib.lib().itts_gemm_forward(_lib.ptr(a.contiguous()), _lib.ptr(w_packed), _lib.ptr(bias), _lib.ptr(out),
-                                            M, N, K, precision, int(prefill_tiles), 0, _lib.stream_ptr()),
-               "itts_gemm_forward")
-    return out
+    with _lib.on_device(a.device):
+        _lib.check(_lib.lib().itts_gemm_forward(_lib.ptr(a.contiguous()), _lib.ptr(w_packed), _lib.ptr(bias), _lib.ptr(out),
+                                                M, N, K, precision, int(prefill_tiles), 0, _lib.stream_ptr(a.device)),
+                   "itts_gemm_forward")
+        return out
 
 
 def layernorm(x, g, b, g2=None, b2=None, eps=1e-5):
     rows, D = x.shape
     out = torch.empty_like(x)
-    _lib.check(_lib.lib().itts_layernorm_forward(_lib.ptr(x.contiguous()), _lib.ptr(g), _lib.ptr(b), _lib.ptr(g2),
-                                                 _lib.ptr(b2), _lib.ptr(out), rows, D, float(eps), _lib.stream_ptr()),
-               "itts_layernorm_forward")
-    return out
+    with _lib.on_device(x.device):
+        _lib.check(_lib.lib().itts_layernorm_forward(_lib.ptr(x.contiguous()), _lib.ptr(g), _lib.ptr(b), _lib.ptr(g2),
+                                                     _lib.ptr(b2), _lib.ptr(out), rows, D, float(eps), _lib.stream_ptr(x.device)),
+                   "itts_layernorm_forward")
+        return out

@@ -14,13 +14,16 @@ from oracle import gpt_oracle as G  # noqa: E402  (seeded synthetic weights only
 BIG = os.environ.get("PROBE_BIG") == "1"       # full-width stack (K = 1280 / 5120 slices) and 40 rows: the 33..64-row decode GEMM
 cfg = (G.GPTConfig(layers=2, model_dim=1280, heads=20, max_text_tokens=60, max_mel_tokens=80, number_text_tokens=200) if BIG
        else G.GPTConfig(layers=3, model_dim=256, heads=4, max_text_tokens=60, max_mel_tokens=80, number_text_tokens=200))
+DIM = int(os.environ.get("PROBE_DIM", "0"))    # odd multiples of 128: split-K slices with an odd number of 32-wide k-blocks
+if DIM:
+    cfg = G.GPTConfig(layers=2, model_dim=DIM, heads=DIM // 64, max_text_tokens=60, max_mel_tokens=80, number_text_tokens=200)
 sd = G.synth_weights(cfg, seed=77)
 m = gpt.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
                      max_mel_tokens=cfg.max_mel_tokens, number_text_tokens=cfg.number_text_tokens, precision="bf16",
                      device="cuda:0")
 m.load_state_dict(sd)
 g = torch.Generator().manual_seed(5)
-B = 40 if BIG else 5
+B = int(os.environ.get("PROBE_B", "40" if BIG else "5"))
 text = torch.randint(2, 200, (B, 37), generator=g)
 text[1, 20:] = 1
 text[3, 9:] = 1

@@ -103,7 +103,8 @@ def test_conv1d_ragged_rows_equal_solo(bv):
         assert (y[b:b + 1, :, :n] - ref).abs().max() < 2e-5 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("Cin,Cout,k,u,T,B", [(128, 64, 8, 4, 70, 2), (48, 24, 4, 2, 300, 2), (64, 32, 8, 4, 1, 1)])
+@pytest.mark.parametrize("Cin,Cout,k,u,T,B", [(128, 64, 8, 4, 70, 2), (48, 24, 4, 2, 300, 2), (64, 32, 8, 4, 1, 1),
+                                               (64, 32, 4, 4, 33, 2), (32, 16, 2, 2, 5, 1), (32, 16, 12, 4, 17, 2)])
 def test_conv_transpose1d_vs_torch(bv, Cin, Cout, k, u, T, B):
     g = torch.Generator().manual_seed(Cin + Cout + k)
     x = torch.randn(B, Cin, T, generator=g)
@@ -158,7 +159,7 @@ def test_generator_ragged_batch_rows_equal_solo(bv):
 def test_generator_v1_variant(bv):
     """v1: latent input (B,T,D), speaker conditioning adds after conv_pre and each upsampler, tanh epilogue."""
     h = dict(O.V2_HPARAMS, upsample_initial_channel=512, use_tanh_at_final=True, use_bias_at_final=True,
-             upsample_rates=[4, 4, 4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 8, 8, 4, 4])
+             upsample_rates=[4, 4, 4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4, 4, 4])
     sd = O.synth_weights(h, seed=5, cond_dim=64, in_dim=48, post_gain=0.2)
     m = _model(bv, h, sd, cond_dim=64, in_channels=48)
     g = torch.Generator().manual_seed(1)

@@ -223,6 +223,49 @@ def test_decode_gemm_kernels_agree():
         assert outs[0] == outs[1], outs
 
 
+@pytest.mark.parametrize("dim,rows", [(128, 5), (384, 40), (640, 20)])
+def test_decode_gemm_odd_kblock_slices(dim, rows):
+    """bf16 decode at widths whose 4-way split-K slices hold an ODD number of 32-wide k-blocks (D/128 odd): the slab kernel's
+    128-byte k-pair DMA cannot represent such a slice, so those GEMMs must take the register path -- outputs bitwise equal
+    to a run with the slab kernel disabled (silent wrong partials at D = 128, 384, 640, ...)."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prefill_probe.py")
+    outs = []
+    for v in ("0", "1"):
+        env = dict(os.environ, ITTS_DECODE_GEMM=v, PROBE_DIM=str(dim), PROBE_B=str(rows))
+        r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert outs[0] == outs[1], outs
+
+
+def test_typical_sampling_at_production_vocab():
+    """TypicalLogitsWarper on the device loop at V = 8194 (two score rows = 65.5 KB of dynamic LDS, above the default
+    64 KiB): ids equal the CPU oracle in sample and beam-sample modes."""
+    cfg = G.GPTConfig(layers=2, model_dim=128, heads=2, max_text_tokens=20, max_mel_tokens=40, number_text_tokens=60)
+    assert cfg.number_mel_codes == 8194
+    sd = G.synth_weights(cfg, seed=21)
+    g = torch.Generator().manual_seed(4)
+    text = torch.randint(2, 60, (2, 7), generator=g)
+    style = torch.randn(1, 192, generator=g)
+    emo = torch.randn(1, cfg.model_dim, generator=g) * 0.1
+    langs = torch.tensor([1, 2])
+    conds = G.conds_latent_campplus(sd, style, emo)
+    m = engine(cfg, sd, "fp32")
+    for nb in (1, 2):
+        n = 6
+        u = torch.rand(n, 2, generator=g, dtype=torch.float64) if nb == 1 else torch.rand(n, 2, 2 * nb, generator=g, dtype=torch.float64)
+        gp = G.GenParams(do_sample=True, num_beams=nb, top_k=30, top_p=0.8, temperature=0.8, repetition_penalty=10.0,
+                         max_generate_length=n, typical_sampling=True, typical_mass=0.9)
+        with torch.no_grad():
+            ref = G.inference_speech(sd, cfg, conds, text, langs, gp, uniforms=u)
+        ids, _ = m.inference_speech(None, text, langs=langs, emo_vec=emo, campplus_embedding=style, max_generate_length=n,
+                                    do_sample=True, num_beams=nb, top_k=30, top_p=0.8, temperature=0.8, repetition_penalty=10.0,
+                                    typical_sampling=True, typical_mass=0.9, uniforms=u)
+        assert torch.equal(ids.cpu(), ref), (nb, ids.cpu().tolist(), ref.tolist())
+
+
 def test_typical_mass_validation():
     from indextts_amd import gpt
     cfg = G.GPTConfig(layers=1, model_dim=128, heads=2, max_text_tokens=20, max_mel_tokens=30, number_text_tokens=50)

@@ -61,7 +61,7 @@ def build_v1():
     g.load_state_dict(sd)
     g.post_init_gpt2_config(kv_cache=True)
     h = dict(BO.V2_HPARAMS, upsample_initial_channel=512, use_tanh_at_final=True, use_bias_at_final=True,
-             upsample_rates=[4, 4, 4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 8, 8, 4, 4])
+             upsample_rates=[4, 4, 4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4, 4, 4])
     bsd = BO.synth_weights(h, seed=42, cond_dim=64, in_dim=128, post_gain=0.2)
     proj = torch.randn(100, 64, generator=torch.Generator().manual_seed(43)) * 0.1
     spk_enc = lambda mel_ref, lens=None: (mel_ref.float().mean(dim=1) @ proj.to(mel_ref.device))   # (1,T,100) -> (1,64)

@@ -24,7 +24,7 @@ def test_every_header_symbol_is_exported_and_bound():
         assert hasattr(L, name), f"{name} declared in include/indextts_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert set(_lib.SIGNATURES) <= declared
-    assert L.itts_abi_version() == 2
+    assert L.itts_abi_version() == _lib.ABI_VERSION
 
 
 def test_product_path_fails_loudly_without_device():
