@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio-seconds generated per wall-second, IndexTTS-2.5 hot path, 64-utterance x 128-token batch.
 
-One "step" = one pass of the hot path over one batch of synthetic input on every rank:
-    speaker-bundle broadcast (RCCL when N > 1)  ->  GPT speech-token decode (prefill + 560 sampled tokens per utterance,
-    top-k 30 / top-p 0.8 / T 0.8 / repetition penalty 10, bf16 weights + KV)  ->  BigVGAN (80-band mel -> 22.05 kHz wave,
-    fp32) on a synthetic mel of the length the pipeline would hand over, int(2 * n_tokens * 1.72) frames
-    (indextts/infer_v2_5.py:833).  The s2mel stage that sits between the two in the reference runs on PyTorch-ROCm and
-    is out of this path, so the mel is synthetic rather than derived from the codes.
+One "step" = one pass of the hot path over the synthetic 64-utterance batch (BASELINE.json configs[2]):
+    speaker-bundle broadcast (RCCL when N > 1)
+    -> GPT speech-token decode of this rank's utterances (prefill + 560 sampled tokens each, top-k 30 / top-p 0.8 / T 0.8 /
+       repetition penalty 10, bf16 weights + KV)
+    -> [s2mel: codes -> mel on the HIP engine when `--s2mel` (default once the stage is built); otherwise a synthetic mel of
+       the length the pipeline would hand over, int(2 * n_tokens * 1.72) frames, indextts/infer_v2_5.py:833]
+    -> BigVGAN (80-band mel -> 22.05 kHz wave, fp32) -> int16 -> waveforms gathered on rank 0.
+Scaling is STRONG by default: the 64 utterances are LPT-sharded over the N ranks (`indextts_amd.dist.shard_utterances`),
+64/N per GPU, as BASELINE.json's metric ("64-utt batch @1/2/4/8") says; `--weak` keeps 64 utterances per GPU instead.
 Inputs (text ids, conditioning vectors, mel) are resident in HBM before the timed region.  Random-init weights of the
 reference architecture (no checkpoints exist offline); EOS is suppressed so every row decodes all 560 tokens.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (torchrun launches N ranks); rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`; with N > 1 and no torchrun environment the script re-executes
+itself under `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU); rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +34,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 MFMA = f32 vector p
 PEAK_HBM_GBPS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
 SR, HOP = 22050, 256
+METRIC = "audio-seconds/sec (RTF) IndexTTS-2.5, 64-utt batch @1/2/4/8 MI355X"
 
 
 def log(*a):
@@ -55,22 +62,23 @@ def usable_cores() -> int:
                     n = min(n, max(1, q // per))
         except Exception:
             pass
-    return max(1, min(n, 64))
+    return max(1, n)
 
 
-def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel):
+def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel, threads):
     """Reference CPU path restated (oracle/), timed on this box's host cores on a bounded sample.
 
     GPT: 1 utterance, `n_text` text tokens, prefill + 120 greedy decode steps (fp32, kv-cache) on the full-size stack.
     BigVGAN: 1 utterance x 480 mel frames (fp32).  About 15-25 s of CPU work; scaled to audio-seconds/second for an
     utterance of `n_gen` tokens / `t_mel` frames (decode cost per token grows with context; the sample covers the first
-    120 of `n_gen` positions, which favours the CPU).
+    120 of `n_gen` positions, which favours the CPU).  The reference itself cannot run on the GPU box (/root/reference
+    does not travel), hence kind = "port": the oracle is the restatement pinned to it by the committed fixtures.
     """
     from oracle import bigvgan_oracle as BO
     from oracle import gpt_oracle as GO
-    cores = min(usable_cores(), max(1, torch.get_num_threads()))     # never above torch's own default
+    cores = max(1, int(threads))
     torch.set_num_threads(cores)
-    log(f"[bench] cpu_baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
+    log(f"[bench] cpu_baseline on {cores} threads (os.cpu_count()={os.cpu_count()}, usable={usable_cores()})")
     cfg = GO.GPTConfig(layers=gpt_cfg["layers"], model_dim=gpt_cfg["model_dim"], heads=gpt_cfg["heads"],
                        max_text_tokens=gpt_cfg["max_text_tokens"], max_mel_tokens=gpt_cfg["max_mel_tokens"],
                        number_text_tokens=gpt_cfg["number_text_tokens"])
@@ -102,9 +110,121 @@ def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel):
     audio_s = t_mel * HOP / SR
     cpu_time = t_prefill + n_gen * t_tok + t_mel * t_frame
     return {"value": audio_s / cpu_time, "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch fp32 CPU restatement): GPT 1 utt x {n_text} text tokens, prefill + {steps} greedy "
-                      f"decode steps; BigVGAN 1 utt x {frames} mel frames; extrapolated to {n_gen} tokens / {t_mel} frames",
+            "sample": f"oracle (torch fp32 CPU restatement of the reference path): GPT 1 utt x {n_text} text tokens, prefill + "
+                      f"{steps} greedy decode steps; BigVGAN 1 utt x {frames} mel frames; extrapolated to {n_gen} tokens / "
+                      f"{t_mel} frames (GPT + BigVGAN stages only, like the GPU line's hot path)",
             "gpt_ms_per_token": t_tok * 1e3, "gpt_prefill_ms": t_prefill * 1e3, "bigvgan_ms_per_frame": t_frame * 1e3}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no torchrun environment re-executes itself with one rank per GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int) -> int:
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] launching", " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# engines
+# ---------------------------------------------------------------------------------------------------------------------
+class HipEngine:
+    """The product path: indextts_amd host classes over libindextts_hip.so."""
+    name = "hip"
+
+    def __init__(self, args, dev, rank):
+        from indextts_amd import bigvgan, gpt, synth
+        t_load = time.perf_counter()
+        self.args, self.dev = args, dev
+        self.gcfg = dict(synth.GPT_V25)
+        self.gsd = synth.gpt_weights(self.gcfg, seed=1234, suppress_eos=True)
+        self.model = gpt.UnifiedVoice(**self.gcfg, spk_cond_mode="campplus", precision=args.precision, device=str(dev))
+        self.model.load_state_dict(self.gsd)
+        self.model.post_init_gpt2_config(kv_cache=True, half=args.precision == "bf16")
+        self.model.use_graph = not args.no_graph
+        self.bh = dict(synth.BIGVGAN_V2_22K)
+        self.bsd = synth.bigvgan_weights(self.bh, seed=1234)
+        self.voc = bigvgan.BigVGAN(self.bh, device=dev)
+        self.voc.load_state_dict(self.bsd)
+        self.voc.to(dev)
+        self.voc.set_profiling(True)
+        self.prof_acc = {}
+        self.gpt_t = {"prefill_ms": 0.0, "decode_ms": 0.0, "steps": 0}
+        self.gen_kw = dict(do_sample=True, top_p=0.8, top_k=30, temperature=0.8, num_beams=1, repetition_penalty=10.0,
+                           length_penalty=0.0)
+        if rank == 0:
+            log(f"[bench] weights synthesised + packed + uploaded in {time.perf_counter() - t_load:.1f}s")
+
+    def step(self, text, langs, mel, style, emo_vec, n_gen, record):
+        """-> int16 waveforms (b, T*256) of this rank's utterances"""
+        B = text.shape[0]
+        codes, _ = self.model.inference_speech(None, text, langs=langs, emo_vec=emo_vec, campplus_embedding=style,
+                                               max_generate_length=n_gen, **self.gen_kw)
+        assert codes.shape == (B, n_gen), codes.shape
+        chunk = self.args.bigvgan_chunk or B
+        outs = []
+        for b0 in range(0, B, chunk):
+            outs.append(self.voc(mel[b0:b0 + chunk]))
+            if record:
+                for k, v in self.voc.profile().items():
+                    a = self.prof_acc.setdefault(k, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+                    for kk in a:
+                        a[kk] += v[kk]
+        if record:
+            for k in ("prefill_ms", "decode_ms", "steps"):
+                self.gpt_t[k] += self.model.last_timing[k]
+        wav = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+        return torch.clamp(32767.0 * wav[:, 0], -32767.0, 32767.0).to(torch.int16)      # infer_v2_5.py:855, :897-898
+
+    # short untimed extras (rank 0, N = 1): the cost of the other GPT modes at the bench shape
+    def extra_modes(self, text, langs, style, emo_vec, n_tok=32):
+        from indextts_amd import gpt
+        out = {}
+        kw = dict(self.gen_kw, num_beams=3)                    # the reference default: 3-beam beam-sample
+        for _ in range(2):
+            self.model.inference_speech(None, text, langs=langs, emo_vec=emo_vec, campplus_embedding=style,
+                                        max_generate_length=n_tok, **kw)
+        t = self.model.last_timing
+        out["gpt_beam3_sample_ms_per_token"] = t["decode_ms"] / max(1, t["steps"] - 1)
+        if self.args.precision == "bf16":
+            m32 = gpt.UnifiedVoice(**self.gcfg, spk_cond_mode="campplus", precision="fp32", device=str(self.dev))
+            m32.load_state_dict(self.gsd)
+            m32.post_init_gpt2_config(kv_cache=True)
+            for _ in range(2):
+                m32.inference_speech(None, text, langs=langs, emo_vec=emo_vec, campplus_embedding=style,
+                                     max_generate_length=n_tok, **self.gen_kw)
+            t = m32.last_timing
+            out["gpt_f32_mode_ms_per_token"] = t["decode_ms"] / max(1, t["steps"] - 1)     # the ids-bit-exact parity mode
+            out["gpt_f32_mode_prefill_ms"] = t["prefill_ms"]
+            del m32
+            torch.cuda.empty_cache()
+        return out
+
+
+class StubEngine:
+    """CPU stand-in used ONLY by tests/test_bench_launcher.py (`--engine stub`, gloo): exercises this file's launcher,
+    sharding, broadcast, gather and timing protocol without a GPU.  Its output is labelled as a stub and is not a result."""
+    name = "stub"
+
+    def __init__(self, args, dev, rank):
+        self.prof_acc, self.gpt_t = {}, {"prefill_ms": 0.0, "decode_ms": 0.0, "steps": 0}
+
+    def step(self, text, langs, mel, style, emo_vec, n_gen, record):
+        b, t = text.shape[0], mel.shape[-1] * HOP
+        base = (text[:, :1].to(torch.int64) % 97).to(torch.int16)           # a value that identifies the utterance
+        return base.expand(b, t).contiguous() + int(style.double().sum() * 0)
 
 
 def main():
@@ -112,14 +232,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--utts", type=int, default=64, help="utterances per GPU (weak scaling: global batch = utts * N)")
+    ap.add_argument("--utts", type=int, default=64, help="utterances in the batch (strong scaling: sharded over the ranks; "
+                                                          "--weak: per GPU)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --utts utterances PER GPU")
     ap.add_argument("--text-tokens", type=int, default=128)
     ap.add_argument("--gen-tokens", type=int, default=560)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--bigvgan-chunk", type=int, default=0, help="utterances per BigVGAN launch group (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all usable cores)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed beam-3 / f32-mode decode measurements")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--engine", default="hip", choices=["hip", "stub"], help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     # stdout carries exactly ONE line (the JSON of rank 0): native libraries (RCCL prints a version banner on init) and any
     # stray print write to fd 1, so fd 1 is pointed at stderr for the run and the result goes to the saved descriptor.
@@ -129,166 +257,173 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus})")
+    stub = args.engine == "stub"
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     dist = None
     if world > 1 or os.environ.get("ITTS_BENCH_FORCE_DIST") == "1":      # the env switch exercises the RCCL path on one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    from indextts_amd import dist as D
 
-    from indextts_amd import bigvgan, gpt, synth
-    t_load = time.perf_counter()
-    gcfg = dict(synth.GPT_V25)
-    gsd = synth.gpt_weights(gcfg, seed=1234, suppress_eos=True)
-    model = gpt.UnifiedVoice(**gcfg, spk_cond_mode="campplus", precision=args.precision, device=str(dev))
-    model.load_state_dict(gsd)
-    model.post_init_gpt2_config(kv_cache=True, half=args.precision == "bf16")
-    model.use_graph = not args.no_graph
-    bh = dict(synth.BIGVGAN_V2_22K)
-    bsd = synth.bigvgan_weights(bh, seed=1234)
-    voc = bigvgan.BigVGAN(bh)
-    voc.load_state_dict(bsd)
-    voc.to(dev)
-    voc.set_profiling(True)
-    if rank == 0:
-        log(f"[bench] weights synthesised + packed + uploaded in {time.perf_counter() - t_load:.1f}s")
-
-    B, n_text, n_gen = args.utts, args.text_tokens, args.gen_tokens
+    eng = (StubEngine if stub else HipEngine)(args, dev, rank)
+    n_text, n_gen = args.text_tokens, args.gen_tokens
     t_mel = int(2 * n_gen * 1.72)
-    g = torch.Generator().manual_seed(100 + rank)
-    text = torch.randint(2, gcfg["number_text_tokens"], (B, n_text), generator=g).to(dev)
+    n_total = args.utts * (world if args.weak else 1)
+    # the whole synthetic batch is generated identically on every rank (seeded), then sharded: strong scaling hands each
+    # rank its LPT share of the SAME 64 utterances (all 128 text tokens long here, so the shares are equal)
+    g = torch.Generator().manual_seed(100)
+    n_text_ids, n_mels, D_model = (12000, 80, 1280) if stub else (eng.gcfg["number_text_tokens"], eng.bh["num_mels"], eng.gcfg["model_dim"])
+    text_all = torch.randint(2, n_text_ids, (n_total, n_text), generator=g)
+    mine = D.shard_utterances(n_total, rank, world, lengths=[n_text] * n_total)
+    B = len(mine)
+    text = text_all[mine].to(dev)
     langs = torch.full((B,), 3, dtype=torch.long, device=dev)
-    mel = (torch.randn(B, bh["num_mels"], t_mel, generator=g) * 2 - 4).to(dev)
+    mel = (torch.randn(B, n_mels, t_mel, generator=torch.Generator().manual_seed(200 + rank)) * 2 - 4).to(dev)
     # speaker bundle: produced by the prompt encoders on rank 0 in the real pipeline, broadcast once per batch
-    style = torch.randn(1, 192, generator=torch.Generator().manual_seed(5)).to(dev)
-    emo_vec = (torch.randn(1, gcfg["model_dim"], generator=torch.Generator().manual_seed(6)) * 0.1).to(dev)
-    gen_kw = dict(do_sample=True, top_p=0.8, top_k=30, temperature=0.8, num_beams=1, repetition_penalty=10.0,
-                  length_penalty=0.0)
-
-    prof_acc = {}
-    gpt_t = {"prefill_ms": 0.0, "decode_ms": 0.0, "steps": 0}
+    bundle0 = None
+    if rank == 0:
+        bundle0 = {"style": torch.randn(1, 192, generator=torch.Generator().manual_seed(5)).to(dev),
+                   "emo_vec": (torch.randn(1, D_model, generator=torch.Generator().manual_seed(6)) * 0.1).to(dev)}
 
     def one_step(record):
-        bundle_s, bundle_e = style, emo_vec
-        if dist is not None:
-            if rank != 0:
-                bundle_s, bundle_e = torch.empty_like(style), torch.empty_like(emo_vec)
-            dist.broadcast(bundle_s, 0)
-            dist.broadcast(bundle_e, 0)
-        codes, _ = model.inference_speech(None, text, langs=langs, emo_vec=bundle_e, campplus_embedding=bundle_s,
-                                          max_generate_length=n_gen, **gen_kw)
-        assert codes.shape == (B, n_gen), codes.shape
-        chunk = args.bigvgan_chunk or B
-        outs = []
-        for b0 in range(0, B, chunk):
-            outs.append(voc(mel[b0:b0 + chunk]))
-            if record:
-                for k, v in voc.profile().items():
-                    a = prof_acc.setdefault(k, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
-                    for kk in a:
-                        a[kk] += v[kk]
-        if record:
-            for k in ("prefill_ms", "decode_ms", "steps"):
-                gpt_t[k] += model.last_timing[k]
-        return codes, outs
+        bundle = D.broadcast_speaker_bundle(bundle0, src=0, device=dev) if dist is not None else bundle0
+        wav16 = eng.step(text, langs, mel, bundle["style"], bundle["emo_vec"], n_gen, record)
+        return D.gather_waveform_tensor(wav16, mine, n_total, dst=0) if dist is not None else wav16
 
     def barrier():
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         tw = time.perf_counter()
         one_step(False)
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if rank == 0:
             log(f"[bench] warmup step {i}: {time.perf_counter() - tw:.2f}s")
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, wavs = one_step(True)
+        wavs = one_step(True)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if rank == 0:
+        assert wavs.shape == (n_total, t_mel * HOP), wavs.shape       # every utterance of the batch arrived on rank 0
 
-    audio_per_step = world * B * (t_mel * HOP) / SR
+    audio_per_step = n_total * (t_mel * HOP) / SR
     value = audio_per_step * args.steps / elapsed
     if rank == 0:
-        conv = prof_acc.get("conv1d_mfma", dict(ms=1e-9, launches=1, flops=0.0, bytes=0.0))
-        achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
-        # HBM traffic of the same kernel: PMC counters cannot be read from inside this process, so the figure comes from
-        # the committed rocprofv3 --pmc summary of the same forward (tools/pmc_bench_traffic.sh), if it matches this shape.
-        traffic, traffic_src = None, None
-        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "conv_traffic.json")
-        if os.path.exists(tp):
-            tj = json.load(open(tp))
-            if tj.get("B") == B and tj.get("mel_frames") == t_mel:
-                traffic, traffic_src = tj["hbm_bytes_per_conv_dispatch"], "profiles/conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-        D, L, V = gcfg["model_dim"], gcfg["layers"], gcfg["number_mel_codes"]
-        esz = 2 if args.precision == "bf16" else 4
-        n_dec = max(1, gpt_t["steps"] - args.steps)                # decode steps (first token comes from prefill)
-        ms_tok = gpt_t["decode_ms"] / n_dec
-        ctx_avg = (n_text + 6) + n_gen / 2.0
-        bytes_step = (12 * D * D * L + D * V) * esz + B * 2 * L * D * ctx_avg * esz
-        s_pre = n_text + 6                                         # 3 cond + text + start/stop text + start mel
-        prefill_flops = 2.0 * (12 * D * D * L) * B * s_pre + 4.0 * L * D * s_pre * s_pre * B / 2 + 2.0 * D * V * B
-        prefill_tflops = prefill_flops / (gpt_t["prefill_ms"] / args.steps * 1e-3) / 1e12
-        stages = {
-            "gpt_prefill_ms_per_step": gpt_t["prefill_ms"] / args.steps,
-            "gpt_prefill_tflops": prefill_tflops,          # whole prefill pass (GEMMs + attention + LayerNorms) per wall time
-            "gpt_prefill_mfma_frac": prefill_tflops / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
-            "gpt_decode_ms_per_step": gpt_t["decode_ms"] / args.steps,
-            "gpt_decode_ms_per_token": ms_tok,
-            "gpt_decode_algorithmic_GBps": bytes_step / (ms_tok * 1e-3) / 1e9,
-            "gpt_decode_hbm_frac": bytes_step / (ms_tok * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-            "bigvgan_ms_per_step": sum(v["ms"] for v in prof_acc.values()) / args.steps,
-            "bigvgan_kernels": {k: dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
-                                        tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
-                                        GBps=(v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0))
-                                for k, v in prof_acc.items()},
-        }
         out = {
-            "metric": "audio-seconds/sec (RTF) IndexTTS-2.5, 64-utt batch @1/2/4/8 MI355X",
+            "metric": METRIC if not stub else "STUB ENGINE (launcher test) -- not a measurement",
             "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
+            "vs_baseline": None,
             "dtype": "bf16 (GPT weights/KV/GEMM inputs, f32 accumulate) + f32 (BigVGAN)" if args.precision == "bf16" else "f32",
             "data": "synthetic (seeded random-init weights of the IndexTTS-2.5 architecture; synthetic text ids, "
                     "conditioning vectors and mel; EOS suppressed so every row decodes all tokens)",
-            "rtf": 1.0 / value * world * B,          # wall seconds per audio second of ONE utterance stream
-            "config": {"workload": f"IndexTTS-2.5 hot path, {B} utterances/GPU x {n_text} text tokens -> {n_gen} speech "
-                                   f"tokens (top-k 30, top-p 0.8, T 0.8, rep-penalty 10, num_beams 1) + BigVGAN-v2 22 kHz "
-                                   f"on {t_mel}-frame mels (BASELINE.json configs[2] shape, {B} utterances per GPU)",
-                       "global_batch": world * B, "text_tokens": n_text, "gen_tokens": n_gen, "mel_frames": t_mel,
-                       "audio_seconds_per_utt": t_mel * HOP / SR, "parallelism": f"utterance-dp{world}",
+            "rtf": 1.0 / value * n_total,          # wall seconds per audio second of ONE utterance stream
+            "engine": eng.name,
+            "config": {"workload": f"IndexTTS-2.5 hot path (GPT speech-token decode + BigVGAN; s2mel excluded: synthetic mel), "
+                                   f"{n_total} utterances x {n_text} text tokens -> {n_gen} speech tokens (top-k 30, top-p 0.8, "
+                                   f"T 0.8, rep-penalty 10, num_beams 1) + BigVGAN-v2 22 kHz on {t_mel}-frame mels "
+                                   f"(BASELINE.json configs[2]), {B} utterances on each of {world} GPU(s)",
+                       "global_batch": n_total, "per_gpu_batch": B, "text_tokens": n_text, "gen_tokens": n_gen,
+                       "mel_frames": t_mel, "audio_seconds_per_utt": t_mel * HOP / SR, "parallelism": f"utterance-dp{world}",
                        "use_hipgraph": not args.no_graph},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (BigVGAN Conv1d implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
-                         "launches_per_step": conv["launches"] // max(1, args.steps),
-                         "avg_launch_ms": conv["ms"] / max(1, conv["launches"])},
-            "stages": stages,
         }
-        log("[bench] GPU result:", json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline", "stages")}))
-        if not args.no_cpu_baseline and world == 1:
-            t_cpu = time.perf_counter()
-            try:
-                out["cpu_baseline"] = cpu_baseline(gsd, gcfg, bsd, bh, n_text, n_gen, t_mel)
-            except Exception as e:      # never lose the GPU line because the baseline leg failed
-                out["cpu_baseline"] = {"error": repr(e)}
-            log(f"[bench] cpu_baseline leg took {time.perf_counter() - t_cpu:.1f}s")
+        if stub:       # launcher test: every utterance of the batch reached rank 0, in utterance order
+            out["stub_rows_ok"] = bool(torch.equal(wavs[:, 0].to(torch.int64), text_all[:, 0].to(torch.int64) % 97))
+        if not stub:
+            out.update(gpu_report(args, eng, B, n_text, n_gen, t_mel))
+            log("[bench] GPU result:", json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline", "stages")}))
+            if not args.no_extras and world == 1:
+                t_x = time.perf_counter()
+                try:
+                    out["stages"].update(eng.extra_modes(text, langs, bundle0["style"], bundle0["emo_vec"]))
+                except Exception as e:
+                    out["stages"]["extras_error"] = repr(e)
+                log(f"[bench] extra modes (beam-3, f32) took {time.perf_counter() - t_x:.1f}s")
+            if not args.no_cpu_baseline and world == 1:
+                t_cpu = time.perf_counter()
+                try:
+                    out["cpu_baseline"] = cpu_baseline(eng.gsd, eng.gcfg, eng.bsd, eng.bh, n_text, n_gen, t_mel,
+                                                       args.cpu_threads or usable_cores())
+                except Exception as e:      # never lose the GPU line because the baseline leg failed
+                    out["cpu_baseline"] = {"error": repr(e)}
+                log(f"[bench] cpu_baseline leg took {time.perf_counter() - t_cpu:.1f}s")
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def gpu_report(args, eng, B, n_text, n_gen, t_mel):
+    """roofline (dominant kernel) + stage split from rank 0's HIP-event records of the timed steps."""
+    prof_acc, gpt_t, gcfg = eng.prof_acc, eng.gpt_t, eng.gcfg
+    conv = prof_acc.get("conv1d_mfma", dict(ms=1e-9, launches=1, flops=0.0, bytes=0.0))
+    achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+    # HBM traffic of the same kernel: PMC counters cannot be read from inside this process, so the figure comes from
+    # the committed rocprofv3 --pmc summary of the same forward (tools/pmc_bench_traffic.sh), if it matches this shape.
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "conv_traffic.json")
+    if os.path.exists(tp):
+        tj = json.load(open(tp))
+        if tj.get("B") == B and tj.get("mel_frames") == t_mel:
+            traffic = tj["hbm_bytes_per_conv_dispatch"]
+            traffic_src = tj.get("source", "profiles/conv_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)")
+    D, L, V = gcfg["model_dim"], gcfg["layers"], gcfg["number_mel_codes"]
+    esz = 2 if args.precision == "bf16" else 4
+    n_dec = max(1, gpt_t["steps"] - args.steps)                # decode steps (first token comes from prefill)
+    ms_tok = gpt_t["decode_ms"] / n_dec
+    ctx_avg = (n_text + 6) + n_gen / 2.0
+    bytes_step = (12 * D * D * L + D * V) * esz + B * 2 * L * D * ctx_avg * esz
+    s_pre = n_text + 6                                         # 3 cond + text + start/stop text + start mel
+    prefill_flops = 2.0 * (12 * D * D * L) * B * s_pre + 4.0 * L * D * s_pre * s_pre * B / 2 + 2.0 * D * V * B
+    prefill_tflops = prefill_flops / (gpt_t["prefill_ms"] / args.steps * 1e-3) / 1e12
+    stages = {
+        "gpt_prefill_ms_per_step": gpt_t["prefill_ms"] / args.steps,
+        "gpt_prefill_tflops": prefill_tflops,          # whole prefill pass (GEMMs + attention + LayerNorms) per wall time
+        "gpt_prefill_mfma_frac": prefill_tflops / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
+        "gpt_decode_ms_per_step": gpt_t["decode_ms"] / args.steps,
+        "gpt_decode_ms_per_token": ms_tok,
+        "gpt_decode_algorithmic_GBps": bytes_step / (ms_tok * 1e-3) / 1e9,
+        "gpt_decode_hbm_frac": bytes_step / (ms_tok * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+        "bigvgan_ms_per_step": sum(v["ms"] for v in prof_acc.values()) / args.steps,
+        "bigvgan_kernels": {k: dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
+                                    tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
+                                    GBps=(v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0))
+                            for k, v in prof_acc.items()},
+    }
+    roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel (BigVGAN Conv1d implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
+                "launches_per_step": conv["launches"] // max(1, args.steps),
+                "avg_launch_ms": conv["ms"] / max(1, conv["launches"])}
+    return {"roofline": roofline, "stages": stages}
 
 
 if __name__ == "__main__":

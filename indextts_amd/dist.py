@@ -92,3 +92,40 @@ def gather_waveforms(wavs: List[torch.Tensor], indices: List[int], n_utts: int, 
         for i, w in part:
             out[i] = w
     return out
+
+
+def gather_waveform_tensor(wav: torch.Tensor, indices: Sequence[int], n_utts: int, dst: int = 0) -> Optional[torch.Tensor]:
+    """Tensor form of `gather_waveforms` for equal-length rows: every rank hands its (n_local, T) int16 block (device tensor
+    for RCCL, CPU tensor for gloo) to `dst`, which returns the (n_utts, T) batch in utterance order.  One `gather` of
+    44 KB per audio-second -- the only collective after the speaker-bundle broadcast, and like it outside the decode loop.
+    Ranks may own different numbers of rows (blocks are padded to the largest shard; shard sizes follow from
+    `shard_utterances`, so no size exchange is needed when `counts` is deterministic -- they are exchanged here once as a
+    small int tensor to keep the function self-contained)."""
+    w = world()
+    if w == 1:
+        out = torch.empty((n_utts,) + tuple(wav.shape[1:]), dtype=wav.dtype, device=wav.device)
+        out[torch.as_tensor(list(indices), dtype=torch.long, device=wav.device)] = wav
+        return out
+    dev = wav.device
+    r = rank()
+    meta = torch.full((n_utts + 1,), -1, dtype=torch.int64, device=dev)
+    meta[0] = len(indices)
+    meta[1:1 + len(indices)] = torch.as_tensor(list(indices), dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(w)]
+    dist.all_gather(metas, meta)
+    cmax = max(int(m[0]) for m in metas)
+    block = torch.zeros((cmax,) + tuple(wav.shape[1:]), dtype=wav.dtype, device=dev)
+    block[: wav.shape[0]] = wav
+    # bytes on the wire: neither RCCL nor gloo carries int16
+    wire = block.view(torch.uint8)
+    parts_b = [torch.empty_like(wire) for _ in range(w)] if r == dst else None
+    dist.gather(wire, parts_b, dst=dst)
+    if r != dst:
+        return None
+    parts = [p.view(wav.dtype) for p in parts_b]
+    out = torch.empty((n_utts,) + tuple(wav.shape[1:]), dtype=wav.dtype, device=dev)
+    for m, part in zip(metas, parts):
+        c = int(m[0])
+        if c:
+            out[m[1:1 + c].to(torch.long)] = part[:c]
+    return out

@@ -258,28 +258,49 @@ class IndexTTS2:
                     interval_silence=200, max_text_tokens_per_segment=120, duration_factor=1.0, text_normalization=True,
                     **generation_kwargs):
         """New capability (BASELINE.json configs[1,2]): many utterances of one speaker in one pass.  Every segment of
-        every utterance is a row of one GPT batch / one ragged BigVGAN batch.  Returns a list of (22050, int16 (T,1))."""
+        every utterance is a row of one GPT batch / one ragged BigVGAN batch.  Returns a list of (22050, int16 (T,1)).
+
+        Under `torch.distributed` (one process per GPU, `indextts_amd.dist`) the segment rows are LPT-sharded over the ranks
+        by text length: rank 0 runs the prompt encoders and broadcasts the speaker bundle (the one collective before the
+        decode loop), every rank decodes and vocodes its own rows, the int16 waveforms are gathered on rank 0, which returns
+        the full list; the other ranks return None per utterance."""
+        from . import dist as D
+        world, rank = D.world(), D.rank()
         if emo_audio_prompt is None:
             emo_audio_prompt, emo_alpha = spk_audio_prompt, 1.0
-        bundle = self._speaker(spk_audio_prompt)
-        emovec = self._emovec(bundle, emo_audio_prompt, emo_alpha, None, False)
+        bundle = None
+        if rank == 0:
+            bundle = dict(self._speaker(spk_audio_prompt))
+            bundle["emo_vec"] = self._emovec(bundle, emo_audio_prompt, emo_alpha, None, False)
+        if world > 1:
+            bundle = D.broadcast_speaker_bundle(bundle, src=0, device=self.device)
+        emovec = bundle["emo_vec"]
         capacity = self.gpt.n_text_pos
         seg_tokens, owner = [], []
-        for u, text in enumerate(texts):
+        for u, text in enumerate(texts):                    # tokenisation is deterministic host work: every rank does it
             segs = self.frontend.text_segments(text, lang, max_text_tokens_per_segment, text_normalization, capacity)
             seg_tokens += segs
             owner += [u] * len(segs)
         if not seg_tokens:
             return [None] * len(texts)
-        wavs = self._synthesize(seg_tokens, [self.frontend.lang_id(lang)] * len(seg_tokens), bundle, emovec,
-                                duration_factor, generation_kwargs, max_text_tokens_per_segment)
+        mine = D.shard_utterances(len(seg_tokens), rank, world, lengths=[int(t.numel()) for t in seg_tokens]) if world > 1 \
+            else list(range(len(seg_tokens)))
+        wavs = []
+        if mine:
+            wavs = self._synthesize([seg_tokens[i] for i in mine], [self.frontend.lang_id(lang)] * len(mine), bundle, emovec,
+                                    duration_factor, generation_kwargs, max_text_tokens_per_segment)
+        if world > 1:
+            wavs = D.gather_waveforms([w.type(torch.int16) for w in wavs], mine, len(seg_tokens), dst=0)
+            if rank != 0:
+                return [None] * len(texts)
+            wavs = [w.float() for w in wavs]                 # int16 -> float is exact; silence is inserted in float
         out = []
         for u in range(len(texts)):
-            mine = [w for w, o in zip(wavs, owner) if o == u]
-            if not mine:
+            seg = [w for w, o in zip(wavs, owner) if o == u]
+            if not seg:
                 out.append(None)
                 continue
-            wav = torch.cat(self.insert_interval_silence(mine, 22050, interval_silence), dim=1)
+            wav = torch.cat(self.insert_interval_silence(seg, 22050, interval_silence), dim=1)
             out.append((22050, wav.type(torch.int16).numpy().T))
         return out
 

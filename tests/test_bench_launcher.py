@@ -1,0 +1,45 @@
+"""bench.py's own multi-rank launcher on CPU: `python bench.py --gpus 2 --engine stub` re-executes itself under
+torch.distributed.run with two gloo ranks, shards the batch (strong scaling), broadcasts the speaker bundle, gathers the
+waveforms on rank 0 and prints ONE JSON line.  The engine is a labelled stub -- the point is the harness around it."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "stub", "--steps", "2", "--warmup", "1",
+                        "--gen-tokens", "8", "--text-tokens", "16"] + extra, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout            # stdout carries exactly one line
+    return json.loads(lines[0])
+
+
+def test_two_ranks_strong_scaling():
+    j = _run(["--gpus", "2", "--utts", "6"])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["engine"] == "stub"
+    assert j["config"]["global_batch"] == 6 and j["config"]["per_gpu_batch"] == 3
+    assert j["config"]["parallelism"] == "utterance-dp2"
+    assert j["stub_rows_ok"] is True
+    assert j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0
+    assert j["metric"].startswith("STUB")       # can never be mistaken for a measurement
+
+
+def test_two_ranks_weak_scaling_and_single_rank():
+    j = _run(["--gpus", "2", "--utts", "3", "--weak"])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 6 and j["stub_rows_ok"] is True
+    j1 = _run(["--gpus", "1", "--utts", "5"])
+    assert j1["n_gpus"] == 1 and j1["config"]["global_batch"] == 5 and j1["config"]["per_gpu_batch"] == 5 and j1["stub_rows_ok"] is True
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "stub", "--gpus", "4"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

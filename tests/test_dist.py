@@ -65,3 +65,77 @@ def test_two_rank_gloo_sharding_broadcast_gather():
     assert k0 == k1 == ["emo_vec", "ref_mel", "spk_cond_emb", "style"]
     assert c0 == c1
     assert g0 is True
+
+
+class _RowGPT:
+    """fake decoder whose codes depend on the row's own text only (so sharding must not change any row)"""
+    n_text_pos = 42
+
+    def __init__(self):
+        self.calls = []
+
+    def inference_speech(self, cond, text, langs, **kw):
+        self.calls.append((text.clone(), kw))
+        B = text.shape[0]
+        codes = torch.full((B, 9), 8193, dtype=torch.long)
+        for b in range(B):
+            n = 3 + int((text[b] != 1).sum()) % 5
+            codes[b, :n] = int(text[b][text[b] != 1].sum()) % 50 + torch.arange(n)      # padding-independent
+        return codes, None
+
+
+class _RowVoc:
+    total_up = 256
+
+    def __call__(self, mel, lens=None):
+        B, _, T = mel.shape
+        w = torch.zeros(B, 1, T * 256)
+        for b in range(B):
+            n = int(lens[b])
+            w[b, :, : n * 256] = 0.5 * torch.tanh(mel[b, :, :n].mean())
+        return w
+
+
+def _make_rowwise():
+    from indextts_amd.infer_v2_5 import IndexTTS2
+    from tests.pipeline_stubs import StubFrontend
+    fe = StubFrontend(64)
+    return IndexTTS2(cfg={"gpt": {"stop_mel_token": 8193}}, device="cpu", frontend=fe, gpt=_RowGPT(), bigvgan=_RowVoc()), fe
+
+
+def _pipeline_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tts, fe = _make_rowwise()
+        res = tts.infer_batch("spk.wav", ["a. bb", "ccc", "d. ee. fff", "gggg"], "en", num_beams=1)
+        speaker_calls = len([c for c in fe.calls if c[0] == "speaker"])
+        rows = tts.gpt.calls[-1][0].shape[0] if tts.gpt.calls else 0
+        q.put((rank, [None if r is None else (r[0], r[1].tobytes()) for r in res], speaker_calls, rows))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_infer_batch_shards_over_two_ranks():
+    """IndexTTS2.infer_batch under a 2-rank group: rank 0 alone runs the prompt encoders, the 7 segment rows are split over
+    the ranks, and rank 0 returns exactly what a single process returns."""
+    tts, _ = _make_rowwise()
+    want = tts.infer_batch("spk.wav", ["a. bb", "ccc", "d. ee. fff", "gggg"], "en", num_beams=1)
+    want = [(r[0], r[1].tobytes()) for r in want]
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, out0, spk0, rows0), (_, out1, spk1, rows1) = res
+    assert out0 == want
+    assert out1 == [None] * 4
+    assert spk0 == 1 and spk1 == 0                      # prompt encoders ran on rank 0 only
+    assert rows0 + rows1 == 7 and rows0 > 0 and rows1 > 0
