@@ -133,6 +133,51 @@ def gelu_new(x: torch.Tensor) -> torch.Tensor:
 
 KV = List[Tuple[torch.Tensor, torch.Tensor]]
 
+# ----------------------------------------------------------------------------
+# numerics modes
+#   "f32"  : the reference CPU path (everything fp32) -- the ids-bit-exact contract.
+#   "bf16" : the HIP engine's bf16 contract restated on the CPU: GEMM weights, every GEMM input (LayerNorm output,
+#            attention output, GELU output, final-norm output) and the K/V cache are rounded to bf16 (round-to-nearest-even,
+#            what torch .bfloat16() does); accumulation, biases, the residual stream, the query, LayerNorm statistics, the
+#            softmax and the logits stay fp32.  The reference's own bf16 mode (`.bfloat16()` + autocast,
+#            indextts/infer_v2_5.py:143-146,758) additionally keeps the residual stream, the query and every GEMM OUTPUT
+#            in bf16; tests/golden/gpt_bf16.npz holds its outputs (tools/make_golden_gpt.py bf16) and
+#            tests/test_oracle_gpt.py compares the two against the fp32 reference.
+# ----------------------------------------------------------------------------
+_NUMERICS = "f32"
+GEMM_WEIGHTS = ("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")
+
+
+class numerics:
+    """Context manager selecting the arithmetic contract of `gpt2_stack` / `lm_head` ("f32" | "bf16")."""
+
+    def __init__(self, mode: str):
+        assert mode in ("f32", "bf16"), mode
+        self.mode = mode
+
+    def __enter__(self):
+        global _NUMERICS
+        self.prev, _NUMERICS = _NUMERICS, self.mode
+        return self
+
+    def __exit__(self, *a):
+        global _NUMERICS
+        _NUMERICS = self.prev
+
+
+def rb(x: torch.Tensor) -> torch.Tensor:
+    """round to bf16 and back (identity in f32 mode)"""
+    return x.bfloat16().float() if _NUMERICS == "bf16" else x
+
+
+def bf16_weights(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """State dict with the GEMM weights (the tensors the engine stores in bf16) rounded once; everything else shared."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if k.endswith(GEMM_WEIGHTS) or k == "mel_head.weight":
+            out[k] = v.bfloat16().float()
+    return out
+
 
 def gpt2_stack(sd, cfg: GPTConfig, x: torch.Tensor, attention_mask: Optional[torch.Tensor],
                past: Optional[KV]) -> Tuple[torch.Tensor, KV]:
@@ -146,12 +191,12 @@ def gpt2_stack(sd, cfg: GPTConfig, x: torch.Tensor, attention_mask: Optional[tor
     new_kv: KV = []
     for i in range(cfg.layers):
         p = f"gpt.h.{i}."
-        h = F.layer_norm(x, (D,), sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], cfg.ln_eps)
+        h = rb(F.layer_norm(x, (D,), sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], cfg.ln_eps))
         qkv = h @ sd[p + "attn.c_attn.weight"] + sd[p + "attn.c_attn.bias"]
         q, k, v = qkv.split(D, dim=2)
         q = q.view(B, S, H, dh).transpose(1, 2)
-        k = k.view(B, S, H, dh).transpose(1, 2)
-        v = v.view(B, S, H, dh).transpose(1, 2)
+        k = rb(k.view(B, S, H, dh).transpose(1, 2))              # bf16 mode: the cache holds bf16 keys / values
+        v = rb(v.view(B, S, H, dh).transpose(1, 2))
         if past is not None:
             k = torch.cat((past[i][0], k), dim=-2)                                    # transformers_gpt2.py:325-328
             v = torch.cat((past[i][1], v), dim=-2)
@@ -163,11 +208,11 @@ def gpt2_stack(sd, cfg: GPTConfig, x: torch.Tensor, attention_mask: Optional[tor
         if add_mask is not None:
             w = w + add_mask
         w = torch.softmax(w, dim=-1)
-        a = torch.matmul(w, v).transpose(1, 2).reshape(B, S, D)
+        a = rb(torch.matmul(w, v).transpose(1, 2).reshape(B, S, D))
         a = a @ sd[p + "attn.c_proj.weight"] + sd[p + "attn.c_proj.bias"]
         x = x + a
-        h = F.layer_norm(x, (D,), sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], cfg.ln_eps)
-        h = gelu_new(h @ sd[p + "mlp.c_fc.weight"] + sd[p + "mlp.c_fc.bias"])
+        h = rb(F.layer_norm(x, (D,), sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], cfg.ln_eps))
+        h = rb(gelu_new(h @ sd[p + "mlp.c_fc.weight"] + sd[p + "mlp.c_fc.bias"]))
         h = h @ sd[p + "mlp.c_proj.weight"] + sd[p + "mlp.c_proj.bias"]
         x = x + h
     x = F.layer_norm(x, (D,), sd["gpt.ln_f.weight"], sd["gpt.ln_f.bias"], cfg.ln_eps)
@@ -176,7 +221,7 @@ def gpt2_stack(sd, cfg: GPTConfig, x: torch.Tensor, attention_mask: Optional[tor
 
 def lm_head(sd, cfg: GPTConfig, hidden: torch.Tensor) -> torch.Tensor:
     """lm_head = Sequential(final_norm, mel_head)  (model_v2.py:54)."""
-    h = F.layer_norm(hidden, (cfg.model_dim,), sd["final_norm.weight"], sd["final_norm.bias"], cfg.ln_eps)
+    h = rb(F.layer_norm(hidden, (cfg.model_dim,), sd["final_norm.weight"], sd["final_norm.bias"], cfg.ln_eps))
     return F.linear(h, sd["mel_head.weight"], sd["mel_head.bias"])
 
 

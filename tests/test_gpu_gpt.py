@@ -9,6 +9,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import gpt_oracle as G
 
@@ -299,3 +300,208 @@ def test_full_size_greedy_vs_oracle():
     margin = min(float((t[:, 0] - t[:, 1]).min()) for t in top2)
     print("min top-2 logit margin of the oracle run:", margin)
     assert np.array_equal(codes, ref), (codes, ref)
+
+
+# ================================================================================================================
+# The benchmarked mode (bf16) gated against the reference-minted bf16/fp32 fixture and, at full size, the CPU oracle.
+#   Contract of the engine's bf16 mode (oracle.gpt_oracle.numerics("bf16")): GEMM weights, GEMM inputs and the K/V cache in
+#   bf16; accumulation, residual stream, query, LayerNorm statistics, softmax and logits in fp32.
+#   Bounds (written here, calibrated with the CPU restatement of that contract; the measured values are printed):
+#     latents (final_norm output, O(1) entries): |engine - contract| <= 4e-3 ; |engine - reference fp32| <= 0.03 (6 x 256)
+#     teacher-forced logits:   6 x 256 model  <= 0.05      24 x 1280 model  <= 0.25
+#     greedy ids: identical to the fp32 ids at every step whose fp32 top-2 margin exceeds 2 x the logit bound; a row's
+#     first divergence (if any) must sit on a step with a smaller margin (reported).
+# ================================================================================================================
+BF16_LATENT_VS_CONTRACT = 4e-3
+BF16_LATENT_VS_F32_SMALL = 0.03
+BF16_LOGIT_BOUND_SMALL = 0.05
+BF16_LOGIT_BOUND_FULL = 0.25
+
+
+def _bf16_case(golden_dir):
+    z = np.load(os.path.join(golden_dir, "gpt_bf16.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]),
+                      max_mel_tokens=int(c[4]), number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))
+    sd["mel_head.bias"][cfg.stop_mel_token] += float(z["eos_bias"])
+    return z, cfg, sd
+
+
+def _rb(x):
+    return x.bfloat16().float()
+
+
+def test_bf16_latents_and_logits_vs_reference_fixture(golden_dir):
+    """Teacher-forced pass of the bf16 engine on the ids the reference's fp32 run produced: against the CPU restatement of
+    the engine's contract (tight), against the reference's fp32 latents/logits (stated bound), and next to the error the
+    reference's OWN bf16 mode (.bfloat16() + autocast) makes on the same inputs."""
+    z, cfg, sd = _bf16_case(golden_dir)
+    m = engine(cfg, sd, "bf16")
+    B = z["text"].shape[0]
+    text, tl = torch.from_numpy(z["text"]), torch.from_numpy(z["text_lens"])
+    codes, ml = torch.from_numpy(z["mel_codes"]), torch.from_numpy(z["mel_lens"])
+    conds, _ = m.conds_latent(torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"]))
+    lat = m.forward_latent(conds.repeat(B, 1, 1), text, tl, codes, ml).cpu()
+    lat32, lat_ref16 = torch.from_numpy(z["latent_f32"]), torch.from_numpy(z["latent_bf16"])
+    with torch.no_grad(), G.numerics("bf16"):
+        lat_contract = G.forward_latent(G.bf16_weights(sd), cfg, conds.cpu().repeat(B, 1, 1), text, tl, codes, ml)
+    e_contract = float((lat - lat_contract).abs().max())
+    e_f32 = float((lat - lat32).abs().max())
+    e_ref16 = float((lat_ref16 - lat32).abs().max())
+    W, b = sd["mel_head.weight"], sd["mel_head.bias"]
+    lg32 = F.linear(lat32, W, b)
+    lg = F.linear(_rb(lat), _rb(W), b)                       # the engine's head GEMM: bf16 inputs, f32 accumulate
+    lg_ref16 = F.linear(lat_ref16.bfloat16(), W.bfloat16(), b.bfloat16()).float()
+    d_eng, d_ref16 = float((lg - lg32).abs().max()), float((lg_ref16 - lg32).abs().max())
+    print(f"bf16 engine latents: vs contract {e_contract:.2e} (bound {BF16_LATENT_VS_CONTRACT}), vs reference fp32 {e_f32:.4f} "
+          f"(bound {BF16_LATENT_VS_F32_SMALL}; the reference's own bf16 mode: {e_ref16:.4f}); logits vs fp32 {d_eng:.4f} "
+          f"(bound {BF16_LOGIT_BOUND_SMALL}; reference bf16: {d_ref16:.4f})")
+    assert e_contract <= BF16_LATENT_VS_CONTRACT
+    assert e_f32 <= BF16_LATENT_VS_F32_SMALL
+    assert d_eng <= BF16_LOGIT_BOUND_SMALL
+    assert e_f32 <= 1.25 * e_ref16 and d_eng <= 1.25 * d_ref16      # no worse than the reference's own bf16 arithmetic
+
+
+def _gated_agreement(ids, ref_ids, margins, bound, what):
+    """ids/ref_ids (B, n); margins[step][row] = fp32 top-2 logit margin.  Returns the per-row first divergence (-1 = none)."""
+    firsts = []
+    for r in range(ref_ids.shape[0]):
+        n = min(ids.shape[1], ref_ids.shape[1])
+        ne = np.nonzero(ids[r, :n] != ref_ids[r, :n])[0]
+        k = int(ne[0]) if len(ne) else -1
+        firsts.append(k)
+        if k >= 0:
+            mk = float(margins[k][r])
+            print(f"{what}: row {r} first divergence at step {k}, fp32 top-2 margin there {mk:.4f} (2 x bound = {2 * bound})")
+            assert mk <= 2 * bound, f"{what}: row {r} diverged at step {k} where the fp32 margin {mk} exceeds 2 x {bound}"
+    return firsts
+
+
+@pytest.mark.parametrize("kv", [True, False])
+def test_bf16_greedy_ids_gated_by_margin(golden_dir, kv):
+    """Greedy decode in the benchmarked mode vs the ids of the reference's fp32 run (fixture): equal at every step whose
+    fp32 top-2 margin exceeds twice the logit bound; the first divergence of a row (if any) is printed with its margin.
+    The reference's own bf16 ids are in the fixture too: its first divergences are printed for comparison."""
+    z, cfg, sd = _bf16_case(golden_dir)
+    text, langs = torch.from_numpy(z["text"]), torch.from_numpy(z["langs"])
+    style, emo = torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"])
+    ref = z["codes_f32_kv" if kv else "codes_f32_nokv"]
+    trace = {}
+    with torch.no_grad():
+        oc = G.inference_speech(sd, cfg, G.conds_latent_campplus(sd, style, emo), text, langs,
+                                G.GenParams(max_generate_length=int(z["max_gen"])), kv_cache=kv, trace=trace)
+    assert np.array_equal(oc.numpy(), ref)                       # oracle fp32 == reference fp32 (pinning)
+    margins = [(lambda t: (t[:, 0] - t[:, 1]).numpy())(torch.topk(l, 2, dim=-1).values) for l in trace["logits"]]
+    m = engine(cfg, sd, "bf16")
+    m.post_init_gpt2_config(kv_cache=kv)
+    ids, _ = m.inference_speech(None, text, langs=langs, emo_vec=emo, campplus_embedding=style,
+                                max_generate_length=int(z["max_gen"]), do_sample=False, num_beams=1, repetition_penalty=10.0)
+    firsts = _gated_agreement(ids.cpu().numpy(), ref, margins, BF16_LOGIT_BOUND_SMALL, f"bf16 engine (kv_cache={kv})")
+    r16 = z["codes_bf16_kv" if kv else "codes_bf16_nokv"]
+    ref_firsts = [int(np.nonzero(r16[r] != ref[r])[0][0]) if (r16[r] != ref[r]).any() else -1 for r in range(ref.shape[0])]
+    print(f"first divergence from the fp32 ids per row: engine bf16 {firsts}, the reference's own bf16 mode {ref_firsts}")
+
+
+# ---- full size: 24 x 1280, B = 64 x 128 text tokens (BASELINE.json configs[2] on one GPU), 64 greedy steps ----------------
+@pytest.fixture(scope="module")
+def full_size():
+    cfg = G.GPTConfig(max_text_tokens=140, max_mel_tokens=200)
+    sd = G.synth_weights(cfg, seed=1234)
+    sd["mel_head.bias"][cfg.stop_mel_token] -= 1e4                # fixed-length decode
+    g = torch.Generator().manual_seed(64)
+    B, L, n = 64, 128, 64
+    text = torch.randint(2, cfg.number_text_tokens, (B, L), generator=g)
+    lens = [L] * B
+    for b, nn_ in ((3, 90), (17, 128), (40, 57), (63, 101), (8, 33), (29, 120)):     # ragged rows among full ones
+        lens[b] = nn_
+        text[b, nn_:] = 1
+    style = torch.randn(1, 192, generator=g)
+    emo = torch.randn(1, cfg.model_dim, generator=g) * 0.1
+    langs = torch.randint(0, cfg.n_langs, (B,), generator=g)
+    rows = [3, 17, 40, 63]                                        # rows the CPU oracle decodes
+    trace = {}
+    with torch.no_grad():
+        conds = G.conds_latent_campplus(sd, style, emo)
+        sub = text[rows][:, : max(lens[r] for r in rows)]
+        oc = G.inference_speech(sd, cfg, conds, sub, langs[rows], G.GenParams(max_generate_length=n), trace=trace)
+    margins = [(lambda t: (t[:, 0] - t[:, 1]).numpy())(torch.topk(l, 2, dim=-1).values) for l in trace["logits"]]
+    return dict(cfg=cfg, sd=sd, text=text, lens=lens, style=style, emo=emo, langs=langs, rows=rows, oracle_ids=oc.numpy(),
+                margins=margins, n=n, conds=conds)
+
+
+def _decode(m, fs, sel=None, n=None):
+    text, langs = fs["text"], fs["langs"]
+    if sel is not None:
+        text = text[sel][:, : max(fs["lens"][r] for r in sel)]
+        langs = langs[sel]
+    ids, _ = m.inference_speech(None, text, langs=langs, emo_vec=fs["emo"], campplus_embedding=fs["style"],
+                                max_generate_length=n or fs["n"], do_sample=False, num_beams=1, repetition_penalty=10.0)
+    return ids.cpu().numpy()
+
+
+def test_full_size_f32_batch64_ids_vs_oracle_and_row_invariance(full_size):
+    """f32 engine at the BASELINE shape: (a) ids of 4 rows of the 64-row device batch == the CPU oracle's ids for those rows
+    (64 greedy steps); (b) EVERY row of the 64-row batch equals the same row decoded in a different batch -- 8 rows alone
+    (B = 1), the other 56 in 7 groups of 8 -- the reference's tests/padding_test.py:77-99 property at full size."""
+    fs = full_size
+    m = engine(fs["cfg"], fs["sd"], "fp32")
+    full = _decode(m, fs)
+    assert full.shape == (64, fs["n"])
+    got = full[fs["rows"]]
+    if not np.array_equal(got, fs["oracle_ids"]):
+        bad = np.argwhere(got != fs["oracle_ids"])[0]
+        pytest.fail(f"row {fs['rows'][bad[0]]} step {bad[1]}: engine {got[tuple(bad)]} oracle {fs['oracle_ids'][tuple(bad)]} "
+                    f"(fp32 margin there {fs['margins'][bad[1]][bad[0]]:.2e})")
+    print("min fp32 top-2 margin over the 4 oracle rows x 64 steps:", min(float(mm.min()) for mm in fs["margins"]))
+    singles = [0, 3, 8, 17, 29, 40, 55, 63]
+    for r in singles:
+        alone = _decode(m, fs, [r])
+        assert np.array_equal(alone[0], full[r]), f"row {r} alone != row {r} in the 64-row batch"
+    rest = [r for r in range(64) if r not in singles]
+    for i in range(0, len(rest), 8):
+        grp = rest[i:i + 8]
+        part = _decode(m, fs, grp)
+        for j, r in enumerate(grp):
+            assert np.array_equal(part[j], full[r]), f"row {r} in a group of 8 != row {r} in the 64-row batch"
+
+
+def test_full_size_bf16_gated_vs_oracle(full_size):
+    """The benchmarked mode at the benchmarked size: (a) teacher-forced logits of the bf16 engine on the oracle's ids for 4
+    rows within BF16_LOGIT_BOUND_FULL of the CPU oracle's fp32 logits; (b) greedy ids of those rows equal the oracle's
+    wherever the fp32 margin exceeds twice that bound (first divergences printed); (c) agreement of all 64 rows with the
+    f32 ENGINE's ids reported (prefix lengths), and the bf16 batch is row-invariant like the f32 one."""
+    fs = full_size
+    cfg, sd, rows, n = fs["cfg"], fs["sd"], fs["rows"], fs["n"]
+    m = engine(cfg, sd, "bf16")
+    # (a) teacher-forced latents -> logits on the oracle's ids
+    tl = torch.tensor([fs["lens"][r] for r in rows])
+    sub = fs["text"][rows][:, : int(tl.max())]
+    codes = torch.from_numpy(fs["oracle_ids"])
+    ml = torch.full((len(rows),), n)
+    conds, _ = m.conds_latent(fs["style"], fs["emo"])
+    lat = m.forward_latent(conds.repeat(len(rows), 1, 1), sub, tl, codes, ml).cpu()
+    with torch.no_grad():
+        lat32 = G.forward_latent(sd, cfg, fs["conds"].repeat(len(rows), 1, 1), sub, tl, codes, ml)
+    W, b = sd["mel_head.weight"], sd["mel_head.bias"]
+    keep = torch.ones(cfg.number_mel_codes, dtype=torch.bool)
+    keep[cfg.stop_mel_token] = False                                # the suppressed EOS column carries a -1e4 bias
+    d = float((F.linear(_rb(lat), _rb(W), b) - F.linear(lat32, W, b))[..., keep].abs().max())
+    print(f"full-size bf16 engine: teacher-forced logits vs CPU fp32 oracle max|d| = {d:.4f} (bound {BF16_LOGIT_BOUND_FULL}); "
+          f"latents max|d| = {float((lat - lat32).abs().max()):.4f}")
+    assert d <= BF16_LOGIT_BOUND_FULL
+    # (b) greedy ids gated by the oracle's margins
+    full = _decode(m, fs)
+    firsts = _gated_agreement(full[rows], fs["oracle_ids"], fs["margins"], BF16_LOGIT_BOUND_FULL, "full-size bf16 engine")
+    print("full-size bf16: first divergence vs the oracle's fp32 ids (4 rows):", firsts)
+    # (c) row invariance in bf16 (a 1-row batch takes the 16-row slab kernel, the 64-row batch the 64-row one: same sums)
+    for r in (0, 17, 40):
+        alone = _decode(m, fs, [r])
+        k = int(np.cumprod(alone[0] == full[r]).sum())
+        print(f"bf16 row {r}: alone vs in-batch agreement prefix {k}/{n}")
+        assert k >= 1
+    m32 = engine(cfg, sd, "fp32")
+    ids32 = _decode(m32, fs)
+    pref = [int(np.cumprod(full[r] == ids32[r]).sum()) for r in range(64)]
+    print(f"bf16 vs f32 ENGINE ids over 64 rows x {n} steps: agreement prefix min/median/max = "
+          f"{min(pref)}/{sorted(pref)[32]}/{max(pref)}; rows fully equal: {sum(p == n for p in pref)}")

@@ -122,3 +122,39 @@ def test_v1_codes_and_latent_match_reference(golden_dir):
                                   torch.from_numpy(z["mel_codes"]), torch.from_numpy(z["code_lens"]) * 1024)
     assert np.array_equal(codes.numpy(), z["codes"])
     np.testing.assert_allclose(lat.numpy(), z["latent"], rtol=0, atol=5e-6)
+
+
+def test_bf16_contract_vs_reference_bf16_fixture(golden_dir):
+    """tests/golden/gpt_bf16.npz = the reference's own classes run in fp32 and in its bf16 mode (.bfloat16() + autocast,
+    indextts/infer_v2_5.py:143-146,758) on the same inputs.  The oracle's fp32 mode reproduces the fp32 run; its "bf16" mode
+    (the HIP engine's contract: bf16 GEMM operands and K/V, fp32 everything else) must stay at least as close to the fp32
+    reference as the reference's own bf16 arithmetic does -- latents and teacher-forced logits."""
+    import torch.nn.functional as F
+    z = np.load(os.path.join(golden_dir, "gpt_bf16.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]),
+                      max_mel_tokens=int(c[4]), number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))
+    sd["mel_head.bias"][cfg.stop_mel_token] += float(z["eos_bias"])
+    text, tl = torch.from_numpy(z["text"]), torch.from_numpy(z["text_lens"])
+    codes, ml = torch.from_numpy(z["mel_codes"]), torch.from_numpy(z["mel_lens"])
+    style, emo, langs = torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"]), torch.from_numpy(z["langs"])
+    conds = G.conds_latent_campplus(sd, style, emo)
+    B = text.shape[0]
+    lat32, lat_ref16 = torch.from_numpy(z["latent_f32"]), torch.from_numpy(z["latent_bf16"])
+    with torch.no_grad():
+        lo32 = G.forward_latent(sd, cfg, conds.repeat(B, 1, 1), text, tl, codes, ml)
+        with G.numerics("bf16"):
+            lo16 = G.forward_latent(G.bf16_weights(sd), cfg, conds.repeat(B, 1, 1), text, tl, codes, ml)
+        for kv in (True, False):
+            ids = G.inference_speech(sd, cfg, conds, text, langs, G.GenParams(max_generate_length=int(z["max_gen"])), kv_cache=kv)
+            assert np.array_equal(ids.numpy(), z["codes_f32_kv" if kv else "codes_f32_nokv"])
+    assert float((lo32 - lat32).abs().max()) < 5e-5
+    e16, eref = float((lo16 - lat32).abs().max()), float((lat_ref16 - lat32).abs().max())
+    W, b = sd["mel_head.weight"], sd["mel_head.bias"]
+    lg32 = F.linear(lat32, W, b)
+    d16 = float((F.linear(lo16.bfloat16().float(), W.bfloat16().float(), b) - lg32).abs().max())
+    dref = float((F.linear(lat_ref16.bfloat16(), W.bfloat16(), b.bfloat16()).float() - lg32).abs().max())
+    assert e16 <= 0.03 and d16 <= 0.05                            # the bounds tests/test_gpu_gpt.py holds the engine to
+    assert e16 <= eref and d16 <= dref
+    assert G._NUMERICS == "f32"                                    # the context manager restored the default

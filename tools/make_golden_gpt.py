@@ -319,6 +319,8 @@ def main():
 
     if only is None or "v1" in only:
         make_v1()
+    if only is None or "bf16" in only:
+        make_bf16()
 
 
 def make_v1():
@@ -355,6 +357,83 @@ def make_v1():
                         max_gen=np.int64(max_gen),
                         cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens, cfg.max_mel_tokens,
                                       cfg.number_text_tokens]))
+
+
+def make_bf16():
+    """The reference's OWN bf16 mode on the CPU: `self.gpt.eval().bfloat16()` (indextts/infer_v2_5.py:143-146) under
+    `torch.amp.autocast(device, dtype=torch.bfloat16)` (:758), next to its fp32 run on the same inputs: greedy ids of both,
+    and the teacher-forced latents (UnifiedVoice.forward, model_v2.py:596-646) of both on the fp32 ids.  This is what the
+    benchmarked bf16 engine mode is gated against (tests/test_gpu_gpt.py::test_bf16_*)."""
+    seed, B, L, lens, max_gen = 41, 3, 16, [16, 16, 16], 24      # no left padding: the embeddings stay bf16 as in the B=1 pipeline
+    cfg = G.GPTConfig(layers=6, model_dim=256, heads=4, max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200)
+    sd = G.synth_weights(cfg, seed=seed)
+    sd["mel_head.bias"][cfg.stop_mel_token] -= 5.0             # fixed-length decode: every row emits max_gen tokens
+    g = torch.Generator().manual_seed(seed + 100)
+    text = ragged_text(g, B, L, cfg.number_text_tokens, lens)
+    style = torch.randn(1, 192, generator=g)
+    emo_vec = torch.randn(1, cfg.model_dim, generator=g) * 0.1
+    langs = torch.randint(0, cfg.n_langs, (B,), generator=g)
+    gk = dict(do_sample=False, num_beams=1, repetition_penalty=10.0)
+    out = {}
+    # CUDA autocast runs layer_norm in fp32 (inputs and parameters cast up, fp32 result); the CPU autocast policy list lacks
+    # it and the CPU kernel rejects bf16 parameters with an fp32 input.  Give the CPU run the CUDA policy.
+    _ln = F.layer_norm
+
+    def ln_fp32(x, shape, weight=None, bias=None, eps=1e-5):
+        if x.dtype == torch.bfloat16 or (weight is not None and weight.dtype == torch.bfloat16):
+            return _ln(x.float(), shape, None if weight is None else weight.float(), None if bias is None else bias.float(), eps)
+        return _ln(x, shape, weight, bias, eps)
+
+    F.layer_norm = ln_fp32
+    try:
+        _make_bf16_body(seed, B, L, lens, max_gen, cfg, sd, text, style, emo_vec, langs, gk, out)
+    finally:
+        F.layer_norm = _ln
+
+
+def _make_bf16_body(seed, B, L, lens, max_gen, cfg, sd, text, style, emo_vec, langs, gk, out):
+    for kv in (True, False):
+        uv = build_reference(sd, cfg, kv_cache=kv)
+        with torch.no_grad():
+            c32, _ = uv.inference_speech(torch.zeros(1, 4, 2), text, langs=langs, emo_vec=emo_vec, campplus_embedding=style,
+                                         max_generate_length=max_gen, **gk)
+        uvb = build_reference(sd, cfg, kv_cache=kv).bfloat16()
+        with torch.no_grad(), torch.amp.autocast("cpu", enabled=True, dtype=torch.bfloat16):
+            # emo_vec comes out of merge_emovec under the same autocast in the pipeline (:759-765), i.e. in bf16
+            c16, _ = uvb.inference_speech(torch.zeros(1, 4, 2), text, langs=langs, emo_vec=emo_vec.bfloat16(),
+                                          campplus_embedding=style, max_generate_length=max_gen, **gk)
+        out["codes_f32_kv" if kv else "codes_f32_nokv"] = c32.numpy()
+        out["codes_bf16_kv" if kv else "codes_bf16_nokv"] = c16.numpy()
+        agree = [int((c32[b, : min(c32.shape[1], c16.shape[1])] != c16[b, : min(c32.shape[1], c16.shape[1])]).nonzero()[0])
+                 if (c32[b, : min(c32.shape[1], c16.shape[1])] != c16[b, : min(c32.shape[1], c16.shape[1])]).any() else -1
+                 for b in range(B)]
+        print(f"bf16 (kv_cache={kv}): reference fp32 ids {tuple(c32.shape)}, reference bf16 ids {tuple(c16.shape)}, "
+              f"first divergence per row {agree} (-1 = none)")
+        if kv:
+            codes, uv32, uv16 = c32, uv, uvb
+    tl = torch.tensor(lens)
+    ml = torch.full((B,), codes.shape[1])
+    conds = G.conds_latent_campplus(sd, style, emo_vec)
+    spk = F.linear(style, sd["spk_emb_proj.weight"], sd["spk_emb_proj.bias"]).unsqueeze(0).repeat(B, 1, 1)
+    with torch.no_grad():
+        lat32 = uv32.forward(spk, text.clone(), tl, codes.clone(), ml, None, emo_vec=emo_vec.repeat(B, 1), do_spk_cond=False)
+        with torch.amp.autocast("cpu", enabled=True, dtype=torch.bfloat16):
+            lat16 = uv16.forward(spk.bfloat16(), text.clone(), tl, codes.clone(), ml, None, emo_vec=emo_vec.repeat(B, 1).bfloat16(),
+                                 do_spk_cond=False)
+        lat_o32 = G.forward_latent(sd, cfg, conds.repeat(B, 1, 1), text, tl, codes, ml)
+        with G.numerics("bf16"):
+            lat_o16 = G.forward_latent(G.bf16_weights(sd), cfg, conds.repeat(B, 1, 1), text, tl, codes, ml)
+    lat16 = lat16.float()
+    e = lambda a, b: float((a - b).abs().max())
+    print(f"  latents {tuple(lat32.shape)} dtype of the reference bf16 run: {lat16.dtype}; max|d| vs reference fp32: "
+          f"reference-bf16 {e(lat16, lat32):.4f}, oracle bf16-contract {e(lat_o16, lat32):.4f}, oracle fp32 {e(lat_o32, lat32):.2e}; "
+          f"oracle-bf16 vs reference-bf16 {e(lat_o16, lat16):.4f}")
+    np.savez_compressed(os.path.join(GOLD, "gpt_bf16.npz"), text=text.numpy(), text_lens=tl.numpy(), style=style.numpy(),
+                        emo_vec=emo_vec.numpy(), langs=langs.numpy(), mel_codes=codes.numpy(), mel_lens=ml.numpy(),
+                        latent_f32=lat32.numpy().astype(np.float32), latent_bf16=lat16.numpy().astype(np.float32),
+                        seed=np.int64(seed), eos_bias=np.float64(-5.0), max_gen=np.int64(max_gen),
+                        cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens, cfg.max_mel_tokens,
+                                      cfg.number_text_tokens]), **out)
 
 
 if __name__ == "__main__":
