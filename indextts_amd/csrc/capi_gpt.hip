@@ -299,7 +299,7 @@ extern "C" size_t itts_gpt_beam_workspace_bytes(const itts_gpt* h, int n_utts, i
 }
 
 // ---- small state kernels ---------------------------------------------------------------------------------------
-__global__ void set_state_kernel(int* state, int step, int pos) { state[0] = step; state[1] = pos; }
+__global__ void set_state_kernel(int* state, int step, int pos) { state[0] = step; state[1] = pos; state[2] = 0; }
 __global__ void fill_i64_kernel(long long* p, long long v, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
@@ -411,8 +411,8 @@ static int decode_step(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, i
     if (rc) return rc;
     if ((rc = run_head(h, w, nseq, 1, 0, pending, st))) return rc;
     SampleArgs s = make_sample(h, w, gp, nseq, tokens, uniforms);
-    if ((rc = launch_sample(s, st))) return rc;
-    return launch_advance(w.state, w.state + 1, st);
+    s.adv_state = w.state;                      // the sample kernel's last block advances step / pos
+    return launch_sample(s, st);
 }
 
 extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int nseq, int S,
@@ -566,8 +566,9 @@ static int decode_step_beam(itts_gpt* h, const GptWs& w, const BeamArgs& ba, int
     if (rc) return rc;
     if ((rc = run_head(h, w, nseq, 1, 0, pending, st))) return rc;
     if ((rc = launch_beam_step(ba, st))) return rc;
-    if ((rc = launch_beam_apply(ba, st))) return rc;
-    return launch_advance(w.state, w.state + 1, st);
+    BeamArgs bb = ba;
+    bb.adv_state = w.state;                     // the apply kernel's last block advances step / pos
+    return launch_beam_apply(bb, st);
 }
 
 extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int n_utts, int num_beams,

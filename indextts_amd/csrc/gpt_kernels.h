@@ -35,6 +35,7 @@ struct GemmArgs {
     // EPI_QKV: n < D -> qbuf[m][n]; D <= n < 2D -> K cache; else V cache, at cache position *pos_ptr + (m % S)
     float* qbuf; void* kcache; void* vcache;
     const int* pos_ptr; int S, H, Tmax, D;
+    int kb_slice;                    // filled by the decode-GEMM launcher: 32-wide k-blocks per K slice
     int seq_mul;                     // EPI_QKV: cache row of sequence b is b * seq_mul (0/1 = identity); beam prefill writes only row b*nb
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);
@@ -70,6 +71,7 @@ struct SampleArgs {
     int stop_token;
     // next-step embedding: x_next[b] = mel_emb[tok] + mel_pos[step + pos_offset]
     const float* mel_emb; const float* mel_pos; float* x_next; int D; int pos_offset; int n_mel_pos;
+    int* adv_state;          // {step, pos, ticket}: when non-null the last block to finish advances step and pos (decode steps)
 };
 int launch_sample(const SampleArgs& a, hipStream_t st);
 int launch_advance(int* step_ptr, int* pos_ptr, hipStream_t st);
@@ -99,6 +101,7 @@ struct BeamArgs {
     float typical_mass;
     int stop_token;
     const float* mel_emb; const float* mel_pos; float* x_next; int D; int pos_offset; int n_mel_pos;
+    int* adv_state;               // as SampleArgs::adv_state, honoured by the apply kernel (the step's last launch)
 };
 int launch_beam_step(const BeamArgs& a, hipStream_t st);
 int launch_beam_apply(const BeamArgs& a, hipStream_t st);

@@ -637,36 +637,100 @@ static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
 //   [8 rows][128 B], 16-byte pieces XOR-permuted on the source side (bank-conflict-free fragment reads).
 //   Accumulation order per output is unchanged -> bitwise equal to the register-staged kernel.
 // ================================================================================================================
-template <int NT, int MT>
+// Epilogue of the decode GEMM, specialised per epilogue kind (a runtime switch per element compiled to a branch tree with
+// the bias and cache-position loads INSIDE it, each followed by vmcnt(0): several serial memory round trips per tile).  Here
+// the per-lane bias and the cache position are fetched at kernel entry, together with the weight stream, and the tile's
+// column-derived quantities (q / K / V selector, head, offset inside the head) are computed once per tile.
+template <int EPI>
+__device__ __forceinline__ void decode_epilogue(const GemmArgs& a, int mbase, int nbase, int lane, int z, f32x4 v, float bias, int pos) {
+    const int n = nbase + (lane & 15);
+    if (n >= a.N) return;
+    const int mrow = mbase + (lane >> 4) * 4;
+    if constexpr (EPI == EPI_PARTIAL) {
+        float* dst = a.partial + ((size_t)z * a.M + mrow) * a.N + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (mrow + r < a.M) dst[(size_t)r * a.N] = v[r];
+    } else if constexpr (EPI == EPI_STORE_F32) {
+        float* dst = a.out_f32 + (size_t)mrow * a.ldo + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (mrow + r < a.M) dst[(size_t)r * a.ldo] = v[r] + bias;
+    } else if constexpr (EPI == EPI_GELU_ACT) {
+        u16* dst = (u16*)a.out_act + (size_t)mrow * a.ldo + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (mrow + r < a.M) dst[(size_t)r * a.ldo] = f32_to_bf16(gelu_new_f(v[r] + bias));
+    } else {                                                       // EPI_QKV (the tile never straddles q | K | V: D % 16 == 0)
+        const int which = nbase / a.D;                             // wave-uniform
+        const int c = n - which * a.D;
+        if (which == 0) {
+            float* dst = a.qbuf + (size_t)mrow * a.D + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (mrow + r < a.M) dst[(size_t)r * a.D] = v[r] + bias;
+        } else {
+            u16* cache = (u16*)(which == 1 ? a.kcache : a.vcache);
+            const int sm = a.seq_mul > 1 ? a.seq_mul : 1;
+            const size_t head_off = (size_t)(c >> 6) * a.Tmax * 64 + (c & 63);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mrow + r;
+                if (m < a.M) {
+                    int b = m, si = 0;
+                    if (a.S != 1) { b = m / a.S; si = m - b * a.S; }          // uniform; decode has S == 1
+                    cache[(size_t)b * sm * a.H * a.Tmax * 64 + head_off + (size_t)(pos + si) * 64] = f32_to_bf16(v[r] + bias);
+                }
+            }
+        }
+    }
+}
+
+template <int NT, int MT, bool WNT, int EPI>     // WNT: non-temporal policy on the weight stream (each fragment is read by ONE block, once per step)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MT == 4 ? 1 : 4))) void gemm_decode64_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];     // [kp][8 row groups][1 KiB]; reused for the reduction
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nkb = a.K >> 5;
     const int z = blockIdx.z;
-    const int kb_lo = (int)((long long)z * nkb / a.nsplit);
-    const int kb_hi = (int)((long long)(z + 1) * nkb / a.nsplit);
-    const int kps = (kb_hi - kb_lo + 1) >> 1;                      // 128-byte k-pairs in the slice (<= 20)
+    // the launcher takes this kernel only when K/32 divides evenly into nsplit slices of an even number of k-blocks; the
+    // slice length comes from the host (a 64-bit division here costs ~300 scalar instructions before the first load)
+    const int nkl = a.kb_slice;                                    // k-blocks in this block's slice (<= 40, even)
+    const int kb_lo = z * nkl;
+    const int kps = nkl >> 1;                                      // 128-byte k-pairs in the slice (<= 20)
     const int ntiles = (a.N + 15) >> 4;
     const int nt0 = blockIdx.x * NT;                               // NT n-tiles (16 columns each) per block
     constexpr int RG = 2 * MT;                                     // 8-row groups of the slab (MT m-tiles of 16 rows)
     const int m0 = blockIdx.y * (16 * MT);
+    // epilogue operands, requested now: wave w finishes tiles w, w + 4, ... whose n-tile is always nt0 + (w mod NT)
+    const int j_epi = w & (NT - 1);
+    float bias_epi = 0.f;
+    int pos_epi = 0;
+    if constexpr (EPI != EPI_PARTIAL) {
+        if (a.bias) {
+            int nb = (nt0 + j_epi) * 16 + (lane & 15);
+            nb = nb < a.N ? nb : a.N - 1;
+            bias_epi = a.bias[nb];
+        }
+    }
+    if constexpr (EPI == EPI_QKV) pos_epi = *a.pos_ptr;
 
     // weight fragments of this wave's k-blocks: straight to registers, all issued now
     v4u bq[10][NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int t = (nt0 + j) < ntiles ? nt0 + j : ntiles - 1;
-        const v4u* wp = (const v4u*)a.Wp + (size_t)t * nkb * 64 + lane;
+        const v4u* wp = (const v4u*)a.Wp + ((size_t)t * nkb + kb_lo) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-            const int kbi = kb_lo + w + 4 * i;
-            const bool ok = kbi < kb_hi;
-            v4u v = wp[(size_t)(ok ? kbi : kb_lo) * 64];
+            const int kl = w + 4 * i;
+            const bool ok = kl < nkl;
+            const v4u* src = wp + (size_t)(ok ? kl : 0) * 64;
+            v4u v = WNT ? __builtin_nontemporal_load(src) : *src;
             if (!ok) v = v4u{0u, 0u, 0u, 0u};
             bq[i][j] = v;
         }
     }
-    // activation slab: chunk c = kp * 8 + rg; wave w DMAs k-pairs [5w, 5w + 5) of all 8 row groups
+    // activation slab: chunk c = kp * RG + rg; wave w DMAs k-pairs [5w, 5w + 5) of all row groups
     {
         const char* arow[RG];
 #pragma unroll
@@ -677,16 +741,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MT == 4 
             m = m < a.M ? m : a.M - 1;
             arow[rg] = (const char*)a.A + ((size_t)m * a.lda + (size_t)kb_lo * 32 + piece * 8) * 2;
         }
-        const long long kmax = ((long long)a.K - (long long)kb_lo * 32) * 2 - 128;    // last full 128-byte piece of a row
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int kp = w * 5 + j;
             if (kp < kps) {                                        // wave-uniform
-                long long koff = (long long)kp * 128;
-                koff = koff < kmax ? koff : kmax;                  // odd k-block count: the tail pair re-reads in-range bytes
 #pragma unroll
                 for (int rg = 0; rg < RG; ++rg)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(arow[rg] + koff),
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(arow[rg] + (size_t)kp * 128),
                                                      (__attribute__((address_space(3))) void*)(dsm + (kp * RG + rg) * 1024), 16, 0, 0);
             }
         }
@@ -702,21 +763,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MT == 4 
     const int row16 = lane & 15, kg = lane >> 4;
     const int a_lane = (row16 >> 3) * 1024 + (row16 & 7) * 128;
     const int sw = (row16 >> 1) & 7;
+    // Straight-line MFMA phase: the A fragments of k-block i+1 are read from LDS while k-block i feeds the MFMAs.  A k-block
+    // past the slice (small K) re-reads the last valid one -- finite data against zeroed weights -- so there is no branch
+    // per k-block (a branch keeps the compiler from hoisting the LDS reads: read, wait, 4 MFMAs, read, wait, ...).
+    auto lds_frag = [&](int i, v4u (&af)[MT]) {
+        int kl = w + 4 * i;
+        kl = kl < nkl ? kl : nkl - 1;
+        const int kp = kl >> 1, pos = (((kl & 1) << 2) + kg) ^ sw;
+        const char* base = dsm + kp * (RG * 1024) + a_lane + pos * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *(const v4u*)(base + mt * 2048);
+    };
+    v4u af_cur[MT], af_nxt[MT];
+    lds_frag(0, af_cur);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const int kl = w + 4 * i;                                  // k-block inside the slice
-        if (kb_lo + kl < kb_hi) {                                  // wave-uniform
-            const int kp = kl >> 1, pos = (((kl & 1) << 2) + kg) ^ sw;
-            const char* base = dsm + kp * (RG * 1024) + a_lane + pos * 16;
+        if (i + 1 < 10) lds_frag(i + 1, af_nxt);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const v4u af = *(const v4u*)(base + mt * 2048);
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bq[i][j]),
-                                                                         acc[mt][j], 0, 0, 0);
-            }
-        }
+            for (int j = 0; j < NT; ++j)
+                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af_cur[mt]), __builtin_bit_cast(bf16x8_t, bq[i][j]),
+                                                                     acc[mt][j], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af_cur[mt] = af_nxt[mt];
     }
     __syncthreads();                                               // every wave is done with the slab: reuse it
     f32x4* r4 = (f32x4*)dsm;
@@ -732,25 +802,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MT == 4 
             const f32x4 o = r4[((size_t)ww * (MT * NT) + tile) * 64 + lane];
             s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
         }
-        const int mt = tile / NT, j = tile - mt * NT;
-        if (nt0 + j < ntiles) gemm_epilogue<true>(a, m0 + mt * 16, (nt0 + j) * 16, lane, z, s);
+        const int mt = tile / NT;                                   // tile - mt * NT == j_epi
+        if (nt0 + j_epi < ntiles) decode_epilogue<EPI>(a, m0 + mt * 16, (nt0 + j_epi) * 16, lane, z, s, bias_epi, pos_epi);
     }
 }
 
 
 
-template <int NT, int MT>
-static int launch_gemm_decode64_nt(const GemmArgs& a, int ntiles, size_t lds, hipStream_t st) {
+template <int NT, int MT, bool WNT, int EPI>
+static int launch_gemm_decode64_e(const GemmArgs& a, int ntiles, size_t lds, hipStream_t st) {
     static int attr_state = 0;                                     // 0 unknown, 1 ok, -1 the device refuses the LDS size
     if (attr_state == 0) {
-        const hipError_t e = hipFuncSetAttribute((const void*)gemm_decode64_kernel<NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 40960 * MT);
+        const hipError_t e = hipFuncSetAttribute((const void*)gemm_decode64_kernel<NT, MT, WNT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 40960 * MT);
         attr_state = (e == hipSuccess) ? 1 : -1;
         if (e != hipSuccess) (void)hipGetLastError();
     }
     if (attr_state < 0) return -1;
-    hipLaunchKernelGGL((gemm_decode64_kernel<NT, MT>), dim3(ceil_div(ntiles, NT), ceil_div(a.M, 16 * MT), a.nsplit), dim3(256), lds, st, a);
+    GemmArgs a2 = a;
+    a2.kb_slice = (a.K / 32) / a.nsplit;                           // exact: the caller checked (K/32) % (2 * nsplit) == 0
+    hipLaunchKernelGGL((gemm_decode64_kernel<NT, MT, WNT, EPI>), dim3(ceil_div(ntiles, NT), ceil_div(a.M, 16 * MT), a.nsplit), dim3(256), lds, st, a2);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
+}
+
+template <int NT, int MT, bool WNT>
+static int launch_gemm_decode64_w(const GemmArgs& a, int ntiles, size_t lds, hipStream_t st) {
+    switch (a.epi) {
+        case EPI_STORE_F32: return launch_gemm_decode64_e<NT, MT, WNT, EPI_STORE_F32>(a, ntiles, lds, st);
+        case EPI_GELU_ACT: return launch_gemm_decode64_e<NT, MT, WNT, EPI_GELU_ACT>(a, ntiles, lds, st);
+        case EPI_PARTIAL: return launch_gemm_decode64_e<NT, MT, WNT, EPI_PARTIAL>(a, ntiles, lds, st);
+        case EPI_QKV: return launch_gemm_decode64_e<NT, MT, WNT, EPI_QKV>(a, ntiles, lds, st);
+        default: return -1;                                        // EPI_RESIDUAL is a prefill epilogue: register-path kernels
+    }
+}
+
+template <int NT, int MT>
+static int launch_gemm_decode64_nt(const GemmArgs& a, int ntiles, size_t lds, hipStream_t st) {
+    // ITTS_DECODE_WNT=0: default cache policy on the weight stream (A/B switch; outputs are identical either way)
+    static const bool wnt = [] { const char* e = getenv("ITTS_DECODE_WNT"); return !e || atoi(e) != 0; }();
+    return wnt ? launch_gemm_decode64_w<NT, MT, true>(a, ntiles, lds, st) : launch_gemm_decode64_w<NT, MT, false>(a, ntiles, lds, st);
 }
 
 // n-tiles per block: the slab is 160 KiB of LDS, i.e. ONE block per CU, so a grid above 256 blocks runs in rounds; take the
@@ -1086,6 +1176,24 @@ __device__ void typical_filter(float* sl, float* q, int V, float mass, int min_k
     __syncthreads();
 }
 
+// The step / cache-position counters advance once per token.  Every block of the step's last kernel reads them at entry, so
+// the LAST block to finish (arrival ticket) can bump them: a separate 1-thread kernel for this costs a full launch slot
+// (4.3 us in the round-1 trace).  state = {step, pos, ticket}.
+__device__ __forceinline__ void advance_when_last(int* state, int nblocks) {
+    if (!state) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int t = atomicAdd(&state[2], 1);
+        if (t == nblocks - 1) {
+            state[2] = 0;
+            state[0] += 1;
+            state[1] += 1;
+            __threadfence();
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     extern __shared__ float sl[];                    // [V] processed scores
     __shared__ unsigned hist[256];
@@ -1250,6 +1358,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         for (int d = tid; d < a.D; d += 256)
             a.x_next[(size_t)b * a.D + d] = a.mel_emb[(size_t)tok * a.D + d] + a.mel_pos[(size_t)p * a.D + d];
     }
+    advance_when_last(a.adv_state, (int)gridDim.x);
 }
 
 // The selection kernels keep the whole score row in LDS ([V] f32, twice that with typical sampling: 65.5 KB at the production
@@ -1597,6 +1706,7 @@ __global__ __launch_bounds__(256) void beam_apply_kernel(BeamArgs a) {
     const int tk = (tok >= 0 && tok < V) ? tok : 0;
     for (int d = tid; d < a.D; d += 256)
         a.x_next[(size_t)i * a.D + d] = a.mel_emb[(size_t)tk * a.D + d] + a.mel_pos[(size_t)p * a.D + d];
+    advance_when_last(a.adv_state, (int)gridDim.x);
 }
 
 int launch_beam_step(const BeamArgs& a, hipStream_t st) {
