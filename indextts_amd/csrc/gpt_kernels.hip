@@ -206,9 +206,9 @@ static int launch_ln_small_t(const LnArgs& a, hipStream_t st) {
     dim3 grid(ceil_div(a.rows, 4));
 #define LN_CASE(NE) case NE: hipLaunchKernelGGL((ln_small_kernel<NE, OUT_BF16>), grid, dim3(256), 0, st, a); break;
     switch (a.D / 64) {
-        LN_CASE(2) LN_CASE(4) LN_CASE(8) LN_CASE(12) LN_CASE(16) LN_CASE(20) LN_CASE(24) LN_CASE(32)
+        LN_CASE(2) LN_CASE(4) LN_CASE(6) LN_CASE(8) LN_CASE(10) LN_CASE(12) LN_CASE(14) LN_CASE(16) LN_CASE(20) LN_CASE(24) LN_CASE(32)
         default:
-            itts_set_error("layernorm: model_dim %d unsupported (need 64 * {2,4,8,12,16,20,24,32})", a.D);
+            itts_set_error("layernorm: model_dim %d unsupported (need 64 * {2,4,6,8,10,12,14,16,20,24,32})", a.D);
             return ITTS_ERR_ARG;
     }
 #undef LN_CASE
@@ -838,8 +838,9 @@ static int launch_gemm_decode64_w(const GemmArgs& a, int ntiles, size_t lds, hip
 
 template <int NT, int MT>
 static int launch_gemm_decode64_nt(const GemmArgs& a, int ntiles, size_t lds, hipStream_t st) {
-    // ITTS_DECODE_WNT=0: default cache policy on the weight stream (A/B switch; outputs are identical either way)
-    static const bool wnt = [] { const char* e = getenv("ITTS_DECODE_WNT"); return !e || atoi(e) != 0; }();
+    // ITTS_DECODE_WNT=1: non-temporal policy on the weight stream (A/B switch; outputs are identical either way).  Measured
+    // (profiles/r02a): no change at 64 rows (1.532 vs 1.536 ms/token), 6 % SLOWER at 8 rows (1.124 vs 1.056) -> default off.
+    static const bool wnt = [] { const char* e = getenv("ITTS_DECODE_WNT"); return e && atoi(e) != 0; }();
     return wnt ? launch_gemm_decode64_w<NT, MT, true>(a, ntiles, lds, st) : launch_gemm_decode64_w<NT, MT, false>(a, ntiles, lds, st);
 }
 

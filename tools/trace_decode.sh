@@ -30,8 +30,8 @@ f = glob.glob(os.path.join(out, "raw", "**", "*kernel_trace.csv"), recursive=Tru
 rows = list(csv.DictReader(open(f[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-# last advance_kernel marks the end of the last decode step; take the step before it
-adv = [i for i, n in enumerate(names) if n.startswith("advance_kernel")]
+# the sample kernel is the last launch of a decode step (it also advances the step counters); take the step before the last
+adv = [i for i, n in enumerate(names) if n.startswith("sample_kernel")]
 a0, a1 = adv[-3], adv[-2]
 step = rows[a0 + 1:a1 + 1]
 t0 = int(step[0]["Start_Timestamp"])
