@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 3
+#define ITTS_ABI_VERSION 4
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -217,6 +217,66 @@ int itts_gemm_forward(const void* A, const void* Wp, const float* bias, float* o
                       int prefill_tiles, int gelu, void* stream);
 int itts_layernorm_forward(const float* x, const float* gamma, const float* beta, const float* gamma2,
                            const float* beta2, float* out, int rows, int D, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * s2mel flow-matching decoder (DiT estimator + classifier-free-guidance Euler solver)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t hidden_dim, num_heads, depth;          /* DiT (head_dim must be 64)                                   */
+    int32_t in_channels;                           /* mel bands (80)                                              */
+    int32_t wavenet_hidden, wavenet_layers, wavenet_kernel, wavenet_dilation_rate;
+    int32_t precision;                             /* 0 f32 (parity), 1 bf16 GEMM operands / Q K V P, f32 accumulate */
+    float norm_eps;
+} itts_s2mel_config;
+
+typedef struct itts_s2mel itts_s2mel;
+
+/* replaces: CFM.__init__ / DiT.__init__ + load_checkpoint2 (indextts/s2mel/modules/flow_matching.py:117-135,
+ *   diffusion_transformer.py:103-184, commons.py load_checkpoint2; call site indextts/infer_v2_5.py:190-206).
+ * Tensors by reference state-dict name under `estimator.` with weight-norm folded into `.weight` (host f32): per layer
+ *   transformer.layers.{i}.attention.{wqkv,wo}.weight, feed_forward.{w1,w2,w3}.weight, {attention_norm,ffn_norm}.norm.weight,
+ *   skip_in_linear.{weight,bias} (layers past the middle); transformer.norm.norm.weight; cond_x_merge_linear.weight (its mel
+ *   columns are used); skip_linear, conv1, res_projection, final_layer.linear, conv2 {weight,bias};
+ *   wavenet.{in_layers,res_skip_layers}.{i}.conv.conv.{weight,bias}. */
+int itts_s2mel_create(const itts_s2mel_config* cfg, itts_s2mel** out);
+int itts_s2mel_device(const itts_s2mel* h);
+int itts_s2mel_load_tensor(itts_s2mel* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int itts_s2mel_finalize(itts_s2mel* h);
+void itts_s2mel_destroy(itts_s2mel* h);
+size_t itts_s2mel_workspace_bytes(const itts_s2mel* h, int n_tok, int n_seq, int t_max);
+/* floats of per-step modulation vectors the host supplies (everything that depends on the timestep only):
+ *   per layer [attention_norm (weight|bias) 2H][ffn_norm 2H], transformer.norm 2H, WaveNet cond_layer output L*2W,
+ *   final-layer (shift|scale) 2W -- AdaptiveLayerNorm.project_layer / WN.cond_layer / FinalLayer.adaLN_modulation applied
+ *   to the timestep embeddings (gpt_fast/model.py:31-37, wavenet.py:150, diffusion_transformer.py:98). */
+int itts_s2mel_mods_per_step(const itts_s2mel* h);
+
+/* Token layout of both calls: the sequences (CFG branch major: all utterances of the conditional branch, then the null
+ * branch) are packed back to back into [n_tok][channels] matrices.  Device int32 tables: tok_seq / tok_t [n_tok] (sequence and
+ * frame of a row), seq_start / seq_T / seq_len [n_seq] (first row, frames processed, valid frames = the reference's x_lens).
+ * rope [t_max][32][2] f32 (cos, sin) = precompute_freqs_cis rows (gpt_fast/model.py:336-345).
+ * const_in [n_tok][hidden] f32 = cond_x_merge_linear applied to the step-invariant columns (prompt mel, projected content,
+ * style) plus its bias (diffusion_transformer.py:205-216).
+ *
+ * replaces: DiT.forward (diffusion_transformer.py:186-257), one call: x [n_tok][in_channels] f32 -> d_out, same shape. */
+int itts_s2mel_estimator(itts_s2mel* h, const float* x, const float* const_in, const float* mods, const float* rope,
+                         const int32_t* tok_seq, const int32_t* tok_t, const int32_t* seq_start, const int32_t* seq_T,
+                         const int32_t* seq_len, int n_seq, int n_tok, int t_max, float* d_out, void* workspace,
+                         size_t workspace_bytes, void* stream);
+/* replaces: BASECFM.solve_euler (flow_matching.py:57-115; call site indextts/infer_v2_5.py:841-845).  x_state
+ * [n_tok / n_branch][in_channels] f32 in/out (noise in, mel out; prompt frames are held at 0), n_branch = 2 with
+ * classifier-free guidance (the estimator sees [cond ; null]) or 1 without; mods [n_steps][mods_per_step] device;
+ * t_span [n_steps + 1] HOST floats; prompt_len [n_seq] device. */
+int itts_s2mel_solve(itts_s2mel* h, float* x_state, const float* const_in, const float* mods, const float* rope,
+                     const int32_t* tok_seq, const int32_t* tok_t, const int32_t* seq_start, const int32_t* seq_T,
+                     const int32_t* seq_len, const int32_t* prompt_len, int n_seq, int n_tok, int t_max, int n_branch, int n_steps,
+                     const float* t_span, float cfg_rate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* unit-level (parity tests): one layer's RoPE + split + non-causal attention.  replaces: Attention.forward between wqkv and wo
+ * (gpt_fast/model.py:262-307): qkv f32 [n_tok][3 * heads * 64] -> out [n_tok][heads * 64] in the precision's activation type. */
+size_t itts_s2mel_attention_scratch_bytes(int n_tok, int n_seq, int heads, int t_max, int precision);
+int itts_s2mel_attention_forward(const float* qkv, const float* rope, const int32_t* tok_seq, const int32_t* tok_t,
+                                 const int32_t* seq_start, const int32_t* seq_T, const int32_t* seq_len, int n_seq, int n_tok,
+                                 int t_max, int heads, int precision, void* out, void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

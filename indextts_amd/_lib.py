@@ -25,13 +25,19 @@ class BigVGANConfig(C.Structure):
     ]
 
 
+class S2MelConfig(C.Structure):
+    _fields_ = [("hidden_dim", C.c_int32), ("num_heads", C.c_int32), ("depth", C.c_int32), ("in_channels", C.c_int32),
+                ("wavenet_hidden", C.c_int32), ("wavenet_layers", C.c_int32), ("wavenet_kernel", C.c_int32),
+                ("wavenet_dilation_rate", C.c_int32), ("precision", C.c_int32), ("norm_eps", C.c_float)]
+
+
 class GPTConfig(C.Structure):
     _fields_ = [("layers", C.c_int32), ("model_dim", C.c_int32), ("heads", C.c_int32), ("vocab", C.c_int32),
                 ("n_mel_pos", C.c_int32), ("precision", C.c_int32), ("start_mel_token", C.c_int32),
                 ("stop_mel_token", C.c_int32), ("ln_eps", C.c_float)]
 
 
-ABI_VERSION = 3          # include/indextts_hip.h ITTS_ABI_VERSION
+ABI_VERSION = 4          # include/indextts_hip.h ITTS_ABI_VERSION
 
 
 class GenParams(C.Structure):
@@ -84,6 +90,19 @@ SIGNATURES = {
                                          vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp, C.c_size_t, C.c_int, vp]),
     "itts_gpt_last_timing": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "itts_gpt_forward_latent": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
+    "itts_s2mel_create": (C.c_int, [C.POINTER(S2MelConfig), C.POINTER(vp)]),
+    "itts_s2mel_device": (C.c_int, [vp]),
+    "itts_s2mel_load_tensor": (C.c_int, [vp, C.c_char_p, vp, c_i64p, C.c_int]),
+    "itts_s2mel_finalize": (C.c_int, [vp]),
+    "itts_s2mel_destroy": (None, [vp]),
+    "itts_s2mel_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int]),
+    "itts_s2mel_mods_per_step": (C.c_int, [vp]),
+    "itts_s2mel_estimator": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
+    "itts_s2mel_solve": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(C.c_float), C.c_float, vp, C.c_size_t, vp]),
+    "itts_s2mel_attention_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "itts_s2mel_attention_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
+                                               C.c_size_t, vp]),
     "itts_gemm_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "itts_layernorm_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
 }

@@ -1,0 +1,461 @@
+// C-ABI entry points for the s2mel flow-matching decoder: DiT estimator + CFG Euler solver (include/indextts_hip.h).
+//
+// Reference call replaced: `self.s2mel.models['cfm'].inference(cat_condition, x_lens, ref_mel, style, None, 25,
+// inference_cfg_rate=0.7)` (indextts/infer_v2_5.py:841-845) = BASECFM.solve_euler around DiT.forward
+// (indextts/s2mel/modules/flow_matching.py:57-115, diffusion_transformer.py:186-257).
+//
+// What stays on the host side (vectors, once per call): the timestep embeddings and everything that depends on t only -- the
+// AdaLN (weight | bias) vectors of every norm, the WaveNet conditioning, the final-layer modulation -- and the step-invariant
+// part of cond_x_merge_linear (prompt, content and style columns).  They arrive as `mods` / `const_in`.
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/indextts_hip.h"
+#include "gpt_kernels.h"
+#include "s2mel_kernels.h"
+
+struct S2Layer {
+    void *w_qkv = 0, *w_o = 0, *w_13 = 0, *w_2 = 0, *w_skip_a = 0, *w_skip_b = 0;
+    float *g_attn = 0, *g_ffn = 0, *b_skip = 0;
+};
+struct S2Wn {
+    void *w_in = 0, *w_rs = 0;
+    float *b_in = 0, *b_rs = 0;
+};
+
+struct itts_s2mel {
+    itts_s2mel_config cfg;
+    int I = 0, Kx = 0;                          // SwiGLU width, padded K of the mel-channel GEMMs
+    std::map<std::string, std::pair<std::vector<float>, std::vector<int64_t>>> host;   // raw tensors until finalize
+    std::vector<S2Layer> layers;
+    std::vector<S2Wn> wn;
+    float* g_norm = 0;
+    void *w_x = 0, *w_sl_a = 0, *w_sl_b = 0, *w_c1 = 0, *w_rp = 0, *w_fl = 0, *w_c2 = 0;
+    float *b_sl = 0, *b_c1 = 0, *b_rp = 0, *b_fl = 0, *b_c2 = 0;
+    std::vector<void*> owned;
+    bool finalized = false;
+    int device = -1;
+};
+
+static int s2_upload(itts_s2mel* h, const void* host, size_t bytes, void** dst) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    h->owned.push_back(d);
+    HIP_TRY(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+    *dst = d;
+    return ITTS_OK;
+}
+
+static int s2_intermediate(int H) {             // gpt_fast/model.py:62-65
+    int n = (int)(2 * (4 * (long long)H) / 3);
+    return n % 256 == 0 ? n : n + 256 - (n % 256);
+}
+
+extern "C" int itts_s2mel_create(const itts_s2mel_config* cfg, itts_s2mel** out) {
+    if (!cfg || !out) { itts_set_error("s2mel_create: null"); return ITTS_ERR_ARG; }
+    const itts_s2mel_config& c = *cfg;
+    if (c.hidden_dim != c.num_heads * 64 || c.hidden_dim % 64 || c.depth < 1 || c.in_channels < 1 || c.in_channels % 4 || c.wavenet_hidden % 64 ||
+        c.wavenet_layers < 1 || c.wavenet_kernel < 1 || (c.wavenet_kernel & 1) == 0 || c.wavenet_dilation_rate < 1 ||
+        (c.precision != PREC_F32 && c.precision != PREC_BF16)) {
+        itts_set_error("s2mel_create: unsupported config (hidden=%d heads=%d: head_dim must be 64; wavenet=%d x %d k=%d; prec=%d)", c.hidden_dim,
+                       c.num_heads, c.wavenet_hidden, c.wavenet_layers, c.wavenet_kernel, c.precision);
+        return ITTS_ERR_ARG;
+    }
+    itts_s2mel* h = new itts_s2mel();
+    h->cfg = c;
+    h->I = s2_intermediate(c.hidden_dim);
+    h->Kx = (c.in_channels + 63) / 64 * 64;
+    h->layers.resize(c.depth);
+    h->wn.resize(c.wavenet_layers);
+    h->device = itts_current_device();
+    *out = h;
+    return ITTS_OK;
+}
+
+extern "C" int itts_s2mel_device(const itts_s2mel* h) { return h ? h->device : -1; }
+
+extern "C" void itts_s2mel_destroy(itts_s2mel* h) {
+    if (!h) return;
+    ItDevGuard dg(h->device);
+    for (void* p : h->owned) (void)hipFree(p);
+    delete h;
+}
+
+// Tensors by reference state-dict name with weight-norm folded into `.weight` (host side): see itts_s2mel_finalize for the list.
+extern "C" int itts_s2mel_load_tensor(itts_s2mel* h, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!h || !name || !data || !shape || ndim < 1 || ndim > 3) { itts_set_error("s2mel_load_tensor: bad args"); return ITTS_ERR_ARG; }
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    auto& e = h->host[name];
+    e.first.assign(data, data + n);
+    e.second.assign(shape, shape + ndim);
+    h->finalized = false;
+    return ITTS_OK;
+}
+
+namespace {
+struct Fin {
+    itts_s2mel* h;
+    std::string missing;
+    const std::vector<float>* get(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = h->host.find(name);
+        if (it == h->host.end()) { missing += name + " "; return nullptr; }
+        const auto& sh = it->second.second;
+        size_t want = 1, have = 1;
+        for (auto v : shape) want *= (size_t)v;
+        for (auto v : sh) have *= (size_t)v;
+        if (want != have) { missing += name + "(shape) "; return nullptr; }
+        return &it->second.first;
+    }
+    // pack a [K][N] row-major host matrix (K padded with zero rows to Kp) and upload
+    int pack_kn(const std::vector<float>& kn, int K, int Kp, int N, void** dst) {
+        std::vector<float> m((size_t)Kp * N, 0.f);
+        memcpy(m.data(), kn.data(), (size_t)K * N * sizeof(float));
+        std::vector<char> pk(itts_packed_gemm_bytes(Kp, N, h->cfg.precision));
+        int rc = itts_pack_gemm_weight(m.data(), Kp, N, 0, h->cfg.precision, pk.data());
+        if (rc) return rc;
+        return s2_upload(h, pk.data(), pk.size(), dst);
+    }
+    // nn.Linear weight w [N][ldw] -> columns [c0, c0 + K) as a [K][N] matrix
+    static std::vector<float> cols_kn(const std::vector<float>& w, int N, int ldw, int c0, int K) {
+        std::vector<float> kn((size_t)K * N);
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < K; ++k) kn[(size_t)k * N + n] = w[(size_t)n * ldw + c0 + k];
+        return kn;
+    }
+    int vec(const std::vector<float>* v, float** dst) { return s2_upload(h, v->data(), v->size() * sizeof(float), (void**)dst); }
+};
+}  // namespace
+
+extern "C" int itts_s2mel_finalize(itts_s2mel* h) {
+    if (!h) { itts_set_error("s2mel_finalize: null"); return ITTS_ERR_ARG; }
+    ItDevGuard dg(h->device);
+    const itts_s2mel_config& c = h->cfg;
+    const int H = c.hidden_dim, I = h->I, W = c.wavenet_hidden, C = c.in_channels, Kx = h->Kx, k = c.wavenet_kernel, L = c.wavenet_layers;
+    Fin f{h, ""};
+    int rc = ITTS_OK;
+    const std::string P = "estimator.";
+#define NEED(var, name, ...) const std::vector<float>* var = f.get(name, {__VA_ARGS__})
+    for (int i = 0; i < c.depth && rc == ITTS_OK; ++i) {
+        const std::string Lp = P + "transformer.layers." + std::to_string(i) + ".";
+        S2Layer& Ly = h->layers[i];
+        NEED(wqkv, Lp + "attention.wqkv.weight", 3 * H, H);
+        NEED(wo, Lp + "attention.wo.weight", H, H);
+        NEED(w1, Lp + "feed_forward.w1.weight", I, H);
+        NEED(w3, Lp + "feed_forward.w3.weight", I, H);
+        NEED(w2, Lp + "feed_forward.w2.weight", H, I);
+        NEED(ga, Lp + "attention_norm.norm.weight", H);
+        NEED(gf, Lp + "ffn_norm.norm.weight", H);
+        const bool skip = i > c.depth / 2;
+        const std::vector<float>* ws = skip ? f.get(Lp + "skip_in_linear.weight", {H, 2 * H}) : nullptr;
+        const std::vector<float>* bs = skip ? f.get(Lp + "skip_in_linear.bias", {H}) : nullptr;
+        if (!wqkv || !wo || !w1 || !w3 || !w2 || !ga || !gf || (skip && (!ws || !bs))) continue;
+        rc = f.pack_kn(Fin::cols_kn(*wqkv, 3 * H, H, 0, H), H, H, 3 * H, &Ly.w_qkv);
+        if (!rc) rc = f.pack_kn(Fin::cols_kn(*wo, H, H, 0, H), H, H, H, &Ly.w_o);
+        if (!rc) {                                              // [w1 ; w3] -> one GEMM of N = 2I
+            std::vector<float> w13(*w1);
+            w13.insert(w13.end(), w3->begin(), w3->end());
+            rc = f.pack_kn(Fin::cols_kn(w13, 2 * I, H, 0, H), H, H, 2 * I, &Ly.w_13);
+        }
+        if (!rc) rc = f.pack_kn(Fin::cols_kn(*w2, H, I, 0, I), I, I, H, &Ly.w_2);
+        if (!rc) rc = f.vec(ga, &Ly.g_attn);
+        if (!rc) rc = f.vec(gf, &Ly.g_ffn);
+        if (!rc && skip) {
+            rc = f.pack_kn(Fin::cols_kn(*ws, H, 2 * H, 0, H), H, H, H, &Ly.w_skip_a);
+            if (!rc) rc = f.pack_kn(Fin::cols_kn(*ws, H, 2 * H, H, H), H, H, H, &Ly.w_skip_b);
+            if (!rc) rc = f.vec(bs, &Ly.b_skip);
+        }
+    }
+    NEED(gn, P + "transformer.norm.norm.weight", H);
+    const std::vector<float>* wmerge = nullptr;                    // [H][C + C + content + style]: only its first C columns are used here
+    {
+        auto it = h->host.find(P + "cond_x_merge_linear.weight");
+        if (it == h->host.end() || it->second.second.size() != 2 || it->second.second[0] != H) f.missing += P + "cond_x_merge_linear.weight ";
+        else wmerge = &it->second.first;
+    }
+    NEED(wsl, P + "skip_linear.weight", H, H + C);
+    NEED(bsl, P + "skip_linear.bias", H);
+    NEED(wc1, P + "conv1.weight", W, H);
+    NEED(bc1, P + "conv1.bias", W);
+    NEED(wrp, P + "res_projection.weight", W, H);
+    NEED(brp, P + "res_projection.bias", W);
+    NEED(wfl, P + "final_layer.linear.weight", W, W);
+    NEED(bfl, P + "final_layer.linear.bias", W);
+    NEED(wc2, P + "conv2.weight", C, W);
+    NEED(bc2, P + "conv2.bias", C);
+    if (rc == ITTS_OK && gn && wmerge && wsl && bsl && wc1 && bc1 && wrp && brp && wfl && bfl && wc2 && bc2) {
+        const int ldm = (int)h->host[P + "cond_x_merge_linear.weight"].second.back();
+        if (ldm < C) { itts_set_error("s2mel_finalize: cond_x_merge_linear has %d input columns, fewer than the mel channels", ldm); return ITTS_ERR_ARG; }
+        rc = f.vec(gn, &h->g_norm);
+        if (!rc) rc = f.pack_kn(Fin::cols_kn(*wmerge, H, ldm, 0, C), C, Kx, H, &h->w_x);          // the x columns only
+        if (!rc) rc = f.pack_kn(Fin::cols_kn(*wsl, H, H + C, 0, H), H, H, H, &h->w_sl_a);
+        if (!rc) rc = f.pack_kn(Fin::cols_kn(*wsl, H, H + C, H, C), C, Kx, H, &h->w_sl_b);
+        if (!rc) rc = f.vec(bsl, &h->b_sl);
+        if (!rc) rc = f.pack_kn(Fin::cols_kn(*wc1, W, H, 0, H), H, H, W, &h->w_c1);
+        if (!rc) rc = f.vec(bc1, &h->b_c1);
+        if (!rc) rc = f.pack_kn(Fin::cols_kn(*wrp, W, H, 0, H), H, H, W, &h->w_rp);
+        if (!rc) rc = f.vec(brp, &h->b_rp);
+        if (!rc) rc = f.pack_kn(Fin::cols_kn(*wfl, W, W, 0, W), W, W, W, &h->w_fl);
+        if (!rc) rc = f.vec(bfl, &h->b_fl);
+        if (!rc) rc = f.pack_kn(Fin::cols_kn(*wc2, C, W, 0, W), W, W, C, &h->w_c2);
+        if (!rc) rc = f.vec(bc2, &h->b_c2);
+    }
+    for (int i = 0; i < L && rc == ITTS_OK; ++i) {
+        const std::string a = P + "wavenet.in_layers." + std::to_string(i) + ".conv.conv.", b = P + "wavenet.res_skip_layers." + std::to_string(i) + ".conv.conv.";
+        const int ro = i < L - 1 ? 2 * W : W;
+        NEED(wi, a + "weight", 2 * W, W, k);
+        NEED(bi, a + "bias", 2 * W);
+        NEED(wr, b + "weight", ro, W, 1);
+        NEED(br, b + "bias", ro);
+        if (!wi || !bi || !wr || !br) continue;
+        // conv weight [2W][W][k] -> GEMM matrix [K = k*W][N = 2W] with K index j*W + c (the im2col column order)
+        std::vector<float> kn((size_t)k * W * 2 * W);
+        for (int n = 0; n < 2 * W; ++n)
+            for (int cc = 0; cc < W; ++cc)
+                for (int j = 0; j < k; ++j) kn[((size_t)j * W + cc) * 2 * W + n] = (*wi)[((size_t)n * W + cc) * k + j];
+        rc = f.pack_kn(kn, k * W, k * W, 2 * W, &h->wn[i].w_in);
+        if (!rc) rc = f.vec(bi, &h->wn[i].b_in);
+        if (!rc) rc = f.pack_kn(Fin::cols_kn(*wr, ro, W, 0, W), W, W, ro, &h->wn[i].w_rs);
+        if (!rc) rc = f.vec(br, &h->wn[i].b_rs);
+    }
+#undef NEED
+    if (rc) return rc;
+    if (!f.missing.empty()) { itts_set_error("s2mel_finalize: missing or mis-shaped tensors: %s", f.missing.c_str()); return ITTS_ERR_STATE; }
+    h->host.clear();
+    h->finalized = true;
+    return ITTS_OK;
+}
+
+extern "C" int itts_s2mel_mods_per_step(const itts_s2mel* h) {
+    if (!h) return 0;
+    const itts_s2mel_config& c = h->cfg;
+    return c.depth * 4 * c.hidden_dim + 2 * c.hidden_dim + c.wavenet_layers * 2 * c.wavenet_hidden + 2 * c.wavenet_hidden;
+}
+
+// ---- workspace -------------------------------------------------------------------------------------------------
+static size_t s_a256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct S2Ws {
+    float *X, *X2, *BIG, *WX, *OUT, *RP, *D;
+    char *HB, *QA, *AO, *FC, *COL, *XA, *SK, *KC, *VC;
+    size_t sk_stride, total;
+};
+
+static S2Ws s2_carve(const itts_s2mel* h, char* base, int n_tok, int n_seq, int t_pad) {
+    const itts_s2mel_config& c = h->cfg;
+    const size_t N = (size_t)n_tok, H = c.hidden_dim, I = h->I, W = c.wavenet_hidden, C = c.in_channels, Kx = h->Kx;
+    const size_t esz = c.precision == PREC_BF16 ? 2 : 4;
+    const size_t big = std::max(std::max(3 * H, 2 * I), 2 * W);
+    const size_t hw = std::max(H, W), fw = std::max(I, W);
+    S2Ws w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += s_a256(bytes); return p; };
+    w.X = (float*)take(N * H * 4);
+    w.X2 = (float*)take(N * H * 4);
+    w.BIG = (float*)take(N * big * 4);
+    w.WX = (float*)take(N * W * 4);
+    w.OUT = (float*)take(N * W * 4);
+    w.RP = (float*)take(N * W * 4);
+    w.D = (float*)take(N * C * 4);
+    w.HB = take(N * hw * esz);
+    w.QA = take(N * H * esz);
+    w.AO = take(N * H * esz);
+    w.FC = take(N * fw * esz);
+    w.COL = take(N * (size_t)c.wavenet_kernel * W * esz);
+    w.XA = take(N * Kx * esz);
+    w.sk_stride = s_a256(N * H * esz);
+    w.SK = take(w.sk_stride * (size_t)(c.depth / 2));
+    const size_t kv = (size_t)n_seq * c.num_heads * t_pad * 64 * esz;
+    w.KC = take(kv);
+    w.VC = take(kv);
+    w.total = off + 256;
+    return w;
+}
+
+extern "C" size_t itts_s2mel_workspace_bytes(const itts_s2mel* h, int n_tok, int n_seq, int t_max) {
+    if (!h || n_tok <= 0 || n_seq <= 0 || t_max <= 0) return 0;
+    return s2_carve(h, nullptr, n_tok, n_seq, (t_max + 63) / 64 * 64).total;
+}
+
+// ---- one estimator call ----------------------------------------------------------------------------------------
+static int s2_gemm(const itts_s2mel* h, const void* A, int lda, const void* Wp, const float* bias, float* out, int ldo, int M, int N, int K,
+                   int epi, hipStream_t st) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.Wp = Wp; g.bias = bias; g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.epi = epi; g.out_f32 = out; g.ldo = ldo; g.D = N;
+    return launch_gemm(g, h->cfg.precision, true, st);
+}
+
+// x_src [src_rows][C] f32 (row m of the token matrix reads x_src row m % src_rows); d_out [n_tok][C]
+static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_pad, const float* x_src, int src_rows, const float* const_in,
+                        const float* mods, const float* rope, float* d_out, hipStream_t st) {
+    const itts_s2mel_config& c = h->cfg;
+    const int H = c.hidden_dim, I = h->I, W = c.wavenet_hidden, C = c.in_channels, Kx = h->Kx, N = tab.n_tok, prec = c.precision;
+    const int nh = c.num_heads;
+    int rc;
+    float *X = w.X, *X2 = w.X2;
+    // x_in = cond_x_merge_linear([x^T | prompt | cond | style]): the x columns here, the rest (+ bias) is const_in
+    if ((rc = launch_cast_pad(x_src, w.XA, N, src_rows, C, Kx, prec, st))) return rc;
+    HIP_TRY(hipMemcpyAsync(X, const_in, (size_t)N * H * 4, hipMemcpyDeviceToDevice, st));
+    if ((rc = s2_gemm(h, w.XA, Kx, h->w_x, nullptr, X, H, N, H, Kx, EPI_RESIDUAL, st))) return rc;
+    int n_skip = 0;
+    for (int i = 0; i < c.depth; ++i) {
+        const S2Layer& L = h->layers[i];
+        if (i > c.depth / 2) {                                     // U-ViT: x = skip_in_linear([x | skip])
+            if ((rc = launch_cast_pad(X, w.HB, N, N, H, H, prec, st))) return rc;
+            --n_skip;
+            if ((rc = s2_gemm(h, w.HB, H, L.w_skip_a, L.b_skip, X2, H, N, H, H, EPI_STORE_F32, st))) return rc;
+            if ((rc = s2_gemm(h, w.SK + w.sk_stride * n_skip, H, L.w_skip_b, nullptr, X2, H, N, H, H, EPI_RESIDUAL, st))) return rc;
+            float* tmp = X; X = X2; X2 = tmp;
+        }
+        if ((rc = launch_ada_rmsnorm(X, L.g_attn, mods + (size_t)i * 4 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
+        if ((rc = s2_gemm(h, w.HB, H, L.w_qkv, nullptr, w.BIG, 3 * H, N, 3 * H, H, EPI_STORE_F32, st))) return rc;
+        if ((rc = launch_rope_split(w.BIG, rope, w.QA, w.KC, w.VC, tab, nh, t_pad, prec, st))) return rc;
+        if ((rc = launch_s2mel_attention(w.QA, w.KC, w.VC, w.AO, tab, nh, t_pad, prec, st))) return rc;
+        if ((rc = s2_gemm(h, w.AO, H, L.w_o, nullptr, X, H, N, H, H, EPI_RESIDUAL, st))) return rc;
+        if ((rc = launch_ada_rmsnorm(X, L.g_ffn, mods + (size_t)i * 4 * H + 2 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
+        if ((rc = s2_gemm(h, w.HB, H, L.w_13, nullptr, w.BIG, 2 * I, N, 2 * I, H, EPI_STORE_F32, st))) return rc;
+        if ((rc = launch_swiglu(w.BIG, w.FC, N, I, prec, st))) return rc;
+        if ((rc = s2_gemm(h, w.FC, I, L.w_2, nullptr, X, H, N, H, I, EPI_RESIDUAL, st))) return rc;
+        if (i < c.depth / 2) {
+            if ((rc = launch_cast_pad(X, w.SK + w.sk_stride * n_skip, N, N, H, H, prec, st))) return rc;
+            ++n_skip;
+        }
+    }
+    const float* m_norm = mods + (size_t)c.depth * 4 * H;
+    const float* m_gc = m_norm + 2 * H;
+    const float* m_fl = m_gc + (size_t)c.wavenet_layers * 2 * W;
+    // x_res = skip_linear([transformer.norm(x) | x^T])
+    if ((rc = launch_ada_rmsnorm(X, h->g_norm, m_norm, w.HB, N, H, c.norm_eps, prec, st))) return rc;
+    if ((rc = s2_gemm(h, w.HB, H, h->w_sl_a, h->b_sl, X2, H, N, H, H, EPI_STORE_F32, st))) return rc;
+    if ((rc = s2_gemm(h, w.XA, Kx, h->w_sl_b, nullptr, X2, H, N, H, Kx, EPI_RESIDUAL, st))) return rc;
+    if ((rc = launch_cast_pad(X2, w.HB, N, N, H, H, prec, st))) return rc;
+    if ((rc = s2_gemm(h, w.HB, H, h->w_c1, h->b_c1, w.WX, W, N, W, H, EPI_STORE_F32, st))) return rc;
+    if ((rc = s2_gemm(h, w.HB, H, h->w_rp, h->b_rp, w.RP, W, N, W, H, EPI_STORE_F32, st))) return rc;
+    // WaveNet (wavenet.py:143-166)
+    int dil = 1;
+    for (int i = 0; i < c.wavenet_layers; ++i) {
+        const S2Wn& Wn = h->wn[i];
+        const int last = i == c.wavenet_layers - 1;
+        if ((rc = launch_im2col_reflect(w.WX, w.COL, tab, W, c.wavenet_kernel, dil, prec, st))) return rc;
+        if ((rc = s2_gemm(h, w.COL, c.wavenet_kernel * W, Wn.w_in, Wn.b_in, w.BIG, 2 * W, N, 2 * W, c.wavenet_kernel * W, EPI_STORE_F32, st))) return rc;
+        if ((rc = launch_wn_gate(w.BIG, m_gc + (size_t)i * 2 * W, w.FC, N, W, prec, st))) return rc;
+        const int ro = last ? W : 2 * W;
+        if ((rc = s2_gemm(h, w.FC, W, Wn.w_rs, Wn.b_rs, w.BIG, ro, N, ro, W, EPI_STORE_F32, st))) return rc;
+        if ((rc = launch_wn_update(w.BIG, w.WX, w.OUT, tab, W, i == 0, last, st))) return rc;
+        dil *= c.wavenet_dilation_rate;
+    }
+    // FinalLayer + conv2
+    if ((rc = launch_final_ln_mod(w.OUT, w.RP, m_fl, w.HB, tab, W, prec, st))) return rc;
+    if ((rc = s2_gemm(h, w.HB, W, h->w_fl, h->b_fl, w.BIG, W, N, W, W, EPI_STORE_F32, st))) return rc;
+    if ((rc = launch_cast_pad(w.BIG, w.FC, N, N, W, W, prec, st))) return rc;
+    return s2_gemm(h, w.FC, W, h->w_c2, h->b_c2, d_out, C, N, C, W, EPI_STORE_F32, st);
+}
+
+static int s2_check(const itts_s2mel* h, const void* a, const void* b, const char* who) {
+    const int da = itts_ptr_device(a), db = itts_ptr_device(b);
+    if ((da >= 0 && da != h->device) || (db >= 0 && db != h->device)) {
+        itts_set_error("%s: tensors are on device %d/%d but the model was created on device %d", who, da, db, h->device);
+        return ITTS_ERR_ARG;
+    }
+    return ITTS_OK;
+}
+
+static SeqTab s2_tab(const int32_t* tok_seq, const int32_t* tok_t, const int32_t* seq_start, const int32_t* seq_T, const int32_t* seq_len,
+                     int n_seq, int n_tok, int t_max) {
+    SeqTab t;
+    t.tok_seq = tok_seq; t.tok_t = tok_t; t.seq_start = seq_start; t.seq_T = seq_T; t.seq_len = seq_len;
+    t.n_seq = n_seq; t.n_tok = n_tok; t.t_max = t_max;
+    return t;
+}
+
+extern "C" int itts_s2mel_estimator(itts_s2mel* h, const float* x, const float* const_in, const float* mods, const float* rope,
+                                    const int32_t* tok_seq, const int32_t* tok_t, const int32_t* seq_start, const int32_t* seq_T,
+                                    const int32_t* seq_len, int n_seq, int n_tok, int t_max, float* d_out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!h || !x || !const_in || !mods || !rope || !tok_seq || !tok_t || !seq_start || !seq_T || !seq_len || !d_out || !workspace) {
+        itts_set_error("s2mel_estimator: null pointer");
+        return ITTS_ERR_ARG;
+    }
+    if (!h->finalized) { itts_set_error("s2mel_estimator: call itts_s2mel_finalize first"); return ITTS_ERR_STATE; }
+    if (n_seq <= 0 || n_tok <= 0 || t_max <= 0) { itts_set_error("s2mel_estimator: bad sizes"); return ITTS_ERR_ARG; }
+    ItDevGuard dg(h->device);
+    if (int rc = s2_check(h, x, workspace, "s2mel_estimator")) return rc;
+    const int t_pad = (t_max + 63) / 64 * 64;
+    const S2Ws w0 = s2_carve(h, nullptr, n_tok, n_seq, t_pad);
+    if (workspace_bytes < w0.total) { itts_set_error("s2mel_estimator: workspace too small (%zu < %zu)", workspace_bytes, w0.total); return ITTS_ERR_ARG; }
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const S2Ws w = s2_carve(h, base, n_tok, n_seq, t_pad);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t kv = (size_t)((char*)w.VC - (char*)w.KC);
+    HIP_TRY(hipMemsetAsync(w.KC, 0, 2 * kv, st));                 // keys / values past a sequence's end must be finite
+    const SeqTab tab = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tok, t_max);
+    return s2_estimator(h, w, tab, t_pad, x, n_tok, const_in, mods, rope, d_out, st);
+}
+
+extern "C" int itts_s2mel_solve(itts_s2mel* h, float* x_state, const float* const_in, const float* mods, const float* rope,
+                                const int32_t* tok_seq, const int32_t* tok_t, const int32_t* seq_start, const int32_t* seq_T,
+                                const int32_t* seq_len, const int32_t* prompt_len, int n_seq, int n_tok, int t_max, int n_branch,
+                                int n_steps, const float* t_span, float cfg_rate, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !x_state || !const_in || !mods || !rope || !tok_seq || !tok_t || !seq_start || !seq_T || !seq_len || !prompt_len || !t_span || !workspace) {
+        itts_set_error("s2mel_solve: null pointer");
+        return ITTS_ERR_ARG;
+    }
+    if (!h->finalized) { itts_set_error("s2mel_solve: call itts_s2mel_finalize first"); return ITTS_ERR_STATE; }
+    if (n_seq <= 0 || n_tok <= 0 || t_max <= 0 || n_steps < 1 || (n_branch != 1 && n_branch != 2) || n_tok % n_branch || n_seq % n_branch) {
+        itts_set_error("s2mel_solve: bad sizes (n_seq=%d n_tok=%d n_branch=%d n_steps=%d)", n_seq, n_tok, n_branch, n_steps);
+        return ITTS_ERR_ARG;
+    }
+    ItDevGuard dg(h->device);
+    if (int rc = s2_check(h, x_state, workspace, "s2mel_solve")) return rc;
+    const int t_pad = (t_max + 63) / 64 * 64;
+    const S2Ws w0 = s2_carve(h, nullptr, n_tok, n_seq, t_pad);
+    if (workspace_bytes < w0.total) { itts_set_error("s2mel_solve: workspace too small (%zu < %zu)", workspace_bytes, w0.total); return ITTS_ERR_ARG; }
+    char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    const S2Ws w = s2_carve(h, base, n_tok, n_seq, t_pad);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t kv = (size_t)((char*)w.VC - (char*)w.KC);
+    HIP_TRY(hipMemsetAsync(w.KC, 0, 2 * kv, st));
+    const SeqTab tab = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tok, t_max);
+    const int mps = itts_s2mel_mods_per_step(h);
+    for (int step = 0; step < n_steps; ++step) {                   // flow_matching.py:84-113
+        int rc = s2_estimator(h, w, tab, t_pad, x_state, n_tok / n_branch, const_in, mods + (size_t)step * mps, rope, w.D, st);
+        if (rc) return rc;
+        const float dt = t_span[step + 1] - t_span[step];
+        if ((rc = launch_euler_update(x_state, w.D, tab, prompt_len, h->cfg.in_channels, n_branch, dt, cfg_rate, st))) return rc;
+    }
+    return ITTS_OK;
+}
+
+// ---- unit-level entry point (parity tests): RoPE + split + non-causal attention of one layer ------------------------------
+// qkv f32 [n_tok][3H] (the fused wqkv output) -> out act dtype [n_tok][H] = softmax(rope(q) rope(k)^T / 8, keys < seq_len) v.
+// scratch: q act [n_tok][H] + K + V act [n_seq * heads * t_pad * 64] each, t_pad = t_max rounded up to 64.
+extern "C" size_t itts_s2mel_attention_scratch_bytes(int n_tok, int n_seq, int heads, int t_max, int precision) {
+    const size_t esz = precision == PREC_BF16 ? 2 : 4;
+    const size_t t_pad = (size_t)(t_max + 63) / 64 * 64;
+    return s_a256((size_t)n_tok * heads * 64 * esz) + 2 * s_a256((size_t)n_seq * heads * t_pad * 64 * esz) + 256;
+}
+
+extern "C" int itts_s2mel_attention_forward(const float* qkv, const float* rope, const int32_t* tok_seq, const int32_t* tok_t,
+                                            const int32_t* seq_start, const int32_t* seq_T, const int32_t* seq_len, int n_seq, int n_tok,
+                                            int t_max, int heads, int precision, void* out, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!qkv || !rope || !tok_seq || !tok_t || !seq_start || !seq_T || !seq_len || !out || !scratch) { itts_set_error("s2mel_attention: null pointer"); return ITTS_ERR_ARG; }
+    if (n_seq <= 0 || n_tok <= 0 || t_max <= 0 || heads <= 0 || (precision != PREC_F32 && precision != PREC_BF16)) { itts_set_error("s2mel_attention: bad sizes"); return ITTS_ERR_ARG; }
+    if (scratch_bytes < itts_s2mel_attention_scratch_bytes(n_tok, n_seq, heads, t_max, precision)) { itts_set_error("s2mel_attention: scratch too small"); return ITTS_ERR_ARG; }
+    const size_t esz = precision == PREC_BF16 ? 2 : 4;
+    const int t_pad = (t_max + 63) / 64 * 64;
+    char* base = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    char* q = base;
+    char* k = q + s_a256((size_t)n_tok * heads * 64 * esz);
+    const size_t kv = s_a256((size_t)n_seq * heads * t_pad * 64 * esz);
+    char* v = k + kv;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(k, 0, 2 * kv, st));
+    const SeqTab tab = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tok, t_max);
+    int rc = launch_rope_split(qkv, rope, q, k, v, tab, heads, t_pad, precision, st);
+    if (rc) return rc;
+    return launch_s2mel_attention(q, k, v, out, tab, heads, t_pad, precision, st);
+}

@@ -1,0 +1,540 @@
+// s2mel flow-matching decoder kernels for gfx950 (MI355X): everything of the DiT estimator that is not a plain GEMM.
+//
+// Reference arithmetic replaced (paths relative to the reference repo root):
+//   AdaptiveLayerNorm / RMSNorm            indextts/s2mel/modules/gpt_fast/model.py:20-38,322-333
+//   apply_rotary_emb + Attention.forward   indextts/s2mel/modules/gpt_fast/model.py:262-307,348-360
+//   FeedForward (SwiGLU)                   indextts/s2mel/modules/gpt_fast/model.py:311-319
+//   WN (gated dilated convs)               indextts/s2mel/modules/wavenet.py:143-166, commons.py:133-141
+//   SConv1d reflect padding                indextts/s2mel/modules/encodec.py:96-113,212-228
+//   FinalLayer (LayerNorm + modulate)      indextts/s2mel/modules/diffusion_transformer.py:85-101
+//   solve_euler CFG combine + Euler step   indextts/s2mel/modules/flow_matching.py:84-113
+//
+// The GEMMs run on the kernels of gpt_kernels.hip (bf16 MFMA 128x128 LDS-DMA tiles, or the exact-f32 MFMA path in parity
+// mode).  Tokens of all sequences (CFG branches x utterances) are packed into one [n_tok][channels] matrix, so the GEMMs see
+// no padding; attention, RoPE, the reflect-padded convs and the masks find a row's sequence through SeqTab.
+// head_dim is 64 (hidden 512 / 8 heads in the shipped configuration).
+#include "s2mel_kernels.h"
+#include "gpt_kernels.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+
+template <bool BF16>
+__device__ __forceinline__ void store_act4(void* base, size_t idx, f32x4 v) {      // 4 consecutive elements at element index idx
+    if constexpr (BF16) {
+        v2u pk{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *(v2u*)((u16*)base + idx) = pk;
+    } else {
+        *(f32x4*)((float*)base + idx) = v;
+    }
+}
+
+// ================================================================================================================
+// AdaptiveLayerNorm: out = w * (x * rsqrt(mean(x^2) + eps) * g) + b,  (w | b) = wb[0:H] | wb[H:2H]  (one vector per step:
+// the conditioning is the timestep embedding, identical for every row).  One wave per row.
+// ================================================================================================================
+template <bool BF16>
+__global__ __launch_bounds__(256) void ada_rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ wb, void* __restrict__ out, int n, int H, float eps) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + w;
+    if (m >= n) return;
+    const float* xr = x + (size_t)m * H;
+    float ss = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    ss = wave_sum(ss);
+    const float rstd = 1.0f / sqrtf(ss / (float)H + eps);
+    for (int c = lane * 4; c < H; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c), gg = *(const f32x4*)(g + c), ww = *(const f32x4*)(wb + c), bb = *(const f32x4*)(wb + H + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ww[j] * ((v[j] * rstd) * gg[j]) + bb[j];
+        store_act4<BF16>(out, (size_t)m * H + c, o);
+    }
+}
+
+int launch_ada_rmsnorm(const float* x, const float* g, const float* wb, void* out, int n_tok, int H, float eps, int prec, hipStream_t st) {
+    if (n_tok <= 0) return ITTS_OK;
+    if (H % 4) { itts_set_error("ada_rmsnorm: hidden size %d must be a multiple of 4", H); return ITTS_ERR_ARG; }
+    const dim3 grid(ceil_div(n_tok, 4));
+    if (prec == PREC_BF16) hipLaunchKernelGGL(ada_rmsnorm_kernel<true>, grid, dim3(256), 0, st, x, g, wb, out, n_tok, H, eps);
+    else hipLaunchKernelGGL(ada_rmsnorm_kernel<false>, grid, dim3(256), 0, st, x, g, wb, out, n_tok, H, eps);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// FinalLayer input and norm: v = wavenet_out * mask + res_projection; LayerNorm(v) (no affine, eps 1e-6) * (1 + scale) + shift,
+// (shift | scale) = mod[0:W] | mod[W:2W]  (diffusion_transformer.py:96-100, :248-253)
+template <bool BF16>
+__global__ __launch_bounds__(256) void final_ln_mod_kernel(const float* __restrict__ wn, const float* __restrict__ rp,
+                                                           const float* __restrict__ mod, void* __restrict__ out, SeqTab tab, int W) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + w;
+    if (m >= tab.n_tok) return;
+    const float mask = tab.tok_t[m] < tab.seq_len[tab.tok_seq[m]] ? 1.f : 0.f;
+    const float* a = wn + (size_t)m * W;
+    const float* b = rp + (size_t)m * W;
+    float s = 0.f;
+    for (int c = lane * 4; c < W; c += 256) {
+        const f32x4 va = *(const f32x4*)(a + c), vb = *(const f32x4*)(b + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += va[j] * mask + vb[j];
+    }
+    const float mean = wave_sum(s) / (float)W;
+    float q = 0.f;
+    for (int c = lane * 4; c < W; c += 256) {
+        const f32x4 va = *(const f32x4*)(a + c), vb = *(const f32x4*)(b + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = (va[j] * mask + vb[j]) - mean; q += d * d; }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + 1e-6f);
+    for (int c = lane * 4; c < W; c += 256) {
+        const f32x4 va = *(const f32x4*)(a + c), vb = *(const f32x4*)(b + c), sh = *(const f32x4*)(mod + c), sc = *(const f32x4*)(mod + W + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (((va[j] * mask + vb[j]) - mean) * rstd) * (1.0f + sc[j]) + sh[j];
+        store_act4<BF16>(out, (size_t)m * W + c, o);
+    }
+}
+
+int launch_final_ln_mod(const float* wn_out, const float* rp, const float* mod, void* out, const SeqTab& tab, int W, int prec, hipStream_t st) {
+    if (tab.n_tok <= 0) return ITTS_OK;
+    if (W % 4) { itts_set_error("final_ln: width %d must be a multiple of 4", W); return ITTS_ERR_ARG; }
+    const dim3 grid(ceil_div(tab.n_tok, 4));
+    if (prec == PREC_BF16) hipLaunchKernelGGL(final_ln_mod_kernel<true>, grid, dim3(256), 0, st, wn_out, rp, mod, out, tab, W);
+    else hipLaunchKernelGGL(final_ln_mod_kernel<false>, grid, dim3(256), 0, st, wn_out, rp, mod, out, tab, W);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// ================================================================================================================
+// f32 -> act dtype with zero padding of the K dimension; output row m reads input row m % src_rows (the CFG branches share x)
+// ================================================================================================================
+template <bool BF16>
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ in, void* __restrict__ out, int rows, int src_rows,
+                                                       int C_in, int C_out) {
+    const int c4n = C_out >> 2;
+    const size_t total = (size_t)rows * c4n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / c4n), c = (int)(i - (size_t)m * c4n) * 4;
+        const float* r = in + (size_t)(m % src_rows) * C_in;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (c + j) < C_in ? r[c + j] : 0.f;
+        store_act4<BF16>(out, (size_t)m * C_out + c, v);
+    }
+}
+
+int launch_cast_pad(const float* in, void* out, int rows, int src_rows, int C_in, int C_out, int prec, hipStream_t st) {
+    if (rows <= 0) return ITTS_OK;
+    if (C_out % 4 || C_out < C_in) { itts_set_error("cast_pad: C_out=%d must be a multiple of 4 and >= C_in=%d", C_out, C_in); return ITTS_ERR_ARG; }
+    const size_t total = (size_t)rows * (C_out >> 2);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 * 8 ? (total + 255) / 256 : 65536 * 8);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(cast_pad_kernel<true>, dim3(grid), dim3(256), 0, st, in, out, rows, src_rows, C_in, C_out);
+    else hipLaunchKernelGGL(cast_pad_kernel<false>, dim3(grid), dim3(256), 0, st, in, out, rows, src_rows, C_in, C_out);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// ================================================================================================================
+// RoPE (interleaved pairs) + split of the fused QKV output.  Block = 4 consecutive frames of one sequence.
+//   Q -> [n_tok][H] act;  K -> [seq][head][t_pad][64] act;  V -> bf16: V^T [seq][head][64][t_pad] (4 frames = one 8-byte
+//   store per channel; the flash kernel's PV product wants 8 consecutive KEYS per lane), f32: [seq][head][t_pad][64].
+// ================================================================================================================
+template <bool BF16>
+__global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict__ qkv, const float* __restrict__ rope,
+                                                         void* __restrict__ q, void* __restrict__ k, void* __restrict__ v, SeqTab tab,
+                                                         int heads, int t_pad) {
+    const int s = blockIdx.y, t0 = blockIdx.x * 4;
+    const int T = tab.seq_T[s];
+    if (t0 >= T) return;
+    const int H = heads * 64, tid = threadIdx.x;
+    const int m0 = tab.seq_start[s] + t0;
+    const int nt = (T - t0) < 4 ? (T - t0) : 4;
+    for (int tt = 0; tt < nt; ++tt) {
+        const float* row = qkv + (size_t)(m0 + tt) * 3 * H;
+        const int t = t0 + tt;
+        for (int p = tid; p < H; p += 256) {                      // p < H/2: a pair of q, else a pair of k
+            const int which = p >= (H >> 1);
+            const int pp = which ? p - (H >> 1) : p;
+            const int h = pp >> 5, i = pp & 31, c = h * 64 + 2 * i;
+            const float x0 = row[which * H + c], x1 = row[which * H + c + 1];
+            const float cs = rope[((size_t)t * 32 + i) * 2], sn = rope[((size_t)t * 32 + i) * 2 + 1];
+            const float y0 = x0 * cs - x1 * sn, y1 = x1 * cs + x0 * sn;
+            const size_t o = which ? (((size_t)(s * heads + h) * t_pad + t) * 64 + 2 * i) : ((size_t)(m0 + tt) * H + c);
+            void* dst = which ? k : q;
+            if constexpr (BF16) *(uint32_t*)((u16*)dst + o) = pack_bf16x2(y0, y1);
+            else { ((float*)dst)[o] = y0; ((float*)dst)[o + 1] = y1; }
+        }
+    }
+    for (int c = tid; c < H; c += 256) {
+        const int h = c >> 6, d = c & 63;
+        float val[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) val[tt] = tt < nt ? qkv[(size_t)(m0 + tt) * 3 * H + 2 * H + c] : 0.f;
+        if constexpr (BF16) {
+            const v2u pk{pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};      // frames past T stay 0
+            *(v2u*)((u16*)v + ((size_t)(s * heads + h) * 64 + d) * t_pad + t0) = pk;
+        } else {
+            for (int tt = 0; tt < nt; ++tt) ((float*)v)[((size_t)(s * heads + h) * t_pad + t0 + tt) * 64 + d] = val[tt];
+        }
+    }
+}
+
+int launch_rope_split(const float* qkv, const float* rope, void* q, void* k, void* v, const SeqTab& tab, int heads, int t_pad, int prec,
+                      hipStream_t st) {
+    if (tab.n_tok <= 0) return ITTS_OK;
+    if (t_pad % 64 || t_pad < tab.t_max) { itts_set_error("rope_split: t_pad=%d must be a multiple of 64 and >= %d", t_pad, tab.t_max); return ITTS_ERR_ARG; }
+    const dim3 grid(ceil_div(tab.t_max, 4), tab.n_seq);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(rope_split_kernel<true>, grid, dim3(256), 0, st, qkv, rope, q, k, v, tab, heads, t_pad);
+    else hipLaunchKernelGGL(rope_split_kernel<false>, grid, dim3(256), 0, st, qkv, rope, q, k, v, tab, heads, t_pad);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// ================================================================================================================
+// Non-causal attention, parity (f32) mode: one wave per (query, head); 16 lanes per key, 4 keys per step, online softmax.
+// ================================================================================================================
+__global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                      float* __restrict__ O, SeqTab tab, int heads, int t_pad) {
+    const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int s = tab.tok_seq[m], len = tab.seq_len[s];
+    const int H = heads * 64, sub = lane & 15, grp = lane >> 4;
+    const f32x4 q = *(const f32x4*)(Q + (size_t)m * H + h * 64 + sub * 4);
+    const float* Kb = K + ((size_t)(s * heads + h) * t_pad) * 64;
+    const float* Vb = V + ((size_t)(s * heads + h) * t_pad) * 64;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < len; t0 += 4) {
+        const int t = t0 + grp;
+        const bool ok = t < len;
+        const int tc = ok ? t : len - 1;
+        const f32x4 kf = *(const f32x4*)(Kb + (size_t)tc * 64 + sub * 4), vf = *(const f32x4*)(Vb + (size_t)tc * 64 + sub * 4);
+        float sc = (q[0] * kf[0] + q[1] * kf[1]) + (q[2] * kf[2] + q[3] * kf[3]);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sc += __shfl_xor(sc, o, 64);
+        sc *= 0.125f;
+        if (ok) {
+            const float nm = fmaxf(m_run, sc);
+            const float al = expf(m_run - nm), p = expf(sc - nm);
+            l_run = l_run * al + p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] * al + p * vf[j];
+            m_run = nm;
+        }
+    }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+        const float om = __shfl_xor(m_run, o, 64), ol = __shfl_xor(l_run, o, 64);
+        const float nm = fmaxf(m_run, om);
+        const float sa = (m_run == -INFINITY) ? 0.f : expf(m_run - nm), sb = (om == -INFINITY) ? 0.f : expf(om - nm);
+        l_run = l_run * sa + ol * sb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = acc[j] * sa + __shfl_xor(acc[j], o, 64) * sb;
+        m_run = nm;
+    }
+    if (lane < 16) {
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = l_run > 0.f ? acc[j] / l_run : 0.f;
+        *(f32x4*)(O + (size_t)m * H + h * 64 + sub * 4) = r;
+    }
+}
+
+// ================================================================================================================
+// Non-causal flash attention on v_mfma_f32_16x16x32_bf16.  Block = 64 queries of one (sequence, head): 4 waves x 16 queries.
+//   S^T = K Q^T   : A = K tile (rows = keys, k = d: 8 consecutive d per lane = row-major K), B = Q^T (lane: its query's 8 d)
+//                   -> C layout: lane (g, q) holds keys 16*kt + 4g + r, r < 4, of query q = lane & 15.
+//   softmax       : per query = per lane column; the reduction over keys is 16 in-lane values and two xor-shuffles (16, 32).
+//   O^T = V^T P^T : A = V^T tile (rows = d, k = keys), B = P^T straight from the S^T registers -- no transpose through LDS:
+//                   the contraction index is permuted identically on both operands (slot (g, j) <-> key 32*ks + 4g + j for
+//                   j < 4, 32*ks + 16 + 4g + j - 4 otherwise), so A reads two 8-byte key runs instead of one 16-byte run.
+//   K tile [64 keys][64 d] and V^T tile [64 d][64 keys] are staged in LDS (row stride 144 B: conflict-free 16-byte fragment
+//   reads); the next tile's global loads are in flight while the current one feeds the MFMAs.
+// ================================================================================================================
+#define FA_LD 72          // bf16 elements per LDS row
+
+__global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ Vt,
+                                                              u16* __restrict__ O, SeqTab tab, int heads, int t_pad, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) u16 ks[64 * FA_LD];
+    __shared__ __attribute__((aligned(16))) u16 vs[64 * FA_LD];
+    const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int T = tab.seq_T[s], len = tab.seq_len[s];
+    if (q0 >= T) return;
+    const int H = heads * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const int qi = q0 + w * 16 + c16;
+    const int qic = qi < T ? qi : T - 1;
+    const u16* qrow = Q + (size_t)(tab.seq_start[s] + qic) * H + h * 64;
+    v4u qf[2];
+    qf[0] = *(const v4u*)(qrow + g * 8);
+    qf[1] = *(const v4u*)(qrow + 32 + g * 8);
+    const u16* Kb = K + ((size_t)(s * heads + h) * t_pad) * 64;
+    const u16* Vb = Vt + ((size_t)(s * heads + h) * 64) * t_pad;
+    // staging assignment: chunk ch = tid + 256 i -> row ch >> 3, 16-byte piece ch & 7
+    const int r0 = tid >> 3, p0 = tid & 7;
+    v4u kreg[2], vreg[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = r0 + 32 * i;
+            kreg[i] = *(const v4u*)(Kb + (size_t)(k0 + r) * 64 + p0 * 8);
+            vreg[i] = *(const v4u*)(Vb + (size_t)r * t_pad + k0 + p0 * 8);
+        }
+    };
+    f32x4 o[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) o[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    fetch(0);
+    for (int k0 = 0; k0 < len; k0 += 64) {
+        __syncthreads();                                           // the previous tile's fragments are consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = r0 + 32 * i;
+            *(v4u*)(ks + r * FA_LD + p0 * 8) = kreg[i];
+            *(v4u*)(vs + r * FA_LD + p0 * 8) = vreg[i];
+        }
+        __syncthreads();
+        if (k0 + 64 < len) fetch(k0 + 64);                         // block-uniform
+        f32x4 st[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx) {
+                const v4u a = *(const v4u*)(ks + (kt * 16 + c16) * FA_LD + kx * 32 + g * 8);
+                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[kx]), st[kt], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+        const bool tail = k0 + 64 > len;                           // block-uniform: only the last tile holds masked keys
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = st[kt][r] * scale_log2e;
+                if (tail && (k0 + kt * 16 + g * 4 + r) >= len) v = -INFINITY;
+                st[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);                      // finite: key k0 < len is valid for every query
+        const float alpha = exp2f(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = exp2f(st[kt][r] - m_new);
+                st[kt][r] = p;
+                ps += p;
+            }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[mt][r] *= alpha;
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx) {
+            const v4u pb{pack_bf16x2(st[2 * kx][0], st[2 * kx][1]), pack_bf16x2(st[2 * kx][2], st[2 * kx][3]),
+                         pack_bf16x2(st[2 * kx + 1][0], st[2 * kx + 1][1]), pack_bf16x2(st[2 * kx + 1][2], st[2 * kx + 1][3])};
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const u16* vrow = vs + (mt * 16 + c16) * FA_LD + kx * 32 + g * 4;
+                const v2u lo = *(const v2u*)vrow, hi = *(const v2u*)(vrow + 16);
+                const v4u a{lo.x, lo.y, hi.x, hi.y};
+                o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, pb), o[mt], 0, 0, 0);
+            }
+        }
+    }
+    if (qi < T) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        u16* orow = O + (size_t)(tab.seq_start[s] + qi) * H + h * 64;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const v2u pk{pack_bf16x2(o[mt][0] * inv, o[mt][1] * inv), pack_bf16x2(o[mt][2] * inv, o[mt][3] * inv)};
+            *(v2u*)(orow + mt * 16 + g * 4) = pk;
+        }
+    }
+}
+
+int launch_s2mel_attention(const void* q, const void* k, const void* v, void* out, const SeqTab& tab, int heads, int t_pad, int prec,
+                           hipStream_t st) {
+    if (tab.n_tok <= 0) return ITTS_OK;
+    if (prec == PREC_BF16) {
+        const dim3 grid(ceil_div(tab.t_max, 64), heads, tab.n_seq);
+        const float scale_log2e = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64) * log2(e)
+        hipLaunchKernelGGL(flash_attn_bf16_kernel, grid, dim3(256), 0, st, (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, tab, heads, t_pad, scale_log2e);
+    } else {
+        hipLaunchKernelGGL(attn_f32_kernel, dim3(tab.n_tok, heads), dim3(64), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, tab, heads, t_pad);
+    }
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// ================================================================================================================
+// element-wise pieces
+// ================================================================================================================
+template <bool BF16>
+__global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ in, void* __restrict__ out, int n, int I) {
+    const int i4n = I >> 2;
+    const size_t total = (size_t)n * i4n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / i4n), c = (int)(i - (size_t)m * i4n) * 4;
+        const f32x4 a = *(const f32x4*)(in + (size_t)m * 2 * I + c), b = *(const f32x4*)(in + (size_t)m * 2 * I + I + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (a[j] / (1.0f + expf(-a[j]))) * b[j];
+        store_act4<BF16>(out, (size_t)m * I + c, o);
+    }
+}
+
+int launch_swiglu(const float* in, void* out, int n_tok, int I, int prec, hipStream_t st) {
+    if (n_tok <= 0) return ITTS_OK;
+    if (I % 4) { itts_set_error("swiglu: width %d must be a multiple of 4", I); return ITTS_ERR_ARG; }
+    const size_t total = (size_t)n_tok * (I >> 2);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 * 8 ? (total + 255) / 256 : 65536 * 8);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(swiglu_kernel<true>, dim3(grid), dim3(256), 0, st, in, out, n_tok, I);
+    else hipLaunchKernelGGL(swiglu_kernel<false>, dim3(grid), dim3(256), 0, st, in, out, n_tok, I);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// SConv1d reflect padding of (k-1)*d frames, left = total - total/2 (encodec.py:212-228); a sequence not longer than the pad is
+// zero-extended on the right first (pad1d, :96-113): source index outside [0, T) after reflection reads 0.
+__device__ __forceinline__ int reflect_src(int p, int Tv) {       // Tv = virtual (zero-extended) length
+    if (p < 0) p = -p;
+    if (p >= Tv) p = 2 * (Tv - 1) - p;
+    return p;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void im2col_reflect_kernel(const float* __restrict__ x, void* __restrict__ col, SeqTab tab, int W, int k,
+                                                             int dil) {
+    const int w4n = W >> 2;
+    const size_t total = (size_t)tab.n_tok * k * w4n;
+    const int pad_total = (k - 1) * dil, right = pad_total / 2, left = pad_total - right;
+    const int maxpad = left > right ? left : right;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % w4n) * 4;
+        const size_t mj = i / w4n;
+        const int j = (int)(mj % k), m = (int)(mj / k);
+        const int s = tab.tok_seq[m], t = tab.tok_t[m], T = tab.seq_T[s];
+        const int Tv = T <= maxpad ? maxpad + 1 : T;
+        const int src = reflect_src(t + j * dil - left, Tv);
+        f32x4 v{0.f, 0.f, 0.f, 0.f};
+        if (src >= 0 && src < T) v = *(const f32x4*)(x + (size_t)(tab.seq_start[s] + src) * W + c);
+        store_act4<BF16>(col, ((size_t)m * k + j) * W + c, v);
+    }
+}
+
+int launch_im2col_reflect(const float* x, void* col, const SeqTab& tab, int W, int k, int dilation, int prec, hipStream_t st) {
+    if (tab.n_tok <= 0) return ITTS_OK;
+    if (W % 4 || k < 1 || dilation < 1) { itts_set_error("im2col: bad W=%d k=%d dilation=%d", W, k, dilation); return ITTS_ERR_ARG; }
+    const size_t total = (size_t)tab.n_tok * k * (W >> 2);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 * 8 ? (total + 255) / 256 : 65536 * 8);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(im2col_reflect_kernel<true>, dim3(grid), dim3(256), 0, st, x, col, tab, W, k, dilation);
+    else hipLaunchKernelGGL(im2col_reflect_kernel<false>, dim3(grid), dim3(256), 0, st, x, col, tab, W, k, dilation);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void wn_gate_kernel(const float* __restrict__ in, const float* __restrict__ gvec, void* __restrict__ out, int n, int W) {
+    const int w4n = W >> 2;
+    const size_t total = (size_t)n * w4n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / w4n), c = (int)(i - (size_t)m * w4n) * 4;
+        const f32x4 a = *(const f32x4*)(in + (size_t)m * 2 * W + c), b = *(const f32x4*)(in + (size_t)m * 2 * W + W + c);
+        const f32x4 ga = *(const f32x4*)(gvec + c), gb = *(const f32x4*)(gvec + W + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = tanhf(a[j] + ga[j]) * (1.0f / (1.0f + expf(-(b[j] + gb[j]))));
+        store_act4<BF16>(out, (size_t)m * W + c, o);
+    }
+}
+
+int launch_wn_gate(const float* in, const float* g, void* out, int n_tok, int W, int prec, hipStream_t st) {
+    if (n_tok <= 0) return ITTS_OK;
+    const size_t total = (size_t)n_tok * (W >> 2);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 * 8 ? (total + 255) / 256 : 65536 * 8);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(wn_gate_kernel<true>, dim3(grid), dim3(256), 0, st, in, g, out, n_tok, W);
+    else hipLaunchKernelGGL(wn_gate_kernel<false>, dim3(grid), dim3(256), 0, st, in, g, out, n_tok, W);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+__global__ __launch_bounds__(256) void wn_update_kernel(const float* __restrict__ rs, float* __restrict__ x, float* __restrict__ out, SeqTab tab,
+                                                        int W, int first, int last) {
+    const int w4n = W >> 2;
+    const size_t total = (size_t)tab.n_tok * w4n;
+    const int ld = last ? W : 2 * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / w4n), c = (int)(i - (size_t)m * w4n) * 4;
+        const float* r = rs + (size_t)m * ld;
+        f32x4 sk;
+        if (!last) {
+            const float mask = tab.tok_t[m] < tab.seq_len[tab.tok_seq[m]] ? 1.f : 0.f;
+            const f32x4 res = *(const f32x4*)(r + c);
+            f32x4 xv = *(const f32x4*)(x + (size_t)m * W + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[j] = (xv[j] + res[j]) * mask;
+            *(f32x4*)(x + (size_t)m * W + c) = xv;
+            sk = *(const f32x4*)(r + W + c);
+        } else {
+            sk = *(const f32x4*)(r + c);
+        }
+        if (!first) {
+            const f32x4 ov = *(const f32x4*)(out + (size_t)m * W + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sk[j] += ov[j];
+        }
+        *(f32x4*)(out + (size_t)m * W + c) = sk;
+    }
+}
+
+int launch_wn_update(const float* rs, float* x, float* out, const SeqTab& tab, int W, int first, int last, hipStream_t st) {
+    if (tab.n_tok <= 0) return ITTS_OK;
+    const size_t total = (size_t)tab.n_tok * (W >> 2);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 * 8 ? (total + 255) / 256 : 65536 * 8);
+    hipLaunchKernelGGL(wn_update_kernel, dim3(grid), dim3(256), 0, st, rs, x, out, tab, W, first, last);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// solver state xs [n_tok / n_branch][C] (the cond branch's rows); d [n_tok][C] estimator output, null branch in the second half
+__global__ __launch_bounds__(256) void euler_update_kernel(float* __restrict__ xs, const float* __restrict__ d, SeqTab tab,
+                                                           const int* __restrict__ prompt_len, int C, int n_branch, float dt, float cfg_rate) {
+    const int n_half = tab.n_tok / n_branch;
+    const size_t total = (size_t)n_half * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / C);
+        float dphi = d[i];
+        if (n_branch == 2) dphi = (1.0f + cfg_rate) * dphi - cfg_rate * d[i + total];
+        float v = xs[i] + dt * dphi;
+        if (tab.tok_t[m] < prompt_len[tab.tok_seq[m]]) v = 0.f;
+        xs[i] = v;
+    }
+}
+
+int launch_euler_update(float* xs, const float* d, const SeqTab& tab, const int* prompt_len, int C, int n_branch, float dt, float cfg_rate,
+                        hipStream_t st) {
+    if (tab.n_tok <= 0) return ITTS_OK;
+    const size_t total = (size_t)(tab.n_tok / n_branch) * C;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 * 8 ? (total + 255) / 256 : 65536 * 8);
+    hipLaunchKernelGGL(euler_update_kernel, dim3(grid), dim3(256), 0, st, xs, d, tab, prompt_len, C, n_branch, dt, cfg_rate);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}

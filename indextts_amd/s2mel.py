@@ -1,0 +1,347 @@
+"""Host-side mirror of the reference's s2mel flow-matching decoder (`CFM` = `BASECFM` around the `DiT` estimator), backed by
+the HIP engine.
+
+Reference interface mirrored (indextts/s2mel/modules/flow_matching.py): `CFM(args)`, `.load_state_dict`, `.estimator(...)`
+(= `DiT.forward`, diffusion_transformer.py:186-257), `.inference(mu, x_lens, prompt, style, f0, n_timesteps, temperature=1.0,
+inference_cfg_rate=0.5)` (:30-55) and `.solve_euler(x, x_lens, prompt, mu, style, f0, t_span, inference_cfg_rate)` (:57-115);
+call site indextts/infer_v2_5.py:841-845.
+
+What runs where: the 25-step CFG Euler loop and the whole estimator (13 transformer layers with adaptive RMSNorm / RoPE /
+SwiGLU / U-ViT skips, non-causal attention, the WaveNet head) run inside `libindextts_hip.so` (`itts_s2mel_solve`).  Host-side
+torch computes only vectors that depend on the timestep alone (timestep embeddings -> AdaLN / WaveNet-conditioning /
+final-layer modulation vectors, one small matrix-vector product each per step) and, once per call, the step-invariant part of
+`cond_x_merge_linear` through the engine's own GEMM entry point.
+
+New capability (the reference runs this stage at batch 1, infer_v2_5.py:201): any number of utterances in one call, each with
+its own length and prompt length; rows are packed, so there is no padding work.  `frame_lens` selects how many frames of a row
+are processed (default: the tensor width for every row -- the reference's semantics, where frames past `x_lens` are still
+computed and the WaveNet's reflect padding sits at the tensor end; the pipeline passes `frame_lens = x_lens`, which is what a
+batch-1 reference call per utterance does).
+"""
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .bigvgan import fold_weight_norm
+from .gpt import gemm as engine_gemm
+from .gpt import pack_gemm_weight
+
+
+def _get(obj, *path, default=None):
+    """attribute-or-key access along a path (the reference passes Munch / OmegaConf objects, tests pass dicts)"""
+    cur = obj
+    for p in path:
+        if cur is None:
+            return default
+        if isinstance(cur, dict):
+            cur = cur.get(p, None)
+        else:
+            cur = getattr(cur, p, None)
+    return default if cur is None else cur
+
+
+class CFM:
+    def __init__(self, args, precision: str = "bf16", device="cuda:0"):
+        """`args` = the reference's `cfg.s2mel` mapping (DiT.*, wavenet.*, style_encoder.dim)."""
+        self.hidden_dim = int(_get(args, "DiT", "hidden_dim"))
+        self.num_heads = int(_get(args, "DiT", "num_heads"))
+        self.depth = int(_get(args, "DiT", "depth"))
+        self.in_channels = int(_get(args, "DiT", "in_channels"))
+        self.content_dim = int(_get(args, "DiT", "content_dim"))
+        self.style_dim = int(_get(args, "style_encoder", "dim"))
+        self.wavenet_hidden = int(_get(args, "wavenet", "hidden_dim"))
+        self.wavenet_layers = int(_get(args, "wavenet", "num_layers"))
+        self.wavenet_kernel = int(_get(args, "wavenet", "kernel_size"))
+        self.wavenet_dilation_rate = int(_get(args, "wavenet", "dilation_rate"))
+        for flag, want in (("long_skip_connection", True), ("uvit_skip_connection", True), ("style_condition", True),
+                           ("is_causal", False), ("time_as_token", False), ("style_as_token", False)):
+            have = _get(args, "DiT", flag, default=want)
+            if bool(have) != want:
+                raise NotImplementedError(f"DiT.{flag}={have}: the engine implements the shipped IndexTTS-2 configuration ({want})")
+        if str(_get(args, "DiT", "final_layer_type", default="wavenet")) != "wavenet":
+            raise NotImplementedError("only final_layer_type='wavenet' is used by the IndexTTS checkpoints")
+        self.zero_prompt_speech_token = bool(_get(args, "DiT", "zero_prompt_speech_token", default=False))
+        self.rope_base = 10000.0
+        self.norm_eps = 1e-5
+        self.device = torch.device(device)
+        self.precision = {"bf16": 1, "bfloat16": 1, "fp32": 0, "float32": 0, "f32": 0}[precision]
+        cfg = _lib.S2MelConfig()
+        cfg.hidden_dim, cfg.num_heads, cfg.depth, cfg.in_channels = self.hidden_dim, self.num_heads, self.depth, self.in_channels
+        cfg.wavenet_hidden, cfg.wavenet_layers = self.wavenet_hidden, self.wavenet_layers
+        cfg.wavenet_kernel, cfg.wavenet_dilation_rate = self.wavenet_kernel, self.wavenet_dilation_rate
+        cfg.precision, cfg.norm_eps = self.precision, self.norm_eps
+        self._h = C.c_void_p()
+        with _lib.on_device(self.device):
+            _lib.check(_lib.lib().itts_s2mel_create(C.byref(cfg), C.byref(self._h)), "itts_s2mel_create")
+        self._p: Dict[str, torch.Tensor] = {}
+        self._loaded = False
+        self._ws = None
+        self.estimator = self._estimator_call
+
+    # ---- checkpoint ------------------------------------------------------------------------------------------
+    _ENGINE = ("attention.wqkv.weight", "attention.wo.weight", "feed_forward.w1.weight", "feed_forward.w2.weight",
+               "feed_forward.w3.weight", "attention_norm.norm.weight", "ffn_norm.norm.weight", "skip_in_linear.weight",
+               "skip_in_linear.bias")
+    _ENGINE_TOP = ("transformer.norm.norm.weight", "cond_x_merge_linear.weight", "skip_linear.weight", "skip_linear.bias",
+                   "conv1.weight", "conv1.bias", "res_projection.weight", "res_projection.bias", "final_layer.linear.weight",
+                   "final_layer.linear.bias", "conv2.weight", "conv2.bias")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        """Reference `s2mel.pth` names for the `cfm` model (`estimator.*`; weight-norm tensors are folded here)."""
+        L = _lib.lib()
+        sd = fold_weight_norm({k: v for k, v in sd.items()})
+        P = "estimator."
+        ignored = []
+        with _lib.on_device(self.device):
+            for name, t in sd.items():
+                if not name.startswith(P):
+                    ignored.append(name)
+                    continue
+                tail = name[len(P):]
+                to_engine = tail in self._ENGINE_TOP or (tail.startswith("transformer.layers.") and tail.split(".", 3)[3] in self._ENGINE) \
+                    or (tail.startswith("wavenet.in_layers.") or tail.startswith("wavenet.res_skip_layers."))
+                if to_engine:
+                    tt = t.detach().to("cpu", torch.float32).contiguous()
+                    if tail in ("conv2.weight",) and tt.dim() == 3:
+                        tt = tt.reshape(tt.shape[0], tt.shape[1]).contiguous()        # Conv1d k=1 == Linear
+                    shape = (C.c_int64 * tt.dim())(*tt.shape)
+                    _lib.check(L.itts_s2mel_load_tensor(self._h, name.encode(), C.c_void_p(tt.data_ptr()), shape, tt.dim()),
+                               f"itts_s2mel_load_tensor({name})")
+                # host-side copies: everything that acts on vectors / the step-invariant merge columns
+                if not to_engine or tail == "cond_x_merge_linear.weight":
+                    self._p[tail] = t.detach().to(self.device, torch.float32).contiguous()
+            _lib.check(L.itts_s2mel_finalize(self._h), "itts_s2mel_finalize")
+        need = ["t_embedder.freqs", "t_embedder.mlp.0.weight", "t_embedder.mlp.2.weight", "t_embedder2.mlp.0.weight",
+                "cond_projection.weight", "cond_x_merge_linear.weight", "cond_x_merge_linear.bias",
+                "wavenet.cond_layer.conv.conv.weight", "final_layer.adaLN_modulation.1.weight",
+                "transformer.norm.project_layer.weight"]
+        missing = [n for n in need if n not in self._p]
+        if missing:
+            raise _lib.HipEngineError(f"CFM.load_state_dict: missing {missing}")
+        # step-invariant merge: columns [C : C + C + H + style) of cond_x_merge_linear, as one packed engine GEMM
+        Cc, H = self.in_channels, self.hidden_dim
+        wm = self._p["cond_x_merge_linear.weight"]
+        k_rest = wm.shape[1] - Cc
+        self._k_rest = k_rest
+        self._k_rest_pad = (k_rest + 63) // 64 * 64
+        w_rest = torch.zeros(self._k_rest_pad, H)
+        w_rest[:k_rest] = wm[:, Cc:].t().cpu()
+        self._w_rest = pack_gemm_weight(w_rest, self.precision).to(self.device)
+        cd = self.content_dim
+        self._cd_pad = (cd + 63) // 64 * 64
+        w_cp = torch.zeros(self._cd_pad, H)
+        w_cp[:cd] = self._p["cond_projection.weight"].t().cpu()
+        self._w_cp = pack_gemm_weight(w_cp, self.precision).to(self.device)
+        self._loaded = True
+        return ignored
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        d = torch.device(device)
+        if d.type == "cuda" and d.index is not None and self.device.index is not None and d.index != self.device.index:
+            raise _lib.HipEngineError(f"CFM was built on {self.device}; construct it with device={device!r} instead")
+        return self
+
+    # ---- per-step vectors (host torch, f32) ------------------------------------------------------------------------
+    def _timestep_embed(self, prefix: str, t: torch.Tensor) -> torch.Tensor:      # diffusion_transformer.py:20-60
+        p = self._p
+        args = 1000 * t[:, None].float() * p[prefix + "freqs"][None]
+        emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        h = F.silu(F.linear(emb, p[prefix + "mlp.0.weight"], p[prefix + "mlp.0.bias"]))
+        return F.linear(h, p[prefix + "mlp.2.weight"], p[prefix + "mlp.2.bias"])
+
+    def _mods(self, t: torch.Tensor) -> torch.Tensor:
+        """t (n_steps,) -> (n_steps, mods_per_step) in the order itts_s2mel_mods_per_step documents."""
+        p = self._p
+        t1 = self._timestep_embed("t_embedder.", t)
+        t2 = self._timestep_embed("t_embedder2.", t)
+        parts = []
+        for i in range(self.depth):
+            L = f"transformer.layers.{i}."
+            for nm in ("attention_norm.", "ffn_norm."):
+                parts.append(F.linear(t1, p[L + nm + "project_layer.weight"], p[L + nm + "project_layer.bias"]))
+        parts.append(F.linear(t1, p["transformer.norm.project_layer.weight"], p["transformer.norm.project_layer.bias"]))
+        wc = p["wavenet.cond_layer.conv.conv.weight"]
+        parts.append(F.linear(t2, wc.reshape(wc.shape[0], -1), p["wavenet.cond_layer.conv.conv.bias"]))
+        parts.append(F.linear(F.silu(t1), p["final_layer.adaLN_modulation.1.weight"], p["final_layer.adaLN_modulation.1.bias"]))
+        out = torch.cat(parts, dim=-1).contiguous()
+        assert out.shape[1] == _lib.lib().itts_s2mel_mods_per_step(self._h), out.shape
+        return out
+
+    def _rope(self, T: int) -> torch.Tensor:                                      # gpt_fast/model.py:336-345
+        n = 64
+        freqs = 1.0 / (self.rope_base ** (torch.arange(0, n, 2, device=self.device)[: n // 2].float() / n))
+        ang = torch.outer(torch.arange(T, device=self.device).float(), freqs)
+        return torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1).contiguous()
+
+    def _act(self, x: torch.Tensor) -> torch.Tensor:
+        return x.bfloat16().contiguous() if self.precision == 1 else x.float().contiguous()
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ---- packing -------------------------------------------------------------------------------------------------
+    def _tables(self, frame_lens, x_lens, n_branch):
+        """Sequence tables for `n_branch` copies of the batch (branch-major)."""
+        dev = self.device
+        fl = torch.as_tensor(frame_lens, dtype=torch.int32).reshape(-1)
+        xl = torch.minimum(torch.as_tensor(x_lens, dtype=torch.int32).reshape(-1), fl)
+        seq_T = fl.repeat(n_branch)
+        seq_len = xl.repeat(n_branch)
+        seq_start = torch.cumsum(seq_T, 0, dtype=torch.int32) - seq_T
+        n_tok = int(seq_T.sum())
+        tok_seq = torch.repeat_interleave(torch.arange(seq_T.numel(), dtype=torch.int32), seq_T.long())
+        tok_t = torch.arange(n_tok, dtype=torch.int32) - seq_start[tok_seq.long()]
+        t = dict(seq_T=seq_T, seq_len=seq_len, seq_start=seq_start, tok_seq=tok_seq, tok_t=tok_t)
+        return {k: v.to(dev).contiguous() for k, v in t.items()}, n_tok, int(fl.max())
+
+    def _const_in(self, prompt_x_rows, mu_rows, style_rows, n_null_rows):
+        """cond_x_merge_linear on the step-invariant columns [prompt | cond_projection(mu) | style] + bias for the conditional
+        rows; the null branch (all three inputs zero) sees cond_projection(0) = its bias.  Engine GEMMs."""
+        p, H = self._p, self.hidden_dim
+        n = mu_rows.shape[0]
+        a = torch.zeros(n, self._cd_pad, device=self.device)
+        a[:, : self.content_dim] = mu_rows
+        cond = engine_gemm(self._act(a), self._w_cp, p["cond_projection.bias"], H, self.precision, prefill_tiles=True)
+        rest = torch.zeros(n, self._k_rest_pad, device=self.device)
+        Cc = self.in_channels
+        rest[:, :Cc] = prompt_x_rows
+        rest[:, Cc:Cc + H] = cond
+        rest[:, Cc + H:Cc + H + self.style_dim] = style_rows
+        cin = engine_gemm(self._act(rest), self._w_rest, p["cond_x_merge_linear.bias"], H, self.precision, prefill_tiles=True)
+        if n_null_rows:
+            null = torch.zeros(1, self._k_rest_pad, device=self.device)
+            null[:, Cc:Cc + H] = p["cond_projection.bias"]
+            nrow = engine_gemm(self._act(null), self._w_rest, p["cond_x_merge_linear.bias"], H, self.precision, prefill_tiles=True)
+            cin = torch.cat([cin, nrow.expand(n_null_rows, -1)], 0)
+        return cin.contiguous()
+
+    @staticmethod
+    def _pack_rows(x_bct: torch.Tensor, lens) -> torch.Tensor:
+        """(B, C, T) -> packed (sum lens, C)"""
+        return torch.cat([x_bct[b, :, : int(n)].t() for b, n in enumerate(lens)], 0).contiguous()
+
+    # ---- DiT.forward (one estimator call; used by the parity tests) -----------------------------------------------
+    def _estimator_call(self, x, prompt_x, x_lens, t, style, cond, frame_lens=None):
+        """x, prompt_x (B, C, T); x_lens (B,) or (B/2,) broadcast over a CFG-stacked batch; t (B,); style (B, style_dim);
+        cond (B, T, content_dim) -> (B, C, T), rows beyond a row's frame_lens left at 0."""
+        if not self._loaded:
+            raise RuntimeError("CFM: load_state_dict() first")
+        dev = self.device
+        B, Cc, T = x.shape
+        x_lens = torch.as_tensor(x_lens).reshape(-1)
+        if x_lens.numel() != B:
+            x_lens = x_lens.repeat(B // x_lens.numel())
+        fl = [T] * B if frame_lens is None else [int(v) for v in frame_lens]
+        tabs, n_tok, t_max = self._tables(fl, x_lens, 1)
+        with _lib.on_device(dev):
+            xs = self._pack_rows(x.to(dev).float(), fl)
+            cin = self._const_in(self._pack_rows(prompt_x.to(dev).float(), fl),
+                                 torch.cat([cond[b, : fl[b]] for b in range(B)], 0).to(dev).float(),
+                                 torch.cat([style[b:b + 1].expand(fl[b], -1) for b in range(B)], 0).to(dev).float(), 0)
+            tt = torch.as_tensor(t, dtype=torch.float32).reshape(-1).to(dev)
+            if not bool((tt == tt[0]).all()):
+                raise NotImplementedError("one timestep per call (the solver never mixes timesteps in a batch)")
+            mods = self._mods(tt[:1])
+            rope = self._rope(t_max)
+            L = _lib.lib()
+            ws = self._workspace(L.itts_s2mel_workspace_bytes(self._h, n_tok, B, t_max))
+            d = torch.empty(n_tok, Cc, dtype=torch.float32, device=dev)
+            _lib.check(L.itts_s2mel_estimator(self._h, _lib.ptr(xs), _lib.ptr(cin), _lib.ptr(mods), _lib.ptr(rope),
+                                              _lib.ptr(tabs["tok_seq"]), _lib.ptr(tabs["tok_t"]), _lib.ptr(tabs["seq_start"]),
+                                              _lib.ptr(tabs["seq_T"]), _lib.ptr(tabs["seq_len"]), B, n_tok, t_max, _lib.ptr(d),
+                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "itts_s2mel_estimator")
+            out = torch.zeros(B, Cc, T, device=dev)
+            o = 0
+            for b in range(B):
+                out[b, :, : fl[b]] = d[o:o + fl[b]].t()
+                o += fl[b]
+        return out
+
+    # ---- BASECFM.inference / solve_euler ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def inference(self, mu, x_lens, prompt, style, f0, n_timesteps, temperature=1.0, inference_cfg_rate=0.5, noise=None,
+                  prompt_lens=None, frame_lens=None):
+        B, T = mu.size(0), mu.size(1)
+        if noise is None:
+            noise = torch.randn([B, self.in_channels, T], device=mu.device) * temperature
+        t_span = torch.linspace(0, 1, n_timesteps + 1)
+        return self.solve_euler(noise, x_lens, prompt, mu, style, f0, t_span, inference_cfg_rate, prompt_lens=prompt_lens,
+                                frame_lens=frame_lens)
+
+    @torch.no_grad()
+    def solve_euler(self, x, x_lens, prompt, mu, style, f0, t_span, inference_cfg_rate=0.5, prompt_lens=None, frame_lens=None):
+        """flow_matching.py:57-115.  x (B, C, T) noise; prompt (B or 1, C, Tp); mu (B, T, content_dim); style (B or 1, style_dim);
+        prompt_lens (B,) when the prompts of a batch differ in length (default: prompt.size(-1) for every row)."""
+        if not self._loaded:
+            raise RuntimeError("CFM: load_state_dict() first")
+        if f0 is not None:
+            raise NotImplementedError("f0 conditioning is not used by the IndexTTS-2 s2mel checkpoint")
+        dev = self.device
+        B, Cc, T = x.shape
+        x_lens = torch.as_tensor(x_lens).reshape(-1)
+        fl = [T] * B if frame_lens is None else [int(v) for v in frame_lens]
+        pl = [int(prompt.size(-1))] * B if prompt_lens is None else [int(v) for v in prompt_lens]
+        nb = 2 if inference_cfg_rate > 0 else 1
+        tabs, n_tok, t_max = self._tables(fl, x_lens, nb)
+        n_steps = int(t_span.numel()) - 1
+        with _lib.on_device(dev):
+            x = x.to(dev).float()
+            prompt = prompt.to(dev).float()
+            if prompt.shape[0] == 1 and B > 1:
+                prompt = prompt.expand(B, -1, -1)
+            if style.shape[0] == 1 and B > 1:
+                style = style.expand(B, -1)
+            prompt_x = torch.zeros_like(x)
+            for b in range(B):
+                prompt_x[b, :, : pl[b]] = prompt[b, :, : pl[b]]
+                x[b, :, : pl[b]] = 0
+            mu = mu.to(dev).float()
+            if self.zero_prompt_speech_token:
+                mu = mu.clone()
+                for b in range(B):
+                    mu[b, : pl[b]] = 0
+            xs = self._pack_rows(x, fl)
+            n_rows = xs.shape[0]
+            cin = self._const_in(self._pack_rows(prompt_x, fl), torch.cat([mu[b, : fl[b]] for b in range(B)], 0),
+                                 torch.cat([style[b:b + 1].to(dev).float().expand(fl[b], -1) for b in range(B)], 0),
+                                 n_rows if nb == 2 else 0)
+            # t accumulates in fp32 exactly as the reference loop does (t = t + dt)
+            ts = t_span.detach().to("cpu", torch.float32)
+            t_list, t = [], ts[0].clone()
+            for k in range(1, n_steps + 1):
+                t_list.append(t.clone())
+                t = t + (ts[k] - ts[k - 1])
+            mods = self._mods(torch.stack(t_list).to(dev))
+            rope = self._rope(t_max)
+            plen = torch.tensor(pl * nb, dtype=torch.int32, device=dev)
+            L = _lib.lib()
+            ws = self._workspace(L.itts_s2mel_workspace_bytes(self._h, n_tok, B * nb, t_max))
+            tsp = (C.c_float * (n_steps + 1))(*[float(v) for v in ts])
+            _lib.check(L.itts_s2mel_solve(self._h, _lib.ptr(xs), _lib.ptr(cin), _lib.ptr(mods), _lib.ptr(rope), _lib.ptr(tabs["tok_seq"]),
+                                          _lib.ptr(tabs["tok_t"]), _lib.ptr(tabs["seq_start"]), _lib.ptr(tabs["seq_T"]),
+                                          _lib.ptr(tabs["seq_len"]), _lib.ptr(plen), B * nb, n_tok, t_max, nb, n_steps, tsp,
+                                          float(inference_cfg_rate), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "itts_s2mel_solve")
+            out = torch.zeros(B, Cc, T, device=dev)
+            o = 0
+            for b in range(B):
+                out[b, :, : fl[b]] = xs[o:o + fl[b]].t()
+                o += fl[b]
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.lib().itts_s2mel_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass

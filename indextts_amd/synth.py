@@ -103,3 +103,70 @@ def bigvgan_weights(h: dict = BIGVGAN_V2_22K, seed: int = 1234, post_gain: float
     act("activation_post", ch)
     conv("conv_post", 1, ch, 7, bias=h.get("use_bias_at_final", True), gain=post_gain)
     return sd
+
+
+# ---- s2mel flow-matching decoder (DiT + WaveNet head) at the shipped IndexTTS-2 / 2.5 widths (Seed-VC style configuration;
+# checkpoints/config.yaml is not in the repository, the widths follow backends/trt/export/export_dit_onnx.py:88-96 and the
+# module defaults: hidden 512, 13 layers, 8 heads, content 512, style 192, WaveNet 512 x 8, k = 5, dilation rate 1) ----------
+S2MEL_V2 = dict(DiT=dict(hidden_dim=512, num_heads=8, depth=13, in_channels=80, content_dim=512, content_codebook_size=1024,
+                         style_condition=True, final_layer_type="wavenet", is_causal=False, long_skip_connection=True,
+                         uvit_skip_connection=True, time_as_token=False, style_as_token=False),
+                wavenet=dict(hidden_dim=512, num_layers=8, kernel_size=5, dilation_rate=1, style_condition=True),
+                style_encoder=dict(dim=192))
+
+
+def s2mel_weights(args: dict = S2MEL_V2, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    """Seeded, roughly variance-preserving weights under the reference's `estimator.*` names (weight-norm already folded)."""
+    g = torch.Generator().manual_seed(seed)
+    d, w = args["DiT"], args["wavenet"]
+    H, C, cd, sd_ = d["hidden_dim"], d["in_channels"], d["content_dim"], args["style_encoder"]["dim"]
+    W, L, k = w["hidden_dim"], w["num_layers"], w["kernel_size"]
+    n = int(2 * (4 * H) / 3)
+    I = n if n % 256 == 0 else n + 256 - (n % 256)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, out, inp, bias=True, scale=1.0, ones=0):
+        sd[name + ".weight"] = torch.randn(out, inp, generator=g) * (scale / math.sqrt(inp))
+        if bias:
+            b = torch.randn(out, generator=g) * 0.02
+            if ones:
+                b[:ones] += 1.0
+            sd[name + ".bias"] = b
+
+    P = "estimator."
+    for i in range(d["depth"]):
+        Lp = f"{P}transformer.layers.{i}."
+        lin(Lp + "attention.wqkv", 3 * H, H, bias=False)
+        lin(Lp + "attention.wo", H, H, bias=False, scale=0.5)
+        lin(Lp + "feed_forward.w1", I, H, bias=False)
+        lin(Lp + "feed_forward.w3", I, H, bias=False)
+        lin(Lp + "feed_forward.w2", H, I, bias=False, scale=0.5)
+        for nm in ("attention_norm", "ffn_norm"):
+            lin(Lp + nm + ".project_layer", 2 * H, H, scale=0.5, ones=H)
+            sd[Lp + nm + ".norm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
+        if i > d["depth"] // 2:
+            lin(Lp + "skip_in_linear", H, 2 * H)
+    lin(P + "transformer.norm.project_layer", 2 * H, H, scale=0.5, ones=H)
+    sd[P + "transformer.norm.norm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
+    lin(P + "cond_projection", H, cd)
+    lin(P + "cond_x_merge_linear", H, H + 2 * C + sd_)
+    lin(P + "skip_linear", H, H + C)
+    for te, wd in (("t_embedder", H), ("t_embedder2", W)):
+        sd[P + te + ".freqs"] = torch.exp(-math.log(10000) * torch.arange(128, dtype=torch.float32) / 128)
+        lin(P + te + ".mlp.0", wd, 256)
+        lin(P + te + ".mlp.2", wd, wd)
+    lin(P + "conv1", W, H)
+    lin(P + "res_projection", W, H)
+    lin(P + "final_layer.linear", W, W)
+    lin(P + "final_layer.adaLN_modulation.1", 2 * W, W, scale=0.5)
+    sd[P + "conv2.weight"] = torch.randn(C, W, 1, generator=g) / math.sqrt(W)
+    sd[P + "conv2.bias"] = torch.randn(C, generator=g) * 0.02
+    for i in range(L):
+        ro = 2 * W if i < L - 1 else W
+        sd[f"{P}wavenet.in_layers.{i}.conv.conv.weight"] = torch.randn(2 * W, W, k, generator=g) / math.sqrt(W * k)
+        sd[f"{P}wavenet.in_layers.{i}.conv.conv.bias"] = torch.randn(2 * W, generator=g) * 0.02
+        sd[f"{P}wavenet.res_skip_layers.{i}.conv.conv.weight"] = torch.randn(ro, W, 1, generator=g) * (0.5 / math.sqrt(W))
+        sd[f"{P}wavenet.res_skip_layers.{i}.conv.conv.bias"] = torch.randn(ro, generator=g) * 0.02
+    sd[P + "wavenet.cond_layer.conv.conv.weight"] = torch.randn(2 * W * L, W, 1, generator=g) / math.sqrt(W)
+    sd[P + "wavenet.cond_layer.conv.conv.bias"] = torch.randn(2 * W * L, generator=g) * 0.02
+    return sd

@@ -1,0 +1,196 @@
+"""GPU parity tests of the s2mel flow-matching decoder (DiT estimator + CFG Euler solver) on the HIP engine, through the C ABI.
+
+Checkers: `tests/golden/s2mel_cfm_hd64.npz` -- outputs of the REFERENCE's own `CFM` / `DiT` classes run at batch 1 on the
+oracle's seeded weights (tools/make_golden_s2mel.py) -- and `oracle/s2mel_oracle.py` for pieces the fixture does not isolate.
+Bars: f32 engine mode within 1e-4 (absolute, values of RMS ~1) of the reference outputs; bf16 mode (bf16 GEMM operands, Q/K/V
+and probabilities; f32 accumulation, residual stream, norms, softmax statistics) within the bounds written below.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import s2mel_oracle as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F32_TOL = 1e-4
+BF16_ESTIMATOR_RMS = 0.03          # RMS error of one estimator call (outputs of RMS ~1)
+BF16_EULER_RMS = 0.03              # RMS error after the 4-step CFG solve
+
+
+def load(golden_dir):
+    z = np.load(os.path.join(golden_dir, "s2mel_cfm_hd64.npz"))
+    c = [int(v) for v in z["cfg"]]
+    cfg = S.S2MelConfig(hidden_dim=c[0], num_heads=c[1], depth=c[2], in_channels=c[3], content_dim=c[4], style_dim=c[5],
+                        wavenet_hidden=c[6], wavenet_layers=c[7], wavenet_kernel=c[8], wavenet_dilation_rate=c[9])
+    return z, cfg, S.synth_weights(cfg, int(z["seed"]))
+
+
+def args_of(cfg):
+    return dict(DiT=dict(hidden_dim=cfg.hidden_dim, num_heads=cfg.num_heads, depth=cfg.depth, in_channels=cfg.in_channels,
+                         content_dim=cfg.content_dim, style_condition=True, final_layer_type="wavenet", is_causal=False,
+                         long_skip_connection=True, uvit_skip_connection=True, time_as_token=False, style_as_token=False),
+                wavenet=dict(hidden_dim=cfg.wavenet_hidden, num_layers=cfg.wavenet_layers, kernel_size=cfg.wavenet_kernel,
+                             dilation_rate=cfg.wavenet_dilation_rate, style_condition=True),
+                style_encoder=dict(dim=cfg.style_dim))
+
+
+def engine(cfg, sd, precision):
+    from indextts_amd import s2mel
+    m = s2mel.CFM(args_of(cfg), precision=precision, device=DEV)
+    m.load_state_dict(sd)
+    return m
+
+
+def rms(a):
+    return float(torch.as_tensor(a).double().pow(2).mean().sqrt())
+
+
+def utt(z, u):
+    g = lambda k: torch.from_numpy(z[f"{k}{u}"])
+    return g("z"), g("prompt"), g("mu"), g("style"), g("x_lens")
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_rope_attention_unit(prec):
+    """RoPE + split + non-causal masked attention (the flash kernel in bf16 mode) vs torch, ragged sequences incl. one whose
+    valid length is shorter than the frames processed and lengths that are not multiples of the 64-key tile."""
+    import ctypes as C
+    from indextts_amd import _lib
+    heads, H = 2, 128
+    frame = [70, 130, 5, 64]
+    valid = [61, 130, 5, 64]
+    g = torch.Generator().manual_seed(3)
+    n_tok, t_max = sum(frame), max(frame)
+    qkv = torch.randn(n_tok, 3 * H, generator=g)
+    cfg = S.S2MelConfig(hidden_dim=H, num_heads=heads)
+    tab = S.rope_table(cfg, t_max)
+    seq_T = torch.tensor(frame, dtype=torch.int32)
+    seq_len = torch.tensor(valid, dtype=torch.int32)
+    seq_start = torch.cumsum(seq_T, 0, dtype=torch.int32) - seq_T
+    tok_seq = torch.repeat_interleave(torch.arange(len(frame), dtype=torch.int32), seq_T.long())
+    tok_t = torch.arange(n_tok, dtype=torch.int32) - seq_start[tok_seq.long()]
+    # torch reference, per sequence
+    ref = torch.zeros(n_tok, H)
+    for s, (T, n) in enumerate(zip(frame, valid)):
+        o = int(seq_start[s])
+        q, k, v = qkv[o:o + T].split(H, dim=-1)
+        q = S.apply_rope(q.view(1, T, heads, 64), tab[:T]).transpose(1, 2)
+        k = S.apply_rope(k.view(1, T, heads, 64), tab[:T]).transpose(1, 2)
+        v = v.view(1, T, heads, 64).transpose(1, 2)
+        if prec == 1:
+            q, k, v = (t.bfloat16().float() for t in (q, k, v))
+        sc = (q @ k.transpose(-1, -2)) / 8.0
+        sc[..., n:] = float("-inf")
+        ref[o:o + T] = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(T, H)
+    L = _lib.lib()
+    d = lambda t: t.to(DEV).contiguous()
+    out = torch.empty(n_tok, H, dtype=torch.bfloat16 if prec == 1 else torch.float32, device=DEV)
+    scratch = torch.empty(L.itts_s2mel_attention_scratch_bytes(n_tok, len(frame), heads, t_max, prec), dtype=torch.uint8, device=DEV)
+    keep = [d(qkv), d(tab), d(tok_seq), d(tok_t), d(seq_start), d(seq_T), d(seq_len)]
+    _lib.check(L.itts_s2mel_attention_forward(*[_lib.ptr(t) for t in keep], len(frame), n_tok, t_max, heads, prec, _lib.ptr(out),
+                                              _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr(torch.device(DEV))), "attention")
+    err = float((out.float().cpu() - ref).abs().max())
+    print(f"attention unit (prec {prec}): max|d| = {err:.3e}")
+    assert err < (2e-2 if prec == 1 else 2e-5)
+
+
+def test_estimator_f32_vs_reference(golden_dir):
+    z, cfg, sd = load(golden_dir)
+    m = engine(cfg, sd, "fp32")
+    for u in range(int(z["n_utts"])):
+        x, prompt, mu, style, x_lens = utt(z, u)
+        T, Tp = x.shape[-1], prompt.shape[-1]
+        px = torch.zeros_like(x)
+        px[..., :Tp] = prompt
+        t = torch.full((2,), float(z["t"]))
+        d = m.estimator(torch.cat([x, x]), torch.cat([px, torch.zeros_like(px)]), x_lens, t,
+                        torch.cat([style, torch.zeros_like(style)]), torch.cat([mu, torch.zeros_like(mu)])).cpu()
+        ref = torch.from_numpy(z[f"estimator_out{u}"])
+        err = float((d - ref).abs().max())
+        print(f"estimator f32 utt {u}: max|d| vs reference = {err:.3e} (rms of the output {rms(ref):.3f})")
+        assert err <= F32_TOL
+
+
+def test_solve_euler_f32_vs_reference_single_and_batched(golden_dir):
+    """The 4-step CFG Euler solve: per utterance (the reference's batch-1 call) and both utterances packed into one call
+    (new capability) -- every utterance of the batch equals its own batch-1 result and the reference output."""
+    z, cfg, sd = load(golden_dir)
+    m = engine(cfg, sd, "fp32")
+    n_steps, rate = int(z["n_steps"]), float(z["cfg_rate"])
+    t_span = torch.linspace(0, 1, n_steps + 1)
+    singles = []
+    for u in range(2):
+        x, prompt, mu, style, x_lens = utt(z, u)
+        y = m.solve_euler(x.clone(), x_lens, prompt, mu, style, None, t_span, rate).cpu()
+        ref = torch.from_numpy(z[f"euler_out{u}"])
+        err = float((y - ref).abs().max())
+        print(f"solve_euler f32 utt {u}: max|d| vs reference = {err:.3e}")
+        assert err <= F32_TOL
+        assert float(y[..., : prompt.shape[-1]].abs().max()) == 0.0          # prompt frames held at zero
+        singles.append(y)
+    # packed batch of the two utterances
+    (x0, p0, mu0, s0, l0), (x1, p1, mu1, s1, l1) = utt(z, 0), utt(z, 1)
+    T0, T1 = x0.shape[-1], x1.shape[-1]
+    Tm = max(T0, T1)
+    x = torch.zeros(2, cfg.in_channels, Tm)
+    x[0, :, :T0], x[1, :, :T1] = x0[0], x1[0]
+    mu = torch.zeros(2, Tm, cfg.content_dim)
+    mu[0, :T0], mu[1, :T1] = mu0[0], mu1[0]
+    Pm = max(p0.shape[-1], p1.shape[-1])
+    prompt = torch.zeros(2, cfg.in_channels, Pm)
+    prompt[0, :, : p0.shape[-1]], prompt[1, :, : p1.shape[-1]] = p0[0], p1[0]
+    y = m.solve_euler(x, torch.cat([l0, l1]), prompt, mu, torch.cat([s0, s1]), None, t_span, rate,
+                      prompt_lens=[p0.shape[-1], p1.shape[-1]], frame_lens=[T0, T1]).cpu()
+    for u, T in ((0, T0), (1, T1)):
+        err = float((y[u:u + 1, :, :T] - singles[u]).abs().max())
+        print(f"solve_euler f32 utt {u} inside the packed batch vs alone: max|d| = {err:.3e}")
+        assert err <= 1e-5
+        assert float((y[u:u + 1, :, :T] - torch.from_numpy(z[f"euler_out{u}"])).abs().max()) <= F32_TOL
+
+
+def test_bf16_mode_within_bounds(golden_dir):
+    """The mode the benchmark runs: error of the estimator and of the full solve against the reference's fp32 outputs."""
+    z, cfg, sd = load(golden_dir)
+    m = engine(cfg, sd, "bf16")
+    n_steps, rate = int(z["n_steps"]), float(z["cfg_rate"])
+    t_span = torch.linspace(0, 1, n_steps + 1)
+    for u in range(2):
+        x, prompt, mu, style, x_lens = utt(z, u)
+        T, Tp = x.shape[-1], prompt.shape[-1]
+        n = int(x_lens[0])
+        px = torch.zeros_like(x)
+        px[..., :Tp] = prompt
+        d = m.estimator(torch.cat([x, x]), torch.cat([px, torch.zeros_like(px)]), x_lens, torch.full((2,), float(z["t"])),
+                        torch.cat([style, torch.zeros_like(style)]), torch.cat([mu, torch.zeros_like(mu)])).cpu()
+        e1 = rms((d - torch.from_numpy(z[f"estimator_out{u}"]))[..., :n])
+        y = m.solve_euler(x.clone(), x_lens, prompt, mu, style, None, t_span, rate).cpu()
+        e2 = rms((y - torch.from_numpy(z[f"euler_out{u}"]))[..., :n])
+        print(f"bf16 utt {u}: estimator rms error {e1:.4f} (bound {BF16_ESTIMATOR_RMS}), solve rms error {e2:.4f} (bound {BF16_EULER_RMS})")
+        assert e1 <= BF16_ESTIMATOR_RMS and e2 <= BF16_EULER_RMS
+
+
+def test_production_width_smoke():
+    """The shipped widths (hidden 512, 8 heads, SwiGLU 1536, WaveNet 512 x 8, k = 5, dilation 1) at a few hundred frames:
+    bf16 engine vs the CPU oracle run in fp32 on the same seeded weights (bound as above), two utterances packed."""
+    cfg = S.S2MelConfig(depth=3, wavenet_layers=2, wavenet_dilation_rate=1)
+    sd = S.synth_weights(cfg, 5)
+    m = engine(cfg, sd, "bf16")
+    g = torch.Generator().manual_seed(6)
+    T, Tp = [150, 97], [40, 33]
+    Tm = max(T)
+    x = torch.randn(2, 80, Tm, generator=g)
+    mu = torch.randn(2, Tm, cfg.content_dim, generator=g)
+    prompt = torch.randn(2, 80, max(Tp), generator=g) * 0.5 - 1.0
+    style = torch.randn(2, cfg.style_dim, generator=g)
+    t_span = torch.linspace(0, 1, 3)
+    y = m.solve_euler(x.clone(), torch.tensor(T), prompt, mu, style, None, t_span, 0.7, prompt_lens=Tp, frame_lens=T).cpu()
+    for u in range(2):
+        with torch.no_grad():
+            ref = S.cfm_solve_euler(sd, cfg, x[u:u + 1, :, : T[u]], torch.tensor([T[u]]), prompt[u:u + 1, :, : Tp[u]],
+                                    mu[u:u + 1, : T[u]], style[u:u + 1], 2, 0.7)
+        e = rms(y[u:u + 1, :, : T[u]] - ref)
+        print(f"production widths, utt {u}: bf16 engine vs fp32 oracle rms error {e:.4f} (output rms {rms(ref):.3f})")
+        assert e <= BF16_EULER_RMS

@@ -79,5 +79,45 @@ def main():
                                       cfg.wavenet_hidden, cfg.wavenet_layers, cfg.wavenet_kernel, cfg.wavenet_dilation_rate]))
 
 
+def main_hd64():
+    """Second fixture for the HIP engine (head_dim 64, all GEMM widths multiples of 64): two utterances of different length and
+    prompt length, each run through the reference at batch 1 (its only mode, infer_v2_5.py:201) -- one estimator call and the
+    CFG Euler solve per utterance.  The engine is tested per utterance and on the packed two-utterance batch."""
+    cfg = S.S2MelConfig(hidden_dim=128, num_heads=2, depth=5, in_channels=80, content_dim=64, style_dim=32, wavenet_hidden=128,
+                        wavenet_layers=3, wavenet_kernel=5, wavenet_dilation_rate=2)
+    seed = 67
+    sd = S.synth_weights(cfg, seed)
+    m = reference(cfg, sd)
+    g = torch.Generator().manual_seed(seed + 1)
+    n_steps, cfg_rate = 4, 0.7
+    out = {}
+    for u, (T, Tp, pad) in enumerate(((57, 19, 6), (83, 30, 0))):
+        z = torch.randn(1, cfg.in_channels, T, generator=g)
+        prompt = torch.randn(1, cfg.in_channels, Tp, generator=g) * 0.5 - 1.0
+        mu = torch.randn(1, T, cfg.content_dim, generator=g)
+        style = torch.randn(1, cfg.style_dim, generator=g)
+        x_lens = torch.tensor([T - pad])
+        with torch.no_grad():
+            t = torch.tensor([0.35, 0.35])
+            px = torch.zeros(1, cfg.in_channels, T)
+            px[..., :Tp] = prompt
+            d_ref = m.estimator(torch.cat([z, z]), torch.cat([px, torch.zeros_like(px)]), x_lens, t,
+                                torch.cat([style, torch.zeros_like(style)]), torch.cat([mu, torch.zeros_like(mu)]))
+            d_o = S.dit_forward(sd, cfg, torch.cat([z, z]), torch.cat([px, torch.zeros_like(px)]), x_lens, t,
+                                torch.cat([style, torch.zeros_like(style)]), torch.cat([mu, torch.zeros_like(mu)]))
+            t_span = torch.linspace(0, 1, n_steps + 1)
+            y_ref = m.solve_euler(z.clone(), x_lens, prompt, mu.clone(), style, None, t_span, inference_cfg_rate=cfg_rate)
+            y_o = S.cfm_solve_euler(sd, cfg, z, x_lens, prompt, mu, style, n_steps, cfg_rate)
+        print(f"hd64 utt {u} (T={T}, prompt {Tp}, x_lens {T - pad}): estimator rms {d_ref.pow(2).mean().sqrt():.3f} oracle max|d| "
+              f"{(d_ref - d_o).abs().max():.3e}; solve_euler rms {y_ref.pow(2).mean().sqrt():.3f} oracle max|d| {(y_ref - y_o).abs().max():.3e}")
+        out.update({f"z{u}": z.numpy(), f"prompt{u}": prompt.numpy(), f"mu{u}": mu.numpy(), f"style{u}": style.numpy(),
+                    f"x_lens{u}": x_lens.numpy(), f"estimator_out{u}": d_ref.numpy(), f"euler_out{u}": y_ref.numpy()})
+    np.savez_compressed(os.path.join(GOLD, "s2mel_cfm_hd64.npz"), t=np.float32(0.35), n_steps=np.int64(n_steps),
+                        cfg_rate=np.float64(cfg_rate), seed=np.int64(seed), n_utts=np.int64(2),
+                        cfg=np.array([cfg.hidden_dim, cfg.num_heads, cfg.depth, cfg.in_channels, cfg.content_dim, cfg.style_dim,
+                                      cfg.wavenet_hidden, cfg.wavenet_layers, cfg.wavenet_kernel, cfg.wavenet_dilation_rate]), **out)
+
+
 if __name__ == "__main__":
     main()
+    main_hd64()
