@@ -278,6 +278,31 @@ int itts_s2mel_attention_forward(const float* qkv, const float* rope, const int3
                                  const int32_t* seq_start, const int32_t* seq_T, const int32_t* seq_len, int n_seq, int n_tok,
                                  int t_max, int heads, int precision, void* out, void* scratch, size_t scratch_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * codes -> content features: EnhancedCodec.decode and the s2mel InterpolateRegulator, as token-major f32 ops on packed
+ * sequences ([n_tok][C]; int32 tables tok_seq / tok_t per row, start / T per sequence).  The dense layers between them
+ * run on itts_gemm_forward (precision 0) and itts_layernorm_forward; indextts_amd/codec.py sequences the calls.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* replaces: FVQ.vq2emb = codebook lookup + weight-normed 1x1 out_project
+ *   (indextts/codec/amphion_codec/quantize/factorized_vector_quantize.py:99-127); codes int64 [n] -> out [n][H] */
+int itts_vq_project_forward(const int64_t* codes, const float* codebook, const float* w, const float* bias, float* out, int n,
+                            int n_codes, int cd, int H, void* stream);
+/* replaces: F.interpolate(mode="nearest") + the im2col of a "same" zero-padded Conv1d that follows it
+ *   (indextts/codec/models.py:226-229 `up`; indextts/s2mel/modules/length_regulator.py:121-125; vocos.py:770 `embed`):
+ *   col [n_dst][k*C], the GEMM with the [k*C][C_out] matrix of the conv weight finishes the conv. */
+int itts_tok_gather_conv_forward(const float* x, float* col, const int32_t* tok_seq, const int32_t* tok_t, const int32_t* src_start,
+                                 const int32_t* src_T, const int32_t* dst_T, int n_dst, int C, int k, void* stream);
+/* replaces: ConvNeXtBlock.dwconv (depthwise Conv1d k=7, vocos.py:490-491,509); w [C][k] */
+int itts_tok_dwconv_forward(const float* x, const float* w, const float* b, float* y, const int32_t* tok_seq, const int32_t* tok_t,
+                            const int32_t* seq_T, int n, int C, int k, void* stream);
+/* replaces: nn.GELU() (erf form) of ConvNeXtBlock (vocos.py:496,515), in place */
+int itts_tok_gelu_forward(float* x, size_t n, void* stream);
+/* replaces: x = residual + gamma * x of ConvNeXtBlock (vocos.py:517-521): x += gamma[c] * y */
+int itts_tok_scale_residual_forward(float* x, const float* y, const float* gamma, int n, int C, void* stream);
+/* replaces: nn.GroupNorm(groups=1, C) + nn.Mish() of the regulator stack (length_regulator.py:52-57), in place */
+int itts_tok_groupnorm_mish_forward(float* x, const float* gamma, const float* beta, const int32_t* seq_start, const int32_t* seq_T,
+                                    int n_seq, int C, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,256 @@
+"""Host-side mirrors of the two modules between the GPT codes and the flow-matching decoder, backed by the HIP engine:
+
+  * `EnhancedCodec.decode(codes)` (indextts/codec/models.py:205-231): codebook lookup + weight-normed projection
+    (FVQ.vq2emb), Vocos ConvNeXt backbone (indextts/codec/kmeans/vocos.py:468-526,719-782), nearest x2 upsampling + `up`
+    conv; call site indextts/infer_v2_5.py:832.
+  * `InterpolateRegulator.forward(x, ylens=...)` (indextts/s2mel/modules/length_regulator.py:90-141, continuous input,
+    no f0 / VQ): content_in_proj, nearest interpolation to the mel length, 4 x (Conv1d k=3, GroupNorm(1), Mish), 1x1 conv;
+    call sites indextts/infer_v2_5.py:651-656,835-838.
+
+The classes sequence C-ABI calls (`itts_vq_project_forward`, `itts_tok_*_forward`, `itts_gemm_forward`,
+`itts_layernorm_forward`); all arithmetic is f32 (the stage is ~40 GFLOP per utterance).  Utterances of a batch are packed
+back to back, each with its own length (the reference runs the stage at batch 1): padding never reaches a conv or a norm.
+"""
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+from .bigvgan import fold_weight_norm
+from .gpt import gemm as engine_gemm
+from .gpt import layernorm as engine_layernorm
+from .gpt import pack_gemm_weight
+
+F32 = 0
+
+
+def _tables(lens: Sequence[int], device):
+    """(tok_seq, tok_t, start, T) int32 device tensors of packed sequences of the given lengths, and the row count."""
+    T = torch.as_tensor(list(lens), dtype=torch.int32)
+    start = torch.cumsum(T, 0, dtype=torch.int32) - T
+    n = int(T.sum())
+    tok_seq = torch.repeat_interleave(torch.arange(T.numel(), dtype=torch.int32), T.long())
+    tok_t = torch.arange(n, dtype=torch.int32) - start[tok_seq.long()]
+    return tuple(t.to(device).contiguous() for t in (tok_seq, tok_t, start, T)), n
+
+
+def _conv_matrix(w: torch.Tensor) -> torch.Tensor:
+    """Conv1d weight [C_out][C_in][k] -> [k*C_in][C_out] (row index j*C_in + c: the im2col column order)"""
+    co, ci, k = w.shape
+    return w.permute(2, 1, 0).reshape(k * ci, co).contiguous()
+
+
+class _TokOps:
+    """thin wrappers over the C ABI, all on packed f32 [n][C] matrices"""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.L = _lib.lib()
+
+    def _st(self):
+        return _lib.stream_ptr(self.device)
+
+    def linear(self, x, wp, bias, n_out):
+        return engine_gemm(x, wp, bias, n_out, F32, prefill_tiles=True)
+
+    def conv(self, x, tabs_dst, n_dst, src_start, src_T, dst_T, k, wp, bias, c_out):
+        """`same` Conv1d over the source sequences nearest-interpolated to the destination lengths"""
+        tok_seq, tok_t = tabs_dst
+        Cc = x.shape[1]
+        col = torch.empty(n_dst, k * Cc, dtype=torch.float32, device=self.device)
+        with _lib.on_device(self.device):
+            _lib.check(self.L.itts_tok_gather_conv_forward(_lib.ptr(x), _lib.ptr(col), _lib.ptr(tok_seq), _lib.ptr(tok_t),
+                                                           _lib.ptr(src_start), _lib.ptr(src_T), _lib.ptr(dst_T), n_dst, Cc, k,
+                                                           self._st()), "itts_tok_gather_conv_forward")
+        return self.linear(col, wp, bias, c_out)
+
+    def dwconv(self, x, w, b, tok_seq, tok_t, seq_T, k):
+        y = torch.empty_like(x)
+        with _lib.on_device(self.device):
+            _lib.check(self.L.itts_tok_dwconv_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), _lib.ptr(tok_seq),
+                                                      _lib.ptr(tok_t), _lib.ptr(seq_T), x.shape[0], x.shape[1], k, self._st()),
+                       "itts_tok_dwconv_forward")
+        return y
+
+    def gelu_(self, x):
+        with _lib.on_device(self.device):
+            _lib.check(self.L.itts_tok_gelu_forward(_lib.ptr(x), x.numel(), self._st()), "itts_tok_gelu_forward")
+        return x
+
+    def scale_residual_(self, x, y, gamma):
+        with _lib.on_device(self.device):
+            _lib.check(self.L.itts_tok_scale_residual_forward(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), x.shape[0], x.shape[1],
+                                                              self._st()), "itts_tok_scale_residual_forward")
+        return x
+
+    def groupnorm_mish_(self, x, gamma, beta, start, T, eps=1e-5):
+        with _lib.on_device(self.device):
+            _lib.check(self.L.itts_tok_groupnorm_mish_forward(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(start),
+                                                              _lib.ptr(T), int(T.numel()), x.shape[1], float(eps), self._st()),
+                       "itts_tok_groupnorm_mish_forward")
+        return x
+
+
+class EnhancedCodec:
+    """The decode half of the reference's semantic codec (quantize / encode stay with the prompt-side PyTorch modules)."""
+
+    def __init__(self, codebook_size=8192, hidden_size=1024, codebook_dim=8, vocos_dim=384, vocos_intermediate_dim=2048,
+                 vocos_num_layers=12, device="cuda:0", **_unused):
+        self.codebook_size, self.hidden_size, self.codebook_dim = codebook_size, hidden_size, codebook_dim
+        self.vocos_dim, self.vocos_intermediate_dim, self.vocos_num_layers = vocos_dim, vocos_intermediate_dim, vocos_num_layers
+        if hidden_size % 16 or vocos_dim % 64 or vocos_intermediate_dim % 16:
+            raise ValueError("EnhancedCodec (HIP engine): hidden_size % 16, vocos_dim % 64, vocos_intermediate_dim % 16 must be 0")
+        self.device = torch.device(device)
+        self._p: Dict[str, torch.Tensor] = {}
+        self._loaded = False
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        dev = self.device
+        sd = fold_weight_norm({k: v for k, v in sd.items()})
+        f = lambda t: t.detach().to(dev, torch.float32).contiguous()
+        pk = lambda kn: pack_gemm_weight(kn.detach().float().cpu(), F32).to(dev)
+        p = self._p
+        Q = "quantizer.quantizers.0."
+        p["codebook"] = f(sd[Q + "codebook.weight"])
+        w = sd[Q + "out_project.weight"]
+        p["out_w"], p["out_b"] = f(w.reshape(w.shape[0], -1)), f(sd[Q + "out_project.bias"])
+        p["embed_w"], p["embed_b"] = pk(_conv_matrix(sd["decoder.0.embed.weight"])), f(sd["decoder.0.embed.bias"])
+        p["norm_g"], p["norm_b"] = f(sd["decoder.0.norm.weight"]), f(sd["decoder.0.norm.bias"])
+        for i in range(self.vocos_num_layers):
+            c = f"decoder.0.convnext.{i}."
+            dw = sd[c + "dwconv.weight"]
+            p[f"dw_w{i}"], p[f"dw_b{i}"] = f(dw.reshape(dw.shape[0], -1)), f(sd[c + "dwconv.bias"])
+            p[f"ln_g{i}"], p[f"ln_b{i}"] = f(sd[c + "norm.weight"]), f(sd[c + "norm.bias"])
+            p[f"pw1_w{i}"], p[f"pw1_b{i}"] = pk(sd[c + "pwconv1.weight"].t()), f(sd[c + "pwconv1.bias"])
+            p[f"pw2_w{i}"], p[f"pw2_b{i}"] = pk(sd[c + "pwconv2.weight"].t()), f(sd[c + "pwconv2.bias"])
+            p[f"gamma{i}"] = f(sd[c + "gamma"])
+        p["fln_g"], p["fln_b"] = f(sd["decoder.0.final_layer_norm.weight"]), f(sd["decoder.0.final_layer_norm.bias"])
+        p["dec1_w"], p["dec1_b"] = pk(sd["decoder.1.weight"].t()), f(sd["decoder.1.bias"])
+        p["up_w"], p["up_b"] = pk(_conv_matrix(sd["up.weight"])), f(sd["up.bias"])
+        self._loaded = True
+        return [k for k in sd if not (k.startswith("decoder.") or k.startswith("up.") or k.startswith(Q))]
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    @torch.no_grad()
+    def decode(self, codes: torch.Tensor, code_lens: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """codes (B, T) or (1, B, T) int -> (B, 2T, hidden) f32; with `code_lens` each row is decoded at its own length (frames
+        beyond 2 * len are zero)."""
+        if not self._loaded:
+            raise RuntimeError("EnhancedCodec: load_state_dict() first")
+        if codes.dim() == 3:
+            codes = codes[0]
+        dev, p, ops = self.device, self._p, _TokOps(self.device)
+        B, T = codes.shape
+        lens = [T] * B if code_lens is None else [int(v) for v in code_lens]
+        (tok_seq, tok_t, start, Tt), n = _tables(lens, dev)
+        out = torch.zeros(B, 2 * T, self.hidden_size, dtype=torch.float32, device=dev)
+        if n == 0:
+            return out
+        flat = torch.cat([codes[b, : lens[b]] for b in range(B)]).to(dev, torch.int64).contiguous()
+        D, H, L = self.vocos_dim, self.hidden_size, _lib.lib()
+        e = torch.empty(n, H, dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(L.itts_vq_project_forward(_lib.ptr(flat), _lib.ptr(p["codebook"]), _lib.ptr(p["out_w"]), _lib.ptr(p["out_b"]),
+                                                 _lib.ptr(e), n, self.codebook_size, self.codebook_dim, H, _lib.stream_ptr(dev)),
+                       "itts_vq_project_forward")
+        x = ops.conv(e, (tok_seq, tok_t), n, start, Tt, Tt, 7, p["embed_w"], p["embed_b"], D)            # VocosBackbone.embed
+        x = engine_layernorm(x, p["norm_g"], p["norm_b"], eps=1e-6)
+        for i in range(self.vocos_num_layers):                                                             # ConvNeXtBlock
+            y = ops.dwconv(x, p[f"dw_w{i}"], p[f"dw_b{i}"], tok_seq, tok_t, Tt, 7)
+            y = engine_layernorm(y, p[f"ln_g{i}"], p[f"ln_b{i}"], eps=1e-6)
+            y = ops.gelu_(ops.linear(y, p[f"pw1_w{i}"], p[f"pw1_b{i}"], self.vocos_intermediate_dim))
+            y = ops.linear(y, p[f"pw2_w{i}"], p[f"pw2_b{i}"], D)
+            ops.scale_residual_(x, y, p[f"gamma{i}"])
+        x = engine_layernorm(x, p["fln_g"], p["fln_b"], eps=1e-6)
+        x = ops.linear(x, p["dec1_w"], p["dec1_b"], H)
+        (tseq2, tt2, start2, T2), n2 = _tables([2 * v for v in lens], dev)                                 # x2 nearest + up conv
+        y = ops.conv(x, (tseq2, tt2), n2, start, Tt, T2, 3, p["up_w"], p["up_b"], H)
+        o = 0
+        for b in range(B):
+            out[b, : 2 * lens[b]] = y[o:o + 2 * lens[b]]
+            o += 2 * lens[b]
+        return out
+
+
+class InterpolateRegulator:
+    def __init__(self, channels: int, sampling_ratios=(1, 1, 1, 1), is_discrete: bool = False, in_channels: Optional[int] = None,
+                 vector_quantize: bool = False, codebook_size: int = 1024, out_channels: Optional[int] = None, groups: int = 1,
+                 n_codebooks: int = 1, quantizer_dropout: float = 0.0, f0_condition: bool = False, n_f0_bins: int = 512,
+                 device="cuda:0"):
+        if is_discrete or vector_quantize or f0_condition or groups != 1 or (out_channels not in (None, channels)):
+            raise NotImplementedError("engine implements the IndexTTS-2 regulator: continuous input, GroupNorm(1), no VQ / f0")
+        if in_channels is None or in_channels % 16 or channels % 16:
+            raise ValueError("InterpolateRegulator (HIP engine): in_channels and channels must be multiples of 16")
+        self.channels, self.in_channels, self.n_layers = channels, in_channels, len(sampling_ratios)
+        self.interpolate = self.n_layers > 0
+        self.device = torch.device(device)
+        self._p: Dict[str, torch.Tensor] = {}
+        self._loaded = False
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        dev = self.device
+        f = lambda t: t.detach().to(dev, torch.float32).contiguous()
+        pk = lambda kn: pack_gemm_weight(kn.detach().float().cpu(), F32).to(dev)
+        p = self._p
+        p["in_w"], p["in_b"] = pk(sd["content_in_proj.weight"].t()), f(sd["content_in_proj.bias"])
+        for i in range(self.n_layers):
+            p[f"cw{i}"], p[f"cb{i}"] = pk(_conv_matrix(sd[f"model.{3 * i}.weight"])), f(sd[f"model.{3 * i}.bias"])
+            p[f"g{i}"], p[f"b{i}"] = f(sd[f"model.{3 * i + 1}.weight"]), f(sd[f"model.{3 * i + 1}.bias"])
+        p["ow"], p["ob"] = pk(_conv_matrix(sd[f"model.{3 * self.n_layers}.weight"])), f(sd[f"model.{3 * self.n_layers}.bias"])
+        self._loaded = True
+        return [k for k in sd if k in ("mask_token", "embedding.weight")]
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, ylens: torch.Tensor = None, n_quantizers=None, f0=None, xlens: Optional[Sequence[int]] = None,
+                frame_lens: Optional[Sequence[int]] = None):
+        """x (B, T, in_channels), ylens (B,) -> (out (B, max ylens, channels) zero beyond each row's ylen, ylens, None, None, None).
+        `xlens`: valid input frames per row (default T for every row).  `frame_lens`: frames each row is stretched to and
+        processed at -- default max(ylens) for EVERY row, which is what the reference does with a batch (rows shorter than the
+        longest are interpolated to the longest, normalised over it and cut by the mask afterwards, :117-141); the pipeline
+        passes `frame_lens = ylens`, i.e. what a batch-1 reference call per utterance computes."""
+        if not self._loaded:
+            raise RuntimeError("InterpolateRegulator: load_state_dict() first")
+        if f0 is not None:
+            raise NotImplementedError("f0 conditioning is not part of the IndexTTS-2 regulator")
+        dev, p, ops = self.device, self._p, _TokOps(self.device)
+        B, T, _ = x.shape
+        xl = [T] * B if xlens is None else [int(v) for v in xlens]
+        yl = [int(v) for v in torch.as_tensor(ylens).reshape(-1)]
+        if not self.interpolate:
+            yl = [min(a, b) for a, b in zip(yl, xl)]
+        Tm = max(yl) if yl else 0
+        fl = ([Tm] * B if self.interpolate else list(xl)) if frame_lens is None else [int(v) for v in frame_lens]
+        (_, _, sstart, sT), ns = _tables(xl, dev)
+        (dseq, dt, dstart, dT), nd = _tables(fl, dev)
+        Cc = self.channels
+        out = torch.zeros(B, Tm, Cc, dtype=torch.float32, device=dev)
+        if ns == 0 or nd == 0:
+            return out, torch.as_tensor(yl, device=dev), None, None, None
+        xs = torch.cat([x[b, : xl[b]] for b in range(B)], 0).to(dev, torch.float32).contiguous()
+        h = ops.linear(xs, p["in_w"], p["in_b"], Cc)                                                       # content_in_proj
+        src_start, src_T = sstart, sT
+        for i in range(self.n_layers):
+            h = ops.conv(h, (dseq, dt), nd, src_start, src_T, dT, 3, p[f"cw{i}"], p[f"cb{i}"], Cc)         # interpolate (i = 0) + conv
+            ops.groupnorm_mish_(h, p[f"g{i}"], p[f"b{i}"], dstart, dT)
+            src_start, src_T = dstart, dT
+        h = ops.linear(h, p["ow"], p["ob"], Cc)                                                            # model[-1]: 1x1 conv
+        o = 0
+        for b in range(B):
+            n_b = min(yl[b], fl[b])
+            out[b, :n_b] = h[o:o + n_b]                                                                    # out * mask
+            o += fl[b]
+        return out, torch.as_tensor(yl, device=dev), None, None, None
+
+    __call__ = forward

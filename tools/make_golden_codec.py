@@ -21,10 +21,9 @@ from oracle import codec_oracle as C  # noqa: E402
 GOLD = os.path.join(HERE, "..", "tests", "golden")
 
 
-def main():
-    cc = C.CodecConfig(codebook_size=64, hidden_size=32, codebook_dim=8, vocos_dim=24, vocos_intermediate_dim=48, vocos_num_layers=3)
-    rc = C.RegulatorConfig(channels=16, in_channels=32, n_layers=4, groups=1, codebook_size=64)
-    seed = 71
+def main(tag="codec", cc=None, rc=None, seed=71, n_codes=13):
+    cc = cc or C.CodecConfig(codebook_size=64, hidden_size=32, codebook_dim=8, vocos_dim=24, vocos_intermediate_dim=48, vocos_num_layers=3)
+    rc = rc or C.RegulatorConfig(channels=16, in_channels=32, n_layers=4, groups=1, codebook_size=64)
     csd, rsd = C.synth_codec_weights(cc, seed), C.synth_regulator_weights(rc, seed + 1)
     codec = EnhancedCodec(codebook_size=cc.codebook_size, hidden_size=cc.hidden_size, codebook_dim=cc.codebook_dim, vocos_dim=cc.vocos_dim,
                           vocos_intermediate_dim=cc.vocos_intermediate_dim, vocos_num_layers=cc.vocos_num_layers).eval()
@@ -40,7 +39,7 @@ def main():
     assert [k for k in reg.state_dict()] == [n for n, _ in C.regulator_param_shapes(rc)]
     reg.load_state_dict(rsd, strict=True)
     g = torch.Generator().manual_seed(seed + 2)
-    codes = torch.randint(0, cc.codebook_size, (2, 13), generator=g)
+    codes = torch.randint(0, cc.codebook_size, (2, n_codes), generator=g)
     with torch.no_grad():
         s_ref = codec.decode(codes)                                            # (2, 26, 32)
         s_o = C.codec_decode(csd, cc, codes)
@@ -49,7 +48,7 @@ def main():
         r_o, _ = C.length_regulator(rsd, rc, s_ref, ylens)
     print(f"codec.decode: ref {tuple(s_ref.shape)} rms {s_ref.pow(2).mean().sqrt():.3f} oracle max|d| = {(s_ref - s_o).abs().max():.3e}")
     print(f"length_regulator: ref {tuple(r_ref.shape)} rms {r_ref.pow(2).mean().sqrt():.3f} oracle max|d| = {(r_ref - r_o).abs().max():.3e}")
-    np.savez_compressed(os.path.join(GOLD, "codec.npz"), codes=codes.numpy(), s_infer=s_ref.numpy(), ylens=ylens.numpy(), cond=r_ref.numpy(),
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), codes=codes.numpy(), s_infer=s_ref.numpy(), ylens=ylens.numpy(), cond=r_ref.numpy(),
                         seed=np.int64(seed),
                         codec_cfg=np.array([cc.codebook_size, cc.hidden_size, cc.codebook_dim, cc.vocos_dim, cc.vocos_intermediate_dim, cc.vocos_num_layers]),
                         reg_cfg=np.array([rc.channels, rc.in_channels, rc.n_layers, rc.groups, rc.codebook_size]))
@@ -57,3 +56,6 @@ def main():
 
 if __name__ == "__main__":
     main()
+    # widths the HIP engine's f32 GEMM / LayerNorm kernels take (multiples of 64 / 16): the fixture of tests/test_gpu_codec.py
+    main("codec_e64", C.CodecConfig(codebook_size=96, hidden_size=64, codebook_dim=8, vocos_dim=64, vocos_intermediate_dim=128, vocos_num_layers=3),
+         C.RegulatorConfig(channels=64, in_channels=64, n_layers=4, groups=1, codebook_size=64), seed=73, n_codes=21)
