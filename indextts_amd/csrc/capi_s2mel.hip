@@ -8,6 +8,7 @@
 // AdaLN (weight | bias) vectors of every norm, the WaveNet conditioning, the final-layer modulation -- and the step-invariant
 // part of cond_x_merge_linear (prompt, content and style columns).  They arrive as `mods` / `const_in`.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -17,6 +18,14 @@
 #include "../../include/indextts_hip.h"
 #include "gpt_kernels.h"
 #include "s2mel_kernels.h"
+
+// bf16: element-wise stages live in the GEMM epilogues (no f32 round trip of the wide intermediates) and the paired weights are
+// packed tile-interleaved for them; the f32 parity mode keeps separate kernels.  ITTS_S2MEL_FUSED=0 (read once, before the
+// weights are packed) forces the separate kernels in bf16 too -- the A/B switch of tests/test_gpu_s2mel.py.
+static bool s2_fused(int precision) {
+    static const bool env = [] { const char* e = getenv("ITTS_S2MEL_FUSED"); return !e || atoi(e) != 0; }();
+    return precision == PREC_BF16 && env;
+}
 
 struct S2Layer {
     void *w_qkv = 0, *w_o = 0, *w_13 = 0, *w_2 = 0, *w_skip_a = 0, *w_skip_b = 0;
@@ -127,6 +136,20 @@ struct Fin {
             for (int k = 0; k < K; ++k) kn[(size_t)k * N + n] = w[(size_t)n * ldw + c0 + k];
         return kn;
     }
+    // [K][N] with N = two halves -> n-tiles interleaved (tile 2j: first half's columns 16j.., tile 2j+1: second half's 16j..): the
+    // layout the bf16 tile kernel's pair epilogues (EPI_SWIGLU / EPI_GATE) expect; identity in the f32 parity mode
+    std::vector<float> pair_tiles(const std::vector<float>& kn, int K, int N) const {
+        if (!s2_fused(h->cfg.precision)) return kn;
+        const int half = N / 2;
+        std::vector<float> o((size_t)K * N);
+        for (int k = 0; k < K; ++k)
+            for (int j = 0; j < half / 16; ++j)
+                for (int c = 0; c < 16; ++c) {
+                    o[(size_t)k * N + (2 * j) * 16 + c] = kn[(size_t)k * N + 16 * j + c];
+                    o[(size_t)k * N + (2 * j + 1) * 16 + c] = kn[(size_t)k * N + half + 16 * j + c];
+                }
+        return o;
+    }
     int vec(const std::vector<float>* v, float** dst) { return s2_upload(h, v->data(), v->size() * sizeof(float), (void**)dst); }
 };
 }  // namespace
@@ -159,7 +182,7 @@ extern "C" int itts_s2mel_finalize(itts_s2mel* h) {
         if (!rc) {                                              // [w1 ; w3] -> one GEMM of N = 2I
             std::vector<float> w13(*w1);
             w13.insert(w13.end(), w3->begin(), w3->end());
-            rc = f.pack_kn(Fin::cols_kn(w13, 2 * I, H, 0, H), H, H, 2 * I, &Ly.w_13);
+            rc = f.pack_kn(f.pair_tiles(Fin::cols_kn(w13, 2 * I, H, 0, H), H, 2 * I), H, H, 2 * I, &Ly.w_13);
         }
         if (!rc) rc = f.pack_kn(Fin::cols_kn(*w2, H, I, 0, I), I, I, H, &Ly.w_2);
         if (!rc) rc = f.vec(ga, &Ly.g_attn);
@@ -217,7 +240,7 @@ extern "C" int itts_s2mel_finalize(itts_s2mel* h) {
         for (int n = 0; n < 2 * W; ++n)
             for (int cc = 0; cc < W; ++cc)
                 for (int j = 0; j < k; ++j) kn[((size_t)j * W + cc) * 2 * W + n] = (*wi)[((size_t)n * W + cc) * k + j];
-        rc = f.pack_kn(kn, k * W, k * W, 2 * W, &h->wn[i].w_in);
+        rc = f.pack_kn(f.pair_tiles(kn, k * W, 2 * W), k * W, k * W, 2 * W, &h->wn[i].w_in);
         if (!rc) rc = f.vec(bi, &h->wn[i].b_in);
         if (!rc) rc = f.pack_kn(Fin::cols_kn(*wr, ro, W, 0, W), W, W, ro, &h->wn[i].w_rs);
         if (!rc) rc = f.vec(br, &h->wn[i].b_rs);
@@ -295,6 +318,7 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     const itts_s2mel_config& c = h->cfg;
     const int H = c.hidden_dim, I = h->I, W = c.wavenet_hidden, C = c.in_channels, Kx = h->Kx, N = tab.n_tok, prec = c.precision;
     const int nh = c.num_heads;
+    const bool fused = s2_fused(prec);
     int rc;
     float *X = w.X, *X2 = w.X2;
     // x_in = cond_x_merge_linear([x^T | prompt | cond | style]): the x columns here, the rest (+ bias) is const_in
@@ -312,13 +336,27 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
             float* tmp = X; X = X2; X2 = tmp;
         }
         if ((rc = launch_ada_rmsnorm(X, L.g_attn, mods + (size_t)i * 4 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
-        if ((rc = s2_gemm(h, w.HB, H, L.w_qkv, nullptr, w.BIG, 3 * H, N, 3 * H, H, EPI_STORE_F32, st))) return rc;
-        if ((rc = launch_rope_split(w.BIG, rope, w.QA, w.KC, w.VC, tab, nh, t_pad, prec, st))) return rc;
+        if (fused) {                                               // wqkv + RoPE + Q / K / V^T scatter in one epilogue
+            GemmArgs g{};
+            g.A = w.HB; g.lda = H; g.Wp = L.w_qkv; g.M = N; g.N = 3 * H; g.K = H; g.nsplit = 1; g.epi = EPI_QKV_ROPE;
+            g.out_act = w.QA; g.kcache = w.KC; g.vcache = w.VC; g.D = H; g.H = nh; g.Tmax = t_pad;
+            g.tok_seq = tab.tok_seq; g.tok_t = tab.tok_t; g.rope = rope;
+            if ((rc = launch_gemm(g, prec, true, st))) return rc;
+        } else {
+            if ((rc = s2_gemm(h, w.HB, H, L.w_qkv, nullptr, w.BIG, 3 * H, N, 3 * H, H, EPI_STORE_F32, st))) return rc;
+            if ((rc = launch_rope_split(w.BIG, rope, w.QA, w.KC, w.VC, tab, nh, t_pad, prec, st))) return rc;
+        }
         if ((rc = launch_s2mel_attention(w.QA, w.KC, w.VC, w.AO, tab, nh, t_pad, prec, st))) return rc;
         if ((rc = s2_gemm(h, w.AO, H, L.w_o, nullptr, X, H, N, H, H, EPI_RESIDUAL, st))) return rc;
         if ((rc = launch_ada_rmsnorm(X, L.g_ffn, mods + (size_t)i * 4 * H + 2 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
-        if ((rc = s2_gemm(h, w.HB, H, L.w_13, nullptr, w.BIG, 2 * I, N, 2 * I, H, EPI_STORE_F32, st))) return rc;
-        if ((rc = launch_swiglu(w.BIG, w.FC, N, I, prec, st))) return rc;
+        if (fused) {                                               // [w1 ; w3] GEMM with the SwiGLU combine in the epilogue
+            GemmArgs g{};
+            g.A = w.HB; g.lda = H; g.Wp = L.w_13; g.M = N; g.N = 2 * I; g.K = H; g.nsplit = 1; g.epi = EPI_SWIGLU; g.out_act = w.FC; g.D = I;
+            if ((rc = launch_gemm(g, prec, true, st))) return rc;
+        } else {
+            if ((rc = s2_gemm(h, w.HB, H, L.w_13, nullptr, w.BIG, 2 * I, N, 2 * I, H, EPI_STORE_F32, st))) return rc;
+            if ((rc = launch_swiglu(w.BIG, w.FC, N, I, prec, st))) return rc;
+        }
         if ((rc = s2_gemm(h, w.FC, I, L.w_2, nullptr, X, H, N, H, I, EPI_RESIDUAL, st))) return rc;
         if (i < c.depth / 2) {
             if ((rc = launch_cast_pad(X, w.SK + w.sk_stride * n_skip, N, N, H, H, prec, st))) return rc;
@@ -341,11 +379,23 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
         const S2Wn& Wn = h->wn[i];
         const int last = i == c.wavenet_layers - 1;
         if ((rc = launch_im2col_reflect(w.WX, w.COL, tab, W, c.wavenet_kernel, dil, prec, st))) return rc;
-        if ((rc = s2_gemm(h, w.COL, c.wavenet_kernel * W, Wn.w_in, Wn.b_in, w.BIG, 2 * W, N, 2 * W, c.wavenet_kernel * W, EPI_STORE_F32, st))) return rc;
-        if ((rc = launch_wn_gate(w.BIG, m_gc + (size_t)i * 2 * W, w.FC, N, W, prec, st))) return rc;
         const int ro = last ? W : 2 * W;
-        if ((rc = s2_gemm(h, w.FC, W, Wn.w_rs, Wn.b_rs, w.BIG, ro, N, ro, W, EPI_STORE_F32, st))) return rc;
-        if ((rc = launch_wn_update(w.BIG, w.WX, w.OUT, tab, W, i == 0, last, st))) return rc;
+        if (fused) {                                               // gate in the in_layer epilogue, residual / skip update in the res_skip one
+            GemmArgs g{};
+            g.A = w.COL; g.lda = c.wavenet_kernel * W; g.Wp = Wn.w_in; g.bias = Wn.b_in; g.M = N; g.N = 2 * W; g.K = c.wavenet_kernel * W;
+            g.nsplit = 1; g.epi = EPI_GATE; g.out_act = w.FC; g.gvec = m_gc + (size_t)i * 2 * W; g.D = W;
+            if ((rc = launch_gemm(g, prec, true, st))) return rc;
+            GemmArgs r{};
+            r.A = w.FC; r.lda = W; r.Wp = Wn.w_rs; r.bias = Wn.b_rs; r.M = N; r.N = ro; r.K = W; r.nsplit = 1; r.epi = EPI_WN_RS;
+            r.out_f32 = w.WX; r.out2 = w.OUT; r.D = W; r.wn_first = i == 0; r.wn_last = last;
+            r.tok_seq = tab.tok_seq; r.tok_t = tab.tok_t; r.seq_len = tab.seq_len;
+            if ((rc = launch_gemm(r, prec, true, st))) return rc;
+        } else {
+            if ((rc = s2_gemm(h, w.COL, c.wavenet_kernel * W, Wn.w_in, Wn.b_in, w.BIG, 2 * W, N, 2 * W, c.wavenet_kernel * W, EPI_STORE_F32, st))) return rc;
+            if ((rc = launch_wn_gate(w.BIG, m_gc + (size_t)i * 2 * W, w.FC, N, W, prec, st))) return rc;
+            if ((rc = s2_gemm(h, w.FC, W, Wn.w_rs, Wn.b_rs, w.BIG, ro, N, ro, W, EPI_STORE_F32, st))) return rc;
+            if ((rc = launch_wn_update(w.BIG, w.WX, w.OUT, tab, W, i == 0, last, st))) return rc;
+        }
         dil *= c.wavenet_dilation_rate;
     }
     // FinalLayer + conv2

@@ -21,7 +21,12 @@ struct LnArgs {
 int launch_ln(const LnArgs& a, int prec, hipStream_t st);
 
 // ---- GEMM  C[M,N] = A[M,K] * W[K,N]  on MFMA ------------------------------------------------------------------
-enum { EPI_STORE_F32 = 0, EPI_GELU_ACT = 1, EPI_PARTIAL = 2, EPI_RESIDUAL = 3, EPI_QKV = 4 };
+enum { EPI_STORE_F32 = 0, EPI_GELU_ACT = 1, EPI_PARTIAL = 2, EPI_RESIDUAL = 3, EPI_QKV = 4,
+       // bf16 prefill-tile kernel only (the s2mel DiT, gpt_kernels.hip::pf_epilogue_pair / pf_epilogue):
+       EPI_SWIGLU = 5,      // W packed with n-tiles interleaved (2j: w1 columns 16j.., 2j+1: w3 columns 16j..): out_act[m][n] = silu(a) * b
+       EPI_GATE = 6,        // same interleave of the WaveNet in_layer halves: out_act[m][n] = tanh(a + bias + g) * sigmoid(b + bias' + g')
+       EPI_QKV_ROPE = 7,    // fused wqkv: RoPE on q / k, Q -> out_act [m][D], K -> kcache [seq][H][Tmax][64], V^T -> vcache [seq][H][64][Tmax]
+       EPI_WN_RS = 8 };     // WaveNet res_skip: n < D: out_f32[m][n] = (out_f32[m][n] + v) * mask(m); n >= D: out2[m][n - D] (=|+=) v
 struct GemmArgs {
     const void* A; int lda;          // act dtype [M][lda]
     const void* Wp;                  // packed weights (itts_pack_gemm_weight)
@@ -36,6 +41,10 @@ struct GemmArgs {
     float* qbuf; void* kcache; void* vcache;
     const int* pos_ptr; int S, H, Tmax, D;
     int kb_slice;                    // filled by the decode-GEMM launcher: 32-wide k-blocks per K slice
+    // s2mel epilogues (packed token rows): sequence / frame of a row, valid frames per sequence, RoPE table [t][32][2],
+    // per-step conditioning vector (EPI_GATE), second f32 output (EPI_WN_RS) with its overwrite / last-layer switches
+    const int* tok_seq; const int* tok_t; const int* seq_len; const float* rope; const float* gvec;
+    float* out2; int wn_first, wn_last;
     int seq_mul;                     // EPI_QKV: cache row of sequence b is b * seq_mul (0/1 = identity); beam prefill writes only row b*nb
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);

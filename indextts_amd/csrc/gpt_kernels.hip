@@ -484,13 +484,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
 #define PF_BK 64
 #define PF_GM 8
 
+__device__ __forceinline__ uint32_t pf_pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+
 template <int EPI>
 __device__ __forceinline__ void pf_epilogue(const GemmArgs& a, int mbase, int nbase, int lane, f32x4 v) {
     const int n = nbase + (lane & 15);
     if (n >= a.N) return;
     const float bias = a.bias ? a.bias[n] : 0.f;
     int which = 0, c = n;
-    if constexpr (EPI == EPI_QKV) { which = n / a.D; c = n - which * a.D; }
+    if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_ROPE) { which = n / a.D; c = n - which * a.D; }
+    if constexpr (EPI == EPI_QKV_ROPE) {
+        // RoPE pairs are adjacent columns = adjacent lanes: partner value by one xor-shuffle (gpt_fast/model.py:348-360)
+        const int hd = c >> 6, d = c & 63, i = d >> 1;
+        const bool odd = d & 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mbase + (lane >> 4) * 4 + r;
+            const int mc = m < a.M ? m : a.M - 1;
+            const float val = v[r] + bias;
+            const float partner = __shfl_xor(val, 1, 64);
+            const int s = a.tok_seq[mc], t = a.tok_t[mc];
+            float y = val;
+            if (which < 2) {
+                const float cs = a.rope[((size_t)t * 32 + i) * 2], sn = a.rope[((size_t)t * 32 + i) * 2 + 1];
+                y = odd ? val * cs + partner * sn : val * cs - partner * sn;
+            }
+            if (m < a.M) {
+                if (which == 0) ((u16*)a.out_act)[(size_t)m * a.D + c] = f32_to_bf16(y);
+                else if (which == 1) ((u16*)a.kcache)[(((size_t)s * a.H + hd) * a.Tmax + t) * 64 + d] = f32_to_bf16(y);
+                else ((u16*)a.vcache)[(((size_t)s * a.H + hd) * 64 + d) * a.Tmax + t] = f32_to_bf16(y);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = mbase + (lane >> 4) * 4 + r;
@@ -499,7 +525,16 @@ __device__ __forceinline__ void pf_epilogue(const GemmArgs& a, int mbase, int nb
         if constexpr (EPI == EPI_STORE_F32) a.out_f32[(size_t)m * a.ldo + n] = val;
         else if constexpr (EPI == EPI_RESIDUAL) a.out_f32[(size_t)m * a.ldo + n] += val;
         else if constexpr (EPI == EPI_GELU_ACT) ((u16*)a.out_act)[(size_t)m * a.ldo + n] = f32_to_bf16(gelu_new_f(val));
-        else {                                                   // EPI_QKV
+        else if constexpr (EPI == EPI_WN_RS) {                   // wavenet.py:158-165
+            if (a.wn_last || n >= a.D) {
+                float* o = a.out2 + (size_t)m * a.D + (a.wn_last ? n : n - a.D);
+                *o = a.wn_first ? val : *o + val;
+            } else {
+                const float mask = a.tok_t[m] < a.seq_len[a.tok_seq[m]] ? 1.f : 0.f;
+                float* o = a.out_f32 + (size_t)m * a.D + n;
+                *o = (*o + val) * mask;
+            }
+        } else {                                                   // EPI_QKV
             if (which == 0) {
                 a.qbuf[(size_t)m * a.D + c] = val;
             } else {
@@ -509,6 +544,29 @@ __device__ __forceinline__ void pf_epilogue(const GemmArgs& a, int mbase, int nb
                 ((u16*)(which == 1 ? a.kcache : a.vcache))[o] = f32_to_bf16(val);
             }
         }
+    }
+}
+
+// Epilogues that combine the two n-tiles of an interleaved pair (tile 2j: first half's columns 16j.., tile 2j+1: the second
+// half's same columns): out_act [M][N/2] bf16.
+template <int EPI>
+__device__ __forceinline__ void pf_epilogue_pair(const GemmArgs& a, int mbase, int ntile, int lane, f32x4 va, f32x4 vb) {
+    const int half = a.N >> 1;
+    const int n = (ntile >> 1) * 16 + (lane & 15);              // column inside a half
+    if (n >= half) return;
+    float ba = 0.f, bb = 0.f;
+    if constexpr (EPI == EPI_GATE) {
+        ba = (a.bias ? a.bias[n] : 0.f) + a.gvec[n];
+        bb = (a.bias ? a.bias[half + n] : 0.f) + a.gvec[half + n];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = mbase + (lane >> 4) * 4 + r;
+        if (m >= a.M) continue;
+        float o;
+        if constexpr (EPI == EPI_SWIGLU) o = (va[r] / (1.0f + expf(-va[r]))) * vb[r];                       // silu(w1 x) * (w3 x)
+        else o = tanhf(va[r] + ba) * (1.0f / (1.0f + expf(-(vb[r] + bb))));                                 // commons.py:133-141
+        ((u16*)a.out_act)[(size_t)m * half + n] = f32_to_bf16(o);
     }
 }
 
@@ -594,13 +652,23 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
                                                                           __builtin_bit_cast(bf16x8_t, bfr[nt]), acc[mt][nt], 0, 0, 0);
         }
     }
+    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GATE) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int ntile = nt0 + wc * 4 + nt;
-            if (ntile < ntiles) pf_epilogue<EPI>(a, m0 + wr * 64 + mt * 16, ntile * 16, lane, acc[mt][nt]);
-        }
+            for (int pr = 0; pr < 2; ++pr) {
+                const int ntile = nt0 + wc * 4 + 2 * pr;
+                if (ntile + 1 < ntiles) pf_epilogue_pair<EPI>(a, m0 + wr * 64 + mt * 16, ntile, lane, acc[mt][2 * pr], acc[mt][2 * pr + 1]);
+            }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int ntile = nt0 + wc * 4 + nt;
+                if (ntile < ntiles) pf_epilogue<EPI>(a, m0 + wr * 64 + mt * 16, ntile * 16, lane, acc[mt][nt]);
+            }
+    }
 }
 
 template <int EPI>
@@ -623,6 +691,10 @@ static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
         case EPI_RESIDUAL: return launch_gemm_prefill_e<EPI_RESIDUAL>(a, st);
         case EPI_GELU_ACT: return launch_gemm_prefill_e<EPI_GELU_ACT>(a, st);
         case EPI_QKV: return launch_gemm_prefill_e<EPI_QKV>(a, st);
+        case EPI_SWIGLU: return launch_gemm_prefill_e<EPI_SWIGLU>(a, st);
+        case EPI_GATE: return launch_gemm_prefill_e<EPI_GATE>(a, st);
+        case EPI_QKV_ROPE: return launch_gemm_prefill_e<EPI_QKV_ROPE>(a, st);
+        case EPI_WN_RS: return launch_gemm_prefill_e<EPI_WN_RS>(a, st);
         default: itts_set_error("gemm prefill: unsupported epilogue %d", a.epi); return ITTS_ERR_ARG;
     }
 }
@@ -886,6 +958,7 @@ static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
         // bf16, K a multiple of the 64-deep K tile, 16-byte aligned rows: the LDS-DMA tile kernel; else the direct-load one
         static const bool old_path = [] { const char* e = getenv("ITTS_PREFILL_GEMM"); return e && atoi(e) == 0; }();
         if (BF16 && !old_path && a.K % PF_BK == 0 && a.lda % 8 == 0 && a.nsplit == 1 && a.epi != EPI_PARTIAL) return launch_gemm_prefill(a, st);
+        if (a.epi > EPI_QKV) { itts_set_error("gemm: epilogue %d needs the bf16 tile kernel (K %% 64 == 0, lda %% 8 == 0)", a.epi); return ITTS_ERR_ARG; }
         return launch_gemm_cfg<BF16, 8, 2, false>(a, st);
     }
     if constexpr (BF16) {

@@ -74,7 +74,8 @@ class Frontend:
 class IndexTTS2:
     def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", use_bf16=False, device=None,
                  use_cuda_kernel=None, use_deepspeed=False, use_accel=False, use_torch_compile=False, use_qwen_emo=False,
-                 *, frontend: Optional[Frontend] = None, gpt=None, bigvgan=None, cfg: Optional[dict] = None):
+                 *, frontend: Optional[Frontend] = None, gpt=None, bigvgan=None, cfg: Optional[dict] = None,
+                 semantic_codec=None, s2mel=None):
         if device is not None:
             self.device = device
         elif torch.cuda.is_available():
@@ -110,6 +111,10 @@ class IndexTTS2:
             from .bigvgan import BigVGAN
             bigvgan = BigVGAN.from_pretrained(os.path.join(model_dir, "hf_cache", "bigvgan")).to(self.device)
         self.bigvgan = bigvgan
+        # codes -> mel on the HIP engine when both stages are given (indextts_amd.codec.EnhancedCodec, indextts_amd.s2mel.MyModel);
+        # otherwise the frontend's codes_to_mel (the reference's PyTorch modules) is used
+        self.semantic_codec = semantic_codec
+        self.s2mel = s2mel
         if frontend is None:
             frontend = ReferenceFrontend(cfg, model_dir, self.device, self.gpt)
         self.frontend = frontend
@@ -304,6 +309,28 @@ class IndexTTS2:
             out.append((22050, wav.type(torch.int16).numpy().T))
         return out
 
+    def codes_to_mel(self, codes: torch.Tensor, code_lens: torch.Tensor, bundle, duration_factor: float = 1.0,
+                     diffusion_steps: int = 25, inference_cfg_rate: float = 0.7, noise: Optional[torch.Tensor] = None):
+        """infer_v2_5.py:830-846 for a whole batch of segments on the HIP engine: semantic_codec.decode -> length_regulator ->
+        [prompt_condition | cond] -> cfm.inference -> drop the prompt frames.  Every row is processed at its own lengths (what the
+        reference's batch-1 call per segment computes).  Returns mel (B, 80, max frames) f32 and the frame counts (B,) int32."""
+        lens = [int(v) for v in code_lens]
+        S_infer = self.semantic_codec.decode(codes, code_lens=lens)                                # (B, 2T, 1024)
+        target = [int(2 * n * 1.72 * duration_factor) for n in lens]                               # :833
+        reg, cfm = self.s2mel.models["length_regulator"], self.s2mel.models["cfm"]
+        cond = reg(S_infer, ylens=torch.tensor(target), n_quantizers=3, f0=None, xlens=[2 * n for n in lens], frame_lens=target)[0]
+        prompt_condition, ref_mel, style = bundle["prompt_condition"], bundle["ref_mel"], bundle["style"]
+        Tp = int(prompt_condition.shape[1])
+        B = codes.shape[0]
+        total = [Tp + t for t in target]
+        cat = torch.zeros(B, max(total), cond.shape[-1], dtype=torch.float32, device=cond.device)
+        cat[:, :Tp] = prompt_condition.to(cond.device, torch.float32)
+        for b in range(B):
+            cat[b, Tp:total[b]] = cond[b, : target[b]]
+        mel = cfm.inference(cat, torch.tensor(total), ref_mel, style, None, diffusion_steps, inference_cfg_rate=inference_cfg_rate,
+                            noise=noise, frame_lens=total)
+        return mel[:, :, Tp:].contiguous(), torch.tensor(target, dtype=torch.int32)
+
     # ---- the hot path: one GPT batch, one ragged vocoder batch -------------------------------------------------------
     def _synthesize(self, segment_tokens: List[torch.Tensor], lang_ids: List[int], bundle, emovec, duration_factor,
                     generation_kwargs, max_text_tokens_per_segment) -> List[torch.Tensor]:
@@ -334,7 +361,10 @@ class IndexTTS2:
                           f"Consider reducing `max_text_tokens_per_segment`({max_text_tokens_per_segment}) or increasing "
                           f"`max_mel_tokens`.", category=RuntimeWarning)
         codes, code_lens = self.trim_codes(codes)
-        mel, mel_lens = self.frontend.codes_to_mel(codes, code_lens, bundle, duration_factor)
+        if self.s2mel is not None and self.semantic_codec is not None:
+            mel, mel_lens = self.codes_to_mel(codes, code_lens, bundle, duration_factor)
+        else:
+            mel, mel_lens = self.frontend.codes_to_mel(codes, code_lens, bundle, duration_factor)
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         t2 = time.perf_counter()
         wav = self.bigvgan(mel.float(), lens=mel_lens)                      # (B, 1, Tmax*256), rows bounded at own length

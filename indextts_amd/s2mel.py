@@ -345,3 +345,37 @@ class CFM:
                 self._h = C.c_void_p()
         except Exception:
             pass
+
+
+class MyModel:
+    """`indextts/s2mel/modules/commons.py::MyModel` as the pipeline uses it (infer_v2_5.py:190-206): a `.models` mapping with
+    the flow-matching decoder and the length regulator, both on the HIP engine."""
+
+    def __init__(self, args, use_gpt_latent: bool = False, precision: str = "bf16", device="cuda:0"):
+        from .codec import InterpolateRegulator
+        lr = _get(args, "length_regulator")
+        self.models = {
+            "cfm": CFM(args, precision=precision, device=device),
+            "length_regulator": InterpolateRegulator(
+                channels=int(_get(lr, "channels")), sampling_ratios=tuple(_get(lr, "sampling_ratios")),
+                is_discrete=bool(_get(lr, "is_discrete", default=False)), in_channels=_get(lr, "in_channels"),
+                vector_quantize=bool(_get(lr, "vector_quantize", default=False)),
+                codebook_size=int(_get(lr, "content_codebook_size", default=1024)),
+                f0_condition=bool(_get(lr, "f0_condition", default=False)), device=device),
+        }
+        if use_gpt_latent:
+            raise NotImplementedError("gpt_layer (IndexTTS-2 latent projector) is three small Linear layers on the PyTorch side")
+
+    def load_state_dict(self, net: Dict[str, Dict[str, torch.Tensor]]):
+        """`net` = the checkpoint's `state['net']` mapping (load_checkpoint2, commons.py): {'cfm': sd, 'length_regulator': sd};
+        `module.` prefixes of DDP checkpoints are stripped."""
+        strip = lambda sd: {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        self.models["cfm"].load_state_dict(strip(net["cfm"]))
+        self.models["length_regulator"].load_state_dict(strip(net["length_regulator"]))
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self

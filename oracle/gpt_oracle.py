@@ -410,6 +410,8 @@ def generate_sample(model: InferenceModel, inputs: torch.Tensor, attention_mask:
         if trace is not None:
             trace.setdefault("logits", []).append(next_logits.clone())
         scores = process_scores(next_logits, input_ids, gp)
+        if trace is not None:
+            trace.setdefault("scores", []).append(scores.clone())     # what the selection actually ranks (after the processors)
         if gp.do_sample:
             probs = torch.softmax(scores, dim=-1)
             nxt = torch.tensor([inverse_cdf_pick(probs[b], float(uniforms[step, b])) for b in range(B)])
