@@ -5,8 +5,9 @@ One "step" = one pass of the hot path over the synthetic 64-utterance batch (BAS
     speaker-bundle broadcast (RCCL when N > 1)
     -> GPT speech-token decode of this rank's utterances (prefill + 560 sampled tokens each, top-k 30 / top-p 0.8 / T 0.8 /
        repetition penalty 10, bf16 weights + KV)
-    -> [s2mel: codes -> mel on the HIP engine when `--s2mel` (default once the stage is built); otherwise a synthetic mel of
-       the length the pipeline would hand over, int(2 * n_tokens * 1.72) frames, indextts/infer_v2_5.py:833]
+    -> codes -> mel: semantic-codec decode, length regulator, 25-step classifier-free-guidance flow matching over
+       [speaker prompt | int(2 * n_tokens * 1.72) target frames] (indextts/infer_v2_5.py:830-846), bf16 GEMMs / attention
+       (`--no-s2mel` vocodes a synthetic mel of that length instead: the round-1 hot-path-only measurement)
     -> BigVGAN (80-band mel -> 22.05 kHz wave, fp32) -> int16 -> waveforms gathered on rank 0.
 Scaling is STRONG by default: the 64 utterances are LPT-sharded over the N ranks (`indextts_amd.dist.shard_utterances`),
 64/N per GPU, as BASELINE.json's metric ("64-utt batch @1/2/4/8") says; `--weak` keeps 64 utterances per GPU instead.
@@ -162,17 +163,59 @@ class HipEngine:
         self.voc.set_profiling(True)
         self.prof_acc = {}
         self.gpt_t = {"prefill_ms": 0.0, "decode_ms": 0.0, "steps": 0}
+        self.s2 = None
+        self.s2_t = {"codec_regulator_ms": 0.0, "cfm_ms": 0.0, "gemm_ms": 0.0, "gemm_flops": 0.0, "attention_ms": 0.0,
+                     "attention_flops": 0.0, "estimator_ms": 0.0, "launches": 0}
+        if not args.no_s2mel:
+            from indextts_amd import codec, s2mel
+            self.codec = codec.EnhancedCodec(**synth.CODEC_V2, device=dev)
+            self.codec.load_state_dict(synth.codec_weights(seed=1234))
+            self.s2_args = dict(synth.S2MEL_V2, length_regulator=synth.REGULATOR_V2)
+            self.s2 = s2mel.MyModel(self.s2_args, precision=args.precision, device=dev)
+            self.s2.models["cfm"].load_state_dict(synth.s2mel_weights(seed=1234))
+            self.s2.models["length_regulator"].load_state_dict(synth.regulator_weights(seed=1234))
+            self.s2.models["cfm"].set_profiling(True)
+            self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         self.gen_kw = dict(do_sample=True, top_p=0.8, top_k=30, temperature=0.8, num_beams=1, repetition_penalty=10.0,
                            length_penalty=0.0)
         if rank == 0:
             log(f"[bench] weights synthesised + packed + uploaded in {time.perf_counter() - t_load:.1f}s")
 
-    def step(self, text, langs, mel, style, emo_vec, n_gen, record):
+    def step(self, text, langs, mel, bundle, n_gen, record):
         """-> int16 waveforms (b, T*256) of this rank's utterances"""
         B = text.shape[0]
+        style, emo_vec = bundle["style"], bundle["emo_vec"]
         codes, _ = self.model.inference_speech(None, text, langs=langs, emo_vec=emo_vec, campplus_embedding=style,
                                                max_generate_length=n_gen, **self.gen_kw)
         assert codes.shape == (B, n_gen), codes.shape
+        if self.s2 is not None:
+            # codes -> content features -> 25-step CFG flow matching -> mel (indextts/infer_v2_5.py:830-846), all on the engine
+            from indextts_amd import s2mel
+            cfm = self.s2.models["cfm"]
+            self._ev[0].record()
+            S_infer = self.codec.decode(codes, code_lens=[n_gen] * B)
+            target = [int(2 * n_gen * 1.72)] * B
+            cond = self.s2.models["length_regulator"](S_infer, ylens=torch.tensor(target), n_quantizers=3, f0=None,
+                                                      xlens=[2 * n_gen] * B, frame_lens=target)[0]
+            self._ev[1].record()
+            Tp = int(bundle["prompt_condition"].shape[1])
+            cat = torch.cat([bundle["prompt_condition"].expand(B, -1, -1), cond], dim=1)
+            total = [Tp + target[0]] * B
+            mel = cfm.inference(cat, torch.tensor(total), bundle["ref_mel"], style, None, 25, inference_cfg_rate=0.7,
+                                frame_lens=total)[:, :, Tp:].contiguous()
+            self._ev[2].record()
+            assert mel.shape == (B, 80, target[0]), mel.shape
+            if record:
+                pr = cfm.profile()                                 # synchronises the launch stream
+                t = self.s2_t
+                t["codec_regulator_ms"] += self._ev[0].elapsed_time(self._ev[1])
+                t["cfm_ms"] += self._ev[1].elapsed_time(self._ev[2])
+                t["gemm_ms"] += pr["gemm"]["ms"]
+                t["gemm_flops"] += pr["gemm"]["flops"]
+                t["attention_ms"] += pr["attention"]["ms"]
+                t["attention_flops"] += 4.0 * cfm.hidden_dim * (2 * B) * float(total[0]) ** 2 * pr["attention"]["launches"]
+                t["estimator_ms"] += pr["estimator_calls"]["ms"]
+                t["launches"] += pr["gemm"]["launches"] + pr["attention"]["launches"]
         chunk = self.args.bigvgan_chunk or B
         outs = []
         for b0 in range(0, B, chunk):
@@ -221,10 +264,10 @@ class StubEngine:
     def __init__(self, args, dev, rank):
         self.prof_acc, self.gpt_t = {}, {"prefill_ms": 0.0, "decode_ms": 0.0, "steps": 0}
 
-    def step(self, text, langs, mel, style, emo_vec, n_gen, record):
+    def step(self, text, langs, mel, bundle, n_gen, record):
         b, t = text.shape[0], mel.shape[-1] * HOP
         base = (text[:, :1].to(torch.int64) % 97).to(torch.int16)           # a value that identifies the utterance
-        return base.expand(b, t).contiguous() + int(style.double().sum() * 0)
+        return base.expand(b, t).contiguous() + int(bundle["style"].double().sum() * 0)
 
 
 def main():
@@ -239,6 +282,9 @@ def main():
     ap.add_argument("--gen-tokens", type=int, default=560)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--bigvgan-chunk", type=int, default=0, help="utterances per BigVGAN launch group (0 = all)")
+    ap.add_argument("--no-s2mel", action="store_true", help="skip codes -> mel (codec, length regulator, 25-step CFM) and vocode a "
+                                                           "synthetic mel instead (the round-1 hot-path-only measurement)")
+    ap.add_argument("--prompt-frames", type=int, default=517, help="reference-speaker prompt length in mel frames (6 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all usable cores)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed beam-3 / f32-mode decode measurements")
@@ -296,12 +342,16 @@ def main():
     # speaker bundle: produced by the prompt encoders on rank 0 in the real pipeline, broadcast once per batch
     bundle0 = None
     if rank == 0:
-        bundle0 = {"style": torch.randn(1, 192, generator=torch.Generator().manual_seed(5)).to(dev),
-                   "emo_vec": (torch.randn(1, D_model, generator=torch.Generator().manual_seed(6)) * 0.1).to(dev)}
+        gb = torch.Generator().manual_seed(5)
+        bundle0 = {"style": torch.randn(1, 192, generator=gb).to(dev),
+                   "emo_vec": (torch.randn(1, D_model, generator=torch.Generator().manual_seed(6)) * 0.1).to(dev),
+                   # what the prompt-side stages hand over for the flow-matching decoder (indextts/infer_v2_5.py:641-667)
+                   "ref_mel": (torch.randn(1, n_mels, args.prompt_frames, generator=gb) * 2 - 4).to(dev),
+                   "prompt_condition": torch.randn(1, args.prompt_frames, 512, generator=gb).to(dev)}
 
     def one_step(record):
         bundle = D.broadcast_speaker_bundle(bundle0, src=0, device=dev) if dist is not None else bundle0
-        wav16 = eng.step(text, langs, mel, bundle["style"], bundle["emo_vec"], n_gen, record)
+        wav16 = eng.step(text, langs, mel, bundle, n_gen, record)
         return D.gather_waveform_tensor(wav16, mine, n_total, dst=0) if dist is not None else wav16
 
     def barrier():
@@ -340,15 +390,20 @@ def main():
             "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None,
-            "dtype": "bf16 (GPT weights/KV/GEMM inputs, f32 accumulate) + f32 (BigVGAN)" if args.precision == "bf16" else "f32",
-            "data": "synthetic (seeded random-init weights of the IndexTTS-2.5 architecture; synthetic text ids, "
-                    "conditioning vectors and mel; EOS suppressed so every row decodes all tokens)",
+            "dtype": ("bf16 (GPT and s2mel GEMM operands / K,V / attention probabilities; f32 accumulate, residual streams, norms) + "
+                      "f32 (codec decode, length regulator, BigVGAN)") if args.precision == "bf16" else "f32",
+            "data": "synthetic (seeded random-init weights of the IndexTTS-2.5 architecture; synthetic text ids, conditioning "
+                    "vectors, prompt mel / prompt condition" + ("" if not args.no_s2mel else " and mel") +
+                    "; EOS suppressed so every row decodes all tokens)",
             "rtf": 1.0 / value * n_total,          # wall seconds per audio second of ONE utterance stream
             "engine": eng.name,
-            "config": {"workload": f"IndexTTS-2.5 hot path (GPT speech-token decode + BigVGAN; s2mel excluded: synthetic mel), "
-                                   f"{n_total} utterances x {n_text} text tokens -> {n_gen} speech tokens (top-k 30, top-p 0.8, "
-                                   f"T 0.8, rep-penalty 10, num_beams 1) + BigVGAN-v2 22 kHz on {t_mel}-frame mels "
-                                   f"(BASELINE.json configs[2]), {B} utterances on each of {world} GPU(s)",
+            "config": {"workload": (f"IndexTTS-2.5 codes-to-waveform path, {n_total} utterances x {n_text} text tokens -> GPT decode of "
+                                    f"{n_gen} speech tokens (top-k 30, top-p 0.8, T 0.8, rep-penalty 10, num_beams 1) -> "
+                                    + (f"semantic-codec decode + length regulator + 25-step CFG flow matching (DiT 13 x 512, "
+                                       f"{args.prompt_frames}-frame speaker prompt) -> " if not args.no_s2mel else
+                                       "[s2mel skipped: synthetic mel] -> ")
+                                    + f"BigVGAN-v2 22 kHz on {t_mel}-frame mels (BASELINE.json configs[2]), {B} utterances on each of "
+                                      f"{world} GPU(s); prompt encoders / text front end not included"),
                        "global_batch": n_total, "per_gpu_batch": B, "text_tokens": n_text, "gen_tokens": n_gen,
                        "mel_frames": t_mel, "audio_seconds_per_utt": t_mel * HOP / SR, "parallelism": f"utterance-dp{world}",
                        "use_hipgraph": not args.no_graph},
@@ -383,6 +438,8 @@ def main():
 def gpu_report(args, eng, B, n_text, n_gen, t_mel):
     """roofline (dominant kernel) + stage split from rank 0's HIP-event records of the timed steps."""
     prof_acc, gpt_t, gcfg = eng.prof_acc, eng.gpt_t, eng.gcfg
+    if args.precision == "fp32" and eng.s2 is not None:
+        eng.s2_t = dict(eng.s2_t)
     conv = prof_acc.get("conv1d_mfma", dict(ms=1e-9, launches=1, flops=0.0, bytes=0.0))
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
     # HBM traffic of the same kernel: PMC counters cannot be read from inside this process, so the figure comes from
@@ -411,6 +468,17 @@ def gpu_report(args, eng, B, n_text, n_gen, t_mel):
         "gpt_decode_ms_per_token": ms_tok,
         "gpt_decode_algorithmic_GBps": bytes_step / (ms_tok * 1e-3) / 1e9,
         "gpt_decode_hbm_frac": bytes_step / (ms_tok * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+        "s2mel": None if eng.s2 is None else {
+            "codec_regulator_ms_per_step": eng.s2_t["codec_regulator_ms"] / args.steps,
+            "cfm_ms_per_step": eng.s2_t["cfm_ms"] / args.steps,        # 25 Euler steps x CFG batch-2 estimator, host prep included
+            "cfm_estimator_ms_per_step": eng.s2_t["estimator_ms"] / args.steps,
+            "cfm_gemm_ms_per_step": eng.s2_t["gemm_ms"] / args.steps,
+            "cfm_gemm_tflops": eng.s2_t["gemm_flops"] / max(1e-9, eng.s2_t["gemm_ms"] * 1e-3) / 1e12,
+            "cfm_gemm_mfma_frac": eng.s2_t["gemm_flops"] / max(1e-9, eng.s2_t["gemm_ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+            "cfm_attention_ms_per_step": eng.s2_t["attention_ms"] / args.steps,
+            "cfm_attention_tflops": eng.s2_t["attention_flops"] / max(1e-9, eng.s2_t["attention_ms"] * 1e-3) / 1e12,
+            "cfm_elementwise_ms_per_step": (eng.s2_t["estimator_ms"] - eng.s2_t["gemm_ms"] - eng.s2_t["attention_ms"]) / args.steps,
+            "prompt_frames": args.prompt_frames, "euler_steps": 25, "cfg_rate": 0.7},
         "bigvgan_ms_per_step": sum(v["ms"] for v in prof_acc.values()) / args.steps,
         "bigvgan_kernels": {k: dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
                                     tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),

@@ -271,6 +271,11 @@ int itts_s2mel_solve(itts_s2mel* h, float* x_state, const float* const_in, const
                      const int32_t* seq_len, const int32_t* prompt_len, int n_seq, int n_tok, int t_max, int n_branch, int n_steps,
                      const float* t_span, float cfg_rate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* HIP-event timing of the last estimator / solve call per kernel class: [0] GEMMs on the MFMA tile kernels (algorithmic FLOPs
+ * reported), [1] attention, [2] the wall span of every estimator call (element-wise time = [2] - [0] - [1]). */
+int itts_s2mel_set_profiling(itts_s2mel* h, int enable);
+int itts_s2mel_profile_read(itts_s2mel* h, double* ms, double* launches, double* flops);
+
 /* unit-level (parity tests): one layer's RoPE + split + non-causal attention.  replaces: Attention.forward between wqkv and wo
  * (gpt_fast/model.py:262-307): qkv f32 [n_tok][3 * heads * 64] -> out [n_tok][heads * 64] in the precision's activation type. */
 size_t itts_s2mel_attention_scratch_bytes(int n_tok, int n_seq, int heads, int t_max, int precision);

@@ -100,6 +100,8 @@ SIGNATURES = {
     "itts_s2mel_estimator": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
     "itts_s2mel_solve": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.POINTER(C.c_float), C.c_float, vp, C.c_size_t, vp]),
+    "itts_s2mel_set_profiling": (C.c_int, [vp, C.c_int]),
+    "itts_s2mel_profile_read": (C.c_int, [vp, vp, vp, vp]),
     "itts_s2mel_attention_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "itts_s2mel_attention_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
                                                C.c_size_t, vp]),

@@ -48,6 +48,34 @@ struct itts_s2mel {
     std::vector<void*> owned;
     bool finalized = false;
     int device = -1;
+    // optional HIP-event timing per kernel class (itts_s2mel_set_profiling): events are recorded on the launch stream around
+    // every launch of the last solve / estimator call
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct Rec { int cls; double flops; };
+    std::vector<Rec> recs;
+    hipStream_t prof_stream = nullptr;
+};
+
+enum { S2_GEMM = 0, S2_ATTN = 1, S2_OTHER = 2, S2_CLASSES = 3 };
+
+struct S2Prof {
+    itts_s2mel* h;
+    hipStream_t st;
+    bool on;
+    size_t idx;
+    S2Prof(itts_s2mel* h_, hipStream_t st_, int cls, double flops) : h(h_), st(st_), on(h_->profiling), idx(0) {
+        if (!on) return;
+        idx = h->recs.size();
+        h->recs.push_back({cls, flops});
+        while (h->ev_pool.size() < 2 * (idx + 1)) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { on = false; h->recs.pop_back(); return; }
+            h->ev_pool.push_back(e);
+        }
+        (void)hipEventRecord(h->ev_pool[2 * idx], st);
+    }
+    ~S2Prof() { if (on) (void)hipEventRecord(h->ev_pool[2 * idx + 1], st); }
 };
 
 static int s2_upload(itts_s2mel* h, const void* host, size_t bytes, void** dst) {
@@ -91,7 +119,31 @@ extern "C" void itts_s2mel_destroy(itts_s2mel* h) {
     if (!h) return;
     ItDevGuard dg(h->device);
     for (void* p : h->owned) (void)hipFree(p);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
+}
+
+extern "C" int itts_s2mel_set_profiling(itts_s2mel* h, int enable) {
+    if (!h) { itts_set_error("s2mel_set_profiling: null"); return ITTS_ERR_ARG; }
+    h->profiling = enable != 0;
+    h->recs.clear();
+    return ITTS_OK;
+}
+
+// Totals of the last solve / estimator call per class (0 GEMMs on the MFMA tile kernels, 1 attention, 2 everything else):
+// GPU milliseconds between the events bracketing each launch, launch count, algorithmic FLOPs.  Synchronises the stream.
+extern "C" int itts_s2mel_profile_read(itts_s2mel* h, double* ms, double* launches, double* flops) {
+    if (!h || !ms || !launches || !flops) { itts_set_error("s2mel_profile_read: null"); return ITTS_ERR_ARG; }
+    ItDevGuard dg(h->device);
+    for (int i = 0; i < S2_CLASSES; ++i) ms[i] = launches[i] = flops[i] = 0;
+    if (h->recs.empty()) return ITTS_OK;
+    HIP_TRY(hipStreamSynchronize(h->prof_stream));
+    for (size_t i = 0; i < h->recs.size(); ++i) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
+        ms[h->recs[i].cls] += t; launches[h->recs[i].cls] += 1; flops[h->recs[i].cls] += h->recs[i].flops;
+    }
+    return ITTS_OK;
 }
 
 // Tensors by reference state-dict name with weight-norm folded into `.weight` (host side): see itts_s2mel_finalize for the list.
@@ -305,16 +357,23 @@ extern "C" size_t itts_s2mel_workspace_bytes(const itts_s2mel* h, int n_tok, int
 }
 
 // ---- one estimator call ----------------------------------------------------------------------------------------
-static int s2_gemm(const itts_s2mel* h, const void* A, int lda, const void* Wp, const float* bias, float* out, int ldo, int M, int N, int K,
-                   int epi, hipStream_t st) {
-    GemmArgs g{};
-    g.A = A; g.lda = lda; g.Wp = Wp; g.bias = bias; g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.epi = epi; g.out_f32 = out; g.ldo = ldo; g.D = N;
+static int s2_launch_gemm(itts_s2mel* h, const GemmArgs& g, hipStream_t st) {
+    S2Prof ps(h, st, S2_GEMM, 2.0 * g.M * (double)g.N * g.K);
     return launch_gemm(g, h->cfg.precision, true, st);
 }
 
+static int s2_gemm(itts_s2mel* h, const void* A, int lda, const void* Wp, const float* bias, float* out, int ldo, int M, int N, int K,
+                   int epi, hipStream_t st) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.Wp = Wp; g.bias = bias; g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.epi = epi; g.out_f32 = out; g.ldo = ldo; g.D = N;
+    return s2_launch_gemm(h, g, st);
+}
+
 // x_src [src_rows][C] f32 (row m of the token matrix reads x_src row m % src_rows); d_out [n_tok][C]
+// attn_flops: 4 * hidden * sum_s T_s * len_s of one attention call (for the profile records only)
 static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_pad, const float* x_src, int src_rows, const float* const_in,
-                        const float* mods, const float* rope, float* d_out, hipStream_t st) {
+                        const float* mods, const float* rope, float* d_out, hipStream_t st, double attn_flops = 0.0) {
+    S2Prof whole(h, st, S2_OTHER, 0.0);          // the call's wall span; the GEMM / attention spans inside are subtracted by the reader
     const itts_s2mel_config& c = h->cfg;
     const int H = c.hidden_dim, I = h->I, W = c.wavenet_hidden, C = c.in_channels, Kx = h->Kx, N = tab.n_tok, prec = c.precision;
     const int nh = c.num_heads;
@@ -341,18 +400,19 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
             g.A = w.HB; g.lda = H; g.Wp = L.w_qkv; g.M = N; g.N = 3 * H; g.K = H; g.nsplit = 1; g.epi = EPI_QKV_ROPE;
             g.out_act = w.QA; g.kcache = w.KC; g.vcache = w.VC; g.D = H; g.H = nh; g.Tmax = t_pad;
             g.tok_seq = tab.tok_seq; g.tok_t = tab.tok_t; g.rope = rope;
-            if ((rc = launch_gemm(g, prec, true, st))) return rc;
+            if ((rc = s2_launch_gemm(h, g, st))) return rc;
         } else {
             if ((rc = s2_gemm(h, w.HB, H, L.w_qkv, nullptr, w.BIG, 3 * H, N, 3 * H, H, EPI_STORE_F32, st))) return rc;
             if ((rc = launch_rope_split(w.BIG, rope, w.QA, w.KC, w.VC, tab, nh, t_pad, prec, st))) return rc;
         }
-        if ((rc = launch_s2mel_attention(w.QA, w.KC, w.VC, w.AO, tab, nh, t_pad, prec, st))) return rc;
+        { S2Prof ps(h, st, S2_ATTN, attn_flops);
+          if ((rc = launch_s2mel_attention(w.QA, w.KC, w.VC, w.AO, tab, nh, t_pad, prec, st))) return rc; }
         if ((rc = s2_gemm(h, w.AO, H, L.w_o, nullptr, X, H, N, H, H, EPI_RESIDUAL, st))) return rc;
         if ((rc = launch_ada_rmsnorm(X, L.g_ffn, mods + (size_t)i * 4 * H + 2 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
         if (fused) {                                               // [w1 ; w3] GEMM with the SwiGLU combine in the epilogue
             GemmArgs g{};
             g.A = w.HB; g.lda = H; g.Wp = L.w_13; g.M = N; g.N = 2 * I; g.K = H; g.nsplit = 1; g.epi = EPI_SWIGLU; g.out_act = w.FC; g.D = I;
-            if ((rc = launch_gemm(g, prec, true, st))) return rc;
+            if ((rc = s2_launch_gemm(h, g, st))) return rc;
         } else {
             if ((rc = s2_gemm(h, w.HB, H, L.w_13, nullptr, w.BIG, 2 * I, N, 2 * I, H, EPI_STORE_F32, st))) return rc;
             if ((rc = launch_swiglu(w.BIG, w.FC, N, I, prec, st))) return rc;
@@ -384,12 +444,12 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
             GemmArgs g{};
             g.A = w.COL; g.lda = c.wavenet_kernel * W; g.Wp = Wn.w_in; g.bias = Wn.b_in; g.M = N; g.N = 2 * W; g.K = c.wavenet_kernel * W;
             g.nsplit = 1; g.epi = EPI_GATE; g.out_act = w.FC; g.gvec = m_gc + (size_t)i * 2 * W; g.D = W;
-            if ((rc = launch_gemm(g, prec, true, st))) return rc;
+            if ((rc = s2_launch_gemm(h, g, st))) return rc;
             GemmArgs r{};
             r.A = w.FC; r.lda = W; r.Wp = Wn.w_rs; r.bias = Wn.b_rs; r.M = N; r.N = ro; r.K = W; r.nsplit = 1; r.epi = EPI_WN_RS;
             r.out_f32 = w.WX; r.out2 = w.OUT; r.D = W; r.wn_first = i == 0; r.wn_last = last;
             r.tok_seq = tab.tok_seq; r.tok_t = tab.tok_t; r.seq_len = tab.seq_len;
-            if ((rc = launch_gemm(r, prec, true, st))) return rc;
+            if ((rc = s2_launch_gemm(h, r, st))) return rc;
         } else {
             if ((rc = s2_gemm(h, w.COL, c.wavenet_kernel * W, Wn.w_in, Wn.b_in, w.BIG, 2 * W, N, 2 * W, c.wavenet_kernel * W, EPI_STORE_F32, st))) return rc;
             if ((rc = launch_wn_gate(w.BIG, m_gc + (size_t)i * 2 * W, w.FC, N, W, prec, st))) return rc;
@@ -443,6 +503,8 @@ extern "C" int itts_s2mel_estimator(itts_s2mel* h, const float* x, const float* 
     const size_t kv = (size_t)((char*)w.VC - (char*)w.KC);
     HIP_TRY(hipMemsetAsync(w.KC, 0, 2 * kv, st));                 // keys / values past a sequence's end must be finite
     const SeqTab tab = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tok, t_max);
+    h->recs.clear();
+    h->prof_stream = st;
     return s2_estimator(h, w, tab, t_pad, x, n_tok, const_in, mods, rope, d_out, st);
 }
 
@@ -471,6 +533,8 @@ extern "C" int itts_s2mel_solve(itts_s2mel* h, float* x_state, const float* cons
     HIP_TRY(hipMemsetAsync(w.KC, 0, 2 * kv, st));
     const SeqTab tab = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tok, t_max);
     const int mps = itts_s2mel_mods_per_step(h);
+    h->recs.clear();
+    h->prof_stream = st;
     for (int step = 0; step < n_steps; ++step) {                   // flow_matching.py:84-113
         int rc = s2_estimator(h, w, tab, t_pad, x_state, n_tok / n_branch, const_in, mods + (size_t)step * mps, rope, w.D, st);
         if (rc) return rc;

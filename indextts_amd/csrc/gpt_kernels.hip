@@ -206,9 +206,9 @@ static int launch_ln_small_t(const LnArgs& a, hipStream_t st) {
     dim3 grid(ceil_div(a.rows, 4));
 #define LN_CASE(NE) case NE: hipLaunchKernelGGL((ln_small_kernel<NE, OUT_BF16>), grid, dim3(256), 0, st, a); break;
     switch (a.D / 64) {
-        LN_CASE(2) LN_CASE(4) LN_CASE(6) LN_CASE(8) LN_CASE(10) LN_CASE(12) LN_CASE(14) LN_CASE(16) LN_CASE(20) LN_CASE(24) LN_CASE(32)
+        LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(6) LN_CASE(8) LN_CASE(10) LN_CASE(12) LN_CASE(14) LN_CASE(16) LN_CASE(20) LN_CASE(24) LN_CASE(32)
         default:
-            itts_set_error("layernorm: model_dim %d unsupported (need 64 * {2,4,6,8,10,12,14,16,20,24,32})", a.D);
+            itts_set_error("layernorm: model_dim %d unsupported (need 64 * {1,2,4,6,8,10,12,14,16,20,24,32})", a.D);
             return ITTS_ERR_ARG;
     }
 #undef LN_CASE
@@ -570,6 +570,120 @@ __device__ __forceinline__ void pf_epilogue_pair(const GemmArgs& a, int mbase, i
     }
 }
 
+typedef __bf16 pf_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float pf_f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+// v_cvt_pk_bf16_f32 (gfx950): hardware round-to-nearest-even of two f32
+__device__ __forceinline__ uint32_t pf_cvt2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(pf_f32x2_t{a, b}, pf_bf16x2_t)); }
+__device__ __forceinline__ v2u_t pf_cvt4(f32x4 v) { return v2u_t{pf_cvt2(v[0], v[1]), pf_cvt2(v[2], v[3])}; }
+
+// Tile store of the bf16 tile kernel: the 128 x 128 f32 accumulator tile has been transposed through LDS (ct, row-major, the
+// 16-float column groups XOR-swizzled by (row >> 2) & 3), so every thread owns 4 CONSECUTIVE columns of a row and the global
+// accesses are 16-byte (f32) / 8-byte (bf16) pieces of full lines.  The MFMA accumulator layout itself gives each lane 4 rows
+// of one column: 64-byte row segments, half-used lines and read-modify-write at that granularity (measured: the N = 512 f32
+// residual GEMMs of the s2mel DiT ran at 1.4 TB/s of output traffic).
+template <int EPI>
+__device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct, int m0, int n0, int tid) {
+    constexpr bool PAIR = (EPI == EPI_SWIGLU || EPI == EPI_GATE);
+    constexpr int CH = PAIR ? 16 : 32;                              // 4-column chunks per tile row
+    const int half = a.N >> 1;
+#pragma unroll 4
+    for (int i = 0; i < (128 * CH) / 256; ++i) {
+        const int chunk = tid + 256 * i;
+        const int row = chunk / CH, c4 = chunk - row * CH;
+        const int m = m0 + row;
+        if (m >= a.M) continue;
+        const int sw = ((row >> 2) & 3) << 4;
+        if constexpr (PAIR) {
+            const int j = c4 >> 2, cc = (c4 & 3) * 4;                 // pair j of the block, column inside the 16-wide tile
+            const int n = (n0 >> 1) + j * 16 + cc;                    // column inside a half
+            if (n >= half) continue;
+            const f32x4 va = *(const f32x4*)(ct + row * 128 + (((2 * j) * 16 + cc) ^ sw));
+            const f32x4 vb = *(const f32x4*)(ct + row * 128 + (((2 * j + 1) * 16 + cc) ^ sw));
+            f32x4 o;
+            if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (va[q] / (1.0f + expf(-va[q]))) * vb[q];
+            } else {
+                const f32x4 b1 = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 b2 = a.bias ? *(const f32x4*)(a.bias + half + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 g1 = *(const f32x4*)(a.gvec + n), g2 = *(const f32x4*)(a.gvec + half + n);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = tanhf(va[q] + b1[q] + g1[q]) * (1.0f / (1.0f + expf(-(vb[q] + b2[q] + g2[q]))));
+            }
+            *(v2u_t*)((u16*)a.out_act + (size_t)m * half + n) = pf_cvt4(o);
+        } else {
+            const int n = n0 + c4 * 4;
+            if (n >= a.N) continue;
+            f32x4 v = *(const f32x4*)(ct + row * 128 + ((c4 * 4) ^ sw));
+            if (a.bias) {
+                const f32x4 b = *(const f32x4*)(a.bias + n);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += b[q];
+            }
+            if constexpr (EPI == EPI_STORE_F32) {
+                *(f32x4*)(a.out_f32 + (size_t)m * a.ldo + n) = v;
+            } else if constexpr (EPI == EPI_RESIDUAL) {
+                f32x4* o = (f32x4*)(a.out_f32 + (size_t)m * a.ldo + n);
+                const f32x4 old = *o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] += old[q];
+                *o = v;
+            } else if constexpr (EPI == EPI_GELU_ACT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gelu_new_f(v[q]);
+                *(v2u_t*)((u16*)a.out_act + (size_t)m * a.ldo + n) = v2u_t{(uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
+                                                                          (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)};
+            } else if constexpr (EPI == EPI_WN_RS) {
+                if (a.wn_last || n >= a.D) {
+                    f32x4* o = (f32x4*)(a.out2 + (size_t)m * a.D + (a.wn_last ? n : n - a.D));
+                    if (!a.wn_first) {
+                        const f32x4 old = *o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += old[q];
+                    }
+                    *o = v;
+                } else {
+                    const float mask = a.tok_t[m] < a.seq_len[a.tok_seq[m]] ? 1.f : 0.f;
+                    f32x4* o = (f32x4*)(a.out_f32 + (size_t)m * a.D + n);
+                    const f32x4 old = *o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (old[q] + v[q]) * mask;
+                    *o = v;
+                }
+            } else if constexpr (EPI == EPI_QKV) {                    // GPT prefill: q f32, K / V appended to the bf16 cache
+                const int which = n / a.D, c = n - which * a.D;
+                if (which == 0) {
+                    *(f32x4*)(a.qbuf + (size_t)m * a.D + c) = v;
+                } else {
+                    const int b = m / a.S, si = m - b * a.S;
+                    const int pos = *a.pos_ptr + si;
+                    const size_t o = (((size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1) * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
+                    *(v2u_t*)((u16*)(which == 1 ? a.kcache : a.vcache) + o) =
+                        v2u_t{(uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16), (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)};
+                }
+            } else {                                                   // EPI_QKV_ROPE (s2mel): both RoPE pairs of the chunk are in-thread
+                const int which = n / a.D, c = n - which * a.D;
+                const int hd = c >> 6, d = c & 63;
+                const int s = a.tok_seq[m], t = a.tok_t[m];
+                if (which < 2) {
+                    const f32x4 cs = *(const f32x4*)(a.rope + ((size_t)t * 32 + (d >> 1)) * 2);       // (cos, sin) of pairs d/2, d/2 + 1
+                    const f32x4 y{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
+                    if (which == 0) *(v2u_t*)((u16*)a.out_act + (size_t)m * a.D + c) = pf_cvt4(y);
+                    else *(v2u_t*)((u16*)a.kcache + (((size_t)s * a.H + hd) * a.Tmax + t) * 64 + d) = pf_cvt4(y);
+                } else {
+                    u16* vt = (u16*)a.vcache + (((size_t)s * a.H + hd) * 64 + d) * a.Tmax + t;
+                    const v2u_t pk = pf_cvt4(v);
+                    vt[0] = (u16)(pk.x & 0xffffu);
+                    vt[(size_t)a.Tmax] = (u16)(pk.x >> 16);
+                    vt[(size_t)2 * a.Tmax] = (u16)(pk.y & 0xffffu);
+                    vt[(size_t)3 * a.Tmax] = (u16)(pk.y >> 16);
+                }
+            }
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB | W 16 KiB]
@@ -651,6 +765,24 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[mt]),
                                                                           __builtin_bit_cast(bf16x8_t, bfr[nt]), acc[mt][nt], 0, 0, 0);
         }
+    }
+    // Epilogue.  Vector path (every shape of the engine: N, ldo, D multiples of 4): transpose the accumulator tile through LDS
+    // and store full-line pieces (pf_store_tile); otherwise the per-lane element path.
+    const bool vec_ok = (a.N % 4 == 0) && (a.ldo % 4 == 0 || (EPI != EPI_STORE_F32 && EPI != EPI_RESIDUAL && EPI != EPI_GELU_ACT)) && (a.D % 4 == 0);
+    if (vec_ok) {
+        __syncthreads();                                           // every wave is done with the operand buffers
+        float* ct = (float*)pf_sm;                                 // [128][128] f32 = the whole 64 KiB
+        const int g = lane >> 4, c16 = lane & 15;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ct[(wr * 64 + mt * 16 + g * 4 + r) * 128 + ((wc * 64 + nt * 16 + c16) ^ (g << 4))] = acc[mt][nt][r];
+        __syncthreads();
+        pf_store_tile<EPI>(a, ct, m0, nt0 * 16, threadIdx.x);
+        return;
     }
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GATE) {
 #pragma unroll

@@ -13,6 +13,7 @@
 // mode).  Tokens of all sequences (CFG branches x utterances) are packed into one [n_tok][channels] matrix, so the GEMMs see
 // no padding; attention, RoPE, the reflect-padded convs and the masks find a row's sequence through SeqTab.
 // head_dim is 64 (hidden 512 / 8 heads in the shipped configuration).
+#include <stdlib.h>
 #include "s2mel_kernels.h"
 #include "gpt_kernels.h"
 
@@ -20,7 +21,12 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// v_cvt_pk_bf16_f32 (gfx950): two f32 -> packed bf16, round-to-nearest-even in hardware (one instruction instead of ~10)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
 
 template <bool BF16>
 __device__ __forceinline__ void store_act4(void* base, size_t idx, f32x4 v) {      // 4 consecutive elements at element index idx
@@ -260,26 +266,32 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 // ================================================================================================================
 #define FA_LD 72          // bf16 elements per LDS row
 
+// QS = 16-query sub-tiles per wave (block = 64 * QS queries).  Every K / V^T fragment read from LDS feeds QS MFMAs: with one
+// sub-tile the kernel is LDS-bound (16 KB of fragment reads per 16 MFMAs per wave), with four the MFMA pipe is the limit.
+template <int QS>
 __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ Vt,
                                                               u16* __restrict__ O, SeqTab tab, int heads, int t_pad, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) u16 ks[64 * FA_LD];
     __shared__ __attribute__((aligned(16))) u16 vs[64 * FA_LD];
-    const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * QS);
     const int T = tab.seq_T[s], len = tab.seq_len[s];
     if (q0 >= T) return;
     const int H = heads * 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, c16 = lane & 15;
-    const int qi = q0 + w * 16 + c16;
-    const int qic = qi < T ? qi : T - 1;
-    const u16* qrow = Q + (size_t)(tab.seq_start[s] + qic) * H + h * 64;
-    v4u qf[2];
-    qf[0] = *(const v4u*)(qrow + g * 8);
-    qf[1] = *(const v4u*)(qrow + 32 + g * 8);
+    const size_t row0 = (size_t)tab.seq_start[s];
+    v4u qf[QS][2];
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+        int qi = q0 + (w * QS + qs) * 16 + c16;
+        qi = qi < T ? qi : T - 1;
+        const u16* qrow = Q + (row0 + qi) * H + h * 64;
+        qf[qs][0] = *(const v4u*)(qrow + g * 8);
+        qf[qs][1] = *(const v4u*)(qrow + 32 + g * 8);
+    }
     const u16* Kb = K + ((size_t)(s * heads + h) * t_pad) * 64;
     const u16* Vb = Vt + ((size_t)(s * heads + h) * 64) * t_pad;
-    // staging assignment: chunk ch = tid + 256 i -> row ch >> 3, 16-byte piece ch & 7
-    const int r0 = tid >> 3, p0 = tid & 7;
+    const int r0 = tid >> 3, p0 = tid & 7;                         // staging: chunk tid + 256 i -> row r0 + 32 i, 16-byte piece p0
     v4u kreg[2], vreg[2];
     auto fetch = [&](int k0) {
 #pragma unroll
@@ -289,10 +301,15 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
             vreg[i] = *(const v4u*)(Vb + (size_t)r * t_pad + k0 + p0 * 8);
         }
     };
-    f32x4 o[4];
+    f32x4 o[QS][4];
+    float m_run[QS], l_run[QS];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) o[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int qs = 0; qs < QS; ++qs) {
+        m_run[qs] = -INFINITY;
+        l_run[qs] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) o[qs][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     fetch(0);
     for (int k0 = 0; k0 < len; k0 += 64) {
         __syncthreads();                                           // the previous tile's fragments are consumed
@@ -304,68 +321,91 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
         }
         __syncthreads();
         if (k0 + 64 < len) fetch(k0 + 64);                         // block-uniform
-        f32x4 st[4];
+        f32x4 st[QS][4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qs = 0; qs < QS; ++qs)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) st[qs][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int kx = 0; kx < 2; ++kx) {
                 const v4u a = *(const v4u*)(ks + (kt * 16 + c16) * FA_LD + kx * 32 + g * 8);
-                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[kx]), st[kt], 0, 0, 0);
+#pragma unroll
+                for (int qs = 0; qs < QS; ++qs)
+                    st[qs][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[qs][kx]),
+                                                                         st[qs][kt], 0, 0, 0);
             }
-        }
-        float mx = -INFINITY;
         const bool tail = k0 + 64 > len;                           // block-uniform: only the last tile holds masked keys
+        v4u pb[QS][2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int qs = 0; qs < QS; ++qs) {
+            float mx = -INFINITY;
+            if (tail) {                                            // uniform branch: full tiles carry no per-element select
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = st[kt][r] * scale_log2e;
-                if (tail && (k0 + kt * 16 + g * 4 + r) >= len) v = -INFINITY;
-                st[kt][r] = v;
-                mx = fmaxf(mx, v);
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((k0 + kt * 16 + g * 4 + r) >= len) st[qs][kt][r] = -INFINITY;
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);                      // finite: key k0 < len is valid for every query
-        const float alpha = exp2f(m_run - m_new);
-        float ps = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(st[kt][r] - m_new);
-                st[kt][r] = p;
-                ps += p;
-            }
-        ps += __shfl_xor(ps, 16, 64);
-        ps += __shfl_xor(ps, 32, 64);
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
+                for (int r = 0; r < 4; ++r) {
+                    const float v = st[qs][kt][r] * scale_log2e;
+                    st[qs][kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qs], mx);              // finite: key k0 < len is valid for every query
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qs] - m_new);
+            float ps = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[mt][r] *= alpha;
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(st[qs][kt][r] - m_new);
+                    st[qs][kt][r] = p;
+                    ps += p;
+                }
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            l_run[qs] = l_run[qs] * alpha + ps;
+            m_run[qs] = m_new;
 #pragma unroll
-        for (int kx = 0; kx < 2; ++kx) {
-            const v4u pb{pack_bf16x2(st[2 * kx][0], st[2 * kx][1]), pack_bf16x2(st[2 * kx][2], st[2 * kx][3]),
-                         pack_bf16x2(st[2 * kx + 1][0], st[2 * kx + 1][1]), pack_bf16x2(st[2 * kx + 1][2], st[2 * kx + 1][3])};
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qs][mt][r] *= alpha;
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx)
+                pb[qs][kx] = v4u{pack_bf16x2(st[qs][2 * kx][0], st[qs][2 * kx][1]), pack_bf16x2(st[qs][2 * kx][2], st[qs][2 * kx][3]),
+                                 pack_bf16x2(st[qs][2 * kx + 1][0], st[qs][2 * kx + 1][1]), pack_bf16x2(st[qs][2 * kx + 1][2], st[qs][2 * kx + 1][3])};
+        }
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const u16* vrow = vs + (mt * 16 + c16) * FA_LD + kx * 32 + g * 4;
                 const v2u lo = *(const v2u*)vrow, hi = *(const v2u*)(vrow + 16);
                 const v4u a{lo.x, lo.y, hi.x, hi.y};
-                o[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, pb), o[mt], 0, 0, 0);
-            }
-        }
-    }
-    if (qi < T) {
-        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-        u16* orow = O + (size_t)(tab.seq_start[s] + qi) * H + h * 64;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const v2u pk{pack_bf16x2(o[mt][0] * inv, o[mt][1] * inv), pack_bf16x2(o[mt][2] * inv, o[mt][3] * inv)};
-            *(v2u*)(orow + mt * 16 + g * 4) = pk;
+                for (int qs = 0; qs < QS; ++qs)
+                    o[qs][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, pb[qs][kx]),
+                                                                        o[qs][mt], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+        const int qi = q0 + (w * QS + qs) * 16 + c16;
+        if (qi < T) {
+            const float inv = l_run[qs] > 0.f ? 1.0f / l_run[qs] : 0.f;
+            u16* orow = O + (row0 + qi) * H + h * 64;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const v2u pk{pack_bf16x2(o[qs][mt][0] * inv, o[qs][mt][1] * inv), pack_bf16x2(o[qs][mt][2] * inv, o[qs][mt][3] * inv)};
+                *(v2u*)(orow + mt * 16 + g * 4) = pk;
+            }
         }
     }
 }
@@ -374,9 +414,14 @@ int launch_s2mel_attention(const void* q, const void* k, const void* v, void* ou
                            hipStream_t st) {
     if (tab.n_tok <= 0) return ITTS_OK;
     if (prec == PREC_BF16) {
-        const dim3 grid(ceil_div(tab.t_max, 64), heads, tab.n_seq);
         const float scale_log2e = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64) * log2(e)
-        hipLaunchKernelGGL(flash_attn_bf16_kernel, grid, dim3(256), 0, st, (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, tab, heads, t_pad, scale_log2e);
+        // query sub-tiles per wave: 4 (256-query blocks) once sequences are long enough to fill the chip that way; ITTS_FA_QS forces
+        static const int force_qs = [] { const char* e = getenv("ITTS_FA_QS"); return e ? atoi(e) : 0; }();
+        int qs = force_qs ? force_qs : (tab.t_max >= 512 ? 4 : (tab.t_max >= 128 ? 2 : 1));
+#define FA_LAUNCH(QS_) hipLaunchKernelGGL(flash_attn_bf16_kernel<QS_>, dim3(ceil_div(tab.t_max, 64 * QS_), heads, tab.n_seq), dim3(256), 0, st, \
+                                          (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, tab, heads, t_pad, scale_log2e)
+        if (qs >= 4) FA_LAUNCH(4); else if (qs == 2) FA_LAUNCH(2); else FA_LAUNCH(1);
+#undef FA_LAUNCH
     } else {
         hipLaunchKernelGGL(attn_f32_kernel, dim3(tab.n_tok, heads), dim3(64), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, tab, heads, t_pad);
     }

@@ -314,22 +314,9 @@ class IndexTTS2:
         """infer_v2_5.py:830-846 for a whole batch of segments on the HIP engine: semantic_codec.decode -> length_regulator ->
         [prompt_condition | cond] -> cfm.inference -> drop the prompt frames.  Every row is processed at its own lengths (what the
         reference's batch-1 call per segment computes).  Returns mel (B, 80, max frames) f32 and the frame counts (B,) int32."""
-        lens = [int(v) for v in code_lens]
-        S_infer = self.semantic_codec.decode(codes, code_lens=lens)                                # (B, 2T, 1024)
-        target = [int(2 * n * 1.72 * duration_factor) for n in lens]                               # :833
-        reg, cfm = self.s2mel.models["length_regulator"], self.s2mel.models["cfm"]
-        cond = reg(S_infer, ylens=torch.tensor(target), n_quantizers=3, f0=None, xlens=[2 * n for n in lens], frame_lens=target)[0]
-        prompt_condition, ref_mel, style = bundle["prompt_condition"], bundle["ref_mel"], bundle["style"]
-        Tp = int(prompt_condition.shape[1])
-        B = codes.shape[0]
-        total = [Tp + t for t in target]
-        cat = torch.zeros(B, max(total), cond.shape[-1], dtype=torch.float32, device=cond.device)
-        cat[:, :Tp] = prompt_condition.to(cond.device, torch.float32)
-        for b in range(B):
-            cat[b, Tp:total[b]] = cond[b, : target[b]]
-        mel = cfm.inference(cat, torch.tensor(total), ref_mel, style, None, diffusion_steps, inference_cfg_rate=inference_cfg_rate,
-                            noise=noise, frame_lens=total)
-        return mel[:, :, Tp:].contiguous(), torch.tensor(target, dtype=torch.int32)
+        from .s2mel import codes_to_mel
+        return codes_to_mel(self.semantic_codec, self.s2mel.models, codes, code_lens, bundle, duration_factor, diffusion_steps,
+                            inference_cfg_rate, noise)
 
     # ---- the hot path: one GPT batch, one ragged vocoder batch -------------------------------------------------------
     def _synthesize(self, segment_tokens: List[torch.Tensor], lang_ids: List[int], bundle, emovec, duration_factor,

@@ -338,6 +338,17 @@ class CFM:
                 o += fl[b]
         return out
 
+    # ---- HIP-event profile of the last solve (bench.py) -----------------------------------------------------------
+    def set_profiling(self, enable: bool):
+        _lib.check(_lib.lib().itts_s2mel_set_profiling(self._h, int(enable)), "itts_s2mel_set_profiling")
+
+    def profile(self):
+        """{gemm: {ms, launches, flops}, attention: {ms, launches}, estimator_calls: {ms, launches}} of the last solve."""
+        arr = [(C.c_double * 3)() for _ in range(3)]
+        _lib.check(_lib.lib().itts_s2mel_profile_read(self._h, *arr), "itts_s2mel_profile_read")
+        names = ("gemm", "attention", "estimator_calls")
+        return {n: dict(ms=arr[0][i], launches=int(arr[1][i]), flops=arr[2][i]) for i, n in enumerate(names)}
+
     def __del__(self):
         try:
             if getattr(self, "_h", None) and self._h.value:
@@ -345,6 +356,30 @@ class CFM:
                 self._h = C.c_void_p()
         except Exception:
             pass
+
+
+def codes_to_mel(semantic_codec, s2mel_models, codes: torch.Tensor, code_lens, bundle, duration_factor: float = 1.0,
+                 diffusion_steps: int = 25, inference_cfg_rate: float = 0.7, noise: Optional[torch.Tensor] = None):
+    """indextts/infer_v2_5.py:830-846 for a whole batch of segments on the HIP engine: semantic_codec.decode -> length_regulator
+    -> [prompt_condition | cond] -> cfm.inference -> drop the prompt frames.  Every row is processed at its own lengths (what the
+    reference's batch-1 call per segment computes).  bundle: prompt_condition (1, Tp, 512), ref_mel (1, 80, Tp), style (1, 192).
+    Returns mel (B, 80, max frames) f32 and the frame counts (B,) int32."""
+    lens = [int(v) for v in code_lens]
+    S_infer = semantic_codec.decode(codes, code_lens=lens)                                     # (B, 2T, 1024)
+    target = [int(2 * n * 1.72 * duration_factor) for n in lens]                               # :833
+    reg, cfm = s2mel_models["length_regulator"], s2mel_models["cfm"]
+    cond = reg(S_infer, ylens=torch.tensor(target), n_quantizers=3, f0=None, xlens=[2 * n for n in lens], frame_lens=target)[0]
+    prompt_condition, ref_mel, style = bundle["prompt_condition"], bundle["ref_mel"], bundle["style"]
+    Tp = int(prompt_condition.shape[1])
+    B = codes.shape[0]
+    total = [Tp + t for t in target]
+    cat = torch.zeros(B, max(total), cond.shape[-1], dtype=torch.float32, device=cond.device)
+    cat[:, :Tp] = prompt_condition.to(cond.device, torch.float32)
+    for b in range(B):
+        cat[b, Tp:total[b]] = cond[b, : target[b]]
+    mel = cfm.inference(cat, torch.tensor(total), ref_mel, style, None, diffusion_steps, inference_cfg_rate=inference_cfg_rate,
+                        noise=noise, frame_lens=total)
+    return mel[:, :, Tp:].contiguous(), torch.tensor(target, dtype=torch.int32)
 
 
 class MyModel:

@@ -170,3 +170,51 @@ def s2mel_weights(args: dict = S2MEL_V2, seed: int = 1234) -> Dict[str, torch.Te
     sd[P + "wavenet.cond_layer.conv.conv.weight"] = torch.randn(2 * W * L, W, 1, generator=g) / math.sqrt(W)
     sd[P + "wavenet.cond_layer.conv.conv.bias"] = torch.randn(2 * W * L, generator=g) * 0.02
     return sd
+
+
+# ---- semantic codec (decode half) and s2mel length regulator at the reference's constructor defaults
+# (indextts/codec/models.py EnhancedCodec: codebook 8192 x 8, hidden 1024, Vocos 384 / 2048 x 12;
+#  InterpolateRegulator: channels 512, in_channels 1024, sampling_ratios [1, 1, 1, 1]) ----------------------------------------
+CODEC_V2 = dict(codebook_size=8192, hidden_size=1024, codebook_dim=8, vocos_dim=384, vocos_intermediate_dim=2048, vocos_num_layers=12)
+REGULATOR_V2 = dict(channels=512, sampling_ratios=(1, 1, 1, 1), is_discrete=False, in_channels=1024, content_codebook_size=1024)
+
+
+def codec_weights(c: dict = CODEC_V2, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    D, H, I = c["vocos_dim"], c["hidden_size"], c["vocos_intermediate_dim"]
+    rn = lambda *s_, fan: torch.randn(*s_, generator=g) / math.sqrt(fan)
+    sd = {"up.weight": rn(H, H, 3, fan=3 * H), "up.bias": torch.randn(H, generator=g) * 0.05,
+          "decoder.0.embed.weight": rn(D, H, 7, fan=7 * H), "decoder.0.embed.bias": torch.randn(D, generator=g) * 0.05,
+          "decoder.0.norm.weight": 1 + 0.1 * torch.randn(D, generator=g), "decoder.0.norm.bias": 0.05 * torch.randn(D, generator=g)}
+    for i in range(c["vocos_num_layers"]):
+        p = f"decoder.0.convnext.{i}."
+        sd[p + "gamma"] = 0.3 + 0.1 * torch.randn(D, generator=g)
+        sd[p + "dwconv.weight"] = rn(D, 1, 7, fan=7)
+        sd[p + "dwconv.bias"] = 0.05 * torch.randn(D, generator=g)
+        sd[p + "norm.weight"] = 1 + 0.1 * torch.randn(D, generator=g)
+        sd[p + "norm.bias"] = 0.05 * torch.randn(D, generator=g)
+        sd[p + "pwconv1.weight"], sd[p + "pwconv1.bias"] = rn(I, D, fan=D), 0.05 * torch.randn(I, generator=g)
+        sd[p + "pwconv2.weight"], sd[p + "pwconv2.bias"] = rn(D, I, fan=I), 0.05 * torch.randn(D, generator=g)
+    sd["decoder.0.final_layer_norm.weight"] = 1 + 0.1 * torch.randn(D, generator=g)
+    sd["decoder.0.final_layer_norm.bias"] = 0.05 * torch.randn(D, generator=g)
+    sd["decoder.1.weight"], sd["decoder.1.bias"] = rn(H, D, fan=D), 0.05 * torch.randn(H, generator=g)
+    Q = "quantizer.quantizers.0."
+    sd[Q + "codebook.weight"] = torch.randn(c["codebook_size"], c["codebook_dim"], generator=g)
+    sd[Q + "out_project.weight"] = rn(H, c["codebook_dim"], 1, fan=c["codebook_dim"])          # weight-norm already folded
+    sd[Q + "out_project.bias"] = 0.05 * torch.randn(H, generator=g)
+    return sd
+
+
+def regulator_weights(c: dict = REGULATOR_V2, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    Cc, n = c["channels"], len(c["sampling_ratios"])
+    sd = {"content_in_proj.weight": torch.randn(Cc, c["in_channels"], generator=g) / math.sqrt(c["in_channels"]),
+          "content_in_proj.bias": 0.05 * torch.randn(Cc, generator=g)}
+    for i in range(n):
+        sd[f"model.{3 * i}.weight"] = torch.randn(Cc, Cc, 3, generator=g) / math.sqrt(3 * Cc)
+        sd[f"model.{3 * i}.bias"] = 0.05 * torch.randn(Cc, generator=g)
+        sd[f"model.{3 * i + 1}.weight"] = 1 + 0.1 * torch.randn(Cc, generator=g)
+        sd[f"model.{3 * i + 1}.bias"] = 0.05 * torch.randn(Cc, generator=g)
+    sd[f"model.{3 * n}.weight"] = torch.randn(Cc, Cc, 1, generator=g) / math.sqrt(Cc)
+    sd[f"model.{3 * n}.bias"] = 0.05 * torch.randn(Cc, generator=g)
+    return sd
