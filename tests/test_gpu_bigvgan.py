@@ -156,6 +156,21 @@ def test_generator_ragged_batch_rows_equal_solo(bv):
         assert float(wav[b, :, n * 256:].abs().max()) == 0.0 if n < 23 else True
 
 
+def test_generator_v1_vs_reference_fixture(bv, golden_dir):
+    """a-13: the HIP generator against the waveform the reference's own v1 `BigVGAN` class produced (bigvgan_v1.npz, minted by
+    tools/make_golden_bigvgan.py v1 with the speaker embedding handed in): 1e-4 RMS, k == u upsamplers included."""
+    z = np.load(os.path.join(golden_dir, "bigvgan_v1.npz"))
+    h = dict(O.V2_HPARAMS, upsample_initial_channel=int(z["upsample_initial_channel"]), use_tanh_at_final=True, use_bias_at_final=True,
+             upsample_rates=[int(v) for v in z["upsample_rates"]], upsample_kernel_sizes=[int(v) for v in z["upsample_kernel_sizes"]])
+    cd, gd = int(z["cond_dim"]), int(z["gpt_dim"])
+    sd = O.synth_weights(h, seed=int(z["seed"]), cond_dim=cd, in_dim=gd, post_gain=float(z["post_gain"]))
+    m = _model(bv, h, sd, cond_dim=cd, in_channels=gd)
+    wav, _ = m(torch.from_numpy(z["latent"]).to(DEV), speaker_embedding=torch.from_numpy(z["spk"]).to(DEV))
+    err = rms(wav.cpu() - torch.from_numpy(z["wav"]))
+    print(f"v1 generator vs reference class: rms {err:.2e}")
+    assert wav.shape == z["wav"].shape and err <= 1e-4
+
+
 def test_generator_v1_variant(bv):
     """v1: latent input (B,T,D), speaker conditioning adds after conv_pre and each upsampler, tanh epilogue."""
     h = dict(O.V2_HPARAMS, upsample_initial_channel=512, use_tanh_at_final=True, use_bias_at_final=True,

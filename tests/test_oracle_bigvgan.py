@@ -64,3 +64,17 @@ def test_v1_variant_runs():
     with torch.no_grad():
         wav = O.bigvgan_forward(sd, lat, h, spk=spk)
     assert wav.shape == (2, 1, 3 * 1024) and float(wav.abs().max()) <= 1.0
+
+
+def test_v1_generator_matches_reference_fixture(golden_dir):
+    """tests/golden/bigvgan_v1.npz = the reference's own `indextts/BigVGAN/models.py::BigVGAN` (IndexTTS-1 / 1.5: GPT latent in,
+    speaker conditioning after conv_pre and every upsampler, tanh out, upsampler kernels [8,8,4,4,4,4] over rates [4,4,4,4,2,2])
+    run with its speaker encoder replaced by the stored embedding (tools/make_golden_bigvgan.py v1): pins the oracle's v1 branch."""
+    z = np.load(os.path.join(golden_dir, "bigvgan_v1.npz"))
+    h = dict(O.V2_HPARAMS, upsample_initial_channel=int(z["upsample_initial_channel"]), use_tanh_at_final=True, use_bias_at_final=True,
+             upsample_rates=[int(v) for v in z["upsample_rates"]], upsample_kernel_sizes=[int(v) for v in z["upsample_kernel_sizes"]])
+    sd = O.synth_weights(h, seed=int(z["seed"]), cond_dim=int(z["cond_dim"]), in_dim=int(z["gpt_dim"]), post_gain=float(z["post_gain"]))
+    with torch.no_grad():
+        wav = O.bigvgan_forward(sd, torch.from_numpy(z["latent"]).transpose(1, 2), h, spk=torch.from_numpy(z["spk"]).unsqueeze(-1))
+    assert wav.shape == z["wav"].shape
+    assert float((wav - torch.from_numpy(z["wav"])).double().pow(2).mean().sqrt()) <= 2e-6

@@ -98,5 +98,55 @@ def main():
                             seed=np.int64(seed), post_gain=np.float64(pg), upsample_initial_channel=np.int64(h["upsample_initial_channel"]))
 
 
+def make_v1():
+    """IndexTTS-1 / 1.5 vocoder: the reference `indextts/BigVGAN/models.py::BigVGAN` (GPT latent in, speaker-conditioned, tanh
+    out) run here with torchaudio stubbed (pulled in only by the ECAPA-TDNN speaker encoder's feature front end).  The speaker
+    encoder is outside the hot path (it stays a PyTorch module in the product): the reference generator is run with its
+    `speaker_encoder` replaced by a module that returns the stored embedding, so everything from `conv_pre` on is the
+    reference's own code.  Upsampler kernels are the v1.5 config's [8, 8, 4, 4, 4, 4] over rates [4, 4, 4, 4, 2, 2] (two k == u
+    stages)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_shim_s2mel as R
+    R.install()
+    from indextts.BigVGAN import models as v1
+
+    h = dict(O.V2_HPARAMS, upsample_initial_channel=512, use_tanh_at_final=True, use_bias_at_final=True,
+             upsample_rates=[4, 4, 4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4, 4, 4])
+    seed, cond_dim, gpt_dim, B, T = 17, 64, 48, 2, 7
+    sd = O.synth_weights(h, seed=seed, cond_dim=cond_dim, in_dim=gpt_dim, post_gain=0.2)
+    hh = AttrDict(dict(h, resblock="1", gpt_dim=gpt_dim, feat_upsample=False, cond_d_vector_in_each_upsampling_layer=True,
+                       speaker_embedding_dim=cond_dim, num_mels=100))
+    model = v1.BigVGAN(hh)
+    model.remove_weight_norm()
+    ref_sd = model.state_dict()
+    load = {k: v for k, v in sd.items() if k in ref_sd}
+    missing, unexpected = model.load_state_dict(load, strict=False)
+    assert not unexpected
+    assert all(m.startswith("speaker_encoder.") or "filter" in m for m in missing), [m for m in missing if not m.startswith("speaker_encoder.")][:5]
+    assert set(sd) - set(ref_sd) == set(), set(sd) - set(ref_sd)
+    g = torch.Generator().manual_seed(seed + 1)
+    latent = torch.randn(B, T, gpt_dim, generator=g)
+    spk = torch.randn(B, cond_dim, generator=g)
+
+    class FixedSpeaker(torch.nn.Module):
+        def forward(self, mel_ref, lens=None):
+            return spk.unsqueeze(1)                                # (B, 1, dim) like ECAPA_TDNN
+
+    model.speaker_encoder = FixedSpeaker()
+    model.eval()
+    with torch.no_grad():
+        wav, _ = model(latent, torch.zeros(B, 5, 100))
+        wav_o = O.bigvgan_forward(sd, latent.transpose(1, 2), h, spk=spk.unsqueeze(-1))
+    d = wav_o - wav
+    print(f"gen v1: wav {tuple(wav.shape)} rms={wav.pow(2).mean().sqrt().item():.4f} oracle-vs-ref rms={d.pow(2).mean().sqrt().item():.3e} "
+          f"max={d.abs().max().item():.3e}")
+    np.savez_compressed(os.path.join(GOLD, "bigvgan_v1.npz"), latent=latent.numpy(), spk=spk.numpy(), wav=wav.numpy().astype(np.float32),
+                        seed=np.int64(seed), post_gain=np.float64(0.2), cond_dim=np.int64(cond_dim), gpt_dim=np.int64(gpt_dim),
+                        upsample_initial_channel=np.int64(512), upsample_rates=np.array(h["upsample_rates"]),
+                        upsample_kernel_sizes=np.array(h["upsample_kernel_sizes"]))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) < 2 or sys.argv[1] != "v1":
+        main()
+    make_v1()
