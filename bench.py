@@ -438,8 +438,6 @@ def main():
 def gpu_report(args, eng, B, n_text, n_gen, t_mel):
     """roofline (dominant kernel) + stage split from rank 0's HIP-event records of the timed steps."""
     prof_acc, gpt_t, gcfg = eng.prof_acc, eng.gpt_t, eng.gcfg
-    if args.precision == "fp32" and eng.s2 is not None:
-        eng.s2_t = dict(eng.s2_t)
     conv = prof_acc.get("conv1d_mfma", dict(ms=1e-9, launches=1, flops=0.0, bytes=0.0))
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
     # HBM traffic of the same kernel: PMC counters cannot be read from inside this process, so the figure comes from

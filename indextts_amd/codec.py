@@ -138,6 +138,30 @@ class EnhancedCodec:
         return self
 
     @torch.no_grad()
+    def vq2emb(self, codes: torch.Tensor) -> torch.Tensor:
+        """`quantizer.vq2emb(codes)` (residual_vq.py:144-152 -> FVQ.vq2emb): codes (B, T) or (1, B, T) or (B, 1, T) int ->
+        (B, hidden, T) f32, the layout the reference returns (indextts/infer_v2.py:657-658 transposes it)."""
+        if not self._loaded:
+            raise RuntimeError("EnhancedCodec: load_state_dict() first")
+        if codes.dim() == 3:
+            codes = codes[0] if codes.shape[0] == 1 else codes[:, 0]
+        dev, p = self.device, self._p
+        B, T = codes.shape
+        flat = codes.reshape(-1).to(dev, torch.int64).contiguous()
+        e = torch.empty(B * T, self.hidden_size, dtype=torch.float32, device=dev)
+        if B * T:
+            with _lib.on_device(dev):
+                _lib.check(_lib.lib().itts_vq_project_forward(_lib.ptr(flat), _lib.ptr(p["codebook"]), _lib.ptr(p["out_w"]),
+                                                              _lib.ptr(p["out_b"]), _lib.ptr(e), B * T, self.codebook_size,
+                                                              self.codebook_dim, self.hidden_size, _lib.stream_ptr(dev)),
+                           "itts_vq_project_forward")
+        return e.reshape(B, T, self.hidden_size).transpose(1, 2)
+
+    @property
+    def quantizer(self):
+        return self                                                    # `semantic_codec.quantizer.vq2emb(...)` call sites
+
+    @torch.no_grad()
     def decode(self, codes: torch.Tensor, code_lens: Optional[Sequence[int]] = None) -> torch.Tensor:
         """codes (B, T) or (1, B, T) int -> (B, 2T, hidden) f32; with `code_lens` each row is decoded at its own length (frames
         beyond 2 * len are zero)."""

@@ -415,9 +415,11 @@ int launch_s2mel_attention(const void* q, const void* k, const void* v, void* ou
     if (tab.n_tok <= 0) return ITTS_OK;
     if (prec == PREC_BF16) {
         const float scale_log2e = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64) * log2(e)
-        // query sub-tiles per wave: 4 (256-query blocks) once sequences are long enough to fill the chip that way; ITTS_FA_QS forces
+        // query sub-tiles per wave.  Measured (profiles/r02d, 16 x 2726 frames x 8 heads, 25 steps): QS = 1 503.6 ms, 2 512.6 ms,
+        // 4 552.3 ms per solve -- the 300-register QS = 4 kernel drops to one wave per SIMD and loses more latency hiding than
+        // it saves in LDS fragment reads.  ITTS_FA_QS forces a variant (A/B).
         static const int force_qs = [] { const char* e = getenv("ITTS_FA_QS"); return e ? atoi(e) : 0; }();
-        int qs = force_qs ? force_qs : (tab.t_max >= 512 ? 4 : (tab.t_max >= 128 ? 2 : 1));
+        const int qs = force_qs ? force_qs : 1;
 #define FA_LAUNCH(QS_) hipLaunchKernelGGL(flash_attn_bf16_kernel<QS_>, dim3(ceil_div(tab.t_max, 64 * QS_), heads, tab.n_seq), dim3(256), 0, st, \
                                           (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, tab, heads, t_pad, scale_log2e)
         if (qs >= 4) FA_LAUNCH(4); else if (qs == 2) FA_LAUNCH(2); else FA_LAUNCH(1);

@@ -20,17 +20,20 @@ from . import _lib
 
 
 class UnifiedVoice:
-    _ALLOW_ENCODER_CONDITIONING = False
+    """`spk_cond_mode="campplus"` (IndexTTS-2.5, infer_v2_5.py:139): 3 conditioning tokens from the CAMPPlus style vector.
+    Any other mode (IndexTTS-2, infer_v2.py:98; the reference default is "conformer"): 34 conditioning tokens -- 32 latents of
+    the Conformer + Perceiver speaker encoder (`get_conditioning`, a prompt-side PyTorch module: set `conditioning_fn` or pass
+    `conds_latent=`) plus the two `speed_emb` rows (model_v2.py:767-773); no language embedding (:680)."""
+    _ALLOW_ENCODER_CONDITIONING = True
 
     def __init__(self, layers=8, model_dim=512, heads=8, max_text_tokens=120, max_mel_tokens=250,
                  max_conditioning_inputs=1, mel_length_compression=1024, number_text_tokens=256, start_text_token=0,
                  stop_text_token=1, number_mel_codes=8194, start_mel_token=8192, stop_mel_token=8193,
                  train_solo_embeddings=False, use_mel_codes_as_input=True, checkpointing=True, types=1,
                  condition_num_latent=32, condition_type="perceiver", condition_module=None, emo_condition_module=None,
-                 use_accel=False, spk_cond_mode="campplus", precision="bf16", device="cuda:0", **_unused):
-        if spk_cond_mode != "campplus" and not self._ALLOW_ENCODER_CONDITIONING:
-            raise NotImplementedError("engine implements the v2.5 'campplus' conditioning path; v1/v2 conditioning "
-                                      "encoders stay on PyTorch -- pass conds_latent= to inference_speech()")
+                 use_accel=False, spk_cond_mode="conformer", precision="bf16", device="cuda:0", conditioning_fn=None, **_unused):
+        self.conditioning_fn = conditioning_fn
+        self.cond_num = condition_num_latent
         self.layers, self.model_dim, self.heads = layers, model_dim, heads
         self.max_text_tokens, self.max_mel_tokens = max_text_tokens, max_mel_tokens
         self.max_conditioning_inputs = max_conditioning_inputs
@@ -84,7 +87,14 @@ class UnifiedVoice:
             elif name not in self._HOST_TENSORS:
                 ignored.append(name)
         _lib.check(L.itts_gpt_finalize(self._h), "itts_gpt_finalize")
-        missing = [n for n in self._HOST_TENSORS if n not in self._emb and n not in self._OPTIONAL_HOST_TENSORS]
+        if "speed_emb.weight" in sd:
+            self._emb["speed_emb.weight"] = sd["speed_emb.weight"].detach().to(self.device, torch.float32).contiguous()
+        optional = set(self._OPTIONAL_HOST_TENSORS)
+        if getattr(self, "spk_cond_mode", "campplus") != "campplus":          # IndexTTS-2: no style projection, speed embedding instead
+            optional |= {"spk_emb_proj.weight", "spk_emb_proj.bias"}
+            if type(self) is UnifiedVoice and "speed_emb.weight" not in self._emb:
+                raise _lib.HipEngineError("UnifiedVoice.load_state_dict: missing ['speed_emb.weight']")
+        missing = [n for n in self._HOST_TENSORS if n not in self._emb and n not in optional]
         if missing:
             raise _lib.HipEngineError(f"UnifiedVoice.load_state_dict: missing {missing}")
         self._loaded = True
@@ -135,7 +145,7 @@ class UnifiedVoice:
         tok_valid = rel >= 0
         pos = rel.clamp(min=0)
         emb = self._emb["text_embedding.weight"][rows] + self._emb["text_pos_embedding.emb.weight"][pos]
-        if langs is not None and "lang_embedding.weight" in self._emb:
+        if langs is not None and "lang_embedding.weight" in self._emb and getattr(self, "spk_cond_mode", "campplus") == "campplus":
             lg = langs.to(dev).long().reshape(-1)
             if lg.numel() == 1:
                 lg = lg.expand(b)
@@ -165,6 +175,21 @@ class UnifiedVoice:
         spk = spk.unsqueeze(0) if spk.ndim != 3 else spk
         emo_vec = emo_vec.to(dev, torch.float32)
         return torch.cat((spk + emo_vec.unsqueeze(1), torch.zeros(spk.size(0), 2, spk.size(2), device=dev)), 1), spk
+
+    def get_conditioning(self, speech_conditioning_input, cond_mel_lengths=None):
+        """IndexTTS-2 speaker latents (model_v2.py:556-586): Conformer + Perceiver, a prompt-side PyTorch module."""
+        if self.conditioning_fn is None:
+            raise NotImplementedError("the conditioning encoder (Conformer + Perceiver) is outside the engine: set "
+                                      "UnifiedVoice.conditioning_fn (e.g. the reference module's bound get_conditioning) or pass conds_latent=")
+        return self.conditioning_fn(speech_conditioning_input, cond_mel_lengths)
+
+    def conds_latent_v2(self, speech_conditioning_latent: torch.Tensor, emo_vec: torch.Tensor) -> torch.Tensor:
+        """34 conditioning tokens of IndexTTS-2 (model_v2.py:767-773): latents + emo_vec, speed_emb(1), speed_emb(0)."""
+        dev = self.device
+        lat = speech_conditioning_latent.to(dev, torch.float32)
+        se = self._emb["speed_emb.weight"]
+        b = lat.shape[0]
+        return torch.cat((lat + emo_vec.to(dev, torch.float32).unsqueeze(1), se[1].expand(b, 1, -1), se[0].expand(b, 1, -1)), 1)
 
     # ---- generation ----------------------------------------------------------------------------------------------
     def _workspace(self, nbytes: int) -> torch.Tensor:
@@ -322,14 +347,23 @@ class UnifiedVoice:
         if typical_sampling and not (typical_mass > 0.0 and typical_mass < 1.0):           # model_v2.py:796-797
             raise ValueError(f"`typical_mass` has to be a float > 0 and < 1, but is {typical_mass}")
         if conds_latent is None:
-            if campplus_embedding is None:
-                raise ValueError("campplus mode requires campplus_embedding or wav")
             if emo_vec is None:
                 raise NotImplementedError("emo_vec=None needs the Conformer/Perceiver emotion encoder (PyTorch side): "
                                           "compute it with merge_emovec / get_emovec and pass emo_vec=")
-            conds_latent, spk_lat = self.conds_latent(campplus_embedding, emo_vec)
+            if self.spk_cond_mode == "campplus":
+                if campplus_embedding is None:
+                    raise ValueError("campplus mode requires campplus_embedding or wav")
+                conds_latent, spk_lat = self.conds_latent(campplus_embedding, emo_vec)
+            else:                                                   # IndexTTS-2 (model_v2.py:761,767-773)
+                if speech_condition.ndim == 2:
+                    speech_condition = speech_condition.unsqueeze(0)
+                if cond_lengths is None:
+                    cond_lengths = torch.tensor([speech_condition.shape[-1]], device=speech_condition.device)
+                spk_lat = self.get_conditioning(speech_condition.transpose(1, 2), cond_lengths)
+                conds_latent = self.conds_latent_v2(spk_lat, emo_vec)
+                langs = None
         else:
-            spk_lat = conds_latent[:, :1]
+            spk_lat = conds_latent[:, :1] if self.spk_cond_mode == "campplus" else conds_latent[:, : self.cond_num]
         input_ids, inputs_embeds, attention_mask = self.prepare_gpt_inputs(conds_latent, text_inputs, langs)
         max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
         hf = dict(hf_generate_kwargs)
@@ -374,6 +408,14 @@ class UnifiedVoice:
             raise NotImplementedError("emo_vec=None needs the emotion encoder (PyTorch side); pass emo_vec=")
         dev = self.device
         spk = speech_conditioning_latent.to(dev, torch.float32)
+        if self.spk_cond_mode != "campplus":                       # IndexTTS-2: latents (b, 32, D) + speed embeddings (:634-637)
+            if do_spk_cond:
+                spk = self.get_conditioning(spk.transpose(1, 2), cond_mel_lengths).to(dev, torch.float32)
+            se = self._emb["speed_emb.weight"]
+            us = torch.zeros(spk.shape[0], dtype=torch.long, device=dev) if use_speed is None else torch.as_tensor(use_speed).to(dev).long()
+            dur, half = se[torch.zeros_like(us)], se[torch.ones_like(us)]
+            conds = torch.cat((spk + emo_vec.to(dev, torch.float32).unsqueeze(1), half.unsqueeze(1), dur.unsqueeze(1)), 1)
+            return self.forward_latent(conds, text_inputs, text_lengths, mel_codes, mel_codes_lengths)
         if do_spk_cond:
             spk = F.linear(spk, self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
             if spk.ndim != 3:

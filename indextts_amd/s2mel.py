@@ -382,6 +382,33 @@ def codes_to_mel(semantic_codec, s2mel_models, codes: torch.Tensor, code_lens, b
     return mel[:, :, Tp:].contiguous(), torch.tensor(target, dtype=torch.int32)
 
 
+class GptLayer:
+    """`s2mel.models['gpt_layer']` of IndexTTS-2 (commons.py:413): Linear(1280, 256) -> Linear(256, 128) -> Linear(128, 1024)
+    on the GPT latents, three engine GEMMs in f32."""
+
+    def __init__(self, dims=(1280, 256, 128, 1024), device="cuda:0"):
+        self.dims, self.device = tuple(dims), torch.device(device)
+        self._w = []
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        self._w = []
+        for i in range(len(self.dims) - 1):
+            w, b = sd[f"{i}.weight"], sd[f"{i}.bias"]
+            if tuple(w.shape) != (self.dims[i + 1], self.dims[i]):
+                raise _lib.HipEngineError(f"gpt_layer.{i}.weight has shape {tuple(w.shape)}, expected {(self.dims[i + 1], self.dims[i])}")
+            self._w.append((pack_gemm_weight(w.detach().float().cpu().t().contiguous(), 0).to(self.device),
+                            b.detach().to(self.device, torch.float32).contiguous(), self.dims[i + 1]))
+        return []
+
+    @torch.no_grad()
+    def __call__(self, latent: torch.Tensor) -> torch.Tensor:
+        shape = latent.shape
+        x = latent.reshape(-1, shape[-1]).to(self.device, torch.float32).contiguous()
+        for wp, b, n in self._w:
+            x = engine_gemm(x, wp, b, n, 0, prefill_tiles=True)
+        return x.reshape(*shape[:-1], self.dims[-1])
+
+
 class MyModel:
     """`indextts/s2mel/modules/commons.py::MyModel` as the pipeline uses it (infer_v2_5.py:190-206): a `.models` mapping with
     the flow-matching decoder and the length regulator, both on the HIP engine."""
@@ -398,8 +425,8 @@ class MyModel:
                 codebook_size=int(_get(lr, "content_codebook_size", default=1024)),
                 f0_condition=bool(_get(lr, "f0_condition", default=False)), device=device),
         }
-        if use_gpt_latent:
-            raise NotImplementedError("gpt_layer (IndexTTS-2 latent projector) is three small Linear layers on the PyTorch side")
+        if use_gpt_latent:                                            # IndexTTS-2 (infer_v2.py:101): latent projector
+            self.models["gpt_layer"] = GptLayer(device=device)
 
     def load_state_dict(self, net: Dict[str, Dict[str, torch.Tensor]]):
         """`net` = the checkpoint's `state['net']` mapping (load_checkpoint2, commons.py): {'cfm': sd, 'length_regulator': sd};
@@ -407,6 +434,8 @@ class MyModel:
         strip = lambda sd: {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
         self.models["cfm"].load_state_dict(strip(net["cfm"]))
         self.models["length_regulator"].load_state_dict(strip(net["length_regulator"]))
+        if "gpt_layer" in self.models:
+            self.models["gpt_layer"].load_state_dict(strip(net["gpt_layer"]))
         return self
 
     def eval(self):

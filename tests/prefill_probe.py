@@ -18,7 +18,7 @@ DIM = int(os.environ.get("PROBE_DIM", "0"))    # odd multiples of 128: split-K s
 if DIM:
     cfg = G.GPTConfig(layers=2, model_dim=DIM, heads=DIM // 64, max_text_tokens=60, max_mel_tokens=80, number_text_tokens=200)
 sd = G.synth_weights(cfg, seed=77)
-m = gpt.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
+m = gpt.UnifiedVoice(spk_cond_mode="campplus", layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
                      max_mel_tokens=cfg.max_mel_tokens, number_text_tokens=cfg.number_text_tokens, precision="bf16",
                      device="cuda:0")
 m.load_state_dict(sd)

@@ -70,7 +70,7 @@ def test_activation_rows_shorter_than_the_filter(T):
 
 def _gpt(cfg, sd):
     from indextts_amd import gpt
-    m = gpt.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
+    m = gpt.UnifiedVoice(spk_cond_mode="campplus", layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
                          max_mel_tokens=cfg.max_mel_tokens, number_text_tokens=cfg.number_text_tokens, precision="fp32",
                          device=DEV)
     m.load_state_dict(sd)

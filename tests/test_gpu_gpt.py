@@ -29,7 +29,7 @@ def load_case(golden_dir, tag):
 
 def engine(cfg, sd, precision="fp32"):
     from indextts_amd import gpt
-    m = gpt.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads,
+    m = gpt.UnifiedVoice(spk_cond_mode="campplus", layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads,
                          max_text_tokens=cfg.max_text_tokens, max_mel_tokens=cfg.max_mel_tokens,
                          number_text_tokens=cfg.number_text_tokens, precision=precision, device=DEV)
     m.load_state_dict(sd)

@@ -18,7 +18,7 @@ def build():
     cfg = G.GPTConfig(layers=2, model_dim=128, heads=2, max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200)
     sd = G.synth_weights(cfg, seed=31)
     sd["mel_head.bias"][cfg.stop_mel_token] += 2.0
-    g = gpt.UnifiedVoice(layers=2, model_dim=128, heads=2, max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200,
+    g = gpt.UnifiedVoice(spk_cond_mode="campplus", layers=2, model_dim=128, heads=2, max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200,
                          precision="fp32", device=DEV)
     g.load_state_dict(sd)
     h = dict(BO.V2_HPARAMS, upsample_initial_channel=512)

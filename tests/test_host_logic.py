@@ -81,7 +81,7 @@ def test_gemm_packing_layout(prec):
 
 def _host_model(cfg, sd):
     from indextts_amd import gpt
-    m = gpt.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
+    m = gpt.UnifiedVoice(spk_cond_mode="campplus", layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
                          max_mel_tokens=cfg.max_mel_tokens, number_text_tokens=cfg.number_text_tokens, device="cpu",
                          precision="fp32")
     for n in m._HOST_TENSORS:

@@ -9,7 +9,7 @@ from indextts_amd import gpt, synth  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n_gen = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 gcfg = dict(synth.GPT_V25)
-m = gpt.UnifiedVoice(**gcfg, precision="bf16", device="cuda:0")
+m = gpt.UnifiedVoice(spk_cond_mode="campplus", **gcfg, precision="bf16", device="cuda:0")
 m.load_state_dict(synth.gpt_weights(gcfg, suppress_eos=True))
 g = torch.Generator().manual_seed(0)
 text = torch.randint(2, 12000, (B, 128), generator=g).cuda()

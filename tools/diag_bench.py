@@ -16,7 +16,7 @@ if which in ("gpt", "both"):
     gcfg = dict(synth.GPT_V25)
     gsd = synth.gpt_weights(gcfg, seed=1234, suppress_eos=True)
     log("gpt weights synthesised")
-    m = gpt.UnifiedVoice(**gcfg, precision="bf16", device=dev)
+    m = gpt.UnifiedVoice(spk_cond_mode="campplus", **gcfg, precision="bf16", device=dev)
     m.load_state_dict(gsd)
     log("gpt loaded")
     style = torch.randn(1, 192).to(dev); emo = (torch.randn(1, 1280) * 0.1).to(dev)

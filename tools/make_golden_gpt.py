@@ -321,6 +321,8 @@ def main():
         make_v1()
     if only is None or "bf16" in only:
         make_bf16()
+    if only is None or "v2" in only:
+        make_v2()
 
 
 def make_v1():
@@ -355,6 +357,55 @@ def make_v1():
                         codes=codes.numpy(), code_lens=code_lens.numpy(), mel_codes=mel_codes.numpy(),
                         latent=lat_ref.numpy().astype(np.float32), seed=np.int64(seed), eos_bias=np.float64(eos_bias),
                         max_gen=np.int64(max_gen),
+                        cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens, cfg.max_mel_tokens,
+                                      cfg.number_text_tokens]))
+
+
+def make_v2():
+    """BASELINE configs[3] in miniature: IndexTTS-2 `UnifiedVoice` with the reference DEFAULT conditioning mode
+    (spk_cond_mode="conformer", indextts/infer_v2.py:98): 34 conditioning tokens = 32 speaker latents (get_conditioning is
+    stubbed to return the latent it is handed -- the Conformer + Perceiver encoder is outside the hot path) + emo_vec, then
+    speed_emb(1), speed_emb(0) (model_v2.py:767-773); no language embedding although a third positional argument is passed
+    (infer_v2.py:584 hands `emo_cond_emb` where `langs` sits; :680 ignores it outside campplus mode).  Greedy decode, then the
+    teacher-forced latent pass `self.gpt(...)` of infer_v2.py:636-651 with use_speed = 0."""
+    seed, B, L, lens, max_gen, eos_bias = 47, 3, 12, [12, 7, 10], 20, 1.6
+    cfg = G.GPTConfig(layers=3, model_dim=128, heads=2, max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200)
+    sd = G.synth_weights(cfg, seed=seed)
+    sd["mel_head.bias"][cfg.stop_mel_token] += eos_bias
+    g = torch.Generator().manual_seed(seed + 100)
+    text = ragged_text(g, B, L, cfg.number_text_tokens, lens)
+    spk_lat = torch.randn(1, 32, cfg.model_dim, generator=g) * 0.3
+    emo_vec = torch.randn(1, cfg.model_dim, generator=g) * 0.1
+    speed = torch.randn(2, cfg.model_dim, generator=g) * 0.3
+    gk = dict(do_sample=False, num_beams=1, repetition_penalty=10.0)
+    uv = build_reference(sd, cfg, kv_cache=True)
+    uv.spk_cond_mode = "conformer"
+    uv.speed_emb = nn.Embedding(2, cfg.model_dim)
+    uv.speed_emb.weight.data.copy_(speed)
+    uv.get_conditioning = lambda x, lengths=None: spk_lat.repeat(B, 1, 1)       # (b, 32, D): the reference concatenates per-row speed embeddings
+    with torch.no_grad():
+        # third positional = `langs` (what infer_v2.py passes there is the emotion feature tensor; ignored in this mode)
+        codes, lat_out = uv.inference_speech(torch.zeros(1, 4, 2), text, torch.zeros(1, 4, 2), emo_vec=emo_vec,
+                                             cond_lengths=torch.tensor([2]), emo_cond_lengths=torch.tensor([2]),
+                                             max_generate_length=max_gen, **gk)
+        conds = torch.cat((spk_lat + emo_vec.unsqueeze(1), speed[1][None, None], speed[0][None, None]), 1)
+        oc = G.inference_speech(sd, cfg, conds, text, None, G.GenParams(max_generate_length=max_gen, **gk))
+    same = codes.shape == oc.shape and bool((codes == oc).all())
+    eos_at = [(int((r == cfg.stop_mel_token).nonzero()[0]) if (r == cfg.stop_mel_token).any() else -1) for r in codes]
+    print(f"v2_greedy (34 conditioning tokens): ref codes {tuple(codes.shape)} eos_at={eos_at} oracle==reference: {same}; "
+          f"returned latent {tuple(lat_out.shape)}")
+    tl = torch.tensor(lens)
+    ml = torch.tensor([max(2, (e if e >= 0 else codes.shape[1])) for e in eos_at])
+    mel_codes = codes[:, : int(ml.max())].clone()
+    with torch.no_grad():
+        lat_ref = uv.forward(spk_lat.repeat(B, 1, 1), text.clone(), tl, mel_codes.clone(), ml, None, emo_vec=emo_vec.repeat(B, 1),
+                             use_speed=torch.zeros(B).long(), do_spk_cond=False)
+        lat_o = G.forward_latent(sd, cfg, conds.repeat(B, 1, 1), text, tl, mel_codes, ml)
+    print(f"  v2 latent pass: ref {tuple(lat_ref.shape)} oracle max|d| = {(lat_ref - lat_o).abs().max().item():.3e}")
+    np.savez_compressed(os.path.join(GOLD, "gpt_v2.npz"), text=text.numpy(), text_lens=tl.numpy(), spk_latent=spk_lat.numpy(),
+                        emo_vec=emo_vec.numpy(), speed_emb=speed.numpy(), codes=codes.numpy(), mel_codes=mel_codes.numpy(),
+                        mel_lens=ml.numpy(), latent=lat_ref.numpy().astype(np.float32), seed=np.int64(seed),
+                        eos_bias=np.float64(eos_bias), max_gen=np.int64(max_gen),
                         cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens, cfg.max_mel_tokens,
                                       cfg.number_text_tokens]))
 

@@ -10,7 +10,7 @@ import sys, torch
 sys.path.insert(0, "$ROOT")
 from indextts_amd import gpt, synth
 gcfg = dict(synth.GPT_V25)
-m = gpt.UnifiedVoice(**gcfg, precision="bf16", device="cuda:0")
+m = gpt.UnifiedVoice(spk_cond_mode="campplus", **gcfg, precision="bf16", device="cuda:0")
 m.load_state_dict(synth.gpt_weights(gcfg, suppress_eos=True))
 B = $B
 text = torch.randint(2, 12000, (B, 128)).cuda(); langs = torch.full((B,), 3, dtype=torch.long).cuda()
