@@ -116,8 +116,18 @@ class IndexTTS2:
         self.semantic_codec = semantic_codec
         self.s2mel = s2mel
         if frontend is None:
-            frontend = ReferenceFrontend(cfg, model_dir, self.device, self.gpt)
+            frontend = ReferenceFrontend(cfg, model_dir, self.device, self.gpt, cfg_path=cfg_path)
         self.frontend = frontend
+        if self.s2mel is None and self.semantic_codec is None and hasattr(frontend, "engine_state_dicts") and "s2mel" in cfg \
+                and "semantic_codec" in cfg:
+            # codes -> mel on the engine, weights taken from the modules the reference loaded (codec.pth / s2mel.pth)
+            from .codec import EnhancedCodec
+            from .s2mel import MyModel
+            sds = frontend.engine_state_dicts()
+            self.semantic_codec = EnhancedCodec(**dict(cfg["semantic_codec"]), device=self.device)
+            self.semantic_codec.load_state_dict(sds["semantic_codec"])
+            self.s2mel = MyModel(cfg["s2mel"], precision="bf16" if self.use_bf16 else "fp32", device=self.device)
+            self.s2mel.load_state_dict({"cfm": sds["cfm"], "length_regulator": sds["length_regulator"]})
         self.tokenizer = getattr(frontend, "tokenizer", None)
         # reference cache attributes (:269-279)
         self.cache_spk_cond = None
@@ -364,30 +374,130 @@ class IndexTTS2:
 
 
 class ReferenceFrontend(Frontend):
-    """Prompt / text / s2mel stages on the reference's own PyTorch modules (lazy imports; needs the reference package,
-    its third-party dependencies and the checkpoint directory).  Mirrors `indextts/infer_v2_5.py:169-266` (loading) and
-    the call sequences cited per method."""
+    """Prompt / text stages on the reference's own PyTorch modules.
 
-    def __init__(self, cfg, model_dir, device, gpt_engine):
-        try:
-            import librosa  # noqa: F401
-            import torchaudio  # noqa: F401
-            from indextts.gpt.model_v2 import UnifiedVoice as RefUnifiedVoice
-            from indextts.s2mel.modules.commons import MyModel, load_checkpoint2
-            from indextts.s2mel.modules.audio import mel_spectrogram
-            from indextts.s2mel.modules.campplus.DTDNN import CAMPPlus
-            from indextts.codec.models import EnhancedCodec
-            from indextts.utils.tokenizer import lang_to_token, get_tokenizer
-            from indextts.utils.front import TextNormalizer
-            from transformers import SeamlessM4TFeatureExtractor, Wav2Vec2BertModel
-        except Exception as e:                                   # loud: there is no fallback
-            raise RuntimeError("ReferenceFrontend needs the reference `indextts` package and its prompt-side dependencies "
-                               f"(torchaudio, librosa, ...): {e!r}.  Inject frontend= instead.") from e
-        self._mods = dict(RefUnifiedVoice=RefUnifiedVoice, MyModel=MyModel, load_checkpoint2=load_checkpoint2,
-                          mel_spectrogram=mel_spectrogram, CAMPPlus=CAMPPlus, EnhancedCodec=EnhancedCodec,
-                          lang_to_token=lang_to_token, get_tokenizer=get_tokenizer, TextNormalizer=TextNormalizer,
-                          SeamlessM4TFeatureExtractor=SeamlessM4TFeatureExtractor, Wav2Vec2BertModel=Wav2Vec2BertModel)
+    The reference package builds every prompt-side module in one place, `indextts.infer_v2_5.IndexTTS2.__init__`
+    (:117-266: w2v-bert feature extractor + model + statistics, semantic codec, s2mel, CAMPPlus, tokenizer, text normaliser,
+    emotion / speaker matrices, mel function).  Instead of restating that loader, this frontend constructs the reference
+    object itself from the same `cfg_path` / `model_dir` (`ref=` injects an existing one) and drives its modules with the call
+    sequences of `infer_generator` (:620-727).  The reference's GPT transformer stack and vocoder are not used (the engine
+    replaces them) and are dropped after construction; its emotion encoder (`gpt.merge_emovec`) is kept.
+
+    Needs the reference `indextts` package with its third-party dependencies (torchaudio, librosa, transformers, ...) and the
+    checkpoint directory: where those are missing the constructor raises ImportError / FileNotFoundError -- there is no fallback.
+    """
+
+    def __init__(self, cfg, model_dir, device, gpt_engine=None, cfg_path=None, ref=None):
+        if ref is None:
+            try:
+                from indextts.infer_v2_5 import IndexTTS2 as RefIndexTTS2
+            except Exception as e:                                   # loud: there is no fallback
+                raise ImportError("ReferenceFrontend needs the reference `indextts` package and its prompt-side dependencies "
+                                  f"(torchaudio, librosa, transformers, ...): {e!r}.  Inject frontend= instead.") from e
+            ref = RefIndexTTS2(cfg_path=cfg_path or os.path.join(model_dir, "config.yaml"), model_dir=model_dir, use_bf16=False,
+                               device=device, use_cuda_kernel=False)
+            for name in ("bigvgan",):                                # replaced by the engine
+                if hasattr(ref, name):
+                    setattr(ref, name, None)
+            if getattr(ref, "gpt", None) is not None:
+                for name in ("gpt", "inference_model"):              # the GPT-2 stack; merge_emovec / get_emovec stay
+                    if hasattr(ref.gpt, name):
+                        setattr(ref.gpt, name, None)
+        self.ref = ref
         self.cfg, self.model_dir, self.device = cfg, model_dir, device
-        raise NotImplementedError(
-            "ReferenceFrontend wiring is exercised only where the reference package + checkpoints exist; "
-            "this build image has neither (SURVEY.md header).  See INTEGRATION.md for the call sequence; inject frontend=.")
+        self.tokenizer = ref.tokenizer
+
+    # ---- the reference's own state dicts, for the engine stages (IndexTTS2.__init__ loads them when none are injected) --------
+    def engine_state_dicts(self):
+        return dict(semantic_codec=self.ref.semantic_codec.state_dict(), cfm=self.ref.s2mel.models["cfm"].state_dict(),
+                    length_regulator=self.ref.s2mel.models["length_regulator"].state_dict())
+
+    # ---- infer_generator :620-667 -------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _w2v(self, audio_16k):
+        r = self.ref
+        inputs = r.extract_features(audio_16k, sampling_rate=16000, return_tensors="pt")
+        return r.get_emb(inputs["input_features"].to(self.device), inputs["attention_mask"].to(self.device))
+
+    @torch.no_grad()
+    def speaker_bundle(self, spk_audio_prompt):
+        import torchaudio
+        r = self.ref
+        audio, sr = r._load_and_cut_audio(spk_audio_prompt, 15, False)
+        audio_22k = torchaudio.transforms.Resample(sr, 22050)(audio)
+        audio_16k = torchaudio.transforms.Resample(sr, 16000)(audio)
+        spk_cond_emb = self._w2v(audio_16k)
+        ref_mel = r.mel_fn(audio_22k.to(spk_cond_emb.device).float())
+        feat = torchaudio.compliance.kaldi.fbank(audio_16k.to(ref_mel.device), num_mel_bins=80, dither=0, sample_frequency=16000)
+        style = r.campplus_model((feat - feat.mean(dim=0, keepdim=True)).unsqueeze(0))
+        prompt_condition = r.s2mel.models["length_regulator"](spk_cond_emb, ylens=torch.LongTensor([ref_mel.size(2)]).to(ref_mel.device),
+                                                              n_quantizers=3, f0=None)[0]
+        return dict(style=style, spk_cond_emb=spk_cond_emb, ref_mel=ref_mel, prompt_condition=prompt_condition)
+
+    @torch.no_grad()
+    def emo_cond(self, emo_audio_prompt):                            # :682-697
+        emo_audio, _ = self.ref._load_and_cut_audio(emo_audio_prompt, 15, False, sr=16000)
+        return self._w2v(emo_audio)
+
+    @torch.no_grad()
+    def merge_emovec(self, spk_cond_emb, emo_cond_emb, alpha):       # :759-765 (the lengths are the feature dims there)
+        dev = spk_cond_emb.device
+        return self.ref.gpt.merge_emovec(spk_cond_emb, emo_cond_emb, torch.tensor([spk_cond_emb.shape[-1]], device=dev),
+                                         torch.tensor([emo_cond_emb.shape[-1]], device=dev), alpha=alpha)
+
+    def emo_vector_mix(self, emo_vector, style, use_random):         # :669-680
+        import random
+        r = self.ref
+        from indextts.infer_v2_5 import find_most_similar_cosine
+        w = torch.tensor(emo_vector, device=self.device)
+        idx = [random.randint(0, x - 1) for x in r.emo_num] if use_random else [find_most_similar_cosine(style, t) for t in r.spk_matrix]
+        mat = torch.cat([t[i].unsqueeze(0) for i, t in zip(idx, r.emo_matrix)], 0)
+        return torch.sum(w.unsqueeze(1) * mat, 0).unsqueeze(0), torch.sum(w)
+
+    def text_segments(self, text, lang, max_text_tokens_per_segment, text_normalization, capacity):     # :699-726
+        import re
+        from indextts import infer_v2_5 as R
+        r, lo = self.ref, lang.lower()
+        prefix = f"<|{lo}|> "
+        text = r.text_process.clean_pattern.sub(lambda x: r.text_process.char_rep_map[x.group()], text)
+        if text_normalization:
+            if lo in ("zh", "zhen", "en"):
+                text = r.text_process.normalize(text)
+            elif lo in ("ja", "es"):
+                text = R.nemo_text_normalize(text, lo)
+        if lo in ("ja", "zh", "zhen", "en"):
+            text = text.lower()
+        if lo == "es":
+            text = text.upper()
+        text = R.apply_pronunciation_annotations(text)
+        if lo == "ja":
+            text = r.ja_text_process.process_ja_text(text)
+        text = re.sub(r"<\|([^|]+)\|>", lambda m: f"<|{m.group(1).upper()}|>", text)
+        out = []
+        for seg in r.split_text_by_tokens(text, max_text_tokens_per_segment, prefix):
+            toks = r.tokenizer.encode(prefix + seg, allowed_special="all")
+            out.append(torch.tensor(list(toks) + [1], dtype=torch.int32))          # F.pad(toks, (0, 1), value=1)
+        return out
+
+    def lang_id(self, lang):
+        from indextts.utils.tokenizer import lang_to_token
+        return int(lang_to_token(lang))
+
+    @torch.no_grad()
+    def codes_to_mel(self, codes, code_lens, bundle, duration_factor):            # :830-846, segment by segment at batch 1
+        r = self.ref
+        mels, lens = [], []
+        for b in range(codes.shape[0]):
+            n = int(code_lens[b])
+            S_infer = r.semantic_codec.decode(codes[b:b + 1, :n])
+            target = torch.LongTensor([int(S_infer.shape[1] * 1.72 * duration_factor)]).to(codes.device)
+            cond = r.s2mel.models["length_regulator"](S_infer, ylens=target, n_quantizers=3, f0=None)[0]
+            cat = torch.cat([bundle["prompt_condition"], cond], dim=1)
+            mel = r.s2mel.models["cfm"].inference(cat, torch.LongTensor([cat.size(1)]).to(cond.device), bundle["ref_mel"], bundle["style"],
+                                                  None, 25, inference_cfg_rate=0.7)[:, :, bundle["ref_mel"].size(-1):]
+            mels.append(mel.float())
+            lens.append(mel.shape[-1])
+        out = torch.zeros(len(mels), mels[0].shape[1], max(lens), device=codes.device)
+        for b, m in enumerate(mels):
+            out[b, :, : lens[b]] = m[0]
+        return out, torch.tensor(lens, dtype=torch.int32)

@@ -58,6 +58,21 @@ class StubFrontend(Frontend):
         return mel, lens.to(torch.int32)
 
 
+    def codes_latent_to_mel(self, codes, code_lens, latent, bundle):
+        """IndexTTS-2 fallback hook (gpt_layer + vq2emb + regulator + CFM on the reference's modules): 1.72 frames per code"""
+        B = codes.shape[0]
+        lens = (code_lens.float() * 1.72).long().clamp(min=1)
+        T = int(lens.max())
+        mel = torch.zeros(B, self.n_mels, T, device=codes.device)
+        cb = self.codebook.to(codes.device)
+        for b in range(B):
+            n = int(code_lens[b])
+            if n > 0:
+                idx = (torch.arange(int(lens[b]), device=codes.device).float() / 1.72).long().clamp(max=n - 1)
+                mel[b, :, : int(lens[b])] = (cb[codes[b, :n].clamp(0, 8193)][idx] + 0.01 * latent[b, :n].mean()).t() - 4.0
+        return mel, lens.to(torch.int32)
+
+
 class StubTokenizerV1:
     """Whitespace 'tokenizer' with the TextTokenizer methods the v1 pipeline calls (indextts/utils/front.py)."""
 

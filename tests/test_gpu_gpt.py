@@ -507,3 +507,35 @@ def test_full_size_bf16_gated_vs_oracle(full_size):
     pref = [int(np.cumprod(full[r] == ids32[r]).sum()) for r in range(64)]
     print(f"bf16 vs f32 ENGINE ids over 64 rows x {n} steps: agreement prefix min/median/max = "
           f"{min(pref)}/{sorted(pref)[32]}/{max(pref)}; rows fully equal: {sum(p == n for p in pref)}")
+
+
+def test_v2_decode_and_latent_vs_reference_golden(golden_dir):
+    """IndexTTS-2 (BASELINE configs[3]) in miniature: `UnifiedVoice` in the reference's default conditioning mode -- 34
+    conditioning tokens (32 speaker latents + emo_vec, speed_emb(1), speed_emb(0)), no language embedding -- greedy ids and the
+    teacher-forced latent pass of infer_v2.py:636-651 against what the reference's own classes produced (gpt_v2.npz)."""
+    from indextts_amd import gpt
+    z = np.load(os.path.join(golden_dir, "gpt_v2.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]),
+                      max_mel_tokens=int(c[4]), number_text_tokens=int(c[5]))
+    sd = dict(G.synth_weights(cfg, seed=int(z["seed"])))
+    sd["mel_head.bias"][cfg.stop_mel_token] += float(z["eos_bias"])
+    sd["speed_emb.weight"] = torch.from_numpy(z["speed_emb"])
+    m = gpt.UnifiedVoice(layers=cfg.layers, model_dim=cfg.model_dim, heads=cfg.heads, max_text_tokens=cfg.max_text_tokens,
+                         max_mel_tokens=cfg.max_mel_tokens, number_text_tokens=cfg.number_text_tokens, precision="fp32", device=DEV)
+    assert m.spk_cond_mode == "conformer"                          # the reference default (model_v2.py:312)
+    m.load_state_dict(sd)
+    m.post_init_gpt2_config(kv_cache=True)
+    text, lat = torch.from_numpy(z["text"]), torch.from_numpy(z["spk_latent"])
+    B = text.shape[0]
+    emo = torch.from_numpy(z["emo_vec"])
+    m.conditioning_fn = lambda x, lengths=None: lat.repeat(B, 1, 1).to(DEV)      # stands in for Conformer + Perceiver
+    # third positional = `langs`: infer_v2.py:584 passes the emotion features there; ignored outside campplus mode
+    codes, spk_out = m.inference_speech(torch.zeros(1, 4, 2), text, torch.zeros(1, 4, 2), emo_vec=emo, cond_lengths=torch.tensor([2]),
+                                        max_generate_length=int(z["max_gen"]), do_sample=False, num_beams=1, repetition_penalty=10.0)
+    assert np.array_equal(codes.cpu().numpy(), z["codes"])
+    assert spk_out.shape == (B, 32, cfg.model_dim)
+    out = m(lat.repeat(B, 1, 1), text, torch.from_numpy(z["text_lens"]), torch.from_numpy(z["mel_codes"]), torch.from_numpy(z["mel_lens"]),
+            None, emo_vec=emo.repeat(B, 1), use_speed=torch.zeros(B).long(), do_spk_cond=False)
+    assert out.shape == z["latent"].shape
+    np.testing.assert_allclose(out.cpu().numpy(), z["latent"], rtol=0, atol=5e-5)

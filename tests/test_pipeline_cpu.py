@@ -98,3 +98,41 @@ def test_save_pcm_wav_roundtrip(tmp_path):
     with wave.open(p) as f:
         data = np.frombuffer(f.readframes(5), dtype=np.int16)
     assert data.tolist()[:3] == [0, 32767, -32767] and data[4] == 32767 and abs(int(data[3]) - 16384) <= 1
+
+
+class FakeGPTV2(FakeGPT):
+    """IndexTTS-2 call sequence: get_conditioning, conds_latent_v2, inference_speech(conds_latent=), then the latent pass"""
+    spk_cond_mode = "conformer"
+
+    def get_conditioning(self, x, lengths=None):
+        return torch.ones(1, 32, 8)
+
+    def conds_latent_v2(self, lat, emo):
+        return torch.cat([lat + emo[:, None, :8], torch.zeros(lat.shape[0], 2, 8)], 1)
+
+    def inference_speech(self, cond, text, langs=None, **kw):
+        assert kw["conds_latent"].shape[1:] == (34, 8) and kw["conds_latent"].shape[0] == text.shape[0]
+        codes, _ = super().inference_speech(cond, text, langs, **kw)
+        return codes, kw["conds_latent"][:, :32]
+
+    def __call__(self, lat, text, text_lens, codes, code_lens, emo_cond, cond_mel_lengths=None, emo_cond_mel_lengths=None, emo_vec=None,
+                 use_speed=None, do_spk_cond=False):
+        assert lat.shape[0] == text.shape[0] == codes.shape[0] == emo_vec.shape[0] and use_speed.shape[0] == text.shape[0]
+        self.latent_calls = getattr(self, "latent_calls", 0) + 1
+        return torch.ones(codes.shape[0], codes.shape[1], 8)
+
+
+def test_v2_pipeline_control_flow():
+    """indextts_amd.infer_v2.IndexTTS2 (IndexTTS-2): decode -> trim -> latent pass -> content features -> vocoder, one batch for
+    all segments; with no engine s2mel stages injected it goes through the frontend's codes_latent_to_mel hook."""
+    from indextts_amd.infer_v2 import IndexTTS2 as V2
+    fe = StubFrontend(64)
+    g = FakeGPTV2()
+    tts = V2(cfg={"gpt": {"stop_mel_token": 8193}, "version": 2.0}, device="cpu", frontend=fe, gpt=g, bigvgan=FakeVoc())
+    assert tts.model_version == 2.0 and tts.use_fp16 is False
+    sr, wav = tts.infer("spk.wav", "hello there. how are you. fine", None, "en", num_beams=1)
+    assert sr == 22050 and wav.dtype == np.int16 and wav.shape[0] > 0
+    assert g.latent_calls == 1 and g.calls[0][0].shape[0] == 3
+    assert set(tts.last_timing) == {"gpt", "gpt_forward", "s2mel", "bigvgan"}
+    res = tts.infer_batch("spk.wav", ["a. b", "c"], "en", num_beams=1)
+    assert len(res) == 2 and all(r[0] == 22050 for r in res)
