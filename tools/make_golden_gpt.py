@@ -237,7 +237,7 @@ def main():
                    dict(do_sample=True, num_beams=1, top_p=0.8, top_k=30, temperature=0.8, repetition_penalty=10.0),
                    True, 1.9),
         "beam": (dict(layers=2, model_dim=128, heads=2), 24, 2, 9, [9, 6],
-                 dict(do_sample=False, num_beams=3, repetition_penalty=10.0, length_penalty=0.0), True, 2.0),
+                 dict(do_sample=False, num_beams=3, repetition_penalty=10.0, length_penalty=0.0), True, 1.2),
         "beam_sample": (dict(layers=2, model_dim=128, heads=2), 25, 3, 9, [9, 5, 7],
                         dict(do_sample=True, num_beams=3, top_p=0.8, top_k=30, temperature=0.8,
                              repetition_penalty=10.0, length_penalty=0.0), True, 1.5),
