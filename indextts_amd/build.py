@@ -17,6 +17,10 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libindextts_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE]
+# per-file extras.  VGPR-form MFMA: the accumulators live in ordinary VGPRs (gfx950 MFMA reads / writes either file), so the
+# softmax / epilogue VALU code works on them in place -- with AGPR accumulators the flash-attention loop carried 80
+# v_accvgpr_read/write moves per key tile and every GEMM epilogue 192.  The BigVGAN conv kernel keeps its tuned allocation.
+EXTRA = {"gpt_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "s2mel_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():
@@ -55,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = _obj(src)
         if not force and not _stale(obj, [src] + hdrs):
             return None
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -316,7 +316,7 @@ static size_t s_a256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct S2Ws {
     float *X, *X2, *BIG, *WX, *OUT, *RP, *D;
-    char *HB, *QA, *AO, *FC, *COL, *XA, *SK, *KC, *VC;
+    char *HB, *QA, *AO, *FC, *COL, *XA, *SK, *KC, *VC, *WXA, *ZR;
     size_t sk_stride, total;
 };
 
@@ -344,7 +344,9 @@ static S2Ws s2_carve(const itts_s2mel* h, char* base, int n_tok, int n_seq, int 
     w.XA = take(N * Kx * esz);
     w.sk_stride = s_a256(N * H * esz);
     w.SK = take(w.sk_stride * (size_t)(c.depth / 2));
+    w.WXA = take(N * W * esz);                                     // act-dtype shadow of WX: the tap-mode GEMM's A operand
     const size_t kv = (size_t)n_seq * c.num_heads * t_pad * 64 * esz;
+    w.ZR = take(256);                                              // a zero row (adjacent to K / V: cleared by the same memset)
     w.KC = take(kv);
     w.VC = take(kv);
     w.total = off + 256;
@@ -435,19 +437,23 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     if ((rc = s2_gemm(h, w.HB, H, h->w_rp, h->b_rp, w.RP, W, N, W, H, EPI_STORE_F32, st))) return rc;
     // WaveNet (wavenet.py:143-166)
     int dil = 1;
+    if (fused && (rc = launch_cast_pad(w.WX, w.WXA, N, N, W, W, prec, st))) return rc;       // bf16 shadow for the tap-mode GEMM
     for (int i = 0; i < c.wavenet_layers; ++i) {
         const S2Wn& Wn = h->wn[i];
         const int last = i == c.wavenet_layers - 1;
-        if ((rc = launch_im2col_reflect(w.WX, w.COL, tab, W, c.wavenet_kernel, dil, prec, st))) return rc;
+        if (!fused && (rc = launch_im2col_reflect(w.WX, w.COL, tab, W, c.wavenet_kernel, dil, prec, st))) return rc;
         const int ro = last ? W : 2 * W;
         if (fused) {                                               // gate in the in_layer epilogue, residual / skip update in the res_skip one
             GemmArgs g{};
-            g.A = w.COL; g.lda = c.wavenet_kernel * W; g.Wp = Wn.w_in; g.bias = Wn.b_in; g.M = N; g.N = 2 * W; g.K = c.wavenet_kernel * W;
+            // dilated reflect-padded conv as a GEMM whose A operand is an implicit im2col of the bf16 shadow (no [n][k*W] buffer)
+            g.A = w.WXA; g.lda = W; g.Wp = Wn.w_in; g.bias = Wn.b_in; g.M = N; g.N = 2 * W; g.K = c.wavenet_kernel * W;
             g.nsplit = 1; g.epi = EPI_GATE; g.out_act = w.FC; g.gvec = m_gc + (size_t)i * 2 * W; g.D = W;
+            g.conv_taps = c.wavenet_kernel; g.conv_dil = dil; g.conv_W = W; g.tok_seq = tab.tok_seq; g.tok_t = tab.tok_t;
+            g.seq_start = tab.seq_start; g.seq_T = tab.seq_T; g.zero_row = w.ZR;
             if ((rc = s2_launch_gemm(h, g, st))) return rc;
             GemmArgs r{};
             r.A = w.FC; r.lda = W; r.Wp = Wn.w_rs; r.bias = Wn.b_rs; r.M = N; r.N = ro; r.K = W; r.nsplit = 1; r.epi = EPI_WN_RS;
-            r.out_f32 = w.WX; r.out2 = w.OUT; r.D = W; r.wn_first = i == 0; r.wn_last = last;
+            r.out_f32 = w.WX; r.out2 = w.OUT; r.D = W; r.wn_first = i == 0; r.wn_last = last; r.out_act2 = last ? nullptr : w.WXA;
             r.tok_seq = tab.tok_seq; r.tok_t = tab.tok_t; r.seq_len = tab.seq_len;
             if ((rc = s2_launch_gemm(h, r, st))) return rc;
         } else {
@@ -501,7 +507,7 @@ extern "C" int itts_s2mel_estimator(itts_s2mel* h, const float* x, const float* 
     const S2Ws w = s2_carve(h, base, n_tok, n_seq, t_pad);
     hipStream_t st = (hipStream_t)stream;
     const size_t kv = (size_t)((char*)w.VC - (char*)w.KC);
-    HIP_TRY(hipMemsetAsync(w.KC, 0, 2 * kv, st));                 // keys / values past a sequence's end must be finite
+    HIP_TRY(hipMemsetAsync(w.ZR, 0, (size_t)((char*)w.KC - (char*)w.ZR) + 2 * kv, st));   // zero row; keys / values past a sequence's end must be finite
     const SeqTab tab = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tok, t_max);
     h->recs.clear();
     h->prof_stream = st;
@@ -530,7 +536,7 @@ extern "C" int itts_s2mel_solve(itts_s2mel* h, float* x_state, const float* cons
     const S2Ws w = s2_carve(h, base, n_tok, n_seq, t_pad);
     hipStream_t st = (hipStream_t)stream;
     const size_t kv = (size_t)((char*)w.VC - (char*)w.KC);
-    HIP_TRY(hipMemsetAsync(w.KC, 0, 2 * kv, st));
+    HIP_TRY(hipMemsetAsync(w.ZR, 0, (size_t)((char*)w.KC - (char*)w.ZR) + 2 * kv, st));
     const SeqTab tab = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tok, t_max);
     const int mps = itts_s2mel_mods_per_step(h);
     h->recs.clear();

@@ -45,6 +45,13 @@ struct GemmArgs {
     // per-step conditioning vector (EPI_GATE), second f32 output (EPI_WN_RS) with its overwrite / last-layer switches
     const int* tok_seq; const int* tok_t; const int* seq_len; const float* rope; const float* gvec;
     float* out2; int wn_first, wn_last;
+    // tap mode of the bf16 tile kernel (conv_taps > 0): the A operand is an IMPLICIT im2col of a [n_tok][conv_W] matrix -- K
+    // index j * conv_W + c reads row src(m, j) = the frame t + j * conv_dil - left of m's sequence, reflect-padded at the
+    // sequence ends (SConv1d, encodec.py:212-228); a source outside the sequence (zero extension of very short inputs) reads
+    // `zero_row`.  K = conv_taps * conv_W, lda = conv_W.
+    int conv_taps, conv_dil, conv_W;
+    const int* seq_start; const int* seq_T; const void* zero_row;
+    void* out_act2;                  // EPI_WN_RS: bf16 shadow copy of the updated out_f32 (the next layer's tap-mode A operand)
     int seq_mul;                     // EPI_QKV: cache row of sequence b is b * seq_mul (0/1 = identity); beam prefill writes only row b*nb
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);

@@ -483,6 +483,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
 #define PF_BN 128
 #define PF_BK 64
 #define PF_GM 8
+#ifndef PF_SCHED
+#define PF_SCHED 1       // explicit LDS-read / MFMA interleave in the tile kernel's main loop (build with -DPF_SCHED=0 for A/B)
+#endif
 
 __device__ __forceinline__ uint32_t pf_pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
 
@@ -650,6 +653,7 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = (old[q] + v[q]) * mask;
                     *o = v;
+                    if (a.out_act2) *(v2u_t*)((u16*)a.out_act2 + (size_t)m * a.D + n) = pf_cvt4(v);
                 }
             } else if constexpr (EPI == EPI_QKV) {                    // GPT prefill: q f32, K / V appended to the bf16 cache
                 const int which = n / a.D, c = n - which * a.D;
@@ -684,7 +688,7 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
     }
 }
 
-template <int EPI>
+template <int EPI, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB | W 16 KiB]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -704,6 +708,11 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     // staging sources of this lane: 4 A chunks (rows) and 4 W chunks per wave per K tile
     const char* asrc[4];
     const char* bsrc[4];
+    int cv_t[4], cv_T[4];
+    const char* cv_base[4];
+    const char* cv_zero[4];
+    const int cv_kpt = CONV ? a.conv_W / PF_BK : 1;            // K tiles per tap
+    const int cv_left = CONV ? (a.conv_taps - 1) * a.conv_dil - ((a.conv_taps - 1) * a.conv_dil) / 2 : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = w * 4 + i;                               // A chunk: tile rows c*8 .. c*8+7
@@ -712,6 +721,13 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
         int m = m0 + row_t;
         m = m < a.M ? m : a.M - 1;
         asrc[i] = (const char*)a.A + ((size_t)m * a.lda + piece * 8) * 2;
+        if constexpr (CONV) {                                  // implicit im2col: remember the row's frame and sequence extent
+            const int sq = a.tok_seq[m];
+            cv_t[i] = a.tok_t[m];
+            cv_T[i] = a.seq_T[sq];
+            cv_base[i] = (const char*)a.A + ((size_t)a.seq_start[sq] * a.lda + piece * 8) * 2;
+            cv_zero[i] = (const char*)a.zero_row + piece * 16;
+        }
         const int nblk = w * 2 + (i >> 1), kb = i & 1;          // W chunk (n-block, k-block of the pair)
         int nt = nt0 + nblk;
         nt = nt < ntiles ? nt : ntiles - 1;
@@ -719,9 +735,21 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     }
     auto issue = [&](int kt, int buf) {
         char* base = pf_sm + buf * 32768;
+        int tap = 0, rem = kt;
+        if constexpr (CONV) { tap = kt / cv_kpt; rem = kt - tap * cv_kpt; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)kt * (PF_BK * 2)),
+            const char* ap = asrc[i] + (size_t)kt * (PF_BK * 2);
+            if constexpr (CONV) {
+                const int maxpad = cv_left;                                        // left >= right
+                const int Tv = cv_T[i] <= maxpad ? maxpad + 1 : cv_T[i];           // zero-extended length of very short inputs
+                int p = cv_t[i] + tap * a.conv_dil - cv_left;
+                p = p < 0 ? -p : p;
+                p = p >= Tv ? 2 * (Tv - 1) - p : p;
+                const bool ok = p >= 0 && p < cv_T[i];
+                ap = ok ? cv_base[i] + ((size_t)p * a.lda + (size_t)rem * PF_BK) * 2 : cv_zero[i];
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap,
                                              (__attribute__((address_space(3))) void*)(base + (w * 4 + i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (size_t)kt * 2048),
                                              (__attribute__((address_space(3))) void*)(base + 16384 + ((w * 2 + (i >> 1)) * 2 + (i & 1)) * 1024), 16, 0, 0);
@@ -751,19 +779,38 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
         __syncthreads();
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const char* base = pf_sm + (kt & 1) * 32768;
+        // Both k-steps' fragments are read up front into separate registers and the second step's reads are interleaved with
+        // the first step's MFMAs (sched_group_barrier: 2 MFMAs per LDS read): left to itself hipcc emitted read-all / wait /
+        // 8 MFMAs / 2 reads / wait / ..., i.e. four exposed LDS round trips per K tile.
+        v4u af0[4], bf0[4], af1[4], bf1[4];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            v4u af[4], bfr[4];
+        for (int mt = 0; mt < 4; ++mt) af0[mt] = *(const v4u*)(base + a_wave + mt * 2048 + a_off[0]);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt] = *(const v4u*)(base + a_wave + mt * 2048 + a_off[s2]);
+        for (int nt = 0; nt < 4; ++nt) bf0[nt] = *(const v4u*)(base + b_wave + (nt * 2 + 0) * 1024);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bfr[nt] = *(const v4u*)(base + b_wave + (nt * 2 + s2) * 1024);
+        for (int mt = 0; mt < 4; ++mt) af1[mt] = *(const v4u*)(base + a_wave + mt * 2048 + a_off[1]);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+        for (int nt = 0; nt < 4; ++nt) bf1[nt] = *(const v4u*)(base + b_wave + (nt * 2 + 1) * 1024);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[mt]),
-                                                                          __builtin_bit_cast(bf16x8_t, bfr[nt]), acc[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af0[mt]),
+                                                                      __builtin_bit_cast(bf16x8_t, bf0[nt]), acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af1[mt]),
+                                                                      __builtin_bit_cast(bf16x8_t, bf1[nt]), acc[mt][nt], 0, 0, 0);
+        if (PF_SCHED) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // 8 DS reads: the first k-step's fragments
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMAs ...
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // ... then one read of the second k-step
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);     // the second k-step's MFMAs
         }
     }
     // Epilogue.  Vector path (every shape of the engine: N, ldo, D multiples of 4): transpose the accumulator tile through LDS
@@ -803,16 +850,16 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     }
 }
 
-template <int EPI>
+template <int EPI, bool CONV = false>
 static int launch_gemm_prefill_e(const GemmArgs& a, hipStream_t st) {
     const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
     const int per = ceil_div(n_mt * n_nt, 8);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_prefill_kernel<EPI>, dim3(per * 8), dim3(256), 65536, st, a);
+    hipLaunchKernelGGL((gemm_prefill_kernel<EPI, CONV>), dim3(per * 8), dim3(256), 65536, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
@@ -824,7 +871,15 @@ static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
         case EPI_GELU_ACT: return launch_gemm_prefill_e<EPI_GELU_ACT>(a, st);
         case EPI_QKV: return launch_gemm_prefill_e<EPI_QKV>(a, st);
         case EPI_SWIGLU: return launch_gemm_prefill_e<EPI_SWIGLU>(a, st);
-        case EPI_GATE: return launch_gemm_prefill_e<EPI_GATE>(a, st);
+        case EPI_GATE:
+            if (a.conv_taps > 0) {
+                if (a.conv_W % PF_BK || a.K != a.conv_taps * a.conv_W || a.lda != a.conv_W || !a.tok_seq || !a.tok_t || !a.seq_start || !a.seq_T || !a.zero_row) {
+                    itts_set_error("gemm tap mode: need conv_W %% 64 == 0, K == taps * conv_W, lda == conv_W and the sequence tables");
+                    return ITTS_ERR_ARG;
+                }
+                return launch_gemm_prefill_e<EPI_GATE, true>(a, st);
+            }
+            return launch_gemm_prefill_e<EPI_GATE>(a, st);
         case EPI_QKV_ROPE: return launch_gemm_prefill_e<EPI_QKV_ROPE>(a, st);
         case EPI_WN_RS: return launch_gemm_prefill_e<EPI_WN_RS>(a, st);
         default: itts_set_error("gemm prefill: unsupported epilogue %d", a.epi); return ITTS_ERR_ARG;

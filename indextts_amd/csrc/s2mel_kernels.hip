@@ -340,7 +340,6 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
         v4u pb[QS][2];
 #pragma unroll
         for (int qs = 0; qs < QS; ++qs) {
-            float mx = -INFINITY;
             if (tail) {                                            // uniform branch: full tiles carry no per-element select
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
@@ -348,35 +347,38 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
                     for (int r = 0; r < 4; ++r)
                         if ((k0 + kt * 16 + g * 4 + r) >= len) st[qs][kt][r] = -INFINITY;
             }
+            // softmax in the exp2 domain on the RAW scores: p = exp2(s * c - m * c) with c = log2(e) / 8 folded into one fma per
+            // element (pairs of elements on the packed-f32 pipe: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), max by v_max3
+            float mx = fmaxf(fmaxf(st[qs][0][0], st[qs][0][1]), fmaxf(st[qs][0][2], st[qs][0][3]));
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = st[qs][kt][r] * scale_log2e;
-                    st[qs][kt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+            for (int kt = 1; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(st[qs][kt][0], st[qs][kt][1])), fmaxf(st[qs][kt][2], st[qs][kt][3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qs], mx);              // finite: key k0 < len is valid for every query
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qs] - m_new);
-            float ps = 0.f;
+            const float m_new = fmaxf(m_run[qs], mx);              // raw-score domain; finite: key k0 < len is valid for every query
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * scale_log2e);
+            const f32x2_t cs{scale_log2e, scale_log2e}, off{-m_new * scale_log2e, -m_new * scale_log2e};
+            f32x2_t psum{0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(st[qs][kt][r] - m_new);
-                    st[qs][kt][r] = p;
-                    ps += p;
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2_t t = f32x2_t{st[qs][kt][2 * h2], st[qs][kt][2 * h2 + 1]} * cs + off;
+                    const f32x2_t p{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    st[qs][kt][2 * h2] = p[0];
+                    st[qs][kt][2 * h2 + 1] = p[1];
+                    psum += p;
                 }
+            float ps = psum[0] + psum[1];
             ps += __shfl_xor(ps, 16, 64);
             ps += __shfl_xor(ps, 32, 64);
             l_run[qs] = l_run[qs] * alpha + ps;
             m_run[qs] = m_new;
+            const f32x2_t al2{alpha, alpha};
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[qs][mt][r] *= alpha;
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x2_t lo = f32x2_t{o[qs][mt][0], o[qs][mt][1]} * al2, hi = f32x2_t{o[qs][mt][2], o[qs][mt][3]} * al2;
+                o[qs][mt] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
 #pragma unroll
             for (int kx = 0; kx < 2; ++kx)
                 pb[qs][kx] = v4u{pack_bf16x2(st[qs][2 * kx][0], st[qs][2 * kx][1]), pack_bf16x2(st[qs][2 * kx][2], st[qs][2 * kx][3]),
