@@ -131,6 +131,9 @@ class UnifiedVoice:
         valid = (text_inputs != self.stop_text_token) & (text_inputs != self.start_text_token)
         n_valid = valid.sum(dim=1)                                     # (b,)
         padding = L - n_valid                                           # left pad per row
+        if L + 2 > self.n_text_pos and int(n_valid.max()) + 2 > self.n_text_pos:
+            # the reference indexes text_pos_embedding out of range here (IndexError on CPU, device assert on a GPU)
+            raise ValueError(f"text of {int(n_valid.max())} tokens exceeds max_text_tokens={self.max_text_tokens}")
         # gather valid ids to the right end of an (b, L+2) row: [pad..][start][ids][stop]
         order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)          # valid ids first, in order
         ids_sorted = torch.gather(text_inputs.long(), 1, order)

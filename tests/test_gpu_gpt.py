@@ -274,6 +274,9 @@ def test_typical_mass_validation():
     with pytest.raises(ValueError):
         m.inference_speech(None, torch.randint(2, 50, (1, 5)), emo_vec=torch.zeros(1, 128), campplus_embedding=torch.zeros(1, 192),
                            typical_sampling=True, typical_mass=1.5, max_generate_length=3)
+    with pytest.raises(ValueError, match="max_text_tokens"):          # 21 text tokens + start/stop need 23 of the 22 positions
+        m.inference_speech(None, torch.randint(2, 50, (1, 21)), emo_vec=torch.zeros(1, 128), campplus_embedding=torch.zeros(1, 192),
+                           max_generate_length=3)
 
 
 def test_full_size_greedy_vs_oracle():

@@ -205,12 +205,12 @@ def test_v2_pipeline_batch16():
     regulator, CFM, BigVGAN) on a batch of 16 segments; every segment of the batch equals the same segment synthesised alone."""
     from indextts_amd import bigvgan, gpt
     from indextts_amd.infer_v2 import IndexTTS2 as IndexTTS2V2
-    cfg = G.GPTConfig(layers=2, model_dim=128, heads=2, max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200)
+    cfg = G.GPTConfig(layers=2, model_dim=128, heads=2, max_text_tokens=60, max_mel_tokens=60, number_text_tokens=200)
     sd = dict(G.synth_weights(cfg, seed=71))
     sd["mel_head.bias"][cfg.stop_mel_token] += 1.5
     sd["speed_emb.weight"] = torch.randn(2, 128, generator=torch.Generator().manual_seed(72)) * 0.3
     lat = torch.randn(1, 32, 128, generator=torch.Generator().manual_seed(73)) * 0.3
-    gm = gpt.UnifiedVoice(layers=2, model_dim=128, heads=2, max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200,
+    gm = gpt.UnifiedVoice(layers=2, model_dim=128, heads=2, max_text_tokens=60, max_mel_tokens=60, number_text_tokens=200,
                           precision="fp32", device=DEV, conditioning_fn=lambda x, lengths=None: lat.to(DEV))
     gm.load_state_dict(sd)
     gm.post_init_gpt2_config(kv_cache=True)
