@@ -483,6 +483,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
 #define PF_BN 128
 #define PF_BK 64
 #define PF_GM 8
+#define PF_LDS 67584     // 2 x (A 16 KiB | W 16 KiB) operand buffers; the epilogue's transposed image [128][132] f32 is the larger
 #ifndef PF_SCHED
 #define PF_SCHED 1       // explicit LDS-read / MFMA interleave in the tile kernel's main loop (build with -DPF_SCHED=0 for A/B)
 #endif
@@ -585,14 +586,14 @@ __device__ __forceinline__ v2u_t pf_cvt4(f32x4 v) { return v2u_t{pf_cvt2(v[0], v
 // accesses are 16-byte (f32) / 8-byte (bf16) pieces of full lines.  The MFMA accumulator layout itself gives each lane 4 rows
 // of one column: 64-byte row segments, half-used lines and read-modify-write at that granularity (measured: the N = 512 f32
 // residual GEMMs of the s2mel DiT ran at 1.4 TB/s of output traffic).
-template <int EPI>
+template <int EPI, int ROWS, int NT>            // ROWS x 128 columns of the tile, stored by NT threads (tid < NT)
 __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct, int m0, int n0, int tid) {
     constexpr bool PAIR = (EPI == EPI_SWIGLU || EPI == EPI_GATE);
     constexpr int CH = PAIR ? 16 : 32;                              // 4-column chunks per tile row
     const int half = a.N >> 1;
 #pragma unroll 4
-    for (int i = 0; i < (128 * CH) / 256; ++i) {
-        const int chunk = tid + 256 * i;
+    for (int i = 0; i < (ROWS * CH) / NT; ++i) {
+        const int chunk = tid + NT * i;
         const int row = chunk / CH, c4 = chunk - row * CH;
         const int m = m0 + row;
         if (m >= a.M) continue;
@@ -684,6 +685,46 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
                     vt[(size_t)3 * a.Tmax] = (u16)(pk.y >> 16);
                 }
             }
+        }
+    }
+}
+
+// V^T part of the fused wqkv epilogue (EPI_QKV_ROPE, 128-column tile regions that lie inside the V columns; D % 128 == 0): the
+// accumulators were written to LDS TRANSPOSED (ctT [128 columns][ROWS + 4], each lane's 4 consecutive rows = one 16-byte write), so
+// a thread owns 4 consecutive frames of one (head, d) row of V^T and a wave's stores walk along t: 8-byte stores when the frame
+// run is 4-aligned, 2-byte stores into shared lines otherwise.  (Read from the row-major image the same stores were one 2-byte
+// element per line per lane: the wqkv GEMM ran at 425 TFLOP/s against 790 for the SwiGLU GEMM of the same K.)
+template <int ROWS, int NT>
+__device__ __forceinline__ void pf_store_vt(const GemmArgs& a, const float* ctT, int m0, int n0, int tid) {
+    constexpr int RQ = ROWS / 4;
+#pragma unroll 4
+    for (int i = 0; i < (128 * RQ) / NT; ++i) {
+        const int chunk = tid + NT * i;
+        const int col = chunk / RQ, rq = chunk - col * RQ;
+        const int m = m0 + 4 * rq, n = n0 + col;
+        if (m >= a.M || n >= a.N) continue;
+        f32x4 v = *(const f32x4*)(ctT + col * (ROWS + 4) + 4 * rq);
+        if (a.bias) {
+            const float b = a.bias[n];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += b;
+        }
+        const int c = n - 2 * a.D, hd = c >> 6, d = c & 63;
+        const int ml = m + 3 < a.M ? m + 3 : a.M - 1;
+        const int s0 = a.tok_seq[m], t0 = a.tok_t[m];
+        const v2u_t pk = pf_cvt4(v);
+        if (m + 3 < a.M && a.tok_seq[ml] == s0) {                 // rows of one sequence are consecutive frames
+            u16* vt = (u16*)a.vcache + (((size_t)s0 * a.H + hd) * 64 + d) * a.Tmax + t0;
+            if (((t0 | a.Tmax) & 3) == 0) {
+                *(v2u_t*)vt = pk;
+            } else {
+                vt[0] = (u16)(pk.x & 0xffffu); vt[1] = (u16)(pk.x >> 16); vt[2] = (u16)(pk.y & 0xffffu); vt[3] = (u16)(pk.y >> 16);
+            }
+        } else {
+            const u16 e[4] = {(u16)(pk.x & 0xffffu), (u16)(pk.x >> 16), (u16)(pk.y & 0xffffu), (u16)(pk.y >> 16)};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (m + q < a.M) ((u16*)a.vcache)[(((size_t)a.tok_seq[m + q] * a.H + hd) * 64 + d) * a.Tmax + a.tok_t[m + q]] = e[q];
         }
     }
 }
@@ -818,8 +859,17 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     const bool vec_ok = (a.N % 4 == 0) && (a.ldo % 4 == 0 || (EPI != EPI_STORE_F32 && EPI != EPI_RESIDUAL && EPI != EPI_GELU_ACT)) && (a.D % 4 == 0);
     if (vec_ok) {
         __syncthreads();                                           // every wave is done with the operand buffers
-        float* ct = (float*)pf_sm;                                 // [128][128] f32 = the whole 64 KiB
+        float* ct = (float*)pf_sm;                                 // [128][128] f32 (row-major) or [128][132] (transposed, V^T tiles)
         const int g = lane >> 4, c16 = lane & 15;
+        if (EPI == EPI_QKV_ROPE && a.D % 128 == 0 && nt0 * 16 >= 2 * a.D) {       // block-uniform: a V tile
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) *(f32x4*)(ct + (wc * 64 + nt * 16 + c16) * 132 + wr * 64 + mt * 16 + g * 4) = acc[mt][nt];
+            __syncthreads();
+            pf_store_vt<128, 256>(a, ct, m0, nt0 * 16, threadIdx.x);
+            return;
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -828,7 +878,7 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
                 for (int r = 0; r < 4; ++r)
                     ct[(wr * 64 + mt * 16 + g * 4 + r) * 128 + ((wc * 64 + nt * 16 + c16) ^ (g << 4))] = acc[mt][nt][r];
         __syncthreads();
-        pf_store_tile<EPI>(a, ct, m0, nt0 * 16, threadIdx.x);
+        pf_store_tile<EPI, 128, 256>(a, ct, m0, nt0 * 16, threadIdx.x);
         return;
     }
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GATE) {
@@ -856,15 +906,276 @@ static int launch_gemm_prefill_e(const GemmArgs& a, hipStream_t st) {
     const int per = ceil_div(n_mt * n_nt, 8);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_prefill_kernel<EPI, CONV>), dim3(per * 8), dim3(256), 65536, st, a);
+    hipLaunchKernelGGL((gemm_prefill_kernel<EPI, CONV>), dim3(per * 8), dim3(256), PF_LDS, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
 
+// ================================================================================================================
+// 256 x 256 tile GEMM, bf16, 8 waves (2 along M x 4 along N; each wave 128 x 64 = 8 x 4 MFMA tiles), BK = 64, for the big-M GEMMs
+// of the s2mel DiT / WaveNet (M = 2 x frames of the whole batch).
+//   Why a second tile kernel: in the 128 x 128 kernel every K tile costs a wave 16 KiB of LDS fragment reads for 32 MFMAs; two
+//   resident blocks read 128 KiB per K tile per CU = 1024 cycles of the 128 B/clk LDS port against 1024 MFMA cycles per SIMD --
+//   the LDS port is as busy as the matrix pipe and every wait in between is exposed (measured 790-850 TFLOP/s).  Here a wave
+//   reads 24 KiB for 64 MFMAs: 192 KiB = 1536 LDS cycles against 2048 MFMA cycles per SIMD.
+//   Schedule: the K tile is computed as 4 quadrants of the wave's output (phases); each phase = [fragment reads of the quadrant,
+//   issue one half-operand LDS-DMA of the NEXT K tile, counted vmcnt] barrier [16 MFMAs] barrier.  The waves form two groups
+//   (waves 0-3 / 4-7 = one wave of each group per SIMD) that run half a phase apart: while one group's MFMAs occupy the matrix
+//   pipe the other group reads its fragments, so neither the LDS reads nor the DMA issue are exposed.
+//   LDS-DMA ordering: a half-operand is waited for (counted s_waitcnt vmcnt by every issuing wave, before the phase's first
+//   barrier) one phase before it is first read; a buffer is restaged one K tile after its last read.
+//   LDS images, fragment read offsets, packed-weight format, accumulation order per output element (k ascending) and the
+//   epilogues are those of gemm_prefill_kernel -> the two kernels are bitwise interchangeable.
+// ================================================================================================================
+#define T2_REGION 34816  // epilogue image of one [64 rows][128 cols] region: row-major 32 KiB, or transposed [128][68] f32
+#define T2_LDS (4 * T2_REGION)   // >= the 2 x 64 KiB operand buffers
+
+template <int VM> __device__ __forceinline__ void t2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory"); }
+
+template <int EPI, bool CONV = false>
+__global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char t2_sm[];      // [2][A 32 KiB | W 32 KiB]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 2, wc = w & 3;                                 // wr = wave group = M half of the tile
+    const int n_mt = (a.M + 255) / 256, n_nt = (a.N + 255) / 256;
+    const int total = n_mt * n_nt, per = (total + 7) >> 3;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= total) return;
+    const int gq = t / (PF_GM * n_nt), first_m = gq * PF_GM;
+    const int gm = (n_mt - first_m) < PF_GM ? (n_mt - first_m) : PF_GM;
+    const int rr = t - gq * PF_GM * n_nt;
+    const int bn = rr / gm, bm = first_m + (rr - bn * gm);
+    const int m0 = bm * 256, nt0 = bn * 16;
+    const int nkb = a.K >> 5, nk = a.K / PF_BK;
+    const int ntiles = (a.N + 15) >> 4;
+
+    // Staging sources of this lane.  Operand halves follow the quadrant order: A half h = m-tiles {8 wr' + 4 h + 0..3, wr' = 0, 1},
+    // W half h = n-tiles {4 wc' + 2 h + 0..1, wc' = 0..3}; a half is 16 chunks of 1 KiB = 2 per wave.
+    const char* asrc[2][2];
+    const char* bsrc[2][2];
+    int a_dst[2][2], b_dst[2][2];
+    int cv_t[2][2], cv_T[2][2];
+    const char* cv_base[2][2];
+    const char* cv_zero[2][2];
+    const int cv_kpt = CONV ? a.conv_W / PF_BK : 1;            // K tiles per tap
+    const int cv_left = CONV ? (a.conv_taps - 1) * a.conv_dil - ((a.conv_taps - 1) * a.conv_dil) / 2 : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cidx = w * 2 + i;
+            const int chunk = (((cidx >> 3) * 8 + h * 4 + ((cidx >> 1) & 3)) << 1) + (cidx & 1);   // 8 tile rows each
+            const int row_t = chunk * 8 + (lane >> 3), row16 = row_t & 15;
+            const int piece = (lane & 7) ^ ((row16 >> 1) & 7);
+            int m = m0 + row_t;
+            m = m < a.M ? m : a.M - 1;
+            asrc[h][i] = (const char*)a.A + ((size_t)m * a.lda + piece * 8) * 2;
+            a_dst[h][i] = chunk * 1024;
+            if constexpr (CONV) {
+                const int sq = a.tok_seq[m];
+                cv_t[h][i] = a.tok_t[m];
+                cv_T[h][i] = a.seq_T[sq];
+                cv_base[h][i] = (const char*)a.A + ((size_t)a.seq_start[sq] * a.lda + piece * 8) * 2;
+                cv_zero[h][i] = (const char*)a.zero_row + piece * 16;
+            }
+            const int ntl = (w >> 1) * 4 + h * 2 + (w & 1);     // n-tile inside the block tile; k-block of the pair = i
+            int nt = nt0 + ntl;
+            nt = nt < ntiles ? nt : ntiles - 1;
+            bsrc[h][i] = (const char*)a.Wp + ((size_t)nt * nkb + i) * 1024 + lane * 16;
+            b_dst[h][i] = 32768 + (ntl * 2 + i) * 1024;
+        }
+    auto issue_a = [&](int kt, int buf, int h) {
+        int tap = 0, rem = kt;
+        if constexpr (CONV) { tap = kt / cv_kpt; rem = kt - tap * cv_kpt; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* ap = asrc[h][i] + (size_t)kt * (PF_BK * 2);
+            if constexpr (CONV) {
+                const int maxpad = cv_left;
+                const int Tv = cv_T[h][i] <= maxpad ? maxpad + 1 : cv_T[h][i];
+                int p = cv_t[h][i] + tap * a.conv_dil - cv_left;
+                p = p < 0 ? -p : p;
+                p = p >= Tv ? 2 * (Tv - 1) - p : p;
+                const bool ok = p >= 0 && p < cv_T[h][i];
+                ap = ok ? cv_base[h][i] + ((size_t)p * a.lda + (size_t)rem * PF_BK) * 2 : cv_zero[h][i];
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap,
+                                             (__attribute__((address_space(3))) void*)(t2_sm + buf * 65536 + a_dst[h][i]), 16, 0, 0);
+        }
+    };
+    auto issue_b = [&](int kt, int buf, int h) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[h][i] + (size_t)kt * 2048),
+                                             (__attribute__((address_space(3))) void*)(t2_sm + buf * 65536 + b_dst[h][i]), 16, 0, 0);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int row16 = lane & 15, kg = lane >> 4;
+    int a_off[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int pos = (s2 * 4 + kg) ^ ((row16 >> 1) & 7);
+        a_off[s2] = (row16 >> 3) * 1024 + ((row16 & 7) * 8 + pos) * 16;
+    }
+    const int a_wave = wr * 8 * 2048;
+    const int b_wave = 32768 + wc * 4 * 2048 + lane * 16;
+
+    v4u af[4][2], b0[2][2], b1[2][2];
+#define T2_READ_A(H_)                                                                                     \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)     \
+        af[mt][s2] = *(const v4u*)(base + a_wave + ((H_) * 4 + mt) * 2048 + a_off[s2]);
+#define T2_READ_B(DST_, H_)                                                                               \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)     \
+        DST_[nt][s2] = *(const v4u*)(base + b_wave + (((H_) * 2 + nt) * 2 + s2) * 1024);
+#define T2_MMA(MH_, NH_, BF_)                                                                             \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)     \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
+            acc[(MH_) * 4 + mt][(NH_) * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                \
+                __builtin_bit_cast(bf16x8_t, af[mt][s2]), __builtin_bit_cast(bf16x8_t, BF_[nt][s2]), acc[(MH_) * 4 + mt][(NH_) * 2 + nt], 0, 0, 0);
+#define T2_PRE_MMA()                                        \
+    __builtin_amdgcn_s_barrier();                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    __builtin_amdgcn_s_setprio(1);
+#define T2_POST_MMA()                                       \
+    __builtin_amdgcn_s_setprio(0);                          \
+    __builtin_amdgcn_sched_barrier(0);                      \
+    __builtin_amdgcn_s_barrier();                           \
+    asm volatile("" ::: "memory");                          \
+    __builtin_amdgcn_sched_barrier(0);
+
+    issue_a(0, 0, 0);
+    issue_b(0, 0, 0);
+    issue_b(0, 0, 1);
+    issue_a(0, 0, 1);
+    t2_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wr == 1) __builtin_amdgcn_s_barrier();                 // group 1 runs half a phase behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* base = t2_sm + (kt & 1) * 65536;
+        const int nb = (kt + 1) & 1;
+        const bool more = kt + 1 < nk;                          // block-uniform
+        // phase 0: quadrant (m-tiles 0-3, n-tiles 0-1)
+        T2_READ_B(b0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        T2_READ_A(0)
+        if (more) { issue_a(kt + 1, nb, 0); t2_wait_vm<4>(); } else t2_wait_vm<0>();
+        T2_PRE_MMA()
+        T2_MMA(0, 0, b0)
+        T2_POST_MMA()
+        // phase 1: (m-tiles 0-3, n-tiles 2-3)
+        T2_READ_B(b1, 1)
+        if (more) { issue_b(kt + 1, nb, 0); t2_wait_vm<4>(); }
+        T2_PRE_MMA()
+        T2_MMA(0, 1, b1)
+        T2_POST_MMA()
+        // phase 2: (m-tiles 4-7, n-tiles 2-3)
+        T2_READ_A(1)
+        if (more) { issue_b(kt + 1, nb, 1); t2_wait_vm<6>(); }
+        T2_PRE_MMA()
+        T2_MMA(1, 1, b1)
+        T2_POST_MMA()
+        // phase 3: (m-tiles 4-7, n-tiles 0-1)
+        if (more) { issue_a(kt + 1, nb, 1); t2_wait_vm<4>(); }
+        T2_PRE_MMA()
+        T2_MMA(1, 0, b0)
+        T2_POST_MMA()
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();                 // group 0 catches up
+#undef T2_READ_A
+#undef T2_READ_B
+#undef T2_MMA
+#undef T2_PRE_MMA
+#undef T2_POST_MMA
+    // Epilogue: two rounds (the wave's m-tiles 0-3, then 4-7) through four [64 rows][128 cols] LDS regions, region w >> 1 written
+    // and stored by waves 2 (w >> 1), 2 (w >> 1) + 1.
+    __syncthreads();
+    const int g = lane >> 4, c16 = lane & 15;
+    const int region = w >> 1;
+    float* ct = (float*)(t2_sm + region * T2_REGION);
+    const int rn0 = nt0 * 16 + (region & 1) * 128;              // first column of the region
+    const bool v_region = EPI == EPI_QKV_ROPE && a.D % 128 == 0 && rn0 >= 2 * a.D;
+    const int ltid = threadIdx.x & 127;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (v_region) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) *(f32x4*)(ct + ((wc & 1) * 64 + nt * 16 + c16) * 68 + mt * 16 + g * 4) = acc[h * 4 + mt][nt];
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ct[(mt * 16 + g * 4 + r) * 128 + (((wc & 1) * 64 + nt * 16 + c16) ^ (g << 4))] = acc[h * 4 + mt][nt][r];
+        }
+        __syncthreads();
+        const int rm0 = m0 + wr * 128 + h * 64;
+        if (rn0 < a.N) {
+            if (v_region) pf_store_vt<64, 128>(a, ct, rm0, rn0, ltid);
+            else pf_store_tile<EPI, 64, 128>(a, ct, rm0, rn0, ltid);
+        }
+        if (h == 0) __syncthreads();
+    }
+}
+
+template <int EPI, bool CONV = false>
+static int launch_gemm_tile256_e(const GemmArgs& a, hipStream_t st) {
+    const int n_mt = ceil_div(a.M, 256), n_nt = ceil_div(a.N, 256);
+    const int per = ceil_div(n_mt * n_nt, 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_tile256_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tile256_kernel<EPI, CONV>), dim3(per * 8), dim3(512), T2_LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// The 256 x 256 kernel holds one block per CU (136 KiB of LDS): it needs several rounds of tiles to amortise the tail, and the
+// vector epilogue (which every shape of the engine has).  ITTS_TILE256=0 keeps the 128 x 128 kernel (A/B, bitwise equal output).
+static bool use_tile256(const GemmArgs& a) {
+    static const int mode = [] { const char* e = getenv("ITTS_TILE256"); return e ? atoi(e) : -1; }();
+    if (mode == 0) return false;
+    const bool vec_ok = (a.N % 16 == 0) && (a.ldo % 4 == 0 || (a.epi != EPI_STORE_F32 && a.epi != EPI_RESIDUAL && a.epi != EPI_GELU_ACT)) && (a.D % 4 == 0);
+    if (!vec_ok || a.N % 128) return false;
+    if (mode == 1) return true;
+    return (long long)ceil_div(a.M, 256) * ceil_div(a.N, 256) >= 1024;
+}
+
 static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
+    if (a.epi == EPI_GATE && a.conv_taps > 0 &&
+        (a.conv_W % PF_BK || a.K != a.conv_taps * a.conv_W || a.lda != a.conv_W || !a.tok_seq || !a.tok_t || !a.seq_start || !a.seq_T || !a.zero_row)) {
+        itts_set_error("gemm tap mode: need conv_W %% 64 == 0, K == taps * conv_W, lda == conv_W and the sequence tables");
+        return ITTS_ERR_ARG;
+    }
+    if (use_tile256(a)) {
+        switch (a.epi) {
+            case EPI_STORE_F32: return launch_gemm_tile256_e<EPI_STORE_F32>(a, st);
+            case EPI_RESIDUAL: return launch_gemm_tile256_e<EPI_RESIDUAL>(a, st);
+            case EPI_GELU_ACT: return launch_gemm_tile256_e<EPI_GELU_ACT>(a, st);
+            case EPI_QKV: return launch_gemm_tile256_e<EPI_QKV>(a, st);
+            case EPI_SWIGLU: return launch_gemm_tile256_e<EPI_SWIGLU>(a, st);
+            case EPI_GATE: return a.conv_taps > 0 ? launch_gemm_tile256_e<EPI_GATE, true>(a, st) : launch_gemm_tile256_e<EPI_GATE>(a, st);
+            case EPI_QKV_ROPE: return launch_gemm_tile256_e<EPI_QKV_ROPE>(a, st);
+            case EPI_WN_RS: return launch_gemm_tile256_e<EPI_WN_RS>(a, st);
+            default: break;
+        }
+    }
     switch (a.epi) {
         case EPI_STORE_F32: return launch_gemm_prefill_e<EPI_STORE_F32>(a, st);
         case EPI_RESIDUAL: return launch_gemm_prefill_e<EPI_RESIDUAL>(a, st);
@@ -872,14 +1183,7 @@ static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
         case EPI_QKV: return launch_gemm_prefill_e<EPI_QKV>(a, st);
         case EPI_SWIGLU: return launch_gemm_prefill_e<EPI_SWIGLU>(a, st);
         case EPI_GATE:
-            if (a.conv_taps > 0) {
-                if (a.conv_W % PF_BK || a.K != a.conv_taps * a.conv_W || a.lda != a.conv_W || !a.tok_seq || !a.tok_t || !a.seq_start || !a.seq_T || !a.zero_row) {
-                    itts_set_error("gemm tap mode: need conv_W %% 64 == 0, K == taps * conv_W, lda == conv_W and the sequence tables");
-                    return ITTS_ERR_ARG;
-                }
-                return launch_gemm_prefill_e<EPI_GATE, true>(a, st);
-            }
-            return launch_gemm_prefill_e<EPI_GATE>(a, st);
+            return a.conv_taps > 0 ? launch_gemm_prefill_e<EPI_GATE, true>(a, st) : launch_gemm_prefill_e<EPI_GATE>(a, st);
         case EPI_QKV_ROPE: return launch_gemm_prefill_e<EPI_QKV_ROPE>(a, st);
         case EPI_WN_RS: return launch_gemm_prefill_e<EPI_WN_RS>(a, st);
         default: itts_set_error("gemm prefill: unsupported epilogue %d", a.epi); return ITTS_ERR_ARG;

@@ -208,6 +208,21 @@ def test_prefill_gemm_kernels_agree():
     assert outs[0] == outs[1], outs
 
 
+def test_prefill_tile256_kernel_agrees():
+    """GPT prefill / latent pass (EPI_QKV cache append, GELU, residual, plain store) through the 256 x 256 tile kernel
+    (ITTS_TILE256=1 forces it for every shape) vs the 128 x 128 kernel: bitwise equal latents and ids."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prefill_probe.py")
+    outs = []
+    for v in ("0", "1"):
+        env = dict(os.environ, ITTS_TILE256=v, PROBE_BIG="1")
+        r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert outs[0] == outs[1], outs
+
+
 def test_decode_gemm_kernels_agree():
     """bf16 decode: the LDS-DMA slab kernel keeps the register-path kernels' k-block split and reduction order -> BITWISE
     equal latents/ids (full-width stack: K slices of 1280, split-K of the 5120-deep projection; and the 16-row slab)."""
