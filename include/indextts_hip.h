@@ -206,6 +206,10 @@ int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, const int32_
                            void* workspace, size_t workspace_bytes, int use_graph, void* stream);
 /* HIP-event timings of the last itts_gpt_generate call on its internal stream */
 int itts_gpt_last_timing(const itts_gpt* h, float* prefill_ms, float* decode_ms, int32_t* steps);
+/* The instantiated decode-step graph is kept in the handle and reused by later generate calls with the same workspace base,
+ * batch rows, prompt-length bucket (multiples of 32), max_new_tokens, generation parameters and codes / uniforms pointers (small
+ * LRU).  Counters since create: graphs captured, generate calls that reused one. */
+int itts_gpt_graph_stats(const itts_gpt* h, int32_t* captures, int32_t* hits);
 
 /* replaces: UnifiedVoice.forward(..., return_latent=True) transformer pass (model_v2.py:596-646, get_logits
  *   :528-554; call site indextts/infer_v2.py:636-651): x [nseq][S][D] -> final_norm(ln_f(blocks(x))) [nseq][S][D]. */

@@ -61,7 +61,49 @@ struct itts_gpt {
     float last_prefill_ms = 0, last_decode_ms = 0;
     int last_steps = 0;
     int device = -1;                   // device current at itts_gpt_create: owns weights, stream, events
+    // Instantiated decode-step graphs, reused across generate calls.  A graph bakes in every pointer and scalar of the step's
+    // 171 launches, so the key is everything those derive from: workspace base, carve shape (rows, bucketed prompt length,
+    // cache stride), output / uniforms pointers, the generation parameters.  Small LRU (a serving process sees a handful of
+    // (batch, prompt-bucket) shapes).
+    struct GraphEntry {
+        const void* base; const void* tokens; const void* uniforms; const void* aux0; const void* aux1; const void* aux2;
+        int nseq, nb, Sb, Tmax, S;           // S: only where the step bakes the exact prompt length in (beam kernels), else 0
+        itts_gen_params gp;
+        hipGraphExec_t exec;
+        unsigned long long stamp;
+    };
+    std::vector<GraphEntry> graphs;
+    unsigned long long graph_clock = 0;
+    int graph_hits = 0, graph_captures = 0;
 };
+#define GRAPH_CACHE_MAX 8
+// prompt lengths are bucketed to multiples of 32 for the workspace carve and the cache stride, so that prompts of nearby lengths
+// share one workspace layout and therefore one decode graph
+static inline int s_bucket(int S) { return (S + 31) & ~31; }
+
+static hipGraphExec_t graph_lookup(itts_gpt* h, const itts_gpt::GraphEntry& k) {
+    for (auto& e : h->graphs)
+        if (e.base == k.base && e.tokens == k.tokens && e.uniforms == k.uniforms && e.aux0 == k.aux0 && e.aux1 == k.aux1 && e.aux2 == k.aux2 &&
+            e.nseq == k.nseq && e.nb == k.nb && e.Sb == k.Sb && e.Tmax == k.Tmax && e.S == k.S && memcmp(&e.gp, &k.gp, sizeof(k.gp)) == 0) {
+            e.stamp = ++h->graph_clock;
+            ++h->graph_hits;
+            return e.exec;
+        }
+    return nullptr;
+}
+static void graph_insert(itts_gpt* h, itts_gpt::GraphEntry k, hipGraphExec_t exec) {
+    k.exec = exec;
+    k.stamp = ++h->graph_clock;
+    ++h->graph_captures;
+    if ((int)h->graphs.size() >= GRAPH_CACHE_MAX) {
+        size_t old = 0;
+        for (size_t i = 1; i < h->graphs.size(); ++i) if (h->graphs[i].stamp < h->graphs[old].stamp) old = i;
+        (void)hipGraphExecDestroy(h->graphs[old].exec);
+        h->graphs[old] = k;
+    } else {
+        h->graphs.push_back(k);
+    }
+}
 
 static int g_upload(itts_gpt* h, const void* host, size_t bytes, void** dst) {
     void* d = nullptr;
@@ -95,6 +137,7 @@ extern "C" int itts_gpt_device(const itts_gpt* h) { return h ? h->device : -1; }
 extern "C" void itts_gpt_destroy(itts_gpt* h) {
     if (!h) return;
     ItDevGuard dg(h->device);
+    for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->host_flag) (void)hipHostFree(h->host_flag);
     if (h->host_fin) (void)hipHostFree(h->host_fin);
@@ -291,15 +334,16 @@ static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tm
 
 extern "C" size_t itts_gpt_workspace_bytes(const itts_gpt* h, int nseq, int S, int Tmax) {
     if (!h || nseq <= 0 || S <= 0 || Tmax < S) return 0;
-    return carve(h->cfg, nullptr, nseq, S, Tmax).total;
+    return carve(h->cfg, nullptr, nseq, s_bucket(S), Tmax + s_bucket(S) - S).total + 256;
 }
 extern "C" size_t itts_gpt_beam_workspace_bytes(const itts_gpt* h, int n_utts, int num_beams, int S, int Tmax) {
     if (!h || n_utts <= 0 || num_beams < 2 || num_beams > BEAM_MAX || S <= 0 || Tmax <= S) return 0;
-    return carve(h->cfg, nullptr, n_utts * num_beams, S, Tmax, num_beams).total;
+    return carve(h->cfg, nullptr, n_utts * num_beams, s_bucket(S), Tmax + s_bucket(S) - S, num_beams).total + 256;
 }
 
 // ---- small state kernels ---------------------------------------------------------------------------------------
 __global__ void set_state_kernel(int* state, int step, int pos) { state[0] = step; state[1] = pos; state[2] = 0; }
+__global__ void set_seed_kernel(int* state, unsigned long long seed) { *(unsigned long long*)(state + 4) = seed; }   // state[4..5]
 __global__ void fill_i64_kernel(long long* p, long long v, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = v;
@@ -384,12 +428,6 @@ static int run_head(itts_gpt* h, const GptWs& w, int nseq, int mul, int add, boo
     return launch_gemm(g, prec, false, st);
 }
 
-// owns the instantiated decode-step graph for the duration of one generate call (error returns included)
-struct GraphExecGuard {
-    hipGraphExec_t e = nullptr;
-    ~GraphExecGuard() { if (e) (void)hipGraphExecDestroy(e); }
-};
-
 static SampleArgs make_sample(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, int nseq, long long* tokens,
                               const double* uniforms) {
     const itts_gpt_config& c = h->cfg;
@@ -401,6 +439,7 @@ static SampleArgs make_sample(itts_gpt* h, const GptWs& w, const itts_gen_params
     s.typical_mass = gp.typical_mass;
     s.stop_token = c.stop_mel_token; s.mel_emb = h->mel_emb; s.mel_pos = h->mel_pos; s.x_next = w.x; s.D = c.model_dim;
     s.pos_offset = gp.pos_offset; s.n_mel_pos = c.n_mel_pos;
+    s.seed_ptr = (const unsigned long long*)(w.state + 4);
     return s;
 }
 
@@ -433,11 +472,11 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
     }
     if (n_penalty_ids < 0 || n_penalty_ids > 16) { itts_set_error("gpt_generate: at most 16 initial penalty ids"); return ITTS_ERR_ARG; }
     if ((size_t)nseq * c.heads > 2147483647u / 4 || S > 65535) { itts_set_error("gpt_generate: batch too large"); return ITTS_ERR_ARG; }
-    const int Tmax = S + gp.max_new_tokens;
-    const GptWs w0 = carve(c, nullptr, nseq, S, Tmax);
+    const int Sb = s_bucket(S), Tmax = Sb + gp.max_new_tokens;      // cache stride / carve shape (bucketed prompt length)
+    const GptWs w0 = carve(c, nullptr, nseq, Sb, Tmax);
     if (workspace_bytes < w0.total) { itts_set_error("gpt_generate: workspace too small (%zu < %zu)", workspace_bytes, w0.total); return ITTS_ERR_ARG; }
     char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    const GptWs w = carve(c, base, nseq, S, Tmax);
+    const GptWs w = carve(c, base, nseq, Sb, Tmax);
     hipStream_t st = h->stream, cs = (hipStream_t)caller_stream;
     long long* tokens = (long long*)codes_out;
     int rc;
@@ -465,6 +504,7 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
         hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tokens, (long long)c.stop_mel_token, n);
     }
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 0, 0);
+    hipLaunchKernelGGL(set_seed_kernel, dim3(1), dim3(1), 0, st, w.state, (unsigned long long)gp.seed);
     HIP_TRY(hipMemcpyAsync(w.x, prefix_embeds, (size_t)nseq * S * c.model_dim * 4, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipGetLastError());
 
@@ -485,25 +525,31 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
     // ---- decode loop ----
     int steps = 1;
     bool graph_ok = false;
-    GraphExecGuard guard;
-    hipGraphExec_t& exec = guard.e;
+    hipGraphExec_t exec = nullptr;
     if (use_graph && gp.max_new_tokens > 1) {
-        // capture one decode step (all step-varying state lives in device memory)
-        hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-            rc = decode_step(h, w, gp, nseq, Tmax, tokens, uniforms, st);
-            e = hipStreamEndCapture(st, &graph);
-            if (rc == ITTS_OK && e == hipSuccess && graph) {
-                e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                graph_ok = (e == hipSuccess && exec);
-            }
-            if (graph) (void)hipGraphDestroy(graph);
-        }
+        itts_gpt::GraphEntry key{};
+        key.base = base; key.tokens = tokens; key.uniforms = uniforms; key.nseq = nseq; key.nb = 1; key.Sb = Sb; key.Tmax = Tmax; key.gp = gp; key.gp.seed = 0;          // the seed lives in device memory
+        exec = graph_lookup(h, key);
+        graph_ok = exec != nullptr;
         if (!graph_ok) {
-            (void)hipGetLastError();
-            itts_set_error("gpt_generate: hipGraph capture failed (%s); rerun with use_graph=0", hipGetErrorString(e));
-            return ITTS_ERR_HIP;
+            // capture one decode step (all step-varying state lives in device memory); kept in the handle for later calls
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                rc = decode_step(h, w, gp, nseq, Tmax, tokens, uniforms, st);
+                e = hipStreamEndCapture(st, &graph);
+                if (rc == ITTS_OK && e == hipSuccess && graph) {
+                    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                    graph_ok = (e == hipSuccess && exec);
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            if (!graph_ok) {
+                (void)hipGetLastError();
+                itts_set_error("gpt_generate: hipGraph capture failed (%s); rerun with use_graph=0", hipGetErrorString(e));
+                return ITTS_ERR_HIP;
+            }
+            graph_insert(h, key, exec);
         }
     }
     const int check_every = 8;
@@ -557,6 +603,7 @@ static BeamArgs make_beam(itts_gpt* h, const GptWs& w, const itts_gen_params& gp
     a.typical_mass = gp.typical_mass;
     a.stop_token = c.stop_mel_token; a.mel_emb = h->mel_emb; a.mel_pos = h->mel_pos; a.x_next = w.x; a.D = c.model_dim;
     a.pos_offset = gp.pos_offset; a.n_mel_pos = c.n_mel_pos;
+    a.seed_ptr = (const unsigned long long*)(w.state + 4);
     return a;
 }
 
@@ -587,11 +634,11 @@ extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, c
     if (B <= 0 || nb < 2 || nb > BEAM_MAX || S <= 0 || gp.max_new_tokens <= 0) { itts_set_error("gpt_generate_beam: bad sizes"); return ITTS_ERR_ARG; }
     if (gp.max_new_tokens + gp.pos_offset > c.n_mel_pos + 1) { itts_set_error("gpt_generate_beam: max_new_tokens exceeds the mel position table"); return ITTS_ERR_ARG; }
     if (n_penalty_ids < 0 || n_penalty_ids > 16) { itts_set_error("gpt_generate_beam: at most 16 initial penalty ids"); return ITTS_ERR_ARG; }
-    const int Tmax = S + gp.max_new_tokens;
-    const GptWs w0 = carve(c, nullptr, nseq, S, Tmax, nb);
+    const int Sb = s_bucket(S), Tmax = Sb + gp.max_new_tokens;
+    const GptWs w0 = carve(c, nullptr, nseq, Sb, Tmax, nb);
     if (workspace_bytes < w0.total) { itts_set_error("gpt_generate_beam: workspace too small (%zu < %zu)", workspace_bytes, w0.total); return ITTS_ERR_ARG; }
     char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    const GptWs w = carve(c, base, nseq, S, Tmax, nb);
+    const GptWs w = carve(c, base, nseq, Sb, Tmax, nb);
     hipStream_t st = h->stream, cs = (hipStream_t)caller_stream;
     int rc;
     if (h->fin_cap < nseq) {
@@ -614,6 +661,7 @@ extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, c
     }
     hipLaunchKernelGGL(beam_init_kernel, dim3(nseq), dim3(256), 0, st, w.row_map[0], w.beam_scores, w.worst, w.n_hyps, w.done, nseq, nb, Tmax, S);
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 0, 0);
+    hipLaunchKernelGGL(set_seed_kernel, dim3(1), dim3(1), 0, st, w.state, (unsigned long long)gp.seed);
     // the nb rows of an utterance carry the same prompt (repeat_interleave): prefill the B unique prompts only
     const size_t row_bytes = (size_t)S * c.model_dim * 4;
     HIP_TRY(hipMemcpy2DAsync(w.x, row_bytes, prefix_embeds, row_bytes * nb, row_bytes, B, hipMemcpyDeviceToDevice, st));
@@ -634,25 +682,31 @@ extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, c
     HIP_TRY(hipEventRecord(h->ev_t1, st));
 
     int steps = 1;
-    GraphExecGuard guard;
-    hipGraphExec_t& exec = guard.e;
+    hipGraphExec_t exec = nullptr;
     bool graph_ok = false;
     if (use_graph && gp.max_new_tokens > 1) {
-        hipGraph_t graph = nullptr;
-        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-            rc = decode_step_beam(h, w, ba, nseq, Tmax, st);
-            e = hipStreamEndCapture(st, &graph);
-            if (rc == ITTS_OK && e == hipSuccess && graph) {
-                e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                graph_ok = (e == hipSuccess && exec);
-            }
-            if (graph) (void)hipGraphDestroy(graph);
-        }
+        itts_gpt::GraphEntry key{};
+        key.base = base; key.uniforms = uniforms; key.nseq = nseq; key.nb = nb; key.Sb = Sb; key.Tmax = Tmax; key.S = S; key.gp = gp; key.gp.seed = 0;
+        exec = graph_lookup(h, key);
+        graph_ok = exec != nullptr;
         if (!graph_ok) {
-            (void)hipGetLastError();
-            itts_set_error("gpt_generate_beam: hipGraph capture failed (%s); rerun with use_graph=0", hipGetErrorString(e));
-            return ITTS_ERR_HIP;
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                rc = decode_step_beam(h, w, ba, nseq, Tmax, st);
+                e = hipStreamEndCapture(st, &graph);
+                if (rc == ITTS_OK && e == hipSuccess && graph) {
+                    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                    graph_ok = (e == hipSuccess && exec);
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            if (!graph_ok) {
+                (void)hipGetLastError();
+                itts_set_error("gpt_generate_beam: hipGraph capture failed (%s); rerun with use_graph=0", hipGetErrorString(e));
+                return ITTS_ERR_HIP;
+            }
+            graph_insert(h, key, exec);
         }
     }
     // the reference loop stops when every utterance is done (checked right after the scorer) or at max_length
@@ -688,6 +742,13 @@ extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, c
     (void)hipEventElapsedTime(&h->last_decode_ms, h->ev_t1, h->ev_t2);
     h->last_steps = steps;
     *n_steps_out = steps;
+    return ITTS_OK;
+}
+
+extern "C" int itts_gpt_graph_stats(const itts_gpt* h, int32_t* captures, int32_t* hits) {
+    if (!h) return ITTS_ERR_ARG;
+    if (captures) *captures = h->graph_captures;
+    if (hits) *hits = h->graph_hits;
     return ITTS_OK;
 }
 

@@ -88,6 +88,7 @@ struct SampleArgs {
     // next-step embedding: x_next[b] = mel_emb[tok] + mel_pos[step + pos_offset]
     const float* mel_emb; const float* mel_pos; float* x_next; int D; int pos_offset; int n_mel_pos;
     int* adv_state;          // {step, pos, ticket}: when non-null the last block to finish advances step and pos (decode steps)
+    const unsigned long long* seed_ptr;   // when non-null the RNG seed is read from device memory (keeps a captured step seed-free)
 };
 int launch_sample(const SampleArgs& a, hipStream_t st);
 int launch_advance(int* step_ptr, int* pos_ptr, hipStream_t st);
@@ -118,6 +119,7 @@ struct BeamArgs {
     int stop_token;
     const float* mel_emb; const float* mel_pos; float* x_next; int D; int pos_offset; int n_mel_pos;
     int* adv_state;               // as SampleArgs::adv_state, honoured by the apply kernel (the step's last launch)
+    const unsigned long long* seed_ptr;   // as SampleArgs::seed_ptr
 };
 int launch_beam_step(const BeamArgs& a, hipStream_t st);
 int launch_beam_apply(const BeamArgs& a, hipStream_t st);

@@ -1146,15 +1146,184 @@ static int launch_gemm_tile256_e(const GemmArgs& a, hipStream_t st) {
     return ITTS_OK;
 }
 
+// ================================================================================================================
+// 256 x 128 tile GEMM, bf16, FOUR waves (2 along M x 2 along N, each 128 x 64 = 8 x 4 MFMA tiles), K step 32, three-stage
+// LDS-DMA ring, two blocks per CU.
+//   The short-K GEMMs of the s2mel DiT (K = 512: 8 or 16 K steps per tile) spend as long in tile prologue + epilogue as in the
+//   main loop, and the eight-wave 256 x 256 kernel (one block per CU) serialises the three.  This shape keeps its wave tile
+//   (0.375 KiB of LDS fragment reads per MFMA against 0.5 for the 128 x 128 kernel's 64 x 64 wave tile: the LDS port at 75 %
+//   of the matrix pipe's time instead of 100 %) but fits two blocks per CU (72 KiB each), so one block's epilogue / first loads
+//   overlap the other's main loop, and the two blocks' waves share each SIMD (MFMA of one under the fragment reads of the other).
+//   Ring: step k reads stage k % 3; the DMA of step k + 2 is issued at the top of step k into the stage read at step k - 1 (every
+//   wave is past that step's closing barrier); a counted s_waitcnt vmcnt(6) + barrier at the bottom of step k leaves exactly
+//   that DMA in flight and makes step k + 1's data visible.  The DMA queue never drains inside a tile.
+//   A image per stage: [16 chunks][16 rows][64 B], 16-byte pieces XOR-permuted by (row >> 2) & 3 on the source side
+//   (conflict-free ds_read_b128 fragments); W image: the packed fragments as they are.  Accumulation order per output element
+//   and the epilogues are those of the other two tile kernels (bitwise interchangeable).
+// ================================================================================================================
+#define T3_STAGE 24576
+#define T3_LDS (3 * T3_STAGE)   // >= 2 epilogue regions of T2_REGION
+
+template <int EPI, bool CONV = false>
+__global__ __launch_bounds__(256, 2) void gemm_tile_4w_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char t3_sm[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int n_mt = (a.M + 255) / 256, n_nt = (a.N + 127) / 128;
+    const int total = n_mt * n_nt, per = (total + 7) >> 3;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= total) return;
+    const int gq = t / (PF_GM * n_nt), first_m = gq * PF_GM;
+    const int gm = (n_mt - first_m) < PF_GM ? (n_mt - first_m) : PF_GM;
+    const int rr = t - gq * PF_GM * n_nt;
+    const int bn = rr / gm, bm = first_m + (rr - bn * gm);
+    const int m0 = bm * 256, nt0 = bn * 8;
+    const int nkb = a.K >> 5;
+    const int ntiles = (a.N + 15) >> 4;
+
+    // staging sources of this lane: 4 A chunks (16 rows x 64 B each) and 2 W chunks per K step
+    const char* asrc[4];
+    const char* bsrc[2];
+    int cv_t[4], cv_T[4];
+    const char* cv_base[4];
+    const char* cv_zero[4];
+    const int cv_kpt = CONV ? a.conv_W >> 5 : 1;               // K steps per tap
+    const int cv_left = CONV ? (a.conv_taps - 1) * a.conv_dil - ((a.conv_taps - 1) * a.conv_dil) / 2 : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = lane >> 2, piece = (lane & 3) ^ ((row >> 2) & 3);
+        int m = m0 + (w * 4 + i) * 16 + row;
+        m = m < a.M ? m : a.M - 1;
+        asrc[i] = (const char*)a.A + ((size_t)m * a.lda + piece * 8) * 2;
+        if constexpr (CONV) {
+            const int sq = a.tok_seq[m];
+            cv_t[i] = a.tok_t[m];
+            cv_T[i] = a.seq_T[sq];
+            cv_base[i] = (const char*)a.A + ((size_t)a.seq_start[sq] * a.lda + piece * 8) * 2;
+            cv_zero[i] = (const char*)a.zero_row + piece * 16;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int nt = nt0 + w * 2 + i;
+        nt = nt < ntiles ? nt : ntiles - 1;
+        bsrc[i] = (const char*)a.Wp + (size_t)nt * nkb * 1024 + lane * 16;
+    }
+    auto issue = [&](int ks, char* stage) {
+        int tap = 0, rem = ks;
+        if constexpr (CONV) { tap = ks / cv_kpt; rem = ks - tap * cv_kpt; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* ap = asrc[i] + (size_t)ks * 64;
+            if constexpr (CONV) {
+                const int maxpad = cv_left;
+                const int Tv = cv_T[i] <= maxpad ? maxpad + 1 : cv_T[i];
+                int p = cv_t[i] + tap * a.conv_dil - cv_left;
+                p = p < 0 ? -p : p;
+                p = p >= Tv ? 2 * (Tv - 1) - p : p;
+                const bool ok = p >= 0 && p < cv_T[i];
+                ap = ok ? cv_base[i] + ((size_t)p * a.lda + (size_t)rem * 32) * 2 : cv_zero[i];
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap,
+                                             (__attribute__((address_space(3))) void*)(stage + (w * 4 + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (size_t)ks * 1024),
+                                             (__attribute__((address_space(3))) void*)(stage + 16384 + (w * 2 + i) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int row16 = lane & 15, kg = lane >> 4;
+    const int a_rd = wr * 8 * 1024 + row16 * 64 + ((kg ^ ((row16 >> 2) & 3)) << 4);
+    const int b_rd = 16384 + wc * 4 * 1024 + lane * 16;
+
+    char* s_cur = t3_sm;                      // stage read at this step
+    char* s_nxt = t3_sm + T3_STAGE;           // step + 1
+    char* s_far = t3_sm + 2 * T3_STAGE;       // step + 2 (read at step - 1)
+    issue(0, s_cur);
+    if (nkb > 1) { issue(1, s_nxt); t2_wait_vm<6>(); } else t2_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int ks = 0; ks < nkb; ++ks) {
+        const bool far = ks + 2 < nkb;                              // block-uniform
+        if (far) issue(ks + 2, s_far);
+        v4u af[8], bf[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bf[nt] = *(const v4u*)(s_cur + b_rd + nt * 1024);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) af[mt] = *(const v4u*)(s_cur + a_rd + mt * 1024);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[mt]), __builtin_bit_cast(bf16x8_t, bf[nt]),
+                                                                      acc[mt][nt], 0, 0, 0);
+        if (far) t2_wait_vm<6>(); else t2_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        char* tmp = s_cur; s_cur = s_nxt; s_nxt = s_far; s_far = tmp;
+    }
+    // Epilogue: two rounds (m-tiles 0-3, 4-7 of every wave) through two [64 rows][128 cols] LDS regions, region wr written and
+    // stored by waves 2 wr, 2 wr + 1.  (The last barrier of the loop has every wave past its fragment reads.)
+    const int g = lane >> 4, c16 = lane & 15;
+    float* ct = (float*)(t3_sm + wr * T2_REGION);
+    const int rn0 = nt0 * 16;
+    const bool v_region = EPI == EPI_QKV_ROPE && a.D % 128 == 0 && rn0 >= 2 * a.D;
+    const int ltid = threadIdx.x & 127;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (v_region) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) *(f32x4*)(ct + (wc * 64 + nt * 16 + c16) * 68 + mt * 16 + g * 4) = acc[h * 4 + mt][nt];
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ct[(mt * 16 + g * 4 + r) * 128 + ((wc * 64 + nt * 16 + c16) ^ (g << 4))] = acc[h * 4 + mt][nt][r];
+        }
+        __syncthreads();
+        const int rm0 = m0 + wr * 128 + h * 64;
+        if (v_region) pf_store_vt<64, 128>(a, ct, rm0, rn0, ltid);
+        else pf_store_tile<EPI, 64, 128>(a, ct, rm0, rn0, ltid);
+        if (h == 0) __syncthreads();
+    }
+}
+
+template <int EPI, bool CONV = false>
+static int launch_gemm_tile_4w_e(const GemmArgs& a, hipStream_t st) {
+    const int n_mt = ceil_div(a.M, 256), n_nt = ceil_div(a.N, 128);
+    const int per = ceil_div(n_mt * n_nt, 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_tile_4w_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tile_4w_kernel<EPI, CONV>), dim3(per * 8), dim3(256), T3_LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
 // The 256 x 256 kernel holds one block per CU (136 KiB of LDS): it needs several rounds of tiles to amortise the tail, and the
 // vector epilogue (which every shape of the engine has).  ITTS_TILE256=0 keeps the 128 x 128 kernel (A/B, bitwise equal output).
-static bool use_tile256(const GemmArgs& a) {
+// Which tile kernel: 0 = 128 x 128 (four waves, two blocks per CU), 1 = 256 x 256 (eight waves, one block per CU), 2 = 256 x 128
+// (four waves, two blocks per CU).  ITTS_TILE256 = 0 | 1 | 2 forces one (A/B; the three are bitwise interchangeable).
+static int pick_tile_kernel(const GemmArgs& a) {
     static const int mode = [] { const char* e = getenv("ITTS_TILE256"); return e ? atoi(e) : -1; }();
-    if (mode == 0) return false;
+    if (mode == 0) return 0;
     const bool vec_ok = (a.N % 16 == 0) && (a.ldo % 4 == 0 || (a.epi != EPI_STORE_F32 && a.epi != EPI_RESIDUAL && a.epi != EPI_GELU_ACT)) && (a.D % 4 == 0);
-    if (!vec_ok || a.N % 128) return false;
-    if (mode == 1) return true;
-    return (long long)ceil_div(a.M, 256) * ceil_div(a.N, 256) >= 1024;
+    if (!vec_ok || a.N % 128) return 0;
+    if (mode == 1 || mode == 2) return mode;
+    return 0;
 }
 
 static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
@@ -1163,19 +1332,22 @@ static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
         itts_set_error("gemm tap mode: need conv_W %% 64 == 0, K == taps * conv_W, lda == conv_W and the sequence tables");
         return ITTS_ERR_ARG;
     }
-    if (use_tile256(a)) {
-        switch (a.epi) {
-            case EPI_STORE_F32: return launch_gemm_tile256_e<EPI_STORE_F32>(a, st);
-            case EPI_RESIDUAL: return launch_gemm_tile256_e<EPI_RESIDUAL>(a, st);
-            case EPI_GELU_ACT: return launch_gemm_tile256_e<EPI_GELU_ACT>(a, st);
-            case EPI_QKV: return launch_gemm_tile256_e<EPI_QKV>(a, st);
-            case EPI_SWIGLU: return launch_gemm_tile256_e<EPI_SWIGLU>(a, st);
-            case EPI_GATE: return a.conv_taps > 0 ? launch_gemm_tile256_e<EPI_GATE, true>(a, st) : launch_gemm_tile256_e<EPI_GATE>(a, st);
-            case EPI_QKV_ROPE: return launch_gemm_tile256_e<EPI_QKV_ROPE>(a, st);
-            case EPI_WN_RS: return launch_gemm_tile256_e<EPI_WN_RS>(a, st);
-            default: break;
-        }
+    const int tk = pick_tile_kernel(a);
+#define ITTS_TILE_DISPATCH(FN)                                                                                                          \
+    switch (a.epi) {                                                                                                                     \
+        case EPI_STORE_F32: return FN<EPI_STORE_F32>(a, st);                                                                             \
+        case EPI_RESIDUAL: return FN<EPI_RESIDUAL>(a, st);                                                                               \
+        case EPI_GELU_ACT: return FN<EPI_GELU_ACT>(a, st);                                                                               \
+        case EPI_QKV: return FN<EPI_QKV>(a, st);                                                                                         \
+        case EPI_SWIGLU: return FN<EPI_SWIGLU>(a, st);                                                                                   \
+        case EPI_GATE: return a.conv_taps > 0 ? FN<EPI_GATE, true>(a, st) : FN<EPI_GATE>(a, st);                                         \
+        case EPI_QKV_ROPE: return FN<EPI_QKV_ROPE>(a, st);                                                                               \
+        case EPI_WN_RS: return FN<EPI_WN_RS>(a, st);                                                                                     \
+        default: break;                                                                                                                  \
     }
+    if (tk == 1) { ITTS_TILE_DISPATCH(launch_gemm_tile256_e) }
+    if (tk == 2) { ITTS_TILE_DISPATCH(launch_gemm_tile_4w_e) }
+#undef ITTS_TILE_DISPATCH
     switch (a.epi) {
         case EPI_STORE_F32: return launch_gemm_prefill_e<EPI_STORE_F32>(a, st);
         case EPI_RESIDUAL: return launch_gemm_prefill_e<EPI_RESIDUAL>(a, st);
@@ -1894,7 +2066,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             if (tid == 0) {
                 double total = 0.0;
                 for (int i = lo; i < n; ++i) total += (double)cand_v[i];
-                const double u = a.uniforms ? a.uniforms[(size_t)step * a.B + b] : rng_uniform(a.seed, (unsigned long long)step, (unsigned long long)b);
+                const double u = a.uniforms ? a.uniforms[(size_t)step * a.B + b] : rng_uniform(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned long long)step, (unsigned long long)b);
                 const double tgt = u * total;
                 double cum = 0.0;
                 int pick = cand_i[n - 1];
@@ -2170,7 +2342,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
             double total = 0.0;
             for (int i = 0; i < un; ++i) total += (double)ue[i];
             const double u = a.uniforms ? a.uniforms[((size_t)step * a.B + b) * ncand + d]
-                                        : rng_uniform(a.seed, (unsigned long long)step * 8 + d, (unsigned long long)b);
+                                        : rng_uniform(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned long long)step * 8 + d, (unsigned long long)b);
             const double tgt = u * total;
             double cum = 0.0;
             int pick = -1, lastfree = -1;

@@ -268,11 +268,27 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 
 // QS = 16-query sub-tiles per wave (block = 64 * QS queries).  Every K / V^T fragment read from LDS feeds QS MFMAs: with one
 // sub-tile the kernel is LDS-bound (16 KB of fragment reads per 16 MFMAs per wave), with four the MFMA pipe is the limit.
+// max over the lanes l, l ^ 16, l ^ 32, l ^ 48 (the four key groups of one query column) on the VALU: v_permlane16_swap /
+// v_permlane32_swap (gfx950) exchange 16- / 32-lane halves between two registers.  The shuffle form (__shfl_xor -> ds_bpermute)
+// put four LDS-pipe round trips per key tile on the softmax's critical path, queued behind the V^T fragment reads.
+__device__ __forceinline__ float fa_colmax(float x) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1\n\tv_mov_b32 %1, %0\n\ts_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1"
+                 : "+v"(a), "+v"(b));
+    return a;
+}
+__device__ __forceinline__ float fa_max3(float a, float b, float c) {       // no NaN canonicalisation (scores are finite or -inf)
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int QS>
 __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ Vt,
                                                               u16* __restrict__ O, SeqTab tab, int heads, int t_pad, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) u16 ks[64 * FA_LD];
-    __shared__ __attribute__((aligned(16))) u16 vs[64 * FA_LD];
+    __shared__ __attribute__((aligned(16))) u16 ks[2][64 * FA_LD];     // two stages: one barrier per key tile
+    __shared__ __attribute__((aligned(16))) u16 vs[2][64 * FA_LD];
     const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (64 * QS);
     const int T = tab.seq_T[s], len = tab.seq_len[s];
     if (q0 >= T) return;
@@ -301,8 +317,16 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
             vreg[i] = *(const v4u*)(Vb + (size_t)r * t_pad + k0 + p0 * 8);
         }
     };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = r0 + 32 * i;
+            *(v4u*)(ks[buf] + r * FA_LD + p0 * 8) = kreg[i];
+            *(v4u*)(vs[buf] + r * FA_LD + p0 * 8) = vreg[i];
+        }
+    };
     f32x4 o[QS][4];
-    float m_run[QS], l_run[QS];
+    float m_run[QS], l_run[QS];                                    // l_run: this lane's share of the row sum (reduced after the loop)
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
         m_run[qs] = -INFINITY;
@@ -311,30 +335,32 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
         for (int mt = 0; mt < 4; ++mt) o[qs][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     fetch(0);
-    for (int k0 = 0; k0 < len; k0 += 64) {
-        __syncthreads();                                           // the previous tile's fragments are consumed
+    stage(0);
+    __syncthreads();
+    // pin the Q fragments here: hipcc otherwise sinks their loads to the loop's doorstep and then has to guard their first use
+    // INSIDE the loop with s_waitcnt vmcnt(0) -- which also drains the next key tile's prefetch every iteration
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = r0 + 32 * i;
-            *(v4u*)(ks + r * FA_LD + p0 * 8) = kreg[i];
-            *(v4u*)(vs + r * FA_LD + p0 * 8) = vreg[i];
-        }
-        __syncthreads();
-        if (k0 + 64 < len) fetch(k0 + 64);                         // block-uniform
+    for (int qs = 0; qs < QS; ++qs) {
+        asm volatile("" : "+v"(qf[qs][0]));
+        asm volatile("" : "+v"(qf[qs][1]));
+    }
+    int buf = 0;
+    for (int k0 = 0; k0 < len; k0 += 64, buf ^= 1) {
+        const bool more = k0 + 64 < len;                           // block-uniform
+        if (more) fetch(k0 + 64);                                  // in flight under this tile's MFMAs
+        const u16* kt_s = ks[buf];
+        const u16* vt_s = vs[buf];
         f32x4 st[QS][4];
+        // S^T: all four key sub-tiles with the first 32 d, then the second 32 d -- consecutive MFMAs never chain on one accumulator
 #pragma unroll
-        for (int qs = 0; qs < QS; ++qs)
+        for (int kx = 0; kx < 2; ++kx)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) st[qs][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int kx = 0; kx < 2; ++kx) {
-                const v4u a = *(const v4u*)(ks + (kt * 16 + c16) * FA_LD + kx * 32 + g * 8);
+            for (int kt = 0; kt < 4; ++kt) {
+                const v4u a = *(const v4u*)(kt_s + (kt * 16 + c16) * FA_LD + kx * 32 + g * 8);
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs)
                     st[qs][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[qs][kx]),
-                                                                         st[qs][kt], 0, 0, 0);
+                                                                         kx == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : st[qs][kt], 0, 0, 0);
             }
         const bool tail = k0 + 64 > len;                           // block-uniform: only the last tile holds masked keys
         v4u pb[QS][2];
@@ -348,13 +374,12 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
                         if ((k0 + kt * 16 + g * 4 + r) >= len) st[qs][kt][r] = -INFINITY;
             }
             // softmax in the exp2 domain on the RAW scores: p = exp2(s * c - m * c) with c = log2(e) / 8 folded into one fma per
-            // element (pairs of elements on the packed-f32 pipe: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), max by v_max3
-            float mx = fmaxf(fmaxf(st[qs][0][0], st[qs][0][1]), fmaxf(st[qs][0][2], st[qs][0][3]));
-#pragma unroll
-            for (int kt = 1; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(st[qs][kt][0], st[qs][kt][1])), fmaxf(st[qs][kt][2], st[qs][kt][3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qs], mx);              // raw-score domain; finite: key k0 < len is valid for every query
+            // element (pairs of elements on the packed-f32 pipe); in-lane max by v_max3, across the query's four lanes by permlane swaps
+            const float t0 = fa_max3(st[qs][0][0], st[qs][0][1], st[qs][0][2]), t1 = fa_max3(st[qs][1][0], st[qs][1][1], st[qs][1][2]);
+            const float t2 = fa_max3(st[qs][2][0], st[qs][2][1], st[qs][2][2]), t3 = fa_max3(st[qs][3][0], st[qs][3][1], st[qs][3][2]);
+            const float u0 = fa_max3(t0, t1, st[qs][0][3]), u1 = fa_max3(t2, t3, st[qs][1][3]);
+            const float mx = fa_colmax(fa_max3(u0, u1, fa_max3(st[qs][2][3], st[qs][3][3], m_run[qs])));
+            const float m_new = mx;                                // >= m_run; finite: key k0 < len is valid for every query
             const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * scale_log2e);
             const f32x2_t cs{scale_log2e, scale_log2e}, off{-m_new * scale_log2e, -m_new * scale_log2e};
             f32x2_t psum{0.f, 0.f};
@@ -368,10 +393,7 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
                     st[qs][kt][2 * h2 + 1] = p[1];
                     psum += p;
                 }
-            float ps = psum[0] + psum[1];
-            ps += __shfl_xor(ps, 16, 64);
-            ps += __shfl_xor(ps, 32, 64);
-            l_run[qs] = l_run[qs] * alpha + ps;
+            l_run[qs] = l_run[qs] * alpha + (psum[0] + psum[1]);
             m_run[qs] = m_new;
             const f32x2_t al2{alpha, alpha};
 #pragma unroll
@@ -388,7 +410,7 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
         for (int kx = 0; kx < 2; ++kx)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const u16* vrow = vs + (mt * 16 + c16) * FA_LD + kx * 32 + g * 4;
+                const u16* vrow = vt_s + (mt * 16 + c16) * FA_LD + kx * 32 + g * 4;
                 const v2u lo = *(const v2u*)vrow, hi = *(const v2u*)(vrow + 16);
                 const v4u a{lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
@@ -396,12 +418,17 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
                     o[qs][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, pb[qs][kx]),
                                                                         o[qs][mt], 0, 0, 0);
             }
+        if (more) stage(buf ^ 1);                                  // the other stage was last read one tile ago (barrier below that tile)
+        __syncthreads();
     }
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
+        float ls = l_run[qs];                                      // the four key groups' shares of the row sum
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
         const int qi = q0 + (w * QS + qs) * 16 + c16;
         if (qi < T) {
-            const float inv = l_run[qs] > 0.f ? 1.0f / l_run[qs] : 0.f;
+            const float inv = ls > 0.f ? 1.0f / ls : 0.f;
             u16* orow = O + (row0 + qi) * H + h * 64;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {

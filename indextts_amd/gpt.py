@@ -59,6 +59,7 @@ class UnifiedVoice:
         self._emb: Dict[str, torch.Tensor] = {}
         self._loaded = False
         self._ws = None
+        self._bufs = {}
         self.last_timing = None
 
     # ---- checkpoint ------------------------------------------------------------------------------------------
@@ -201,9 +202,34 @@ class UnifiedVoice:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def _persistent(self, name: str, shape, dtype) -> torch.Tensor:
+        key = (name, tuple(int(v) for v in shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            if len(self._bufs) >= 32:
+                self._bufs.clear()
+            t = self._bufs[key] = torch.empty(*key[1], dtype=dtype, device=self.device)
+        return t
+
+    @staticmethod
+    def _seed(seed, do_sample, uniforms) -> int:
+        """Device RNG seed.  `seed=None` (the default) draws it from torch's global generator, so sampled calls differ from
+        call to call and follow `torch.manual_seed` like the reference's `torch.multinomial` does; an explicit seed is kept."""
+        if seed is not None:
+            return int(seed)
+        if not do_sample or uniforms is not None:
+            return 0
+        return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+    def graph_stats(self) -> dict:
+        """decode-step hipGraphs captured / reused by this engine handle (itts_gpt_graph_stats)"""
+        cap, hit = C.c_int32(0), C.c_int32(0)
+        _lib.lib().itts_gpt_graph_stats(self._h, C.byref(cap), C.byref(hit))
+        return dict(captures=cap.value, hits=hit.value)
+
     def generate(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int, do_sample=False,
                  num_beams=1, top_p=1.0, top_k=50, temperature=1.0, repetition_penalty=1.0, length_penalty=1.0,
-                 uniforms: Optional[torch.Tensor] = None, seed: int = 0, typical_mass: float = 0.0, **unused) -> torch.Tensor:
+                 uniforms: Optional[torch.Tensor] = None, seed: Optional[int] = None, typical_mass: float = 0.0, **unused) -> torch.Tensor:
         """`GPT2InferenceModel.generate` for greedy / multinomial sampling (typical_mass > 0: the reference's
         TypicalLogitsWarper sits between the repetition penalty and the warpers, model_v2.py:794-799).  inputs_embeds (B,s,D) = the cached prefix;
         attention_mask (B,s+1).  Returns generated ids (B, n) (what `output[:, trunc_index:]` is in the reference)."""
@@ -224,20 +250,22 @@ class UnifiedVoice:
         gp.pos_offset = 2 if self.kv_cache else 1
         gp.top_p, gp.temperature = float(top_p), float(temperature)
         gp.repetition_penalty = float(repetition_penalty if repetition_penalty is not None else 1.0)
-        gp.length_penalty, gp.seed = float(length_penalty), int(seed)
+        gp.length_penalty, gp.seed = float(length_penalty), self._seed(seed, do_sample, uniforms)
         gp.typical_mass = float(typical_mass)
         L = _lib.lib()
         Tmax = S + int(max_new_tokens)
         need = L.itts_gpt_workspace_bytes(self._h, B, S, Tmax)
         ws = self._workspace(need)
-        codes = torch.empty(B, int(max_new_tokens), dtype=torch.int64, device=dev)
+        # output / uniforms buffers persist per shape: their addresses are part of the cached decode graph's key
+        codes = self._persistent("codes", (B, int(max_new_tokens)), torch.int64)
         n_steps = C.c_int32(0)
         pen = (C.c_int32 * 2)(1, self.start_mel_token)          # fake prefix ids (all ones) + start_mel
         u = None
         if uniforms is not None:
-            u = uniforms.to(dev, torch.float64).contiguous()
-            if u.shape[0] < max_new_tokens or u.shape[1] != B:
+            if uniforms.shape[0] < max_new_tokens or uniforms.shape[1] != B:
                 raise ValueError("uniforms must be (>= max_new_tokens, B)")
+            u = self._persistent("uniforms", (int(max_new_tokens), B), torch.float64)
+            u.copy_(uniforms[: int(max_new_tokens)])
         rc = L.itts_gpt_generate(self._h, _lib.ptr(x), _lib.ptr(pad), B, S, C.byref(gp), pen, 2, _lib.ptr(u),
                                  _lib.ptr(codes), C.byref(n_steps), _lib.ptr(ws), ws.numel(), int(self.use_graph),
                                  _lib.stream_ptr(self.device))
@@ -249,7 +277,7 @@ class UnifiedVoice:
         is_stop = codes == self.stop_mel_token
         first = torch.where(is_stop.any(1), is_stop.int().argmax(1) + 1, torch.full((B,), codes.shape[1], device=dev))
         n = int(min(int(first.max().item()), n_steps.value))
-        return codes[:, :n]
+        return codes[:, :n].clone()
 
     # ---- beam search / beam-sample (num_beams > 1; the reference default is 3-beam beam-sample) ------------------------
     def _generate_beam(self, inputs_embeds, attention_mask, max_new_tokens, do_sample, num_beams, top_p, top_k, temperature,
@@ -269,7 +297,7 @@ class UnifiedVoice:
         gp.pos_offset = 2 if self.kv_cache else 1
         gp.top_p, gp.temperature = float(top_p), float(temperature)
         gp.repetition_penalty = float(repetition_penalty if repetition_penalty is not None else 1.0)
-        gp.length_penalty, gp.seed = float(length_penalty), int(seed)
+        gp.length_penalty, gp.seed = float(length_penalty), self._seed(seed, do_sample, uniforms)
         gp.typical_mass = float(typical_mass)
         L = _lib.lib()
         Tmax = S + max_new
@@ -284,10 +312,10 @@ class UnifiedVoice:
         pen = (C.c_int32 * 2)(1, self.start_mel_token)
         u = None
         if uniforms is not None:
-            u = uniforms.to(dev, torch.float64).contiguous()
-            if u.dim() != 3 or u.shape[0] < max_new or u.shape[1] != B or u.shape[2] != 2 * nb:
+            if uniforms.dim() != 3 or uniforms.shape[0] < max_new or uniforms.shape[1] != B or uniforms.shape[2] != 2 * nb:
                 raise ValueError("uniforms must be (>= max_new_tokens, B, 2*num_beams)")
-            u = u[:max_new].contiguous()
+            u = self._persistent("beam_uniforms", (max_new, B, 2 * nb), torch.float64)
+            u.copy_(uniforms[:max_new])
         rc = L.itts_gpt_generate_beam(self._h, _lib.ptr(x), _lib.ptr(pad), B, nb, S, C.byref(gp), pen, 2, _lib.ptr(u),
                                       _lib.ptr(hist_tok), _lib.ptr(hist_par), _lib.ptr(beam_scores), _lib.ptr(hyps),
                                       _lib.ptr(n_hyps), _lib.ptr(done), C.byref(n_steps), _lib.ptr(ws), ws.numel(),

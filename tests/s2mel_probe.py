@@ -1,6 +1,6 @@
 """Helper for test_gpu_s2mel.py::test_tile_gemm_kernels_agree: runs the bf16 s2mel solve at the shipped widths on three ragged
 utterances and prints a digest of the raw output.  ITTS_TILE256 (read once per process) selects the tile GEMM kernel: 0 = the
-128 x 128 kernel, 1 = the 256 x 256 eight-wave kernel for every shape -- hence one process per setting."""
+128 x 128 kernel, 1 = the 256 x 256 eight-wave kernel, 2 = the 256 x 128 four-wave kernel, for every shape -- hence one process per setting."""
 import hashlib
 import os
 import sys

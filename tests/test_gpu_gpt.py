@@ -208,19 +208,19 @@ def test_prefill_gemm_kernels_agree():
     assert outs[0] == outs[1], outs
 
 
-def test_prefill_tile256_kernel_agrees():
-    """GPT prefill / latent pass (EPI_QKV cache append, GELU, residual, plain store) through the 256 x 256 tile kernel
-    (ITTS_TILE256=1 forces it for every shape) vs the 128 x 128 kernel: bitwise equal latents and ids."""
+def test_prefill_tile_kernels_agree():
+    """GPT prefill / latent pass (EPI_QKV cache append, GELU, residual, plain store) through the 256 x 256 and 256 x 128 tile
+    kernels (ITTS_TILE256 = 1 / 2 force them for every shape) vs the 128 x 128 kernel: bitwise equal latents and ids."""
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prefill_probe.py")
     outs = []
-    for v in ("0", "1"):
+    for v in ("0", "1", "2"):
         env = dict(os.environ, ITTS_TILE256=v, PROBE_BIG="1")
         r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
-    assert outs[0] == outs[1], outs
+    assert outs[0] == outs[1] == outs[2], outs
 
 
 def test_decode_gemm_kernels_agree():
@@ -280,6 +280,48 @@ def test_typical_sampling_at_production_vocab():
                                     do_sample=True, num_beams=nb, top_k=30, top_p=0.8, temperature=0.8, repetition_penalty=10.0,
                                     typical_sampling=True, typical_mass=0.9, uniforms=u)
         assert torch.equal(ids.cpu(), ref), (nb, ids.cpu().tolist(), ref.tolist())
+
+
+def test_decode_graph_is_cached_across_calls():
+    """The instantiated decode-step hipGraph lives in the engine handle: a second call with the same batch rows, prompt-length
+    bucket (multiples of 32), max_new_tokens and generation parameters replays it; results stay bit-exact vs the oracle; a
+    different seed does not force a new capture (the seed is read from device memory); another bucket does."""
+    cfg = G.GPTConfig(layers=2, model_dim=128, heads=2, max_text_tokens=80, max_mel_tokens=40, number_text_tokens=60)
+    sd = G.synth_weights(cfg, seed=11)
+    m = engine(cfg, sd, "fp32")
+    g = torch.Generator().manual_seed(1)
+    style, emo = torch.randn(1, 192, generator=g), torch.randn(1, 128, generator=g) * 0.1
+    conds = G.conds_latent_campplus(sd, style, emo)
+    langs = torch.full((3,), 2)
+
+    def run(n_text, **kw):
+        text = torch.randint(2, 60, (3, n_text), generator=torch.Generator().manual_seed(n_text))
+        ids, _ = m.inference_speech(None, text, langs=langs, emo_vec=emo, campplus_embedding=style, max_generate_length=10,
+                                    num_beams=1, repetition_penalty=10.0, **kw)
+        return text, ids.cpu()
+
+    s0 = m.graph_stats()
+    text, ids = run(20, do_sample=False)                             # S = 3 + 22 + 1 = 26 -> bucket 32
+    with torch.no_grad():
+        ref = G.inference_speech(sd, cfg, conds, text, langs, G.GenParams(max_generate_length=10))
+    assert torch.equal(ids, ref)
+    s1 = m.graph_stats()
+    assert (s1["captures"] - s0["captures"], s1["hits"] - s0["hits"]) == (1, 0)
+    text2, ids2 = run(24, do_sample=False)                           # S = 30: same bucket, same graph
+    with torch.no_grad():
+        ref2 = G.inference_speech(sd, cfg, conds, text2, langs, G.GenParams(max_generate_length=10))
+    assert torch.equal(ids2, ref2)
+    s2 = m.graph_stats()
+    assert (s2["captures"] - s1["captures"], s2["hits"] - s1["hits"]) == (0, 1)
+    run(40, do_sample=False)                                         # S = 46: next bucket
+    s3 = m.graph_stats()
+    assert s3["captures"] - s2["captures"] == 1
+    a = run(20, do_sample=True, top_k=30, top_p=0.8, temperature=1.5, seed=1)[1]
+    b = run(20, do_sample=True, top_k=30, top_p=0.8, temperature=1.5, seed=2)[1]
+    c = run(20, do_sample=True, top_k=30, top_p=0.8, temperature=1.5, seed=1)[1]
+    s4 = m.graph_stats()
+    assert s4["captures"] - s3["captures"] == 1 and s4["hits"] - s3["hits"] == 2
+    assert torch.equal(a[:, : c.shape[1]], c[:, : a.shape[1]]) and not torch.equal(a, b)
 
 
 def test_typical_mass_validation():

@@ -198,18 +198,19 @@ def test_production_width_smoke():
 
 @pytest.mark.parametrize("dil", [1, 2])
 def test_tile_gemm_kernels_agree(dil):
-    """The 256 x 256 eight-wave tile GEMM (counted-vmcnt LDS-DMA pipeline, two staggered wave groups) and the 128 x 128 kernel
-    issue the same MFMAs on the same fragments in the same K order and share their epilogues: the whole bf16 solve (fused
-    wqkv + RoPE + transposed V^T store, SwiGLU, tap-mode WaveNet conv + gate, res/skip, residual, plain stores) must be BITWISE
-    equal between them, on every one of three repeats (an LDS-DMA race would show up as an intermittent difference)."""
+    """The three bf16 tile GEMM kernels -- 128 x 128 (four waves), 256 x 256 (eight waves: counted-vmcnt LDS-DMA pipeline, two
+    staggered wave groups) and 256 x 128 (four waves, three-stage DMA ring) -- issue the same MFMAs on the same fragments in the
+    same K order and share their epilogues: the whole bf16 solve (fused wqkv + RoPE + transposed V^T store, SwiGLU, tap-mode
+    WaveNet conv + gate, res/skip, residual, plain stores) must be BITWISE equal between them, on every one of three repeats (an
+    LDS-DMA race would show up as an intermittent difference)."""
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "s2mel_probe.py")
     outs = []
-    for v in ("0", "1"):
+    for v in ("0", "1", "2"):
         env = dict(os.environ, ITTS_TILE256=v, PROBE_DIL=str(dil))
         r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
     assert float(outs[0].split()[2]) > 1e-3
-    assert outs[0] == outs[1], outs
+    assert outs[0] == outs[1] == outs[2], outs
