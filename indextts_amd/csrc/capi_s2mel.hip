@@ -364,10 +364,13 @@ static int s2_launch_gemm(itts_s2mel* h, const GemmArgs& g, hipStream_t st) {
     return launch_gemm(g, h->cfg.precision, true, st);
 }
 
+// shadow: optional bf16 copy [M][ldo] of the f32 result written by the same epilogue (fused bf16 path only) -- the operand of the
+// GEMM that consumes it next, instead of a separate cast pass over the f32 matrix
 static int s2_gemm(itts_s2mel* h, const void* A, int lda, const void* Wp, const float* bias, float* out, int ldo, int M, int N, int K,
-                   int epi, hipStream_t st) {
+                   int epi, hipStream_t st, void* shadow = nullptr) {
     GemmArgs g{};
     g.A = A; g.lda = lda; g.Wp = Wp; g.bias = bias; g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.epi = epi; g.out_f32 = out; g.ldo = ldo; g.D = N;
+    g.out_act2 = shadow;
     return s2_launch_gemm(h, g, st);
 }
 
@@ -390,7 +393,7 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     for (int i = 0; i < c.depth; ++i) {
         const S2Layer& L = h->layers[i];
         if (i > c.depth / 2) {                                     // U-ViT: x = skip_in_linear([x | skip])
-            if ((rc = launch_cast_pad(X, w.HB, N, N, H, H, prec, st))) return rc;
+            if (!fused && (rc = launch_cast_pad(X, w.HB, N, N, H, H, prec, st))) return rc;     // fused: the previous w2 GEMM left the bf16 copy in HB
             --n_skip;
             if ((rc = s2_gemm(h, w.HB, H, L.w_skip_a, L.b_skip, X2, H, N, H, H, EPI_STORE_F32, st))) return rc;
             if ((rc = s2_gemm(h, w.SK + w.sk_stride * n_skip, H, L.w_skip_b, nullptr, X2, H, N, H, H, EPI_RESIDUAL, st))) return rc;
@@ -419,9 +422,14 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
             if ((rc = s2_gemm(h, w.HB, H, L.w_13, nullptr, w.BIG, 2 * I, N, 2 * I, H, EPI_STORE_F32, st))) return rc;
             if ((rc = launch_swiglu(w.BIG, w.FC, N, I, prec, st))) return rc;
         }
-        if ((rc = s2_gemm(h, w.FC, I, L.w_2, nullptr, X, H, N, H, I, EPI_RESIDUAL, st))) return rc;
+        // fused: the residual epilogue also writes the bf16 copy the U-ViT wiring needs -- the saved skip (first half of the stack)
+        // or the next layer's skip_in_linear operand (second half)
+        void* shadow = nullptr;
+        if (fused && i < c.depth / 2) shadow = w.SK + w.sk_stride * n_skip;
+        else if (fused && i + 1 < c.depth && i + 1 > c.depth / 2) shadow = w.HB;
+        if ((rc = s2_gemm(h, w.FC, I, L.w_2, nullptr, X, H, N, H, I, EPI_RESIDUAL, st, shadow))) return rc;
         if (i < c.depth / 2) {
-            if ((rc = launch_cast_pad(X, w.SK + w.sk_stride * n_skip, N, N, H, H, prec, st))) return rc;
+            if (!fused && (rc = launch_cast_pad(X, w.SK + w.sk_stride * n_skip, N, N, H, H, prec, st))) return rc;
             ++n_skip;
         }
     }
@@ -431,13 +439,13 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     // x_res = skip_linear([transformer.norm(x) | x^T])
     if ((rc = launch_ada_rmsnorm(X, h->g_norm, m_norm, w.HB, N, H, c.norm_eps, prec, st))) return rc;
     if ((rc = s2_gemm(h, w.HB, H, h->w_sl_a, h->b_sl, X2, H, N, H, H, EPI_STORE_F32, st))) return rc;
-    if ((rc = s2_gemm(h, w.XA, Kx, h->w_sl_b, nullptr, X2, H, N, H, Kx, EPI_RESIDUAL, st))) return rc;
-    if ((rc = launch_cast_pad(X2, w.HB, N, N, H, H, prec, st))) return rc;
-    if ((rc = s2_gemm(h, w.HB, H, h->w_c1, h->b_c1, w.WX, W, N, W, H, EPI_STORE_F32, st))) return rc;
+    if ((rc = s2_gemm(h, w.XA, Kx, h->w_sl_b, nullptr, X2, H, N, H, Kx, EPI_RESIDUAL, st, fused ? w.HB : nullptr))) return rc;
+    if (!fused && (rc = launch_cast_pad(X2, w.HB, N, N, H, H, prec, st))) return rc;
+    if ((rc = s2_gemm(h, w.HB, H, h->w_c1, h->b_c1, w.WX, W, N, W, H, EPI_STORE_F32, st, fused ? w.WXA : nullptr))) return rc;
     if ((rc = s2_gemm(h, w.HB, H, h->w_rp, h->b_rp, w.RP, W, N, W, H, EPI_STORE_F32, st))) return rc;
     // WaveNet (wavenet.py:143-166)
     int dil = 1;
-    if (fused && (rc = launch_cast_pad(w.WX, w.WXA, N, N, W, W, prec, st))) return rc;       // bf16 shadow for the tap-mode GEMM
+    // (fused: WXA, the bf16 shadow of WX that the tap-mode GEMM reads, was written by the conv1 GEMM above)
     for (int i = 0; i < c.wavenet_layers; ++i) {
         const S2Wn& Wn = h->wn[i];
         const int last = i == c.wavenet_layers - 1;
@@ -466,8 +474,8 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     }
     // FinalLayer + conv2
     if ((rc = launch_final_ln_mod(w.OUT, w.RP, m_fl, w.HB, tab, W, prec, st))) return rc;
-    if ((rc = s2_gemm(h, w.HB, W, h->w_fl, h->b_fl, w.BIG, W, N, W, W, EPI_STORE_F32, st))) return rc;
-    if ((rc = launch_cast_pad(w.BIG, w.FC, N, N, W, W, prec, st))) return rc;
+    if ((rc = s2_gemm(h, w.HB, W, h->w_fl, h->b_fl, w.BIG, W, N, W, W, EPI_STORE_F32, st, fused ? w.FC : nullptr))) return rc;
+    if (!fused && (rc = launch_cast_pad(w.BIG, w.FC, N, N, W, W, prec, st))) return rc;
     return s2_gemm(h, w.FC, W, h->w_c2, h->b_c2, d_out, C, N, C, W, EPI_STORE_F32, st);
 }
 

@@ -51,7 +51,8 @@ struct GemmArgs {
     // `zero_row`.  K = conv_taps * conv_W, lda = conv_W.
     int conv_taps, conv_dil, conv_W;
     const int* seq_start; const int* seq_T; const void* zero_row;
-    void* out_act2;                  // EPI_WN_RS: bf16 shadow copy of the updated out_f32 (the next layer's tap-mode A operand)
+    void* out_act2;                  // EPI_WN_RS / EPI_STORE_F32 / EPI_RESIDUAL (bf16 tile kernels): bf16 shadow copy [M][ldo] of the f32
+                                     // output (the next GEMM's A operand; for EPI_WN_RS the next layer's tap-mode operand, stride D)
     int seq_mul;                     // EPI_QKV: cache row of sequence b is b * seq_mul (0/1 = identity); beam prefill writes only row b*nb
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);

@@ -526,9 +526,14 @@ __device__ __forceinline__ void pf_epilogue(const GemmArgs& a, int mbase, int nb
         const int m = mbase + (lane >> 4) * 4 + r;
         if (m >= a.M) continue;
         const float val = v[r] + bias;
-        if constexpr (EPI == EPI_STORE_F32) a.out_f32[(size_t)m * a.ldo + n] = val;
-        else if constexpr (EPI == EPI_RESIDUAL) a.out_f32[(size_t)m * a.ldo + n] += val;
-        else if constexpr (EPI == EPI_GELU_ACT) ((u16*)a.out_act)[(size_t)m * a.ldo + n] = f32_to_bf16(gelu_new_f(val));
+        if constexpr (EPI == EPI_STORE_F32) {
+            a.out_f32[(size_t)m * a.ldo + n] = val;
+            if (a.out_act2) ((u16*)a.out_act2)[(size_t)m * a.ldo + n] = f32_to_bf16(val);
+        } else if constexpr (EPI == EPI_RESIDUAL) {
+            const float nv = a.out_f32[(size_t)m * a.ldo + n] + val;
+            a.out_f32[(size_t)m * a.ldo + n] = nv;
+            if (a.out_act2) ((u16*)a.out_act2)[(size_t)m * a.ldo + n] = f32_to_bf16(nv);
+        } else if constexpr (EPI == EPI_GELU_ACT) ((u16*)a.out_act)[(size_t)m * a.ldo + n] = f32_to_bf16(gelu_new_f(val));
         else if constexpr (EPI == EPI_WN_RS) {                   // wavenet.py:158-165
             if (a.wn_last || n >= a.D) {
                 float* o = a.out2 + (size_t)m * a.D + (a.wn_last ? n : n - a.D);
@@ -551,29 +556,6 @@ __device__ __forceinline__ void pf_epilogue(const GemmArgs& a, int mbase, int nb
     }
 }
 
-// Epilogues that combine the two n-tiles of an interleaved pair (tile 2j: first half's columns 16j.., tile 2j+1: the second
-// half's same columns): out_act [M][N/2] bf16.
-template <int EPI>
-__device__ __forceinline__ void pf_epilogue_pair(const GemmArgs& a, int mbase, int ntile, int lane, f32x4 va, f32x4 vb) {
-    const int half = a.N >> 1;
-    const int n = (ntile >> 1) * 16 + (lane & 15);              // column inside a half
-    if (n >= half) return;
-    float ba = 0.f, bb = 0.f;
-    if constexpr (EPI == EPI_GATE) {
-        ba = (a.bias ? a.bias[n] : 0.f) + a.gvec[n];
-        bb = (a.bias ? a.bias[half + n] : 0.f) + a.gvec[half + n];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = mbase + (lane >> 4) * 4 + r;
-        if (m >= a.M) continue;
-        float o;
-        if constexpr (EPI == EPI_SWIGLU) o = (va[r] / (1.0f + expf(-va[r]))) * vb[r];                       // silu(w1 x) * (w3 x)
-        else o = tanhf(va[r] + ba) * (1.0f / (1.0f + expf(-(vb[r] + bb))));                                 // commons.py:133-141
-        ((u16*)a.out_act)[(size_t)m * half + n] = f32_to_bf16(o);
-    }
-}
-
 typedef __bf16 pf_bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float pf_f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
@@ -586,53 +568,71 @@ __device__ __forceinline__ v2u_t pf_cvt4(f32x4 v) { return v2u_t{pf_cvt2(v[0], v
 // accesses are 16-byte (f32) / 8-byte (bf16) pieces of full lines.  The MFMA accumulator layout itself gives each lane 4 rows
 // of one column: 64-byte row segments, half-used lines and read-modify-write at that granularity (measured: the N = 512 f32
 // residual GEMMs of the s2mel DiT ran at 1.4 TB/s of output traffic).
+// sigmoid / tanh of the fused s2mel epilogues through v_exp_f32 + v_rcp_f32 (about 1 ulp each; the results are rounded to bf16):
+// expf + an IEEE division per element made the SwiGLU / gate epilogues as long as a K = 512 main loop.
+__device__ __forceinline__ float pf_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float pf_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+
 template <int EPI, int ROWS, int NT>            // ROWS x 128 columns of the tile, stored by NT threads (tid < NT)
 __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct, int m0, int n0, int tid) {
     constexpr bool PAIR = (EPI == EPI_SWIGLU || EPI == EPI_GATE);
     constexpr int CH = PAIR ? 16 : 32;                              // 4-column chunks per tile row
+    constexpr int RSTEP = NT / CH;                                  // a thread keeps its column chunk and walks down the rows
     const int half = a.N >> 1;
+    const int c4 = tid % CH, row0 = tid / CH;
+    // ---- column-derived quantities: once per thread ----
+    const int j = c4 >> 2, cc = (c4 & 3) * 4;                       // PAIR: pair j of the region, column inside the 16-wide tile
+    const int n = PAIR ? (n0 >> 1) + j * 16 + cc : n0 + c4 * 4;     // output column (inside a half for the pair epilogues)
+    if (PAIR ? n >= half : n >= a.N) return;
+    const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
+    f32x4 b1 = zero4, b2 = zero4;
+    if constexpr (EPI == EPI_GATE) {
+        b1 = *(const f32x4*)(a.gvec + n);
+        b2 = *(const f32x4*)(a.gvec + half + n);
+        if (a.bias) {
+            const f32x4 x1 = *(const f32x4*)(a.bias + n), x2 = *(const f32x4*)(a.bias + half + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { b1[q] += x1[q]; b2[q] += x2[q]; }
+        }
+    } else if constexpr (!PAIR) {
+        if (a.bias) b1 = *(const f32x4*)(a.bias + n);
+    }
+    int which = 0, c = n;
+    if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_ROPE) { which = n / a.D; c = n - which * a.D; }
+    const int hd = c >> 6, d = c & 63;
+    const int ca = PAIR ? (2 * j) * 16 + cc : c4 * 4, cb = (2 * j + 1) * 16 + cc;      // columns inside the LDS image
 #pragma unroll 4
-    for (int i = 0; i < (ROWS * CH) / NT; ++i) {
-        const int chunk = tid + NT * i;
-        const int row = chunk / CH, c4 = chunk - row * CH;
+    for (int i = 0; i < ROWS / RSTEP; ++i) {
+        const int row = row0 + i * RSTEP;
         const int m = m0 + row;
-        if (m >= a.M) continue;
+        if (m >= a.M) break;
         const int sw = ((row >> 2) & 3) << 4;
         if constexpr (PAIR) {
-            const int j = c4 >> 2, cc = (c4 & 3) * 4;                 // pair j of the block, column inside the 16-wide tile
-            const int n = (n0 >> 1) + j * 16 + cc;                    // column inside a half
-            if (n >= half) continue;
-            const f32x4 va = *(const f32x4*)(ct + row * 128 + (((2 * j) * 16 + cc) ^ sw));
-            const f32x4 vb = *(const f32x4*)(ct + row * 128 + (((2 * j + 1) * 16 + cc) ^ sw));
+            const f32x4 va = *(const f32x4*)(ct + row * 128 + (ca ^ sw));
+            const f32x4 vb = *(const f32x4*)(ct + row * 128 + (cb ^ sw));
             f32x4 o;
             if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = (va[q] / (1.0f + expf(-va[q]))) * vb[q];
+                for (int q = 0; q < 4; ++q) o[q] = va[q] * pf_sigmoid(va[q]) * vb[q];                       // silu(w1 x) * (w3 x)
             } else {
-                const f32x4 b1 = a.bias ? *(const f32x4*)(a.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const f32x4 b2 = a.bias ? *(const f32x4*)(a.bias + half + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const f32x4 g1 = *(const f32x4*)(a.gvec + n), g2 = *(const f32x4*)(a.gvec + half + n);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = tanhf(va[q] + b1[q] + g1[q]) * (1.0f / (1.0f + expf(-(vb[q] + b2[q] + g2[q]))));
+                for (int q = 0; q < 4; ++q) o[q] = pf_tanh(va[q] + b1[q]) * pf_sigmoid(vb[q] + b2[q]);      // commons.py:133-141
             }
             *(v2u_t*)((u16*)a.out_act + (size_t)m * half + n) = pf_cvt4(o);
         } else {
-            const int n = n0 + c4 * 4;
-            if (n >= a.N) continue;
-            f32x4 v = *(const f32x4*)(ct + row * 128 + ((c4 * 4) ^ sw));
-            if (a.bias) {
-                const f32x4 b = *(const f32x4*)(a.bias + n);
+            f32x4 v = *(const f32x4*)(ct + row * 128 + (ca ^ sw));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] += b[q];
-            }
+            for (int q = 0; q < 4; ++q) v[q] += b1[q];
             if constexpr (EPI == EPI_STORE_F32) {
                 *(f32x4*)(a.out_f32 + (size_t)m * a.ldo + n) = v;
+                if (a.out_act2) *(v2u_t*)((u16*)a.out_act2 + (size_t)m * a.ldo + n) = pf_cvt4(v);      // bf16 shadow: the next GEMM's A operand
             } else if constexpr (EPI == EPI_RESIDUAL) {
                 f32x4* o = (f32x4*)(a.out_f32 + (size_t)m * a.ldo + n);
                 const f32x4 old = *o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] += old[q];
                 *o = v;
+                if (a.out_act2) *(v2u_t*)((u16*)a.out_act2 + (size_t)m * a.ldo + n) = pf_cvt4(v);
             } else if constexpr (EPI == EPI_GELU_ACT) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = gelu_new_f(v[q]);
@@ -657,27 +657,24 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
                     if (a.out_act2) *(v2u_t*)((u16*)a.out_act2 + (size_t)m * a.D + n) = pf_cvt4(v);
                 }
             } else if constexpr (EPI == EPI_QKV) {                    // GPT prefill: q f32, K / V appended to the bf16 cache
-                const int which = n / a.D, c = n - which * a.D;
                 if (which == 0) {
                     *(f32x4*)(a.qbuf + (size_t)m * a.D + c) = v;
                 } else {
                     const int b = m / a.S, si = m - b * a.S;
                     const int pos = *a.pos_ptr + si;
-                    const size_t o = (((size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1) * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
+                    const size_t o = (((size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1) * a.H + hd) * a.Tmax + pos) * 64 + d;
                     *(v2u_t*)((u16*)(which == 1 ? a.kcache : a.vcache) + o) =
                         v2u_t{(uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16), (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)};
                 }
             } else {                                                   // EPI_QKV_ROPE (s2mel): both RoPE pairs of the chunk are in-thread
-                const int which = n / a.D, c = n - which * a.D;
-                const int hd = c >> 6, d = c & 63;
-                const int s = a.tok_seq[m], t = a.tok_t[m];
+                const int sq = a.tok_seq[m], t = a.tok_t[m];
                 if (which < 2) {
                     const f32x4 cs = *(const f32x4*)(a.rope + ((size_t)t * 32 + (d >> 1)) * 2);       // (cos, sin) of pairs d/2, d/2 + 1
                     const f32x4 y{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
                     if (which == 0) *(v2u_t*)((u16*)a.out_act + (size_t)m * a.D + c) = pf_cvt4(y);
-                    else *(v2u_t*)((u16*)a.kcache + (((size_t)s * a.H + hd) * a.Tmax + t) * 64 + d) = pf_cvt4(y);
-                } else {
-                    u16* vt = (u16*)a.vcache + (((size_t)s * a.H + hd) * 64 + d) * a.Tmax + t;
+                    else *(v2u_t*)((u16*)a.kcache + (((size_t)sq * a.H + hd) * a.Tmax + t) * 64 + d) = pf_cvt4(y);
+                } else {                                               // only when D % 128 != 0 (else pf_store_vt takes the V regions)
+                    u16* vt = (u16*)a.vcache + (((size_t)sq * a.H + hd) * 64 + d) * a.Tmax + t;
                     const v2u_t pk = pf_cvt4(v);
                     vt[0] = (u16)(pk.x & 0xffffu);
                     vt[(size_t)a.Tmax] = (u16)(pk.x >> 16);
@@ -696,13 +693,24 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
 // element per line per lane: the wqkv GEMM ran at 425 TFLOP/s against 790 for the SwiGLU GEMM of the same K.)
 template <int ROWS, int NT>
 __device__ __forceinline__ void pf_store_vt(const GemmArgs& a, const float* ctT, int m0, int n0, int tid) {
-    constexpr int RQ = ROWS / 4;
+    constexpr int RQ = ROWS / 4, CSTEP = NT / RQ;                   // a thread keeps its 4-frame run and walks over the columns
+    const int rq = tid % RQ, col0 = tid / RQ;
+    const int m = m0 + 4 * rq;
+    if (m >= a.M) return;
+    const int ml = m + 3 < a.M ? m + 3 : a.M - 1;
+    const int s0 = a.tok_seq[m], t0 = a.tok_t[m];
+    const bool run = m + 3 < a.M && a.tok_seq[ml] == s0;          // rows of one sequence are consecutive frames
+    const bool wide = run && (((t0 | a.Tmax) & 3) == 0);
+    int sq[4], tq[4];
+    if (!run) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int mq = m + q < a.M ? m + q : a.M - 1; sq[q] = a.tok_seq[mq]; tq[q] = a.tok_t[mq]; }
+    }
 #pragma unroll 4
-    for (int i = 0; i < (128 * RQ) / NT; ++i) {
-        const int chunk = tid + NT * i;
-        const int col = chunk / RQ, rq = chunk - col * RQ;
-        const int m = m0 + 4 * rq, n = n0 + col;
-        if (m >= a.M || n >= a.N) continue;
+    for (int i = 0; i < 128 / CSTEP; ++i) {
+        const int col = col0 + i * CSTEP;
+        const int n = n0 + col;
+        if (n >= a.N) break;
         f32x4 v = *(const f32x4*)(ctT + col * (ROWS + 4) + 4 * rq);
         if (a.bias) {
             const float b = a.bias[n];
@@ -710,12 +718,10 @@ __device__ __forceinline__ void pf_store_vt(const GemmArgs& a, const float* ctT,
             for (int q = 0; q < 4; ++q) v[q] += b;
         }
         const int c = n - 2 * a.D, hd = c >> 6, d = c & 63;
-        const int ml = m + 3 < a.M ? m + 3 : a.M - 1;
-        const int s0 = a.tok_seq[m], t0 = a.tok_t[m];
         const v2u_t pk = pf_cvt4(v);
-        if (m + 3 < a.M && a.tok_seq[ml] == s0) {                 // rows of one sequence are consecutive frames
+        if (run) {
             u16* vt = (u16*)a.vcache + (((size_t)s0 * a.H + hd) * 64 + d) * a.Tmax + t0;
-            if (((t0 | a.Tmax) & 3) == 0) {
+            if (wide) {
                 *(v2u_t*)vt = pk;
             } else {
                 vt[0] = (u16)(pk.x & 0xffffu); vt[1] = (u16)(pk.x >> 16); vt[2] = (u16)(pk.y & 0xffffu); vt[3] = (u16)(pk.y >> 16);
@@ -724,12 +730,12 @@ __device__ __forceinline__ void pf_store_vt(const GemmArgs& a, const float* ctT,
             const u16 e[4] = {(u16)(pk.x & 0xffffu), (u16)(pk.x >> 16), (u16)(pk.y & 0xffffu), (u16)(pk.y >> 16)};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (m + q < a.M) ((u16*)a.vcache)[(((size_t)a.tok_seq[m + q] * a.H + hd) * 64 + d) * a.Tmax + a.tok_t[m + q]] = e[q];
+                if (m + q < a.M) ((u16*)a.vcache)[(((size_t)sq[q] * a.H + hd) * 64 + d) * a.Tmax + tq[q]] = e[q];
         }
     }
 }
 
-template <int EPI, bool CONV = false>
+template <int EPI, bool CONV = false, bool VEC = true>      // VEC: the LDS-transposed vector epilogue (N, ldo, D multiples of 4)
 __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB | W 16 KiB]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -854,10 +860,10 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);     // the second k-step's MFMAs
         }
     }
-    // Epilogue.  Vector path (every shape of the engine: N, ldo, D multiples of 4): transpose the accumulator tile through LDS
-    // and store full-line pieces (pf_store_tile); otherwise the per-lane element path.
-    const bool vec_ok = (a.N % 4 == 0) && (a.ldo % 4 == 0 || (EPI != EPI_STORE_F32 && EPI != EPI_RESIDUAL && EPI != EPI_GELU_ACT)) && (a.D % 4 == 0);
-    if (vec_ok) {
+    // Epilogue.  Vector path (every shape of the engine except an odd-width GPT head: N, ldo, D multiples of 4): transpose the
+    // accumulator tile through LDS and store full-line pieces (pf_store_tile); otherwise (VEC = false instantiations of the
+    // GPT epilogues) the per-lane element path.
+    if constexpr (VEC) {
         __syncthreads();                                           // every wave is done with the operand buffers
         float* ct = (float*)pf_sm;                                 // [128][128] f32 (row-major) or [128][132] (transposed, V^T tiles)
         const int g = lane >> 4, c16 = lane & 15;
@@ -879,16 +885,6 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
                     ct[(wr * 64 + mt * 16 + g * 4 + r) * 128 + ((wc * 64 + nt * 16 + c16) ^ (g << 4))] = acc[mt][nt][r];
         __syncthreads();
         pf_store_tile<EPI, 128, 256>(a, ct, m0, nt0 * 16, threadIdx.x);
-        return;
-    }
-    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GATE) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int ntile = nt0 + wc * 4 + 2 * pr;
-                if (ntile + 1 < ntiles) pf_epilogue_pair<EPI>(a, m0 + wr * 64 + mt * 16, ntile, lane, acc[mt][2 * pr], acc[mt][2 * pr + 1]);
-            }
     } else {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -900,16 +896,30 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     }
 }
 
+static bool pf_vec_ok(const GemmArgs& a) {
+    return (a.N % 4 == 0) && (a.ldo % 4 == 0 || (a.epi != EPI_STORE_F32 && a.epi != EPI_RESIDUAL && a.epi != EPI_GELU_ACT)) && (a.D % 4 == 0);
+}
+
 template <int EPI, bool CONV = false>
 static int launch_gemm_prefill_e(const GemmArgs& a, hipStream_t st) {
     const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
     const int per = ceil_div(n_mt * n_nt, 8);
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS));
+        if constexpr (EPI <= EPI_QKV) HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_prefill_kernel<EPI, CONV>), dim3(per * 8), dim3(256), PF_LDS, st, a);
+    if (pf_vec_ok(a)) {
+        hipLaunchKernelGGL((gemm_prefill_kernel<EPI, CONV, true>), dim3(per * 8), dim3(256), PF_LDS, st, a);
+    } else {
+        if constexpr (EPI <= EPI_QKV) {
+            hipLaunchKernelGGL((gemm_prefill_kernel<EPI, CONV, false>), dim3(per * 8), dim3(256), PF_LDS, st, a);
+        } else {
+            itts_set_error("gemm: the fused s2mel epilogue %d needs N, D multiples of 4", EPI);
+            return ITTS_ERR_ARG;
+        }
+    }
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
@@ -917,10 +927,10 @@ static int launch_gemm_prefill_e(const GemmArgs& a, hipStream_t st) {
 // ================================================================================================================
 // 256 x 256 tile GEMM, bf16, 8 waves (2 along M x 4 along N; each wave 128 x 64 = 8 x 4 MFMA tiles), BK = 64, for the big-M GEMMs
 // of the s2mel DiT / WaveNet (M = 2 x frames of the whole batch).
-//   Why a second tile kernel: in the 128 x 128 kernel every K tile costs a wave 16 KiB of LDS fragment reads for 32 MFMAs; two
-//   resident blocks read 128 KiB per K tile per CU = 1024 cycles of the 128 B/clk LDS port against 1024 MFMA cycles per SIMD --
-//   the LDS port is as busy as the matrix pipe and every wait in between is exposed (measured 790-850 TFLOP/s).  Here a wave
-//   reads 24 KiB for 64 MFMAs: 192 KiB = 1536 LDS cycles against 2048 MFMA cycles per SIMD.
+//   Why a second tile kernel: a 64 x 64 wave tile reads 0.5 KiB of LDS fragments per MFMA, a 128 x 64 one 0.375 KiB, and the
+//   128 x 128 kernel drains its LDS-DMA queue (vmcnt(0) + barrier) once per K tile.  Measured (profiles/r02f..r02h): +10..14 % on
+//   the GPT prefill shapes (K = 1280 / 5120: 790 -> 900 TFLOP/s), +13 % on the K = 512 residual GEMMs of the DiT, par on its other
+//   GEMMs, whose time is set by their epilogues (one block per CU: nothing overlaps a tile's epilogue or first loads).
 //   Schedule: the K tile is computed as 4 quadrants of the wave's output (phases); each phase = [fragment reads of the quadrant,
 //   issue one half-operand LDS-DMA of the NEXT K tile, counted vmcnt] barrier [16 MFMAs] barrier.  The waves form two groups
 //   (waves 0-3 / 4-7 = one wave of each group per SIMD) that run half a phase apart: while one group's MFMAs occupy the matrix
@@ -1149,11 +1159,10 @@ static int launch_gemm_tile256_e(const GemmArgs& a, hipStream_t st) {
 // ================================================================================================================
 // 256 x 128 tile GEMM, bf16, FOUR waves (2 along M x 2 along N, each 128 x 64 = 8 x 4 MFMA tiles), K step 32, three-stage
 // LDS-DMA ring, two blocks per CU.
-//   The short-K GEMMs of the s2mel DiT (K = 512: 8 or 16 K steps per tile) spend as long in tile prologue + epilogue as in the
-//   main loop, and the eight-wave 256 x 256 kernel (one block per CU) serialises the three.  This shape keeps its wave tile
-//   (0.375 KiB of LDS fragment reads per MFMA against 0.5 for the 128 x 128 kernel's 64 x 64 wave tile: the LDS port at 75 %
-//   of the matrix pipe's time instead of 100 %) but fits two blocks per CU (72 KiB each), so one block's epilogue / first loads
-//   overlap the other's main loop, and the two blocks' waves share each SIMD (MFMA of one under the fragment reads of the other).
+//   An attempt to keep the 256 x 256 kernel's wave tile (0.375 KiB of LDS fragment reads per MFMA) AND two blocks per CU
+//   (72 KiB each), so that one block's epilogue / first loads overlap the other's main loop.  Measured (profiles/r02h): par with
+//   the 256 x 256 kernel on the DiT shapes, behind both other kernels on the GPT prefill shapes (64-byte row pieces per DMA).
+//   Kept for the A/B harness (ITTS_TILE256=2); not selected by default.
 //   Ring: step k reads stage k % 3; the DMA of step k + 2 is issued at the top of step k into the stage read at step k - 1 (every
 //   wave is past that step's closing barrier); a counted s_waitcnt vmcnt(6) + barrier at the bottom of step k leaves exactly
 //   that DMA in flight and makes step k + 1's data visible.  The DMA queue never drains inside a tile.
@@ -1320,8 +1329,7 @@ static int launch_gemm_tile_4w_e(const GemmArgs& a, hipStream_t st) {
 static int pick_tile_kernel(const GemmArgs& a) {
     static const int mode = [] { const char* e = getenv("ITTS_TILE256"); return e ? atoi(e) : -1; }();
     if (mode == 0) return 0;
-    const bool vec_ok = (a.N % 16 == 0) && (a.ldo % 4 == 0 || (a.epi != EPI_STORE_F32 && a.epi != EPI_RESIDUAL && a.epi != EPI_GELU_ACT)) && (a.D % 4 == 0);
-    if (!vec_ok || a.N % 128) return 0;
+    if (!pf_vec_ok(a) || a.N % 128) return 0;
     if (mode == 1 || mode == 2) return mode;
     return 0;
 }
@@ -1621,7 +1629,7 @@ static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
         // bf16, K a multiple of the 64-deep K tile, 16-byte aligned rows: the LDS-DMA tile kernel; else the direct-load one
         static const bool old_path = [] { const char* e = getenv("ITTS_PREFILL_GEMM"); return e && atoi(e) == 0; }();
         if (BF16 && !old_path && a.K % PF_BK == 0 && a.lda % 8 == 0 && a.nsplit == 1 && a.epi != EPI_PARTIAL) return launch_gemm_prefill(a, st);
-        if (a.epi > EPI_QKV) { itts_set_error("gemm: epilogue %d needs the bf16 tile kernel (K %% 64 == 0, lda %% 8 == 0)", a.epi); return ITTS_ERR_ARG; }
+        if (a.epi > EPI_QKV || a.out_act2) { itts_set_error("gemm: epilogue %d / bf16 shadow output needs the bf16 tile kernel (K %% 64 == 0, lda %% 8 == 0)", a.epi); return ITTS_ERR_ARG; }
         return launch_gemm_cfg<BF16, 8, 2, false>(a, st);
     }
     if constexpr (BF16) {

@@ -265,6 +265,9 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 //   reads); the next tile's global loads are in flight while the current one feeds the MFMAs.
 // ================================================================================================================
 #define FA_LD 72          // bf16 elements per LDS row
+#ifndef FA_ABL
+#define FA_ABL 0          // tools/microbench/flash_ablate.hip builds variants with pieces of the loop removed (bit mask); 0 in the product
+#endif
 
 // QS = 16-query sub-tiles per wave (block = 64 * QS queries).  Every K / V^T fragment read from LDS feeds QS MFMAs: with one
 // sub-tile the kernel is LDS-bound (16 KB of fragment reads per 16 MFMAs per wave), with four the MFMA pipe is the limit.
@@ -346,10 +349,10 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
     }
     int buf = 0;
     for (int k0 = 0; k0 < len; k0 += 64, buf ^= 1) {
-        const bool more = k0 + 64 < len;                           // block-uniform
+        const bool more = (FA_ABL & 1) ? false : k0 + 64 < len;    // block-uniform
         if (more) fetch(k0 + 64);                                  // in flight under this tile's MFMAs
-        const u16* kt_s = ks[buf];
-        const u16* vt_s = vs[buf];
+        const u16* kt_s = ks[(FA_ABL & 1) ? 0 : buf];
+        const u16* vt_s = vs[(FA_ABL & 1) ? 0 : buf];
         f32x4 st[QS][4];
         // S^T: all four key sub-tiles with the first 32 d, then the second 32 d -- consecutive MFMAs never chain on one accumulator
 #pragma unroll
@@ -359,7 +362,8 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
                 const v4u a = *(const v4u*)(kt_s + (kt * 16 + c16) * FA_LD + kx * 32 + g * 8);
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs)
-                    st[qs][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[qs][kx]),
+                    if (FA_ABL & 32) { st[qs][kt] = f32x4{0.f, 1.f, 2.f, 3.f}; asm volatile("" ::"v"(a)); }
+                    else st[qs][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[qs][kx]),
                                                                          kx == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : st[qs][kt], 0, 0, 0);
             }
         const bool tail = k0 + 64 > len;                           // block-uniform: only the last tile holds masked keys
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
             const float t0 = fa_max3(st[qs][0][0], st[qs][0][1], st[qs][0][2]), t1 = fa_max3(st[qs][1][0], st[qs][1][1], st[qs][1][2]);
             const float t2 = fa_max3(st[qs][2][0], st[qs][2][1], st[qs][2][2]), t3 = fa_max3(st[qs][3][0], st[qs][3][1], st[qs][3][2]);
             const float u0 = fa_max3(t0, t1, st[qs][0][3]), u1 = fa_max3(t2, t3, st[qs][1][3]);
-            const float mx = fa_colmax(fa_max3(u0, u1, fa_max3(st[qs][2][3], st[qs][3][3], m_run[qs])));
+            const float mx = (FA_ABL & 8) ? fmaxf(m_run[qs], 0.f) : fa_colmax(fa_max3(u0, u1, fa_max3(st[qs][2][3], st[qs][3][3], m_run[qs])));
             const float m_new = mx;                                // >= m_run; finite: key k0 < len is valid for every query
             const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * scale_log2e);
             const f32x2_t cs{scale_log2e, scale_log2e}, off{-m_new * scale_log2e, -m_new * scale_log2e};
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const f32x2_t t = f32x2_t{st[qs][kt][2 * h2], st[qs][kt][2 * h2 + 1]} * cs + off;
-                    const f32x2_t p{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    const f32x2_t p = (FA_ABL & 4) ? t : f32x2_t{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
                     st[qs][kt][2 * h2] = p[0];
                     st[qs][kt][2 * h2 + 1] = p[1];
                     psum += p;
@@ -415,11 +419,12 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
                 const v4u a{lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs)
-                    o[qs][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, pb[qs][kx]),
-                                                                        o[qs][mt], 0, 0, 0);
+                    if (FA_ABL & 16) asm volatile("" ::"v"(a), "v"(pb[qs][kx]));
+                    else o[qs][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, pb[qs][kx]),
+                                                                             o[qs][mt], 0, 0, 0);
             }
         if (more) stage(buf ^ 1);                                  // the other stage was last read one tile ago (barrier below that tile)
-        __syncthreads();
+        if (!(FA_ABL & 2)) __syncthreads();
     }
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
