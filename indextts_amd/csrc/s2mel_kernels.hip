@@ -14,6 +14,7 @@
 // no padding; attention, RoPE, the reflect-padded convs and the masks find a row's sequence through SeqTab.
 // head_dim is 64 (hidden 512 / 8 heads in the shipped configuration).
 #include <stdlib.h>
+#include <type_traits>
 #include "s2mel_kernels.h"
 #include "gpt_kernels.h"
 
@@ -265,6 +266,11 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 //   reads); the next tile's global loads are in flight while the current one feeds the MFMAs.
 // ================================================================================================================
 #define FA_LD 72          // bf16 elements per LDS row
+#ifndef FA_OPT
+#define FA_OPT 0          // variants kept for A/B (microbench): 1 = compile-time LDS stage (loop unrolled x2), 2 = row sums of P on the PV MFMAs
+                          // (a fifth m-tile of ones), 4 = rescale the accumulators only when some query's maximum moved.  Measured
+                          // (profiles/r02k, r02l): none of them pays -- the loop is not instruction-issue bound
+#endif
 #ifndef FA_ABL
 #define FA_ABL 0          // tools/microbench/flash_ablate.hip builds variants with pieces of the loop removed (bit mask); 0 in the product
 #endif
@@ -288,7 +294,7 @@ __device__ __forceinline__ float fa_max3(float a, float b, float c) {       // n
 }
 
 template <int QS>
-__global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ Vt,
+__global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_attn_bf16_kernel(const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ Vt,
                                                               u16* __restrict__ O, SeqTab tab, int heads, int t_pad, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) u16 ks[2][64 * FA_LD];     // two stages: one barrier per key tile
     __shared__ __attribute__((aligned(16))) u16 vs[2][64 * FA_LD];
@@ -328,15 +334,18 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
             *(v4u*)(vs[buf] + r * FA_LD + p0 * 8) = vreg[i];
         }
     };
-    f32x4 o[QS][4];
+    f32x4 o[QS][4], osum[QS];                                      // osum (FA_OPT & 2): row 0 of a fifth V^T m-tile of ones = the row sums of P
     float m_run[QS], l_run[QS];                                    // l_run: this lane's share of the row sum (reduced after the loop)
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
         m_run[qs] = -INFINITY;
         l_run[qs] = 0.f;
+        osum[qs] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) o[qs][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    const unsigned one2 = c16 == 0 ? 0x3f803f80u : 0u;              // bf16 1.0 pairs in row 0 of the ones tile
+    const v4u ones_frag{one2, one2, one2, one2};
     fetch(0);
     stage(0);
     __syncthreads();
@@ -347,12 +356,13 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
         asm volatile("" : "+v"(qf[qs][0]));
         asm volatile("" : "+v"(qf[qs][1]));
     }
-    int buf = 0;
-    for (int k0 = 0; k0 < len; k0 += 64, buf ^= 1) {
+    // One key tile; the LDS stage is a compile-time constant when the loop is unrolled by two (FA_OPT & 1), else bufc carries it at run time.
+    auto tile = [&](auto bufc, int k0) {
+        const int BUF = bufc;
         const bool more = (FA_ABL & 1) ? false : k0 + 64 < len;    // block-uniform
         if (more) fetch(k0 + 64);                                  // in flight under this tile's MFMAs
-        const u16* kt_s = ks[(FA_ABL & 1) ? 0 : buf];
-        const u16* vt_s = vs[(FA_ABL & 1) ? 0 : buf];
+        const u16* kt_s = ks[(FA_ABL & 1) ? 0 : BUF];
+        const u16* vt_s = vs[(FA_ABL & 1) ? 0 : BUF];
         f32x4 st[QS][4];
         // S^T: all four key sub-tiles with the first 32 d, then the second 32 d -- consecutive MFMAs never chain on one accumulator
 #pragma unroll
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
                 for (int qs = 0; qs < QS; ++qs)
                     if (FA_ABL & 32) { st[qs][kt] = f32x4{0.f, 1.f, 2.f, 3.f}; asm volatile("" ::"v"(a)); }
                     else st[qs][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[qs][kx]),
-                                                                         kx == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : st[qs][kt], 0, 0, 0);
+                                                                              kx == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : st[qs][kt], 0, 0, 0);
             }
         const bool tail = k0 + 64 > len;                           // block-uniform: only the last tile holds masked keys
         v4u pb[QS][2];
@@ -377,41 +387,43 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
                     for (int r = 0; r < 4; ++r)
                         if ((k0 + kt * 16 + g * 4 + r) >= len) st[qs][kt][r] = -INFINITY;
             }
-            // softmax in the exp2 domain on the RAW scores: p = exp2(s * c - m * c) with c = log2(e) / 8 folded into one fma per
-            // element (pairs of elements on the packed-f32 pipe); in-lane max by v_max3, across the query's four lanes by permlane swaps
+            // softmax in the exp2 domain on the RAW scores: p = exp2(s * c - m * c), c = log2(e) / 8, one fma per element;
+            // in-lane max by v_max3, across the query's four lanes by permlane swaps
             const float t0 = fa_max3(st[qs][0][0], st[qs][0][1], st[qs][0][2]), t1 = fa_max3(st[qs][1][0], st[qs][1][1], st[qs][1][2]);
             const float t2 = fa_max3(st[qs][2][0], st[qs][2][1], st[qs][2][2]), t3 = fa_max3(st[qs][3][0], st[qs][3][1], st[qs][3][2]);
             const float u0 = fa_max3(t0, t1, st[qs][0][3]), u1 = fa_max3(t2, t3, st[qs][1][3]);
-            const float mx = (FA_ABL & 8) ? fmaxf(m_run[qs], 0.f) : fa_colmax(fa_max3(u0, u1, fa_max3(st[qs][2][3], st[qs][3][3], m_run[qs])));
-            const float m_new = mx;                                // >= m_run; finite: key k0 < len is valid for every query
-            const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * scale_log2e);
-            const f32x2_t cs{scale_log2e, scale_log2e}, off{-m_new * scale_log2e, -m_new * scale_log2e};
-            f32x2_t psum{0.f, 0.f};
+            const float m_new = (FA_ABL & 8) ? fmaxf(m_run[qs], 0.f)
+                                             : fa_colmax(fa_max3(u0, u1, fa_max3(st[qs][2][3], st[qs][3][3], m_run[qs])));   // >= m_run, finite
+            if (!(FA_OPT & 4) || __builtin_amdgcn_ballot_w64(m_new > m_run[qs]) != 0) {      // (FA_OPT & 4: wave-uniform skip)
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * scale_log2e);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qs][mt][r] *= alpha;
+                if (FA_OPT & 2) osum[qs][0] *= alpha; else l_run[qs] *= alpha;
+                m_run[qs] = m_new;
+            }
+            // plain f32 VALU on purpose (the file is built with -fno-slp-vectorize): beside MFMAs a v_pk_fma/mul/add_f32 costs ~13
+            // cycles more than the two scalar ops it replaces (MI355X guide)
+            const float off = -m_new * scale_log2e;
+            float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {
-                    const f32x2_t t = f32x2_t{st[qs][kt][2 * h2], st[qs][kt][2 * h2 + 1]} * cs + off;
-                    const f32x2_t p = (FA_ABL & 4) ? t : f32x2_t{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                    st[qs][kt][2 * h2] = p[0];
-                    st[qs][kt][2 * h2 + 1] = p[1];
-                    psum += p;
+                for (int r = 0; r < 4; ++r) {
+                    const float t = __builtin_fmaf(st[qs][kt][r], scale_log2e, off);
+                    const float p = (FA_ABL & 4) ? t : __builtin_amdgcn_exp2f(t);
+                    st[qs][kt][r] = p;
+                    if (!(FA_OPT & 2)) psum += p;
                 }
-            l_run[qs] = l_run[qs] * alpha + (psum[0] + psum[1]);
-            m_run[qs] = m_new;
-            const f32x2_t al2{alpha, alpha};
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const f32x2_t lo = f32x2_t{o[qs][mt][0], o[qs][mt][1]} * al2, hi = f32x2_t{o[qs][mt][2], o[qs][mt][3]} * al2;
-                o[qs][mt] = f32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
+            if (!(FA_OPT & 2)) l_run[qs] += psum;
 #pragma unroll
             for (int kx = 0; kx < 2; ++kx)
                 pb[qs][kx] = v4u{pack_bf16x2(st[qs][2 * kx][0], st[qs][2 * kx][1]), pack_bf16x2(st[qs][2 * kx][2], st[qs][2 * kx][3]),
                                  pack_bf16x2(st[qs][2 * kx + 1][0], st[qs][2 * kx + 1][1]), pack_bf16x2(st[qs][2 * kx + 1][2], st[qs][2 * kx + 1][3])};
         }
 #pragma unroll
-        for (int kx = 0; kx < 2; ++kx)
+        for (int kx = 0; kx < 2; ++kx) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const u16* vrow = vt_s + (mt * 16 + c16) * FA_LD + kx * 32 + g * 4;
@@ -423,14 +435,34 @@ __global__ __launch_bounds__(256) void flash_attn_bf16_kernel(const u16* __restr
                     else o[qs][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, pb[qs][kx]),
                                                                              o[qs][mt], 0, 0, 0);
             }
-        if (more) stage(buf ^ 1);                                  // the other stage was last read one tile ago (barrier below that tile)
+#pragma unroll
+            for (int qs = 0; qs < QS; ++qs)
+                if ((FA_OPT & 2) && !(FA_ABL & 16)) osum[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones_frag),
+                                                                                        __builtin_bit_cast(bf16x8_t, pb[qs][kx]), osum[qs], 0, 0, 0);
+        }
+        if (more) stage(BUF ^ 1);                                  // the other stage was last read one tile ago (barrier below that tile)
         if (!(FA_ABL & 2)) __syncthreads();
+    };
+    if (FA_OPT & 1) {
+        for (int k0 = 0; k0 < len; k0 += 128) {
+            tile(std::integral_constant<int, 0>{}, k0);
+            if (k0 + 64 >= len) break;
+            tile(std::integral_constant<int, 1>{}, k0 + 64);
+        }
+    } else {
+        int buf = 0;
+        for (int k0 = 0; k0 < len; k0 += 64, buf ^= 1) tile(buf, k0);
     }
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
-        float ls = l_run[qs];                                      // the four key groups' shares of the row sum
-        ls += __shfl_xor(ls, 16, 64);
-        ls += __shfl_xor(ls, 32, 64);
+        float ls;
+        if (FA_OPT & 2) {
+            ls = __shfl(osum[qs][0], c16, 64);                     // row 0 of the ones tile lives in lanes 0..15 (g = 0), element 0
+        } else {
+            ls = l_run[qs];                                        // the four key groups' shares of the row sum
+            ls += __shfl_xor(ls, 16, 64);
+            ls += __shfl_xor(ls, 32, 64);
+        }
         const int qi = q0 + (w * QS + qs) * 16 + c16;
         if (qi < T) {
             const float inv = ls > 0.f ? 1.0f / ls : 0.f;
