@@ -20,11 +20,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE]
 # per-file extras.  VGPR-form MFMA: the accumulators live in ordinary VGPRs (gfx950 MFMA reads / writes either file), so the
 # softmax / epilogue VALU code works on them in place -- with AGPR accumulators the flash-attention loop carried 80
 # v_accvgpr_read/write moves per key tile and every GEMM epilogue 192.  The BigVGAN conv kernel keeps its tuned allocation.
-# s2mel_kernels.hip: no SLP vectorisation -- hipcc otherwise packs the flash-attention softmax into v_pk_*_f32, which beside MFMAs
-# cost ~13 cycles more per instruction than the scalar pair (MI355X guide; measured in profiles/r02i/flash_ablate.log).
+# No SLP vectorisation in s2mel_kernels.hip / bigvgan_kernels.hip: hipcc otherwise packs adjacent f32 adds / muls / fmas into
+# v_pk_*_f32, which cost more than the scalar pair they replace (MI355X guide: ~13 extra cycles each beside MFMAs).  Measured: the
+# anti-aliased activation kernel 2.32 -> 2.55 TB/s (profiles/r02l/voc_*.log), the flash-attention solve -4 % (profiles/r02j).
 EXTRA = {"gpt_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-         "s2mel_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
-
+         "s2mel_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
+         "bigvgan_kernels.hip": ["-fno-slp-vectorize"]}
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))

@@ -1331,6 +1331,11 @@ static int pick_tile_kernel(const GemmArgs& a) {
     if (mode == 0) return 0;
     if (!pf_vec_ok(a) || a.N % 128) return 0;
     if (mode == 1 || mode == 2) return mode;
+    // The 256 x 256 kernel holds one block per CU: it needs whole rounds of tiles.  Measured (profiles/r02f..r02i): ahead of the
+    // 128 x 128 kernel by 10-14 % on K >= 1280 at >= 2 rounds (GPT prefill at B = 64), by 3 % over the s2mel solve at >= 4 rounds
+    // (-16 % on the residual / plain-store GEMMs, par on the rest), behind it below that (tail of the last round).
+    const long long tiles = (long long)ceil_div(a.M, 256) * ceil_div(a.N, 256);
+    if (tiles >= 1024 || (tiles >= 480 && a.K >= 1024)) return 1;
     return 0;
 }
 

@@ -262,14 +262,18 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 //   O^T = V^T P^T : A = V^T tile (rows = d, k = keys), B = P^T straight from the S^T registers -- no transpose through LDS:
 //                   the contraction index is permuted identically on both operands (slot (g, j) <-> key 32*ks + 4g + j for
 //                   j < 4, 32*ks + 16 + 4g + j - 4 otherwise), so A reads two 8-byte key runs instead of one 16-byte run.
-//   K tile [64 keys][64 d] and V^T tile [64 d][64 keys] are staged in LDS (row stride 144 B: conflict-free 16-byte fragment
-//   reads); the next tile's global loads are in flight while the current one feeds the MFMAs.
+//   K tile [64 keys][64 d] and V^T tile [64 d][64 keys] are staged in LDS: 128-byte rows, the eight 16-byte pieces of row r
+//   XOR-permuted by (r >> 1) & 7 -- conflict-free for the staging writes, the 16-byte K fragment reads and the 8-byte V^T fragment
+//   reads under the real lane grouping of ds_read_b128 (4 groups of 16 non-contiguous lanes).  A padded 144-byte stride (the usual
+//   recipe) measured 43 % of all LDS cycles as bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r02l).
+//   The next tile's global loads are in flight while the current one feeds the MFMAs.
 // ================================================================================================================
-#define FA_LD 72          // bf16 elements per LDS row
+#define FA_LD 64          // bf16 elements per LDS row (128 B, pieces swizzled)
 #ifndef FA_OPT
-#define FA_OPT 0          // variants kept for A/B (microbench): 1 = compile-time LDS stage (loop unrolled x2), 2 = row sums of P on the PV MFMAs
-                          // (a fifth m-tile of ones), 4 = rescale the accumulators only when some query's maximum moved.  Measured
-                          // (profiles/r02k, r02l): none of them pays -- the loop is not instruction-issue bound
+#define FA_OPT 5          // bit 1: compile-time LDS stage (loop unrolled x2: immediate offsets instead of address adds), bit 4: rescale the
+                          // accumulators only when some query's running maximum moved (wave-uniform branch), bit 2: row sums of P on the
+                          // PV MFMAs (a fifth m-tile of ones).  Same-box A/B (tools/microbench/flash_ablate.hip, profiles/r02l, r02m;
+                          // 64 x 2443 frames x 8 heads): 0: 1284 us, 1: 1266, 4: 1260, 5: 1255, 7: 1359 (176 registers: two waves per SIMD)
 #endif
 #ifndef FA_ABL
 #define FA_ABL 0          // tools/microbench/flash_ablate.hip builds variants with pieces of the loop removed (bit mask); 0 in the product
@@ -330,10 +334,20 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = r0 + 32 * i;
-            *(v4u*)(ks[buf] + r * FA_LD + p0 * 8) = kreg[i];
-            *(v4u*)(vs[buf] + r * FA_LD + p0 * 8) = vreg[i];
+            const int pc = (p0 ^ ((r >> 1) & 7)) * 8;                // r and r + 32 share the swizzle
+            *(v4u*)(ks[buf] + r * FA_LD + pc) = kreg[i];
+            *(v4u*)(vs[buf] + r * FA_LD + pc) = vreg[i];
         }
     };
+    // fragment read offsets (elements) inside a stage: row c16 of a 16-row group, pieces swizzled by (c16 >> 1) & 7
+    const int fsw = (c16 >> 1) & 7;
+    int k_off[2], v_off[2][2];
+#pragma unroll
+    for (int kx = 0; kx < 2; ++kx) {
+        k_off[kx] = c16 * FA_LD + (((kx * 4 + g) ^ fsw) << 3);
+        v_off[kx][0] = c16 * FA_LD + (((kx * 4 + (g >> 1)) ^ fsw) << 3) + (g & 1) * 4;          // keys 32 kx + 4 g .. + 3
+        v_off[kx][1] = c16 * FA_LD + (((kx * 4 + (g >> 1) + 2) ^ fsw) << 3) + (g & 1) * 4;      // keys 32 kx + 16 + 4 g .. + 3
+    }
     f32x4 o[QS][4], osum[QS];                                      // osum (FA_OPT & 2): row 0 of a fifth V^T m-tile of ones = the row sums of P
     float m_run[QS], l_run[QS];                                    // l_run: this lane's share of the row sum (reduced after the loop)
 #pragma unroll
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
         for (int kx = 0; kx < 2; ++kx)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const v4u a = *(const v4u*)(kt_s + (kt * 16 + c16) * FA_LD + kx * 32 + g * 8);
+                const v4u a = *(const v4u*)(kt_s + kt * 16 * FA_LD + k_off[kx]);
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs)
                     if (FA_ABL & 32) { st[qs][kt] = f32x4{0.f, 1.f, 2.f, 3.f}; asm volatile("" ::"v"(a)); }
@@ -426,8 +440,7 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
         for (int kx = 0; kx < 2; ++kx) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const u16* vrow = vt_s + (mt * 16 + c16) * FA_LD + kx * 32 + g * 4;
-                const v2u lo = *(const v2u*)vrow, hi = *(const v2u*)(vrow + 16);
+                const v2u lo = *(const v2u*)(vt_s + mt * 16 * FA_LD + v_off[kx][0]), hi = *(const v2u*)(vt_s + mt * 16 * FA_LD + v_off[kx][1]);
                 const v4u a{lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs)
@@ -481,11 +494,11 @@ int launch_s2mel_attention(const void* q, const void* k, const void* v, void* ou
     if (tab.n_tok <= 0) return ITTS_OK;
     if (prec == PREC_BF16) {
         const float scale_log2e = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64) * log2(e)
-        // query sub-tiles per wave.  Measured (profiles/r02d, 16 x 2726 frames x 8 heads, 25 steps): QS = 1 503.6 ms, 2 512.6 ms,
-        // 4 552.3 ms per solve -- the 300-register QS = 4 kernel drops to one wave per SIMD and loses more latency hiding than
-        // it saves in LDS fragment reads.  ITTS_FA_QS forces a variant (A/B).
+        // query sub-tiles per wave (ITTS_FA_QS forces a variant).  One sub-tile is LDS-bound (every K / V^T fragment read feeds one
+        // MFMA: SQ_LDS_IDX_ACTIVE at 70-90 % of the kernel's cycles, profiles/r02l), two halve the fragment traffic per MFMA and
+        // still fit three waves per SIMD; four need 256 registers (one wave per SIMD) and lose to latency.
         static const int force_qs = [] { const char* e = getenv("ITTS_FA_QS"); return e ? atoi(e) : 0; }();
-        const int qs = force_qs ? force_qs : 1;
+        const int qs = force_qs ? force_qs : 2;
 #define FA_LAUNCH(QS_) hipLaunchKernelGGL(flash_attn_bf16_kernel<QS_>, dim3(ceil_div(tab.t_max, 64 * QS_), heads, tab.n_seq), dim3(256), 0, st, \
                                           (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, tab, heads, t_pad, scale_log2e)
         if (qs >= 4) FA_LAUNCH(4); else if (qs == 2) FA_LAUNCH(2); else FA_LAUNCH(1);
