@@ -186,6 +186,16 @@ int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const int32_t* pa
                       const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids,
                       const double* uniforms, int64_t* codes_out, int32_t* n_steps_out, void* workspace,
                       size_t workspace_bytes, int use_graph, void* stream);
+/* Chunked form of itts_gpt_generate for streaming (replaces: GPTTRTEngine.generate_chunks, backends/trt/runtime/
+ *   gpt_trtllm_runtime.py:381-520, whose TRT-LLM session yields tokens from inside its decode loop).  First call: prefix_embeds
+ *   non-NULL -- prefill + decode until `step_limit` tokens exist (or every row finished).  Later calls: prefix_embeds NULL --
+ *   the decode loop continues from the device state left in the SAME workspace (KV cache, step / position, finished flags,
+ *   repetition set) up to the new step_limit; nseq, S, params->max_new_tokens, codes_out, uniforms must be those of the first
+ *   call.  *n_steps_out = tokens generated so far (< step_limit only when every row has finished). */
+int itts_gpt_generate_chunk(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int nseq, int S,
+                            const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids,
+                            const double* uniforms, int64_t* codes_out, int32_t step_limit, int32_t* n_steps_out,
+                            void* workspace, size_t workspace_bytes, int use_graph, void* stream);
 /* replaces: the same generate() call in beam mode, num_beams > 1 (the reference default is 3-beam beam-sample,
  *   indextts/infer_v2_5.py:732-740) -> vendored GenerationMixin._beam_search (transformers_generation_utils.py:3325-3609),
  *   BeamSearchScorer.process (3rd-party; mirror indextts/gpt/transformers_beam_search.py:215-305,930-1013) and

@@ -85,6 +85,8 @@ SIGNATURES = {
     "itts_gpt_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int]),
     "itts_gpt_generate": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.POINTER(GenParams), c_i32p, C.c_int, vp, vp,
                                     C.POINTER(C.c_int32), vp, C.c_size_t, C.c_int, vp]),
+    "itts_gpt_generate_chunk": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.POINTER(GenParams), c_i32p, C.c_int, vp, vp, C.c_int32,
+                                          C.POINTER(C.c_int32), vp, C.c_size_t, C.c_int, vp]),
     "itts_gpt_beam_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "itts_gpt_generate_beam": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GenParams), c_i32p, C.c_int, vp,
                                          vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp, C.c_size_t, C.c_int, vp]),

@@ -75,6 +75,9 @@ struct itts_gpt {
     std::vector<GraphEntry> graphs;
     unsigned long long graph_clock = 0;
     int graph_hits = 0, graph_captures = 0;
+    // chunked generation (itts_gpt_generate_chunk): tokens generated so far and the shape / workspace of the call being resumed
+    int chunk_steps = 0, chunk_nseq = 0, chunk_S = 0, chunk_max_new = 0;
+    const void* chunk_ws = nullptr;
 };
 #define GRAPH_CACHE_MAX 8
 // prompt lengths are bucketed to multiples of 32 for the workspace carve and the cache stride, so that prompts of nearby lengths
@@ -454,17 +457,25 @@ static int decode_step(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, i
     return launch_sample(s, st);
 }
 
-extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int nseq, int S,
-                                 const itts_gen_params* gpp, const int32_t* penalty_ids, int n_penalty_ids,
-                                 const double* uniforms, int64_t* codes_out, int32_t* n_steps_out, void* workspace,
-                                 size_t workspace_bytes, int use_graph, void* caller_stream) {
-    if (!h || !prefix_embeds || !gpp || !codes_out || !n_steps_out || !workspace) { itts_set_error("gpt_generate: null pointer"); return ITTS_ERR_ARG; }
+// step_limit: stop after that many generated tokens (<= max_new_tokens) -- the chunked form used for streaming; resume: continue
+// the decode loop of an earlier chunk call from the device state left in the same workspace (no prefill, no state init).
+static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int nseq, int S,
+                             const itts_gen_params* gpp, const int32_t* penalty_ids, int n_penalty_ids,
+                             const double* uniforms, int64_t* codes_out, int32_t* n_steps_out, void* workspace,
+                             size_t workspace_bytes, int use_graph, void* caller_stream, int step_limit, bool resume) {
+    if (!h || (!prefix_embeds && !resume) || !gpp || !codes_out || !n_steps_out || !workspace) { itts_set_error("gpt_generate: null pointer"); return ITTS_ERR_ARG; }
     if (!h->finalized) { itts_set_error("gpt_generate: call itts_gpt_finalize first"); return ITTS_ERR_STATE; }
     ItDevGuard dg(h->device);
-    if (int rcd = check_same_device(h, prefix_embeds, workspace, "gpt_generate")) return rcd;
+    if (int rcd = check_same_device(h, resume ? (const void*)codes_out : (const void*)prefix_embeds, workspace, "gpt_generate")) return rcd;
     const itts_gpt_config& c = h->cfg;
     const itts_gen_params gp = *gpp;
     if (nseq <= 0 || S <= 0 || gp.max_new_tokens <= 0) { itts_set_error("gpt_generate: nseq, S, max_new_tokens must be > 0"); return ITTS_ERR_ARG; }
+    if (step_limit < 1 || step_limit > gp.max_new_tokens) step_limit = gp.max_new_tokens;
+    if (resume && (h->chunk_steps < 1 || h->chunk_nseq != nseq || h->chunk_S != S || h->chunk_max_new != gp.max_new_tokens ||
+                   h->chunk_ws != workspace)) {
+        itts_set_error("gpt_generate_chunk: resume without a matching first chunk (same workspace, nseq, S, max_new_tokens)");
+        return ITTS_ERR_STATE;
+    }
     if (gp.num_beams != 1) { itts_set_error("gpt_generate: num_beams=%d not supported by the device loop yet (use 1)", gp.num_beams); return ITTS_ERR_ARG; }
     if (gp.max_new_tokens + gp.pos_offset > c.n_mel_pos + 1) {
         itts_set_error("gpt_generate: max_new_tokens=%d exceeds the mel position table (%d rows)", gp.max_new_tokens, c.n_mel_pos);
@@ -490,6 +501,8 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
     HIP_TRY(hipEventRecord(h->ev_in, cs));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_in, 0));
 
+    int steps = resume ? h->chunk_steps : 1;
+    if (!resume) {
     // ---- state init ----
     HIP_TRY(hipMemsetAsync(w.seen, 0, (size_t)nseq * c.vocab, st));
     HIP_TRY(hipMemsetAsync(w.finished, 0, nseq, st));
@@ -520,10 +533,12 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
         if ((rc = launch_sample(s, st))) return rc;
     }
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 1, S);
+    } else {
+        HIP_TRY(hipEventRecord(h->ev_t0, st));
+    }
     HIP_TRY(hipEventRecord(h->ev_t1, st));
 
     // ---- decode loop ----
-    int steps = 1;
     bool graph_ok = false;
     hipGraphExec_t exec = nullptr;
     if (use_graph && gp.max_new_tokens > 1) {
@@ -553,11 +568,11 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
         }
     }
     const int check_every = 8;
-    while (steps < gp.max_new_tokens) {
+    while (steps < step_limit) {
         if (graph_ok) { HIP_TRY(hipGraphLaunch(exec, st)); }
         else if ((rc = decode_step(h, w, gp, nseq, Tmax, tokens, uniforms, st))) return rc;
         ++steps;
-        if (steps % check_every == 0 && steps < gp.max_new_tokens) {
+        if (steps % check_every == 0 && steps < step_limit) {
             HIP_TRY(hipMemcpyAsync(h->host_fin, w.finished, nseq, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             bool all = true;
@@ -572,8 +587,25 @@ extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const 
     (void)hipEventElapsedTime(&h->last_prefill_ms, h->ev_t0, h->ev_t1);
     (void)hipEventElapsedTime(&h->last_decode_ms, h->ev_t1, h->ev_t2);
     h->last_steps = steps;
+    h->chunk_steps = steps; h->chunk_nseq = nseq; h->chunk_S = S; h->chunk_max_new = gp.max_new_tokens; h->chunk_ws = workspace;
     *n_steps_out = steps;
     return ITTS_OK;
+}
+
+extern "C" int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int nseq, int S,
+                                 const itts_gen_params* gpp, const int32_t* penalty_ids, int n_penalty_ids,
+                                 const double* uniforms, int64_t* codes_out, int32_t* n_steps_out, void* workspace,
+                                 size_t workspace_bytes, int use_graph, void* caller_stream) {
+    return gpt_generate_impl(h, prefix_embeds, pad_lens, nseq, S, gpp, penalty_ids, n_penalty_ids, uniforms, codes_out, n_steps_out,
+                             workspace, workspace_bytes, use_graph, caller_stream, 0, false);
+}
+
+extern "C" int itts_gpt_generate_chunk(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int nseq, int S,
+                                       const itts_gen_params* gpp, const int32_t* penalty_ids, int n_penalty_ids,
+                                       const double* uniforms, int64_t* codes_out, int32_t step_limit, int32_t* n_steps_out,
+                                       void* workspace, size_t workspace_bytes, int use_graph, void* caller_stream) {
+    return gpt_generate_impl(h, prefix_embeds, pad_lens, nseq, S, gpp, penalty_ids, n_penalty_ids, uniforms, codes_out, n_steps_out,
+                             workspace, workspace_bytes, use_graph, caller_stream, step_limit, prefix_embeds == nullptr);
 }
 
 // ---- beam search / beam-sample ------------------------------------------------------------------------------------

@@ -279,6 +279,77 @@ class UnifiedVoice:
         n = int(min(int(first.max().item()), n_steps.value))
         return codes[:, :n].clone()
 
+    def generate_chunks(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int, chunk_size: int,
+                        overlap_size: int, do_sample=False, num_beams=1, top_p=1.0, top_k=50, temperature=1.0, repetition_penalty=1.0,
+                        length_penalty=1.0, uniforms: Optional[torch.Tensor] = None, seed: Optional[int] = None,
+                        typical_mass: float = 0.0, **unused):
+        """Streaming form of `generate` (`GPTTRTEngine.generate_chunks`, backends/trt/runtime/gpt_trtllm_runtime.py:381-520):
+        yields `(chunk_codes (B, <= chunk_size), is_last, batch_done [B], chunk_code_lens (B,))` as soon as `chunk_size` codes
+        exist, consecutive chunks overlapping by `overlap_size` codes; the decode loop is suspended between chunks with its whole
+        state (KV cache, position, finished flags) on the device (`itts_gpt_generate_chunk`).  Sampling / greedy only: the engine
+        streams one hypothesis per row."""
+        stride = int(chunk_size) - int(overlap_size)
+        if stride <= 0:
+            raise ValueError(f"overlap_size ({overlap_size}) must be less than chunk_size ({chunk_size}); "
+                             f"got stride={stride} which would cause an infinite loop.")
+        if num_beams != 1:
+            raise NotImplementedError("generate_chunks streams num_beams=1 (a beam's prefix is not final until the search ends)")
+        if not self._loaded:
+            raise RuntimeError("UnifiedVoice: load_state_dict() first")
+        dev = self.device
+        B, s, D = inputs_embeds.shape
+        start = (self._emb["mel_embedding.weight"][self.start_mel_token] + self._emb["mel_pos_embedding.emb.weight"][0])
+        x = torch.cat([inputs_embeds.to(dev, torch.float32), start.expand(B, 1, D)], dim=1).contiguous()
+        S, max_new = s + 1, int(max_new_tokens)
+        pad = (attention_mask[:, :S] == 0).sum(dim=1).to(torch.int32).contiguous()
+        gp = _lib.GenParams()
+        gp.do_sample, gp.num_beams, gp.top_k = int(bool(do_sample)), 1, int(top_k or 0)
+        gp.min_tokens_to_keep, gp.max_new_tokens = 1, max_new
+        gp.pos_offset = 2 if self.kv_cache else 1
+        gp.top_p, gp.temperature = float(top_p), float(temperature)
+        gp.repetition_penalty = float(repetition_penalty if repetition_penalty is not None else 1.0)
+        gp.length_penalty, gp.seed = float(length_penalty), self._seed(seed, do_sample, uniforms)
+        gp.typical_mass = float(typical_mass)
+        L = _lib.lib()
+        ws = self._workspace(L.itts_gpt_workspace_bytes(self._h, B, S, S + max_new))
+        codes = self._persistent("codes", (B, max_new), torch.int64)
+        u = None
+        if uniforms is not None:
+            if uniforms.shape[0] < max_new or uniforms.shape[1] != B:
+                raise ValueError("uniforms must be (>= max_new_tokens, B)")
+            u = self._persistent("uniforms", (max_new, B), torch.float64)
+            u.copy_(uniforms[:max_new])
+        pen = (C.c_int32 * 2)(1, self.start_mel_token)
+        n_steps = C.c_int32(0)
+        next_chunk_at = int(chunk_size)
+        first = True
+        while True:
+            limit = min(next_chunk_at, max_new)
+            rc = L.itts_gpt_generate_chunk(self._h, _lib.ptr(x) if first else None, _lib.ptr(pad), B, S, C.byref(gp), pen, 2, _lib.ptr(u),
+                                           _lib.ptr(codes), limit, C.byref(n_steps), _lib.ptr(ws), ws.numel(), int(self.use_graph),
+                                           _lib.stream_ptr(self.device))
+            _lib.check(rc, "itts_gpt_generate_chunk")
+            first = False
+            steps = int(n_steps.value)
+            got = codes[:, :steps]
+            is_stop = got == self.stop_mel_token
+            done = is_stop.any(1)
+            lens = torch.where(done, is_stop.int().argmax(1), torch.full((B,), steps, device=dev))      # codes before the stop token
+            current_len = int(lens.max().item())
+            done_l, lens_l = done.tolist(), lens.tolist()
+            finished = all(done_l) or steps >= max_new or steps < limit
+            while current_len >= next_chunk_at:
+                pos = next_chunk_at - chunk_size
+                yield (codes[:, pos:next_chunk_at].clone(), False, [d and n <= next_chunk_at for d, n in zip(done_l, lens_l)],
+                       torch.tensor([max(0, min(n - pos, chunk_size)) for n in lens_l], dtype=torch.long, device=dev))
+                next_chunk_at += stride
+            if finished:
+                pos = next_chunk_at - chunk_size
+                if pos < current_len:
+                    yield (codes[:, pos:current_len].clone(), True, [True] * B,
+                           torch.tensor([max(0, n - pos) for n in lens_l], dtype=torch.long, device=dev))
+                return
+
     # ---- beam search / beam-sample (num_beams > 1; the reference default is 3-beam beam-sample) ------------------------
     def _generate_beam(self, inputs_embeds, attention_mask, max_new_tokens, do_sample, num_beams, top_p, top_k, temperature,
                        repetition_penalty, length_penalty, uniforms, seed, typical_mass=0.0) -> torch.Tensor:
@@ -368,11 +439,9 @@ class UnifiedVoice:
             out[b, : len(t)] = torch.tensor(t[:sent_max], dtype=torch.int64)
         return out.to(dev)
 
-    def inference_speech(self, speech_condition, text_inputs, langs=None, emo_speech_condition=None, cond_lengths=None,
-                         emo_cond_lengths=None, emo_vec=None, use_speed=False, campplus_embedding=None, wav=None,
-                         input_tokens=None, num_return_sequences=1, max_generate_length=None, typical_sampling=False,
-                         typical_mass=.9, conds_latent=None, uniforms=None, **hf_generate_kwargs):
-        """model_v2.py:716-825 (campplus conditioning).  Returns (codes, speech_conditioning_latent)."""
+    def _prepare_inference(self, speech_condition, text_inputs, langs, cond_lengths, emo_vec, campplus_embedding, input_tokens,
+                           num_return_sequences, max_generate_length, typical_sampling, typical_mass, conds_latent, hf_generate_kwargs):
+        """Argument handling of `inference_speech` up to the `generate` call (model_v2.py:716-803)."""
         if input_tokens is not None or num_return_sequences != 1:
             raise NotImplementedError("input_tokens / num_return_sequences > 1 are not used by the v2.5 pipeline")
         if typical_sampling and not (typical_mass > 0.0 and typical_mass < 1.0):           # model_v2.py:796-797
@@ -399,9 +468,30 @@ class UnifiedVoice:
         max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
         hf = dict(hf_generate_kwargs)
         hf.pop("logits_processor", None)
-        codes = self.generate(inputs_embeds, attention_mask, max_new, uniforms=uniforms,
-                              typical_mass=float(typical_mass) if typical_sampling else 0.0, **hf)
+        hf["typical_mass"] = float(typical_mass) if typical_sampling else 0.0
+        return inputs_embeds, attention_mask, max_new, hf, spk_lat
+
+    def inference_speech(self, speech_condition, text_inputs, langs=None, emo_speech_condition=None, cond_lengths=None,
+                         emo_cond_lengths=None, emo_vec=None, use_speed=False, campplus_embedding=None, wav=None,
+                         input_tokens=None, num_return_sequences=1, max_generate_length=None, typical_sampling=False,
+                         typical_mass=.9, conds_latent=None, uniforms=None, **hf_generate_kwargs):
+        """model_v2.py:716-825 (campplus conditioning).  Returns (codes, speech_conditioning_latent)."""
+        inputs_embeds, attention_mask, max_new, hf, spk_lat = self._prepare_inference(
+            speech_condition, text_inputs, langs, cond_lengths, emo_vec, campplus_embedding, input_tokens, num_return_sequences,
+            max_generate_length, typical_sampling, typical_mass, conds_latent, hf_generate_kwargs)
+        codes = self.generate(inputs_embeds, attention_mask, max_new, uniforms=uniforms, **hf)
         return codes, spk_lat
+
+    def inference_speech_stream(self, speech_condition, text_inputs, chunk_size=100, overlap_size=20, langs=None, cond_lengths=None,
+                                emo_vec=None, campplus_embedding=None, max_generate_length=None, typical_sampling=False,
+                                typical_mass=.9, conds_latent=None, uniforms=None, **hf_generate_kwargs):
+        """`inference_speech` whose generate call yields code chunks as they are decoded (see `generate_chunks`): returns the
+        (inputs_embeds, attention_mask, max_new_tokens, generate kwargs) a `streaming.StreamingDecoder` feeds back to this engine."""
+        inputs_embeds, attention_mask, max_new, hf, _ = self._prepare_inference(
+            speech_condition, text_inputs, langs, cond_lengths, emo_vec, campplus_embedding, None, 1, max_generate_length,
+            typical_sampling, typical_mass, conds_latent, hf_generate_kwargs)
+        hf["uniforms"] = uniforms
+        return inputs_embeds, attention_mask, max_new, hf
 
     # ---- teacher-forced latent pass (model_v2.py:596-646) ----------------------------------------------------------
     def forward_latent(self, conds: torch.Tensor, text_inputs: torch.Tensor, text_lengths: torch.Tensor,

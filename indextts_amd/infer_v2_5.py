@@ -319,6 +319,55 @@ class IndexTTS2:
             out.append((22050, wav.type(torch.int16).numpy().T))
         return out
 
+    def infer_stream(self, spk_audio_prompt, texts: Sequence[str], lang, emo_audio_prompt=None, emo_alpha=1.0, chunk_size: int = 100,
+                     overlap_size: int = 20, max_text_tokens_per_segment=120, duration_factor=1.0, text_normalization=True,
+                     **generation_kwargs):
+        """Streaming synthesis of a batch of single-segment texts (`FasterIndexTTS2` streaming path,
+        backends/trt/pipeline/streaming.py): a generator of `(22050, [int16 array | None per text], [done per text])`, one item per
+        GPT chunk of `chunk_size` codes (consecutive chunks share `overlap_size` codes and are cross-faded).  The first audio
+        leaves after prefill + `chunk_size` decode steps + one chunk of codes -> mel -> waveform instead of after the whole
+        utterance.  Sampling uses one hypothesis per row (`num_beams` is forced to 1: a beam's prefix is not final mid-search)."""
+        from .streaming import StreamingDecoder
+        if emo_audio_prompt is None:
+            emo_audio_prompt, emo_alpha = spk_audio_prompt, 1.0
+        bundle = dict(self._speaker(spk_audio_prompt))
+        emovec = self._emovec(bundle, emo_audio_prompt, emo_alpha, None, False)
+        seg_tokens = []
+        for text in texts:
+            segs = self.frontend.text_segments(text, lang, max_text_tokens_per_segment, text_normalization, self.gpt.n_text_pos)
+            if len(segs) != 1:
+                raise ValueError("infer_stream takes texts of one segment each (split long texts with the frontend first)")
+            seg_tokens.append(segs[0])
+        gk = dict(generation_kwargs)
+        gk.pop("do_sample", None)
+        gk.pop("num_beams", None)
+        max_mel_tokens = gk.pop("max_mel_tokens", 1500)
+        gen = dict(do_sample=True, top_p=gk.pop("top_p", 0.8), top_k=gk.pop("top_k", 30), temperature=gk.pop("temperature", 0.8),
+                   repetition_penalty=gk.pop("repetition_penalty", 10.0), length_penalty=gk.pop("length_penalty", 0.0), num_beams=1, **gk)
+        dev = self.device
+        L = max(int(t.numel()) for t in seg_tokens)
+        text_ids = torch.full((len(seg_tokens), L), 1, dtype=torch.int32)
+        for i, t in enumerate(seg_tokens):
+            text_ids[i, : t.numel()] = t.reshape(-1).to(torch.int32)
+        langs = torch.tensor([self.frontend.lang_id(lang)] * len(seg_tokens), dtype=torch.long)
+        inputs_embeds, attention_mask, max_new, hf = self.gpt.inference_speech_stream(
+            bundle["spk_cond_emb"], text_ids.to(dev), chunk_size, overlap_size, langs=langs.to(dev), emo_vec=emovec,
+            campplus_embedding=bundle["style"], max_generate_length=max_mel_tokens, **gen)
+        up = self.bigvgan.total_up
+
+        def codes_to_audio(codes, code_lens):
+            lens = torch.as_tensor(code_lens).to(torch.int32).cpu().clamp(min=1)          # finished rows render one frame pair, dropped by the decoder
+            if self.s2mel is not None and self.semantic_codec is not None:
+                mel, mel_lens = self.codes_to_mel(codes, lens, bundle, duration_factor)
+            else:
+                mel, mel_lens = self.frontend.codes_to_mel(codes, lens, bundle, duration_factor)
+            wav = self.bigvgan(mel.float(), lens=mel_lens)
+            return [wav[i, 0, : int(mel_lens[i]) * up].float().cpu().numpy() for i in range(wav.shape[0])]
+
+        dec = StreamingDecoder(self.gpt, codes_to_audio, chunk_size=chunk_size, overlap_size=overlap_size)
+        self.last_stream = dec
+        yield from dec.generate(inputs_embeds, attention_mask, max_new, **hf)
+
     def codes_to_mel(self, codes: torch.Tensor, code_lens: torch.Tensor, bundle, duration_factor: float = 1.0,
                      diffusion_steps: int = 25, inference_cfg_rate: float = 0.7, noise: Optional[torch.Tensor] = None):
         """infer_v2_5.py:830-846 for a whole batch of segments on the HIP engine: semantic_codec.decode -> length_regulator ->

@@ -1,0 +1,116 @@
+"""In-process serving shell: a speaker-bundle cache keyed by the prompt audio's bytes and a dynamic
+batcher that turns concurrent single-utterance requests into `IndexTTS2.infer_batch` calls -- the pieces of the reference's
+Triton front end that decide WHAT runs as one batch (`SpeakerCache`, backends/trt/serving/triton_server.py:44-94; the `@batch`
+decorated `infer_non_streaming`, :170-230), without its network layer.  The engine batches utterances of ONE speaker bundle, so
+requests are grouped by (speaker prompt, emotion prompt, emo_alpha, language, generation settings)."""
+import collections
+import hashlib
+import threading
+import time
+from concurrent.futures import Future
+from typing import Any, Callable, Dict, Hashable, List, Optional, Tuple
+
+
+class SpeakerCache:
+    """LRU of computed speaker bundles keyed by a hash of the prompt audio (bytes or a path): the prompt encoders run once per
+    distinct prompt (triton_server.py:44-94)."""
+
+    def __init__(self, compute: Callable[[Any], Any], max_size: int = 64):
+        self.compute, self.max_size = compute, int(max_size)
+        self._d: "collections.OrderedDict[str, Any]" = collections.OrderedDict()
+        self._lock = threading.Lock()
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def key_of(audio) -> str:
+        data = audio if isinstance(audio, (bytes, bytearray, memoryview)) else str(audio).encode()
+        return hashlib.sha256(bytes(data)).hexdigest()
+
+    def get_or_compute(self, audio):
+        k = self.key_of(audio)
+        with self._lock:
+            if k in self._d:
+                self._d.move_to_end(k)
+                self.hits += 1
+                return self._d[k]
+        v = self.compute(audio)                      # outside the lock: prompt encoders take a while
+        with self._lock:
+            self.misses += 1
+            self._d[k] = v
+            self._d.move_to_end(k)
+            while len(self._d) > self.max_size:
+                self._d.popitem(last=False)
+        return v
+
+
+class _Request:
+    __slots__ = ("group", "text", "future", "t")
+
+    def __init__(self, group, text):
+        self.group, self.text, self.future, self.t = group, text, Future(), time.monotonic()
+
+
+class DynamicBatcher:
+    """submit(...) returns a Future of `(sample_rate, int16 array)`; a worker thread collects the requests of one group until
+    `max_batch` of them wait or the oldest has waited `max_wait_ms`, and runs them as ONE `infer_batch` call.  Groups are served
+    oldest-first; a failing batch fails exactly its own futures."""
+
+    def __init__(self, tts, max_batch: int = 64, max_wait_ms: float = 10.0):
+        self.tts, self.max_batch, self.max_wait = tts, int(max_batch), float(max_wait_ms) / 1000.0
+        self._q: List[_Request] = []
+        self._cv = threading.Condition()
+        self._stop = False
+        self.batches: List[int] = []                 # size of every batch that ran (observability / tests)
+        self._worker = threading.Thread(target=self._run, name="indextts-batcher", daemon=True)
+        self._worker.start()
+
+    def submit(self, spk_audio_prompt, text: str, lang, emo_audio_prompt=None, emo_alpha: float = 1.0, **generation_kwargs) -> Future:
+        group: Tuple[Hashable, ...] = (SpeakerCache.key_of(spk_audio_prompt), None if emo_audio_prompt is None else SpeakerCache.key_of(emo_audio_prompt),
+                                       float(emo_alpha), lang, tuple(sorted(generation_kwargs.items())))
+        r = _Request((group, spk_audio_prompt, emo_audio_prompt), text)
+        with self._cv:
+            if self._stop:
+                raise RuntimeError("DynamicBatcher is closed")
+            self._q.append(r)
+            self._cv.notify()
+        return r.future
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify()
+        self._worker.join()
+
+    def _take(self) -> Optional[List[_Request]]:
+        with self._cv:
+            while True:
+                if self._q:
+                    head = self._q[0]
+                    same = [r for r in self._q if r.group[0] == head.group[0]]
+                    wait = self.max_wait - (time.monotonic() - head.t)
+                    if len(same) >= self.max_batch or wait <= 0 or self._stop:
+                        take = same[: self.max_batch]
+                        ids = {id(r) for r in take}
+                        self._q = [r for r in self._q if id(r) not in ids]
+                        return take
+                    self._cv.wait(timeout=wait)
+                elif self._stop:
+                    return None
+                else:
+                    self._cv.wait()
+
+    def _run(self):
+        while True:
+            reqs = self._take()
+            if reqs is None:
+                return
+            (key, spk, emo) = reqs[0].group
+            _, _, emo_alpha, lang, gen = key
+            self.batches.append(len(reqs))
+            try:
+                res = self.tts.infer_batch(spk, [r.text for r in reqs], lang, emo_audio_prompt=emo, emo_alpha=emo_alpha, **dict(gen))
+                for r, out in zip(reqs, res):
+                    r.future.set_result(out)
+            except Exception as e:                    # noqa: BLE001 -- delivered to the callers of this batch
+                for r in reqs:
+                    r.future.set_exception(e)

@@ -286,3 +286,63 @@ def test_constructor_from_checkpoint_directory(tmp_path):
     b = ref.infer("spk.wav", "loaded from a checkpoint directory. second segment", None, "en", **kw)
     assert a[0] == b[0] == 22050 and a[1].shape == b[1].shape
     assert np.abs(a[1].astype(np.int32) - b[1].astype(np.int32)).max() <= 1
+
+
+# ---- streaming ---------------------------------------------------------------------------------
+def test_generate_chunks_reassemble_to_one_shot_codes():
+    """`generate_chunks` suspends the device decode loop between chunks (itts_gpt_generate_chunk): the chunks, laid back at their
+    offsets, are exactly the codes of the one-shot `generate` (greedy AND sampled with a fixed uniform stream), rows finishing
+    at different steps; chunk lengths / done flags follow the reference engine's rules (gpt_trtllm_runtime.py:381-520)."""
+    tts = build()
+    g = tts.gpt
+    style, emo = tts.frontend.style.to(DEV), tts.frontend.emo.to(DEV)
+    text = torch.randint(2, 200, (5, 17), generator=torch.Generator().manual_seed(3)).to(DEV)
+    langs = torch.full((5,), 3, dtype=torch.long, device=DEV)
+    u = torch.rand(40, 5, generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+    for kw in (dict(do_sample=False), dict(do_sample=True, top_k=30, top_p=0.8, temperature=1.3, uniforms=u)):
+        full, _ = g.inference_speech(None, text, langs, emo_vec=emo, campplus_embedding=style, max_generate_length=40, num_beams=1,
+                                     repetition_penalty=10.0, **kw)
+        full = full.cpu()
+        emb, mask, max_new, hf = g.inference_speech_stream(None, text, 8, 3, langs=langs, emo_vec=emo, campplus_embedding=style,
+                                                           max_generate_length=40, num_beams=1, repetition_penalty=10.0, **kw)
+        got = torch.full((5, 40), 8193, dtype=torch.int64)
+        n_chunks, last_seen = 0, False
+        for codes, is_last, done, lens in g.generate_chunks(emb, mask, max_new, 8, 3, **hf):
+            pos = n_chunks * 5
+            assert not last_seen and codes.shape[1] <= 8
+            got[:, pos: pos + codes.shape[1]] = codes.cpu()
+            stop = (full == 8193)
+            true_len = torch.where(stop.any(1), stop.int().argmax(1), torch.full((5,), full.shape[1]))
+            assert lens.cpu().tolist() == [max(0, min(int(n) - pos, codes.shape[1] if is_last else 8)) for n in true_len]
+            n_chunks += 1
+            last_seen = is_last
+        assert n_chunks >= 2
+        assert torch.equal(got[:, : full.shape[1]], full), (kw, got[:, : full.shape[1]].tolist(), full.tolist())
+    st = g.graph_stats()
+    assert st["hits"] >= 2                       # the resumed chunk calls replay the cached decode graph
+
+
+def test_infer_stream_yields_crossfaded_chunks():
+    tts = build()
+    texts = ["a first streamed sentence", "short", "another one of middle size"]
+    kw = dict(top_k=1, max_mel_tokens=30, chunk_size=8, overlap_size=2)
+    pieces = [[] for _ in texts]
+    done_at = [None] * len(texts)
+    n = 0
+    for sr, audio, done in tts.infer_stream("spk.wav", texts, "en", **kw):
+        assert sr == 22050 and len(audio) == len(texts)
+        for b, a in enumerate(audio):
+            if a is not None:
+                assert done_at[b] is None and a.dtype == np.int16 and a.ndim == 1
+                pieces[b].append(a)
+            if done[b]:
+                assert done_at[b] is None
+                done_at[b] = n
+        n += 1
+    assert all(d is not None for d in done_at) and n >= 2
+    # total length per row = its one-shot length (cross-fading replaces overlaps, it neither adds nor drops samples)
+    one = tts.infer_batch("spk.wav", texts, "en", num_beams=1, top_k=1, max_mel_tokens=30)
+    for b in range(len(texts)):
+        total = sum(len(p) for p in pieces[b])
+        assert abs(total - one[b][1].shape[0]) <= 2 * 256, (b, total, one[b][1].shape)
+    assert tts.last_stream.first_chunk_latency is not None
