@@ -114,3 +114,40 @@ class DynamicBatcher:
             except Exception as e:                    # noqa: BLE001 -- delivered to the callers of this batch
                 for r in reqs:
                     r.future.set_exception(e)
+
+
+def synthesize_tasks(tts, tasks: List[Dict[str, Any]], lang=None, max_batch: int = 64, **generation_kwargs) -> List[str]:
+    """Batch-file synthesis (`_run_batch`, indextts/cli_v2.py:605-678, which calls `tts.infer` once per task): tasks that share
+    the voice prompt and emotion settings run as real `infer_batch` batches of up to `max_batch` utterances; every task's audio
+    is written to its own `output_path` (16-bit PCM WAV, `save_pcm_wav` semantics).  A task is a dict with `voice_path`, `text`,
+    `output_path` and optional `emotion_kwargs` (`emo_audio_prompt`, `emo_alpha`) / `line_number`, as `_load_batch_tasks` builds
+    them.  Returns the written paths in task order; a failing batch raises with the line numbers it covered."""
+    import os
+    import torch
+    from .infer_v2_5 import save_pcm_wav
+    groups: "collections.OrderedDict[Tuple, List[int]]" = collections.OrderedDict()
+    for i, t in enumerate(tasks):
+        ek = dict(t.get("emotion_kwargs") or {})
+        unsupported = set(ek) - {"emo_audio_prompt", "emo_alpha"}
+        if unsupported:
+            raise ValueError(f"batch line {t.get('line_number', i + 1)}: {sorted(unsupported)} need the per-utterance infer() path")
+        key = (str(t["voice_path"]), None if ek.get("emo_audio_prompt") is None else str(ek["emo_audio_prompt"]), float(ek.get("emo_alpha", 1.0)))
+        groups.setdefault(key, []).append(i)
+    written: List[Optional[str]] = [None] * len(tasks)
+    for (voice, emo, alpha), idx in groups.items():
+        for j in range(0, len(idx), max_batch):
+            part = idx[j: j + max_batch]
+            try:
+                res = tts.infer_batch(voice, [tasks[i]["text"] for i in part], lang, emo_audio_prompt=emo, emo_alpha=alpha, **generation_kwargs)
+            except Exception as e:                # noqa: BLE001
+                lines = [tasks[i].get("line_number", i + 1) for i in part]
+                raise RuntimeError(f"batch file lines {lines} inference failed: {e}") from e
+            for i, out in zip(part, res):
+                if out is None:
+                    continue
+                path = str(tasks[i]["output_path"])
+                os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+                sr, wav = out
+                save_pcm_wav(path, torch.from_numpy(wav.T.copy()).float(), sr)
+                written[i] = path
+    return written

@@ -95,3 +95,19 @@ def test_speaker_cache_lru():
     c = SpeakerCache(lambda a: (seen.append(a), len(a))[1], max_size=2)
     assert [c.get_or_compute(x) for x in (b"a", b"bb", b"a", b"ccc", b"bb")] == [1, 2, 1, 3, 2]
     assert seen == [b"a", b"bb", b"ccc", b"bb"] and (c.hits, c.misses) == (1, 4)
+
+
+def test_synthesize_tasks_runs_real_batches(tmp_path):
+    import wave
+    from indextts_amd.serving import synthesize_tasks
+    tts = _FakeTTS()
+    tasks = [dict(voice_path="a.wav", text=f"line {i}", output_path=tmp_path / "out" / f"{i}.wav", line_number=i + 1) for i in range(5)]
+    tasks.insert(2, dict(voice_path="b.wav", text="other", output_path=tmp_path / "o.wav", emotion_kwargs={"emo_alpha": 0.5}, line_number=9))
+    paths = synthesize_tasks(tts, tasks, lang="en", max_batch=4, top_k=5)
+    assert [len(c[1]) for c in tts.calls] == [4, 1, 1]                      # a.wav: 4 + 1, b.wav: 1 -- not six sequential calls
+    assert tts.calls[2][0] == "b.wav" and tts.calls[2][4] == 0.5 and tts.calls[0][5] == {"top_k": 5}
+    assert paths == [str(t["output_path"]) for t in tasks]
+    with wave.open(paths[0], "rb") as w:
+        assert (w.getframerate(), w.getsampwidth(), w.getnchannels(), w.getnframes()) == (22050, 2, 1, len("line 0"))
+    with pytest.raises(ValueError, match="per-utterance"):
+        synthesize_tasks(tts, [dict(voice_path="a", text="t", output_path=tmp_path / "x.wav", emotion_kwargs={"emo_text": "sad"})])
