@@ -97,6 +97,12 @@ __device__ __forceinline__ float sin_reduced(float x) {
     return __builtin_amdgcn_sinf(r * inv2pi);     // v_sin_f32: sin(2*pi*arg), arg in [-0.5, 0.5]
 }
 
+// LDS image of the 2x-rate window: a thread touches 16-byte chunks 2*tid + k, so within one ds_*_b128 lane group (16 lanes, e.g.
+// {0-3, 12-15, 20-27}) chunks 16 apart meet on the same banks (2-way conflicts on every access; PMC: 78 % of the kernel's LDS
+// cycles were bank conflicts, LDS array busy 74 % -- profiles/r02p).  Flipping the low chunk bit in odd groups of 16 chunks makes
+// the stride-2-chunk pattern conflict-free.  i = dword index of a 16-byte aligned chunk or of a single element.
+__device__ __forceinline__ int aa_sw(int i) { return i ^ (((i >> 6) & 1) << 2); }
+
 template <int OPT, bool FAST_SIN>     // OPT = outputs per thread (4 or 8); tile = 256 * OPT outputs per block
 __global__ __launch_bounds__(256) void aa_act_kernel_v2(const float* __restrict__ x, float* __restrict__ y,
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void aa_act_kernel_v2(const float* __restrict_
                                                         int logscale) {
     constexpr int TILE = 256 * OPT;
     __shared__ __attribute__((aligned(16))) float xs[TILE + 16];
-    __shared__ __attribute__((aligned(16))) float vs[2 * TILE + 32];
+    __shared__ __attribute__((aligned(16))) float vs[2 * TILE + 64];
     const int b = blockIdx.z, c = blockIdx.y;
     const int t0 = blockIdx.x * TILE;
     const int len = lens ? min(lens[b] * len_mult, T) : T;
@@ -134,9 +140,10 @@ __global__ __launch_bounds__(256) void aa_act_kernel_v2(const float* __restrict_
     __syncthreads();
     // 2x-rate window: vs[vi] <-> i = 2*t0 - 6 + vi.  Thread owns vi = 2*OPT*tid .. +2*OPT-1; threads 0..1 also the tail.
     auto snake8 = [&](int vb, float* v) {
-        float xw[10];
-#pragma unroll
-        for (int j = 0; j < 10; ++j) xw[j] = xs[(vb >> 1) + j];
+        float xw[12];
+        *(f32x4*)&xw[0] = *(const f32x4*)&xs[(vb >> 1)];                  // (vb >> 1) is a multiple of 4: 16-byte chunks, lane stride 1 chunk
+        *(f32x4*)&xw[4] = *(const f32x4*)&xs[(vb >> 1) + 4];
+        *(f32x4*)&xw[8] = *(const f32x4*)&xs[(vb >> 1) + 8];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {            // q = q0 + p ; xw[p + 3] = x[q]
             float ue = 0.f, uo = 0.f;
@@ -156,37 +163,46 @@ __global__ __launch_bounds__(256) void aa_act_kernel_v2(const float* __restrict_
         float v[8];
         const int vb = 2 * OPT * tid + 8 * g;
         snake8(vb, v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) vs[vb + j] = v[j];
+        *(f32x4*)&vs[aa_sw(vb)] = *(const f32x4*)&v[0];
+        *(f32x4*)&vs[aa_sw(vb + 4)] = *(const f32x4*)&v[4];
     }
     if (tid < 2) {                               // tail: vi = 2*TILE .. 2*TILE+15 (only the first 12 are used)
         float vt[8];
         snake8(2 * TILE + 8 * tid, vt);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) vs[2 * TILE + 8 * tid + j] = vt[j];
+        *(f32x4*)&vs[aa_sw(2 * TILE + 8 * tid)] = *(const f32x4*)&vt[0];
+        *(f32x4*)&vs[aa_sw(2 * TILE + 8 * tid + 4)] = *(const f32x4*)&vt[4];
     }
     __syncthreads();
     // replicate padding at the 2x rate (5 left / 6 right): entries outside [0, 2*len-1] take the edge value
-    if (t0 == 0 && tid < 6) vs[tid] = vs[6];
+    if (t0 == 0 && tid < 6) vs[aa_sw(tid)] = vs[aa_sw(6)];
     const int vi_end = (2 * len - 1) - (2 * t0 - 6);          // window index of the last real 2x-rate sample
     if (vi_end < 2 * TILE + 12 - 1) {
         const int vi = vi_end + 1 + tid;
-        if (tid < 8 && vi < 2 * TILE + 16) vs[vi] = vs[vi_end];
+        if (tid < 8 && vi < 2 * TILE + 16) vs[aa_sw(vi)] = vs[aa_sw(vi_end)];
     }
     __syncthreads();
     // outputs OPT*tid .. OPT*tid+OPT-1: y[t] = sum_j fd[j] * vs[2*(t - t0) + j + 1]
 #pragma unroll
     for (int g = 0; g < OPT / 4; ++g) {
-        float vw[19];
+        float vw[20];
+        const int base = 2 * (OPT * tid + 4 * g);                 // multiple of 8
 #pragma unroll
-        for (int j = 0; j < 19; ++j) vw[j] = vs[2 * (OPT * tid + 4 * g) + j];
+        for (int k = 0; k < 5; ++k) *(f32x4*)&vw[4 * k] = *(const f32x4*)&vs[aa_sw(base + 4 * k)];
+        f32x4 o;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int i = OPT * tid + 4 * g + p;
             float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < 12; ++j) acc = fmaf(fds[j], vw[2 * p + j + 1], acc);
-            if (i < n_out) yr[t0 + i] = acc;
+            o[p] = acc;
+        }
+        const int i0 = OPT * tid + 4 * g;
+        if (i0 + 3 < n_out && ((t0 + i0) & 3) == 0 && (T & 3) == 0) {
+            *(f32x4*)&yr[t0 + i0] = o;                             // rows start 16-byte aligned when T % 4 == 0
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (i0 + p < n_out) yr[t0 + i0 + p] = o[p];
         }
     }
 }
