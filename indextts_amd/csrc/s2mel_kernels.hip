@@ -260,11 +260,16 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 //                   -> C layout: lane (g, q) holds keys 16*kt + 4g + r, r < 4, of query q = lane & 15.
 //   softmax       : per query = per lane column; the reduction over keys is 16 in-lane values and two xor-shuffles (16, 32).
 //   O^T = V^T P^T : A = V^T tile (rows = d, k = keys), B = P^T straight from the S^T registers -- no transpose through LDS:
-//                   the contraction index is permuted identically on both operands (slot (g, j) <-> key 32*ks + 4g + j for
-//                   j < 4, 32*ks + 16 + 4g + j - 4 otherwise), so A reads two 8-byte key runs instead of one 16-byte run.
-//   K tile [64 keys][64 d] and V^T tile [64 d][64 keys] are staged in LDS: 128-byte rows, the eight 16-byte pieces of row r
-//   XOR-permuted by (r >> 1) & 7 -- conflict-free for the staging writes, the 16-byte K fragment reads and the 8-byte V^T fragment
-//   reads under the real lane grouping of ds_read_b128 (4 groups of 16 non-contiguous lanes).  A padded 144-byte stride (the usual
+//                   the ROWS of the S^T MFMA tiles are a permutation of the keys (row 4a + c of sub-tile kt is key
+//                   32 (kt >> 1) + 8 a + 4 (kt & 1) + c; a K fragment lane simply reads that key's row), chosen so that lane g's
+//                   eight P values of half kx are keys 32 kx + 8 g .. + 7 in order = the standard B fragment, and the V^T fragment
+//                   is ONE 16-byte read.  (A first version kept the natural key order and read V^T as two 8-byte runs: every
+//                   such ds_read2_b64 took 16 LDS cycles, half of them bank conflicts -- all of the kernel's conflicts, PMC
+//                   ablation in profiles/r02s.)
+//   K tile [64 keys][64 d] and V^T tile [64 d][64 keys] are staged in LDS: 128-byte rows, the eight 16-byte pieces of a row
+//   XOR-permuted -- V^T row r by (r >> 1) & 7, K row r by ((r >> 1) & 1) | (((r >> 3) & 3) << 1) (the sixteen key rows a K fragment
+//   touches are {0-3, 8-11, 16-19, 24-27} + const) -- conflict-free for the staging writes and both 16-byte fragment reads under
+//   the real lane grouping of ds_read_b128 (4 groups of 16 non-contiguous lanes).  A padded 144-byte stride (the usual
 //   recipe) measured 43 % of all LDS cycles as bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r02l).
 //   The next tile's global loads are in flight while the current one feeds the MFMAs.
 // ================================================================================================================
@@ -334,19 +339,22 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = r0 + 32 * i;
-            const int pc = (p0 ^ ((r >> 1) & 7)) * 8;                // r and r + 32 share the swizzle
-            *(v4u*)(ks[buf] + r * FA_LD + pc) = kreg[i];
-            *(v4u*)(vs[buf] + r * FA_LD + pc) = vreg[i];
+            const int pk = (p0 ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1))) * 8;      // r and r + 32 share both swizzles
+            const int pv = (p0 ^ ((r >> 1) & 7)) * 8;
+            if (FA_ABL & 256) { asm volatile("" ::"v"(kreg[i]), "v"(vreg[i])); continue; }
+            *(v4u*)(ks[buf] + r * FA_LD + pk) = kreg[i];
+            *(v4u*)(vs[buf] + r * FA_LD + pv) = vreg[i];
         }
     };
-    // fragment read offsets (elements) inside a stage: row c16 of a 16-row group, pieces swizzled by (c16 >> 1) & 7
-    const int fsw = (c16 >> 1) & 7;
-    int k_off[2], v_off[2][2];
+    // fragment read offsets (elements) inside a stage.  K: lane row c16 = 4 a + c of sub-tile kt reads key row 8 a + c (+ 32 (kt >> 1)
+    // + 4 (kt & 1): immediates); V^T: row c16 of a 16-row group.
+    const int krow = 8 * (c16 >> 2) + (c16 & 3);
+    const int ksw = ((c16 >> 1) & 1) | ((c16 >> 2) << 1), vsw = (c16 >> 1) & 7;
+    int k_off[2], v_off[2];
 #pragma unroll
     for (int kx = 0; kx < 2; ++kx) {
-        k_off[kx] = c16 * FA_LD + (((kx * 4 + g) ^ fsw) << 3);
-        v_off[kx][0] = c16 * FA_LD + (((kx * 4 + (g >> 1)) ^ fsw) << 3) + (g & 1) * 4;          // keys 32 kx + 4 g .. + 3
-        v_off[kx][1] = c16 * FA_LD + (((kx * 4 + (g >> 1) + 2) ^ fsw) << 3) + (g & 1) * 4;      // keys 32 kx + 16 + 4 g .. + 3
+        k_off[kx] = krow * FA_LD + (((kx * 4 + g) ^ ksw) << 3);
+        v_off[kx] = c16 * FA_LD + (((kx * 4 + g) ^ vsw) << 3);                                  // keys 32 kx + 8 g .. + 7
     }
     f32x4 o[QS][4], osum[QS];                                      // osum (FA_OPT & 2): row 0 of a fifth V^T m-tile of ones = the row sums of P
     float m_run[QS], l_run[QS];                                    // l_run: this lane's share of the row sum (reduced after the loop)
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
         for (int kx = 0; kx < 2; ++kx)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const v4u a = *(const v4u*)(kt_s + kt * 16 * FA_LD + k_off[kx]);
+                const v4u a = (FA_ABL & 64) ? v4u{1u, 2u, 3u, 4u} : *(const v4u*)(kt_s + (32 * (kt >> 1) + 4 * (kt & 1)) * FA_LD + k_off[kx]);
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs)
                     if (FA_ABL & 32) { st[qs][kt] = f32x4{0.f, 1.f, 2.f, 3.f}; asm volatile("" ::"v"(a)); }
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if ((k0 + kt * 16 + g * 4 + r) >= len) st[qs][kt][r] = -INFINITY;
+                        if ((k0 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r) >= len) st[qs][kt][r] = -INFINITY;
             }
             // softmax in the exp2 domain on the RAW scores: p = exp2(s * c - m * c), c = log2(e) / 8, one fma per element;
             // in-lane max by v_max3, across the query's four lanes by permlane swaps
@@ -440,8 +448,7 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
         for (int kx = 0; kx < 2; ++kx) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const v2u lo = *(const v2u*)(vt_s + mt * 16 * FA_LD + v_off[kx][0]), hi = *(const v2u*)(vt_s + mt * 16 * FA_LD + v_off[kx][1]);
-                const v4u a{lo.x, lo.y, hi.x, hi.y};
+                const v4u a = (FA_ABL & 128) ? v4u{1u, 2u, 3u, 4u} : *(const v4u*)(vt_s + mt * 16 * FA_LD + v_off[kx]);
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs)
                     if (FA_ABL & 16) asm volatile("" ::"v"(a), "v"(pb[qs][kx]));
