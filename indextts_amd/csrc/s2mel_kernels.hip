@@ -275,10 +275,11 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 // ================================================================================================================
 #define FA_LD 64          // bf16 elements per LDS row (128 B, pieces swizzled)
 #ifndef FA_OPT
-#define FA_OPT 5          // bit 1: compile-time LDS stage (loop unrolled x2: immediate offsets instead of address adds), bit 4: rescale the
+#define FA_OPT 7          // bit 1: compile-time LDS stage (loop unrolled x2: immediate offsets instead of address adds), bit 4: rescale the
                           // accumulators only when some query's running maximum moved (wave-uniform branch), bit 2: row sums of P on the
-                          // PV MFMAs (a fifth m-tile of ones).  Same-box A/B (tools/microbench/flash_ablate.hip, profiles/r02l, r02m;
-                          // 64 x 2443 frames x 8 heads): 0: 1284 us, 1: 1266, 4: 1260, 5: 1255, 7: 1359 (176 registers: two waves per SIMD)
+                          // PV MFMAs (a fifth m-tile of ones; the normaliser is then the sum of the bf16 probabilities the PV product uses).
+                          // Same-box A/B (tools/microbench/flash_ablate.hip, 64 x 2443 frames x 8 heads, two sub-tiles): before the
+                          // V^T read fix 0: 1284 us, 5: 1255, 7: 1359 (176 registers); after it 5: 1200, 7: 1180 (160 registers)
 #endif
 #ifndef FA_ABL
 #define FA_ABL 0          // tools/microbench/flash_ablate.hip builds variants with pieces of the loop removed (bit mask); 0 in the product
