@@ -322,6 +322,25 @@ int itts_tok_scale_residual_forward(float* x, const float* y, const float* gamma
 int itts_tok_groupnorm_mish_forward(float* x, const float* gamma, const float* beta, const int32_t* seq_start, const int32_t* seq_T,
                                     int n_seq, int C, float eps, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * conditioning encoders: the Conformer encoder + Perceiver resampler behind UnifiedVoice.get_conditioning /
+ * get_emo_conditioning / get_emovec (indextts/gpt/model_v2.py:556-593,827-838), as f32 unit ops on packed rows; the dense layers run
+ * on itts_gemm_forward, LayerNorms on itts_layernorm_forward, the depthwise conv on itts_tok_dwconv_forward;
+ * indextts_amd/cond.py sequences the calls.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* replaces: softmax(Q K^T * scale + key mask) V of RelPositionMultiHeadedAttention.forward (matrix_ac + matrix_bd as ONE product of
+ *   [q + u | q + v] with [k | p], indextts/gpt/conformer/attention.py:232-312,85-120) and of perceiver.py Attend.forward.
+ *   q [n_q][heads][dq], k [n_k][heads][dq], v [n_k][heads][dv], out [n_q][heads][dv]; query row m attends key rows
+ *   kstart[m] .. kstart[m] + klen[m] - 1 (klen 0 -> zeros, as the reference's masked softmax). */
+int itts_attention_forward(const float* q, const float* k, const float* v, float* out, const int32_t* kstart, const int32_t* klen,
+                           int n_q, int heads, int dq, int dv, float scale, void* stream);
+/* replaces: F.glu (mode 0, conformer_encoder.py:147) / GEGLU (mode 1, perceiver.py): x [n][2C] -> out [n][C] */
+int itts_tok_glu_forward(const float* x, float* out, int n, int C, int mode, void* stream);
+/* replaces: ReLU (mode 0, subsampling.py:150) / SiLU (mode 1, conformer activation), in place */
+int itts_tok_act_forward(float* x, size_t n, int mode, void* stream);
+/* replaces: perceiver.py RMSNorm (F.normalize(x) * sqrt(dim) * gamma), in place */
+int itts_tok_l2norm_forward(float* x, const float* gamma, int n, int C, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,6 +183,138 @@ extern "C" int itts_tok_scale_residual_forward(float* x, const float* y, const f
     return ITTS_OK;
 }
 
+// ---- conditioning encoders (Conformer + Perceiver): generic f32 attention and gated activations ----------
+// One wave per (query row, head): lanes take keys j = lane, lane + 64, ... of the query's key range, keep an online-softmax state
+// and a Dv-wide accumulator each, and merge at the end.  Q [n_q][H][Dq], K [n_k][H][Dq], V [n_k][H][Dv] (Dq, Dv <= 128, % 4 == 0).
+template <int DV4>       // Dv / 4 rounded up to 16 or 32
+__global__ __launch_bounds__(64) void attn_generic_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                          float* __restrict__ out, const int* __restrict__ kstart, const int* __restrict__ klen,
+                                                          int H, int Dq, int Dv, float scale) {
+    const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int ks = kstart[m], kl = klen[m];
+    float* o = out + ((size_t)m * H + h) * Dv;
+    if (kl <= 0) {                                                // every key masked: the reference's softmax row is filled with 0
+        for (int d = lane; d < Dv; d += 64) o[d] = 0.f;
+        return;
+    }
+    const float* qr = q + ((size_t)m * H + h) * Dq;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc[DV4];
+#pragma unroll
+    for (int i = 0; i < DV4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = lane; j < kl; j += 64) {
+        const float* kr = k + ((size_t)(ks + j) * H + h) * Dq;
+        float s = 0.f;
+        for (int d = 0; d < Dq; d += 4) {
+            const f32x4 a = *(const f32x4*)(qr + d), b = *(const f32x4*)(kr + d);
+            s += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+        }
+        s *= scale;
+        const float nm = fmaxf(m_run, s);
+        const float al = expf(m_run - nm), p = expf(s - nm);
+        l_run = l_run * al + p;
+        const float* vr = v + ((size_t)(ks + j) * H + h) * Dv;
+#pragma unroll
+        for (int i = 0; i < DV4; ++i) {
+            if (4 * i < Dv) {
+                const f32x4 vv = *(const f32x4*)(vr + 4 * i);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[i][c] = acc[i][c] * al + p * vv[c];
+            }
+        }
+        m_run = nm;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float om = __shfl_xor(m_run, off, 64), ol = __shfl_xor(l_run, off, 64);
+        const float nm = fmaxf(m_run, om);
+        const float sa = (m_run == -INFINITY) ? 0.f : expf(m_run - nm), sb = (om == -INFINITY) ? 0.f : expf(om - nm);
+        l_run = l_run * sa + ol * sb;
+#pragma unroll
+        for (int i = 0; i < DV4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[i][c] = acc[i][c] * sa + __shfl_xor(acc[i][c], off, 64) * sb;
+        m_run = nm;
+    }
+    if (lane == 0) {
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int i = 0; i < DV4; ++i)
+            if (4 * i < Dv) {
+                f32x4 r;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) r[c] = acc[i][c] * inv;
+                *(f32x4*)(o + 4 * i) = r;
+            }
+    }
+}
+
+// x [n][2C] -> out [n][C].  mode 0: GLU  a * sigmoid(b) (F.glu, conformer conv module); mode 1: GEGLU  a * gelu_erf(b) (perceiver FF)
+__global__ __launch_bounds__(256) void glu_kernel(const float* __restrict__ x, float* __restrict__ out, size_t n, int C, int mode) {
+    const size_t total = n * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / C;
+        const int c = (int)(i - m * C);
+        const float a = x[m * 2 * C + c], b = x[m * 2 * C + C + c];
+        out[i] = mode == 0 ? a * (1.0f / (1.0f + expf(-b))) : a * (0.5f * b * (1.0f + erff(b * 0.70710678118654752440f)));
+    }
+}
+
+// in place.  mode 0: ReLU, 1: SiLU
+__global__ __launch_bounds__(256) void act_kernel(float* __restrict__ x, size_t n, int mode) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = x[i];
+        x[i] = mode == 0 ? fmaxf(v, 0.f) : v / (1.0f + expf(-v));
+    }
+}
+
+// perceiver.py RMSNorm: out = x / max(||x||_2, 1e-12) * scale * gamma, one wave per row, in place
+__global__ __launch_bounds__(64) void l2norm_kernel(float* __restrict__ x, const float* __restrict__ gamma, int C, float scale) {
+    float* r = x + (size_t)blockIdx.x * C;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < C; c += 64) ss += r[c] * r[c];
+    ss = wave_sum(ss);
+    const float inv = scale / fmaxf(sqrtf(ss), 1e-12f);
+    for (int c = threadIdx.x; c < C; c += 64) r[c] = r[c] * inv * gamma[c];
+}
+
+extern "C" int itts_attention_forward(const float* q, const float* k, const float* v, float* out, const int32_t* kstart, const int32_t* klen,
+                                      int n_q, int heads, int dq, int dv, float scale, void* stream) {
+    if (!q || !k || !v || !out || !kstart || !klen || heads < 1 || dq < 4 || dv < 4 || (dq & 3) || (dv & 3) || dv > 128) {
+        itts_set_error("attention_forward: need non-null tensors, dq %% 4 == 0, dv %% 4 == 0, dv <= 128");
+        return ITTS_ERR_ARG;
+    }
+    if (n_q <= 0) return ITTS_OK;
+    if (dv <= 64) hipLaunchKernelGGL(attn_generic_kernel<16>, dim3(n_q, heads), dim3(64), 0, (hipStream_t)stream, q, k, v, out, kstart, klen, heads, dq, dv, scale);
+    else hipLaunchKernelGGL(attn_generic_kernel<32>, dim3(n_q, heads), dim3(64), 0, (hipStream_t)stream, q, k, v, out, kstart, klen, heads, dq, dv, scale);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+extern "C" int itts_tok_glu_forward(const float* x, float* out, int n, int C, int mode, void* stream) {
+    if (!x || !out || C < 1 || mode < 0 || mode > 1) { itts_set_error("tok_glu: bad args"); return ITTS_ERR_ARG; }
+    if (n <= 0) return ITTS_OK;
+    hipLaunchKernelGGL(glu_kernel, dim3(grid_for((size_t)n * C)), dim3(256), 0, (hipStream_t)stream, x, out, (size_t)n, C, mode);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+extern "C" int itts_tok_act_forward(float* x, size_t n, int mode, void* stream) {
+    if (!x || mode < 0 || mode > 1) { itts_set_error("tok_act: bad args"); return ITTS_ERR_ARG; }
+    if (n == 0) return ITTS_OK;
+    hipLaunchKernelGGL(act_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, mode);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+extern "C" int itts_tok_l2norm_forward(float* x, const float* gamma, int n, int C, float scale, void* stream) {
+    if (!x || !gamma || C < 1) { itts_set_error("tok_l2norm: bad args"); return ITTS_ERR_ARG; }
+    if (n <= 0) return ITTS_OK;
+    hipLaunchKernelGGL(l2norm_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, x, gamma, C, scale);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
 extern "C" int itts_tok_groupnorm_mish_forward(float* x, const float* gamma, const float* beta, const int32_t* seq_start, const int32_t* seq_T,
                                                int n_seq, int C, float eps, void* stream) {
     if (!x || !gamma || !beta || !seq_start || !seq_T || C < 1) { itts_set_error("tok_groupnorm_mish: bad args"); return ITTS_ERR_ARG; }

@@ -34,6 +34,10 @@ class UnifiedVoice:
                  use_accel=False, spk_cond_mode="conformer", precision="bf16", device="cuda:0", conditioning_fn=None, **_unused):
         self.conditioning_fn = conditioning_fn
         self.cond_num = condition_num_latent
+        # Conformer + Perceiver conditioning encoders on the engine (indextts_amd/cond.py): built in load_state_dict when the config
+        # carries their `condition_module` / `emo_condition_module` sections and the checkpoint their weights
+        self.condition_type, self.condition_module, self.emo_condition_module = condition_type, condition_module, emo_condition_module
+        self.cond_encoders = None
         self.layers, self.model_dim, self.heads = layers, model_dim, heads
         self.max_text_tokens, self.max_mel_tokens = max_text_tokens, max_mel_tokens
         self.max_conditioning_inputs = max_conditioning_inputs
@@ -98,6 +102,15 @@ class UnifiedVoice:
         missing = [n for n in self._HOST_TENSORS if n not in self._emb and n not in optional]
         if missing:
             raise _lib.HipEngineError(f"UnifiedVoice.load_state_dict: missing {missing}")
+        emo_cm = getattr(self, "emo_condition_module", None)
+        if emo_cm is not None and "emo_conditioning_encoder.after_norm.weight" in sd and "emovec_layer.weight" in sd:
+            from .cond import ConditioningEncoders
+            spk_cm = self.condition_module if (self.condition_type == "conformer_perceiver" and self.spk_cond_mode != "campplus"
+                                                and "conditioning_encoder.after_norm.weight" in sd) else None
+            self.cond_encoders = ConditioningEncoders(self.model_dim, spk_cm, emo_cm, cond_num=self.cond_num, device=self.device)
+            self.cond_encoders.load_state_dict(sd)
+            ignored = [n for n in ignored if not n.startswith(("emo_conditioning_encoder.", "emo_perceiver_encoder.", "emovec_layer.", "emo_layer."))
+                       and not (spk_cm is not None and n.startswith(("conditioning_encoder.", "perceiver_encoder.")))]
         self._loaded = True
         return ignored
 
@@ -181,11 +194,35 @@ class UnifiedVoice:
         return torch.cat((spk + emo_vec.unsqueeze(1), torch.zeros(spk.size(0), 2, spk.size(2), device=dev)), 1), spk
 
     def get_conditioning(self, speech_conditioning_input, cond_mel_lengths=None):
-        """IndexTTS-2 speaker latents (model_v2.py:556-586): Conformer + Perceiver, a prompt-side PyTorch module."""
-        if self.conditioning_fn is None:
-            raise NotImplementedError("the conditioning encoder (Conformer + Perceiver) is outside the engine: set "
-                                      "UnifiedVoice.conditioning_fn (e.g. the reference module's bound get_conditioning) or pass conds_latent=")
-        return self.conditioning_fn(speech_conditioning_input, cond_mel_lengths)
+        """IndexTTS-2 speaker latents (model_v2.py:556-586): Conformer + Perceiver -- on the engine when the checkpoint carried the
+        encoders (`cond_encoders`), else through the injected `conditioning_fn` (e.g. the reference module's bound method)."""
+        if self.conditioning_fn is not None:
+            return self.conditioning_fn(speech_conditioning_input, cond_mel_lengths)
+        if self.cond_encoders is not None and self.cond_encoders.spk is not None:
+            if cond_mel_lengths is None:
+                cond_mel_lengths = torch.full((speech_conditioning_input.shape[0],), speech_conditioning_input.shape[-1])
+            return self.cond_encoders.get_conditioning(speech_conditioning_input, cond_mel_lengths)
+        raise NotImplementedError("no conditioning encoder: load a checkpoint with conditioning_encoder.* / perceiver_encoder.* and a "
+                                  "`condition_module` config, set UnifiedVoice.conditioning_fn, or pass conds_latent=")
+
+    def get_emo_conditioning(self, speech_conditioning_input, cond_mel_lengths=None):        # model_v2.py:588-593
+        self._need_cond("get_emo_conditioning")
+        if cond_mel_lengths is None:
+            cond_mel_lengths = torch.full((speech_conditioning_input.shape[0],), speech_conditioning_input.shape[-1])
+        return self.cond_encoders.get_emo_conditioning(speech_conditioning_input, cond_mel_lengths)
+
+    def get_emovec(self, emo_speech_conditioning_latent, emo_cond_lengths):                   # model_v2.py:827-831
+        self._need_cond("get_emovec")
+        return self.cond_encoders.get_emovec(emo_speech_conditioning_latent, emo_cond_lengths)
+
+    def merge_emovec(self, speech_conditioning_latent, emo_speech_conditioning_latent, cond_lengths, emo_cond_lengths, alpha=1.0):
+        self._need_cond("merge_emovec")                                                       # model_v2.py:833-838
+        return self.cond_encoders.merge_emovec(speech_conditioning_latent, emo_speech_conditioning_latent, cond_lengths, emo_cond_lengths, alpha)
+
+    def _need_cond(self, who):
+        if self.cond_encoders is None:
+            raise NotImplementedError(f"{who}: the checkpoint / config carried no emotion Conformer + Perceiver encoders "
+                                      "(emo_condition_module, emo_conditioning_encoder.*, emo_perceiver_encoder.*, emovec_layer.*, emo_layer.*)")
 
     def conds_latent_v2(self, speech_conditioning_latent: torch.Tensor, emo_vec: torch.Tensor) -> torch.Tensor:
         """34 conditioning tokens of IndexTTS-2 (model_v2.py:767-773): latents + emo_vec, speed_emb(1), speed_emb(0)."""

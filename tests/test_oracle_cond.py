@@ -25,6 +25,16 @@ def test_conditioning_oracle_matches_reference_classes(golden_dir):
     for got, key in ((h, "enc_out"), (conds, "conds"), (ev, "emovec"), (merged, "merged")):
         assert float(np.abs(got.numpy() - z[key]).max()) <= 1e-5, key
     assert float(np.abs(z["conds"]).mean()) > 0.1
+    # every prompt alone (the pipeline's call pattern, and what the packed engine layout computes for every row of a batch)
+    for b in range(3):
+        n = int(lens[b])
+        with torch.no_grad():
+            hb, _ = CO.conformer_encoder(sd, CCFG, feats[b:b + 1, :n], lens[b:b + 1], "conditioning_encoder.")
+            cb = CO.conditioning(sd, CCFG, PCFG, feats[b:b + 1, :n], lens[b:b + 1], "conditioning_encoder.", "perceiver_encoder.")
+        assert float(np.abs(hb[0].numpy() - z[f"enc_out_alone{b}"]).max()) <= 1e-5
+        assert float(np.abs(cb[0].numpy() - z[f"conds_alone{b}"]).max()) <= 1e-5
+    # the reference's batch-composition dependence is real: a padded row differs from its alone result
+    assert float(np.abs(z["enc_out"][1, :11] - z["enc_out_alone1"]).max()) > 1e-3
 
 
 def test_padding_rows_do_not_leak_into_valid_rows():

@@ -9,9 +9,6 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-sys.path.insert(0, "/root/reference")
-import types  # noqa: E402
-sys.modules.setdefault("torchaudio", types.ModuleType("torchaudio"))        # indextts/utils/common.py imports it for the WAV helpers only
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from oracle import cond_oracle as CO  # noqa: E402
 
@@ -36,6 +33,13 @@ def weights(seed=11):
 
 
 def main():
+    import importlib.machinery
+    import types
+    sys.path.insert(0, "/root/reference")
+    if "torchaudio" not in sys.modules:                 # indextts/utils/common.py imports it for the WAV helpers only
+        stub = types.ModuleType("torchaudio")
+        stub.__spec__ = importlib.machinery.ModuleSpec("torchaudio", None)
+        sys.modules["torchaudio"] = stub
     from indextts.gpt.conformer_encoder import ConformerEncoder
     from indextts.gpt.perceiver import PerceiverResampler
     sd = weights()
@@ -76,7 +80,22 @@ def main():
             hh, mm = eenc(f, l)
             v = epr(hh, nn.ConstantPad1d((1, 0), True)(mm.squeeze(1))).squeeze(1)
             return emo_layer(emovec_layer(v))
+        # every prompt ALONE (what the pipeline runs: one prompt per call).  Inside a padded batch the reference's conv module lets
+        # GLU(bias of pointwise_conv1) at the PADDED positions into the depthwise conv of a shorter row's last frames
+        # (conformer_encoder.py:131-148 zeroes the padding before the biased pointwise conv, not after it), so a shorter row's
+        # output depends on how far the batch pads it; the engine (packed rows) computes the alone result for every row.
+        for b in range(B):
+            n = int(lens[b])
+            hb, mb = enc(feats[b:b + 1, :n], lens[b:b + 1])
+            cb = pr(hb, nn.ConstantPad1d((PCFG.num_latents, 0), True)(mb.squeeze(1)))
+            out[f"enc_out_alone{b}"], out[f"conds_alone{b}"] = hb[0].numpy(), cb[0].numpy()
         ev = emovec(emo_feats, emo_lens)
+        for b in range(2):
+            n = int(emo_lens[b])
+            out[f"emovec_alone{b}"] = emovec(emo_feats[b:b + 1, :n], emo_lens[b:b + 1])[0].numpy()
+        base_alone = torch.stack([emovec(feats[b:b + 1, :n], torch.tensor([n]))[0] for b, n in ((0, 29), (1, 23))])
+        ev_alone = torch.stack([torch.from_numpy(out[f"emovec_alone{b}"]) for b in range(2)])
+        out["merged_alone"] = (base_alone + 0.6 * (ev_alone - base_alone)).numpy()
         base = emovec(feats[:2, :29], torch.tensor([29, 23]))
         out.update(emovec=ev.numpy(), merged=(base + 0.6 * (ev - base)).numpy())
         # oracle check right here
