@@ -189,7 +189,14 @@ class IndexTTS2:
 
     def _emovec(self, bundle, emo_audio_prompt, emo_alpha, emo_vector, use_random):
         emo_cond_emb = self._emotion(emo_audio_prompt)
-        emovec = self.frontend.merge_emovec(bundle["spk_cond_emb"], emo_cond_emb, emo_alpha)
+        if getattr(self.gpt, "cond_encoders", None) is not None:      # emotion Conformer + Perceiver on the engine (indextts_amd/cond.py)
+            spk = bundle["spk_cond_emb"]
+            # the reference passes the feature WIDTH (1024) as the "length" (:760-765): every frame of a
+            # prompt shorter than 1024 frames is valid, a longer one is cut there
+            emovec = self.gpt.merge_emovec(spk, emo_cond_emb, torch.tensor([min(spk.shape[-1], spk.shape[1])]),
+                                           torch.tensor([min(emo_cond_emb.shape[-1], emo_cond_emb.shape[1])]), alpha=emo_alpha)
+        else:
+            emovec = self.frontend.merge_emovec(bundle["spk_cond_emb"], emo_cond_emb, emo_alpha)
         if emo_vector is not None:
             emovec_mat, wsum = self.frontend.emo_vector_mix(emo_vector, bundle["style"], use_random)
             emovec = emovec_mat + (1 - wsum) * emovec                 # (:767-769)
