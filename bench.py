@@ -35,6 +35,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 MFMA = f32 vector p
 PEAK_HBM_GBPS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
 SR, HOP = 22050, 256
+EULER_STEPS = 25                  # diffusion steps of cfm.inference in the pipeline (indextts/infer_v2_5.py:843)
 METRIC = "audio-seconds/sec (RTF) IndexTTS-2.5, 64-utt batch @1/2/4/8 MI355X"
 
 
@@ -66,11 +67,12 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel, threads):
+def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel, threads, s2mel_frames=None):
     """Reference CPU path restated (oracle/), timed on this box's host cores on a bounded sample.
 
     GPT: 1 utterance, `n_text` text tokens, prefill + 120 greedy decode steps (fp32, kv-cache) on the full-size stack.
-    BigVGAN: 1 utterance x 480 mel frames (fp32).  About 15-25 s of CPU work; scaled to audio-seconds/second for an
+    BigVGAN: 1 utterance x 480 mel frames (fp32).  s2mel: one of the 25 CFG Euler steps at the bench's frame count.
+    About 20-35 s of CPU work; scaled to audio-seconds/second for an
     utterance of `n_gen` tokens / `t_mel` frames (decode cost per token grows with context; the sample covers the first
     120 of `n_gen` positions, which favours the CPU).  The reference itself cannot run on the GPU box (/root/reference
     does not travel), hence kind = "port": the oracle is the restatement pinned to it by the committed fixtures.
@@ -108,13 +110,31 @@ def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel, threads):
         t0 = time.perf_counter()
         BO.bigvgan_forward(bv_sd, mel, bv_h)
         t_frame = (time.perf_counter() - t0) / frames
+        # s2mel: ONE Euler step (one CFG-stacked estimator call of the DiT 13 x 512 + WaveNet 8 x 512) at the bench's frame count,
+        # x euler_steps; skipped (and left out of `value`) when the GPU line runs without the s2mel stage
+        t_euler = None
+        if s2mel_frames:
+            from oracle import s2mel_oracle as SO
+            scfg = SO.S2MelConfig()
+            ssd = SO.synth_weights(scfg, 3)
+            T, Tp = s2mel_frames
+            z = torch.randn(1, scfg.in_channels, T, generator=g)
+            t0 = time.perf_counter()
+            SO.cfm_solve_euler(ssd, scfg, z, torch.tensor([T]), torch.randn(1, scfg.in_channels, Tp, generator=g),
+                               torch.randn(1, T, scfg.content_dim, generator=g), torch.randn(1, scfg.style_dim, generator=g), 1, 0.7)
+            t_euler = time.perf_counter() - t0
     audio_s = t_mel * HOP / SR
-    cpu_time = t_prefill + n_gen * t_tok + t_mel * t_frame
-    return {"value": audio_s / cpu_time, "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch fp32 CPU restatement of the reference path): GPT 1 utt x {n_text} text tokens, prefill + "
-                      f"{steps} greedy decode steps; BigVGAN 1 utt x {frames} mel frames; extrapolated to {n_gen} tokens / "
-                      f"{t_mel} frames (GPT + BigVGAN stages only, like the GPU line's hot path)",
-            "gpt_ms_per_token": t_tok * 1e3, "gpt_prefill_ms": t_prefill * 1e3, "bigvgan_ms_per_frame": t_frame * 1e3}
+    cpu_time = t_prefill + n_gen * t_tok + t_mel * t_frame + (EULER_STEPS * t_euler if t_euler is not None else 0.0)
+    res = {"value": audio_s / cpu_time, "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+           "sample": f"oracle (torch fp32 CPU restatement of the reference path): GPT 1 utt x {n_text} text tokens, prefill + "
+                     f"{steps} greedy decode steps; BigVGAN 1 utt x {frames} mel frames"
+                     + (f"; s2mel 1 utt x {s2mel_frames[0]} frames, 1 of {EULER_STEPS} CFG Euler steps" if t_euler is not None else "")
+                     + f"; extrapolated to {n_gen} tokens / {t_mel} frames / {EULER_STEPS} steps (codec decode + length regulator, "
+                       "1 % of the GPU step, not included)",
+           "gpt_ms_per_token": t_tok * 1e3, "gpt_prefill_ms": t_prefill * 1e3, "bigvgan_ms_per_frame": t_frame * 1e3}
+    if t_euler is not None:
+        res["s2mel_ms_per_euler_step"] = t_euler * 1e3
+    return res
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -424,7 +444,8 @@ def main():
                 t_cpu = time.perf_counter()
                 try:
                     out["cpu_baseline"] = cpu_baseline(eng.gsd, eng.gcfg, eng.bsd, eng.bh, n_text, n_gen, t_mel,
-                                                       args.cpu_threads or usable_cores())
+                                                       args.cpu_threads or usable_cores(),
+                                                       None if args.no_s2mel else (args.prompt_frames + t_mel, args.prompt_frames))
                 except Exception as e:      # never lose the GPU line because the baseline leg failed
                     out["cpu_baseline"] = {"error": repr(e)}
                 log(f"[bench] cpu_baseline leg took {time.perf_counter() - t_cpu:.1f}s")
