@@ -573,8 +573,25 @@ __device__ __forceinline__ v2u_t pf_cvt4(f32x4 v) { return v2u_t{pf_cvt2(v[0], v
 __device__ __forceinline__ float pf_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float pf_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 
+// Row metadata of a tile region for the epilogues that need the row's (sequence, frame): staged ONCE per region into LDS (meta[row],
+// meta[ROWS + row]) by pf_stage_meta -- read per chunk from global they were two dependent L2 round trips in front of every RoPE
+// table load / masked store (the wqkv GEMM ran 35 % behind the SwiGLU GEMM of the same K).
+//   EPI_QKV_ROPE: (tok_seq, tok_t);  EPI_WN_RS: (tok_t < seq_len[tok_seq] as 0 / 1, unused)
+template <int EPI, int ROWS>
+__device__ __forceinline__ void pf_stage_meta(const GemmArgs& a, int* meta, int m0, int ltid) {
+    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_WN_RS) {
+        if (ltid < ROWS) {
+            int m = m0 + ltid;
+            m = m < a.M ? m : a.M - 1;
+            const int sq = a.tok_seq[m], t = a.tok_t[m];
+            if constexpr (EPI == EPI_QKV_ROPE) { meta[ltid] = sq; meta[ROWS + ltid] = t; }
+            else meta[ltid] = (a.wn_last || t < a.seq_len[sq]) ? 1 : 0;
+        }
+    }
+}
+
 template <int EPI, int ROWS, int NT>            // ROWS x 128 columns of the tile, stored by NT threads (tid < NT)
-__device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct, int m0, int n0, int tid) {
+__device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct, const int* meta, int m0, int n0, int tid) {
     constexpr bool PAIR = (EPI == EPI_SWIGLU || EPI == EPI_GATE);
     constexpr int CH = PAIR ? 16 : 32;                              // 4-column chunks per tile row
     constexpr int RSTEP = NT / CH;                                  // a thread keeps its column chunk and walks down the rows
@@ -648,7 +665,7 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
                     }
                     *o = v;
                 } else {
-                    const float mask = a.tok_t[m] < a.seq_len[a.tok_seq[m]] ? 1.f : 0.f;
+                    const float mask = (float)meta[row];
                     f32x4* o = (f32x4*)(a.out_f32 + (size_t)m * a.D + n);
                     const f32x4 old = *o;
 #pragma unroll
@@ -667,7 +684,7 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
                         v2u_t{(uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16), (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)};
                 }
             } else {                                                   // EPI_QKV_ROPE (s2mel): both RoPE pairs of the chunk are in-thread
-                const int sq = a.tok_seq[m], t = a.tok_t[m];
+                const int sq = meta[row], t = meta[ROWS + row];
                 if (which < 2) {
                     const f32x4 cs = *(const f32x4*)(a.rope + ((size_t)t * 32 + (d >> 1)) * 2);       // (cos, sin) of pairs d/2, d/2 + 1
                     const f32x4 y{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
@@ -883,8 +900,10 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     ct[(wr * 64 + mt * 16 + g * 4 + r) * 128 + ((wc * 64 + nt * 16 + c16) ^ (g << 4))] = acc[mt][nt][r];
+        int* meta = (int*)(pf_sm + 65536);                          // 1 KiB of the slack above the 64 KiB row-major image
+        pf_stage_meta<EPI, 128>(a, meta, m0, threadIdx.x);
         __syncthreads();
-        pf_store_tile<EPI, 128, 256>(a, ct, m0, nt0 * 16, threadIdx.x);
+        pf_store_tile<EPI, 128, 256>(a, ct, meta, m0, nt0 * 16, threadIdx.x);
     } else {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -1132,11 +1151,13 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ct[(mt * 16 + g * 4 + r) * 128 + (((wc & 1) * 64 + nt * 16 + c16) ^ (g << 4))] = acc[h * 4 + mt][nt][r];
         }
-        __syncthreads();
         const int rm0 = m0 + wr * 128 + h * 64;
+        int* meta = (int*)((char*)ct + 32768);                     // 512 B of the region's slack above the 32 KiB row-major image
+        if (!v_region) pf_stage_meta<EPI, 64>(a, meta, rm0, ltid);
+        __syncthreads();
         if (rn0 < a.N) {
             if (v_region) pf_store_vt<64, 128>(a, ct, rm0, rn0, ltid);
-            else pf_store_tile<EPI, 64, 128>(a, ct, rm0, rn0, ltid);
+            else pf_store_tile<EPI, 64, 128>(a, ct, meta, rm0, rn0, ltid);
         }
         if (h == 0) __syncthreads();
     }
@@ -1300,10 +1321,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_4w_kernel(GemmArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ct[(mt * 16 + g * 4 + r) * 128 + ((wc * 64 + nt * 16 + c16) ^ (g << 4))] = acc[h * 4 + mt][nt][r];
         }
-        __syncthreads();
         const int rm0 = m0 + wr * 128 + h * 64;
+        int* meta = (int*)((char*)ct + 32768);
+        if (!v_region) pf_stage_meta<EPI, 64>(a, meta, rm0, ltid);
+        __syncthreads();
         if (v_region) pf_store_vt<64, 128>(a, ct, rm0, rn0, ltid);
-        else pf_store_tile<EPI, 64, 128>(a, ct, rm0, rn0, ltid);
+        else pf_store_tile<EPI, 64, 128>(a, ct, meta, rm0, rn0, ltid);
         if (h == 0) __syncthreads();
     }
 }
