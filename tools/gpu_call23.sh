@@ -2,7 +2,7 @@
 # GPU box: checkpoint -- smoke, full GPU suite, bench, rocprof kernel stats of the bench
 set -u
 cd "$(dirname "$0")/.."
-O=gpurun_out/r02w
+O=gpurun_out/r02y
 mkdir -p $O
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" > $O/status.txt
 timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_all.log 2>&1; echo "pytest_all rc=$?" >> $O/status.txt
