@@ -341,6 +341,22 @@ int itts_tok_act_forward(float* x, size_t n, int mode, void* stream);
 /* replaces: perceiver.py RMSNorm (F.normalize(x) * sqrt(dim) * gamma), in place */
 int itts_tok_l2norm_forward(float* x, const float* gamma, int n, int C, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * CAMPPlus speaker encoder (indextts/s2mel/modules/campplus/{DTDNN,layers}.py, eval mode): BatchNorm folded
+ * into the adjacent conv where it follows one, else applied by itts_tok_affine_forward; convs are row gathers + itts_gemm_forward;
+ * indextts_amd/campplus.py sequences the calls.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* replaces: get_nonlinear('batchnorm-relu') in eval mode (layers.py): out[m][c] = act(x[m][c] * scale[c] + shift[c]); x rows may be
+ *   wider than C (row stride ld_x): the dense blocks' growing feature matrix */
+int itts_tok_affine_forward(const float* x, int ld_x, const float* scale, const float* shift, float* out, int n, int C, int relu,
+                            void* stream);
+/* replaces: CAMLayer context = x.mean(-1) + seg_pooling(x, 100) (layers.py CAMLayer.forward / seg_pooling), one sequence of n rows */
+int itts_tok_ctxpool_forward(const float* h, float* out, int n, int C, int seg_len, void* stream);
+/* replaces: y * sigmoid(linear2(...)) of CAMLayer.forward, in place on y */
+int itts_tok_gate_forward(float* y, const float* g, size_t n, void* stream);
+/* replaces: StatsPool (mean | unbiased std over time, layers.py statistics_pooling): x [n][C] -> out [2C] */
+int itts_tok_statspool_forward(const float* x, float* out, int n, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

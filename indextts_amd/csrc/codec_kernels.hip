@@ -278,6 +278,85 @@ __global__ __launch_bounds__(64) void l2norm_kernel(float* __restrict__ x, const
     for (int c = threadIdx.x; c < C; c += 64) r[c] = r[c] * inv * gamma[c];
 }
 
+// ---- CAMPPlus speaker encoder: eval-mode BatchNorm + ReLU, context pooling, gate, statistics pooling -----
+// out[m][c] = act(x[m * ld_x + c] * scale[c] + shift[c])   (BatchNorm in eval mode = a per-channel affine map; x may be the first C
+// columns of a wider row: the dense blocks grow their feature matrix in place)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ out, size_t n, int C, int relu) {
+    const size_t total = n * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / C;
+        const int c = (int)(i - m * C);
+        const float v = fmaf(x[m * ld_x + c], scale[c], shift[c]);
+        out[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+// CAMLayer context (layers.py): out[t][c] = mean_t'(h[t'][c]) + mean over t's segment of seg_len frames (ceil_mode: the last
+// segment averages the frames it has).  One sequence of n rows; one wave per channel.
+__global__ __launch_bounds__(64) void ctxpool_kernel(const float* __restrict__ h, float* __restrict__ out, int n, int C, int seg_len) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float tot = 0.f;
+    for (int t = lane; t < n; t += 64) tot += h[(size_t)t * C + c];
+    tot = wave_sum(tot) / (float)n;
+    for (int s0 = 0; s0 < n; s0 += seg_len) {
+        const int s1 = s0 + seg_len < n ? s0 + seg_len : n;
+        float ss = 0.f;
+        for (int t = s0 + lane; t < s1; t += 64) ss += h[(size_t)t * C + c];
+        ss = wave_sum(ss) / (float)(s1 - s0);
+        for (int t = s0 + lane; t < s1; t += 64) out[(size_t)t * C + c] = tot + ss;
+    }
+}
+
+// y *= sigmoid(g)
+__global__ __launch_bounds__(256) void gate_kernel(float* __restrict__ y, const float* __restrict__ g, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] *= 1.0f / (1.0f + expf(-g[i]));
+}
+
+// StatsPool: out[c] = mean over the n rows, out[C + c] = unbiased standard deviation; one wave per channel, two passes
+__global__ __launch_bounds__(64) void statspool_kernel(const float* __restrict__ x, float* __restrict__ out, int n, int C) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int t = lane; t < n; t += 64) s += x[(size_t)t * C + c];
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+    for (int t = lane; t < n; t += 64) { const float d = x[(size_t)t * C + c] - mean; q += d * d; }
+    q = wave_sum(q);
+    if (lane == 0) { out[c] = mean; out[C + c] = sqrtf(q / (float)(n - 1)); }
+}
+
+extern "C" int itts_tok_affine_forward(const float* x, int ld_x, const float* scale, const float* shift, float* out, int n, int C, int relu,
+                                       void* stream) {
+    if (!x || !scale || !shift || !out || C < 1 || ld_x < C) { itts_set_error("tok_affine: bad args"); return ITTS_ERR_ARG; }
+    if (n <= 0) return ITTS_OK;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for((size_t)n * C)), dim3(256), 0, (hipStream_t)stream, x, ld_x, scale, shift, out, (size_t)n, C, relu);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+extern "C" int itts_tok_ctxpool_forward(const float* h, float* out, int n, int C, int seg_len, void* stream) {
+    if (!h || !out || C < 1 || seg_len < 1) { itts_set_error("tok_ctxpool: bad args"); return ITTS_ERR_ARG; }
+    if (n <= 0) return ITTS_OK;
+    hipLaunchKernelGGL(ctxpool_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, h, out, n, C, seg_len);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+extern "C" int itts_tok_gate_forward(float* y, const float* g, size_t n, void* stream) {
+    if (!y || !g) { itts_set_error("tok_gate: null"); return ITTS_ERR_ARG; }
+    if (n == 0) return ITTS_OK;
+    hipLaunchKernelGGL(gate_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, g, n);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+extern "C" int itts_tok_statspool_forward(const float* x, float* out, int n, int C, void* stream) {
+    if (!x || !out || C < 1 || n < 2) { itts_set_error("tok_statspool: need n >= 2 rows"); return ITTS_ERR_ARG; }
+    hipLaunchKernelGGL(statspool_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, x, out, n, C);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
 extern "C" int itts_attention_forward(const float* q, const float* k, const float* v, float* out, const int32_t* kstart, const int32_t* klen,
                                       int n_q, int heads, int dq, int dv, float scale, void* stream) {
     if (!q || !k || !v || !out || !kstart || !klen || heads < 1 || dq < 4 || dv < 4 || (dq & 3) || (dv & 3) || dv > 128) {

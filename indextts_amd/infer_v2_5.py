@@ -462,6 +462,16 @@ class ReferenceFrontend(Frontend):
         self.ref = ref
         self.cfg, self.model_dir, self.device = cfg, model_dir, device
         self.tokenizer = ref.tokenizer
+        # the CAMPPlus speaker encoder runs on the engine (indextts_amd/campplus.py) from the weights the reference module loaded;
+        # the reference's own module stays in place only when its configuration is not the shipped one
+        self.campplus = None
+        cm = getattr(ref, "campplus_model", None)
+        if cm is not None and torch.cuda.is_available() and str(device).startswith("cuda"):
+            try:
+                from .campplus import CAMPPlus
+                self.campplus = CAMPPlus(feat_dim=80, embedding_size=192, device=device).load_state_dict(cm.state_dict())
+            except NotImplementedError:
+                self.campplus = None
 
     # ---- the reference's own state dicts, for the engine stages (IndexTTS2.__init__ loads them when none are injected) --------
     def engine_state_dicts(self):
@@ -485,7 +495,7 @@ class ReferenceFrontend(Frontend):
         spk_cond_emb = self._w2v(audio_16k)
         ref_mel = r.mel_fn(audio_22k.to(spk_cond_emb.device).float())
         feat = torchaudio.compliance.kaldi.fbank(audio_16k.to(ref_mel.device), num_mel_bins=80, dither=0, sample_frequency=16000)
-        style = r.campplus_model((feat - feat.mean(dim=0, keepdim=True)).unsqueeze(0))
+        style = (self.campplus or r.campplus_model)((feat - feat.mean(dim=0, keepdim=True)).unsqueeze(0))
         prompt_condition = r.s2mel.models["length_regulator"](spk_cond_emb, ylens=torch.LongTensor([ref_mel.size(2)]).to(ref_mel.device),
                                                               n_quantizers=3, f0=None)[0]
         return dict(style=style, spk_cond_emb=spk_cond_emb, ref_mel=ref_mel, prompt_condition=prompt_condition)
