@@ -334,6 +334,17 @@ int itts_tok_groupnorm_mish_forward(float* x, const float* gamma, const float* b
  *   kstart[m] .. kstart[m] + klen[m] - 1 (klen 0 -> zeros, as the reference's masked softmax). */
 int itts_attention_forward(const float* q, const float* k, const float* v, float* out, const int32_t* kstart, const int32_t* klen,
                            int n_q, int heads, int dq, int dv, float scale, void* stream);
+/* replaces: Wav2Vec2BertSelfAttention.forward with position_embeddings_type "relative_key" (transformers modeling_wav2vec2_bert.py, the
+ *   `semantic_model` of indextts/infer_v2_5.py:171-176,282-290): scores = (q . k_j + q . dist_emb[clamp(j - qpos, -left, right) + left]) * scale
+ *   over the query's key range, softmax, . V.  dist_emb [left + right + 1][dq] (shared by the heads), qpos[m] = the query's index inside
+ *   its own key range; the rest as itts_attention_forward. */
+int itts_attention_relkey_forward(const float* q, const float* k, const float* v, float* out, const int32_t* kstart, const int32_t* klen,
+                                  const int32_t* qpos, const float* dist_emb, int left, int right, int n_q, int heads, int dq, int dv,
+                                  float scale, void* stream);
+/* replaces: the causal depthwise Conv1d of Wav2Vec2BertConvolutionModule (left pad k - 1, no bias: b may be NULL); layout as
+ *   itts_tok_dwconv_forward */
+int itts_tok_dwconv_causal_forward(const float* x, const float* w, const float* b, float* y, const int32_t* tok_seq, const int32_t* tok_t,
+                                   const int32_t* seq_T, int n, int C, int k, void* stream);
 /* replaces: F.glu (mode 0, conformer_encoder.py:147) / GEGLU (mode 1, perceiver.py): x [n][2C] -> out [n][C] */
 int itts_tok_glu_forward(const float* x, float* out, int n, int C, int mode, void* stream);
 /* replaces: ReLU (mode 0, subsampling.py:150) / SiLU (mode 1, conformer activation), in place */

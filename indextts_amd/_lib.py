@@ -113,6 +113,8 @@ SIGNATURES = {
     "itts_tok_dwconv_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "itts_tok_gelu_forward": (C.c_int, [vp, C.c_size_t, vp]),
     "itts_attention_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "itts_attention_relkey_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "itts_tok_dwconv_causal_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "itts_tok_glu_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "itts_tok_act_forward": (C.c_int, [vp, C.c_size_t, C.c_int, vp]),
     "itts_tok_l2norm_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),

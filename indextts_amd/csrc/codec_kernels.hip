@@ -67,14 +67,14 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const float* __restric
 // depthwise conv, k taps, zero padding at the sequence's own ends: y[m][c] = b[c] + sum_j w[c][j] * x[m + j - (k-1)/2][c]
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                      float* __restrict__ y, const int* __restrict__ tok_seq, const int* __restrict__ tok_t,
-                                                     const int* __restrict__ seq_T, int n, int C, int k) {
+                                                     const int* __restrict__ seq_T, int n, int C, int k, int pad_left) {
     const size_t total = (size_t)n * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int m = (int)(i / C), c = (int)(i - (size_t)m * C);
         const int t = tok_t[m], T = seq_T[tok_seq[m]];
-        float acc = b[c];
+        float acc = b ? b[c] : 0.f;
         for (int j = 0; j < k; ++j) {
-            const int u = t + j - (k - 1) / 2;
+            const int u = t + j - pad_left;
             if (u >= 0 && u < T) acc = fmaf(w[(size_t)c * k + j], x[(size_t)(m + u - t) * C + c], acc);
         }
         y[i] = acc;
@@ -162,7 +162,16 @@ extern "C" int itts_tok_dwconv_forward(const float* x, const float* w, const flo
                                        const int32_t* seq_T, int n, int C, int k, void* stream) {
     if (!x || !w || !b || !y || !tok_seq || !tok_t || !seq_T || k < 1 || (k & 1) == 0) { itts_set_error("tok_dwconv: bad args"); return ITTS_ERR_ARG; }
     if (n <= 0) return ITTS_OK;
-    hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for((size_t)n * C)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, tok_seq, tok_t, seq_T, n, C, k);
+    hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for((size_t)n * C)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, tok_seq, tok_t, seq_T, n, C, k, (k - 1) / 2);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+extern "C" int itts_tok_dwconv_causal_forward(const float* x, const float* w, const float* b, float* y, const int32_t* tok_seq, const int32_t* tok_t,
+                                              const int32_t* seq_T, int n, int C, int k, void* stream) {
+    if (!x || !w || !y || !tok_seq || !tok_t || !seq_T || C < 1 || k < 1) { itts_set_error("tok_dwconv_causal: bad args"); return ITTS_ERR_ARG; }
+    if (n <= 0) return ITTS_OK;
+    hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for((size_t)n * C)), dim3(256), 0, (hipStream_t)stream, x, w, b, y, tok_seq, tok_t, seq_T, n, C, k, k - 1);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
@@ -186,10 +195,13 @@ extern "C" int itts_tok_scale_residual_forward(float* x, const float* y, const f
 // ---- conditioning encoders (Conformer + Perceiver): generic f32 attention and gated activations ----------
 // One wave per (query row, head): lanes take keys j = lane, lane + 64, ... of the query's key range, keep an online-softmax state
 // and a Dv-wide accumulator each, and merge at the end.  Q [n_q][H][Dq], K [n_k][H][Dq], V [n_k][H][Dv] (Dq, Dv <= 128, % 4 == 0).
+#define ATTN_REL_MAX 512
 template <int DV4>       // Dv / 4 rounded up to 16 or 32
 __global__ __launch_bounds__(64) void attn_generic_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                           float* __restrict__ out, const int* __restrict__ kstart, const int* __restrict__ klen,
-                                                          int H, int Dq, int Dv, float scale) {
+                                                          int H, int Dq, int Dv, float scale, const float* __restrict__ rel,
+                                                          const int* __restrict__ qpos, int left, int right) {
+    __shared__ float qpe[ATTN_REL_MAX];                           // relative_key: q . distance_embedding[r] for this (query, head)
     const int m = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     const int ks = kstart[m], kl = klen[m];
     float* o = out + ((size_t)m * H + h) * Dv;
@@ -198,6 +210,20 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const float* __restric
         return;
     }
     const float* qr = q + ((size_t)m * H + h) * Dq;
+    int qp = 0;
+    if (rel) {
+        qp = qpos[m];
+        for (int r = lane; r <= left + right; r += 64) {
+            const float* er = rel + (size_t)r * Dq;
+            float s = 0.f;
+            for (int d = 0; d < Dq; d += 4) {
+                const f32x4 a = *(const f32x4*)(qr + d), b = *(const f32x4*)(er + d);
+                s += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+            }
+            qpe[r] = s;
+        }
+        __syncthreads();
+    }
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 acc[DV4];
 #pragma unroll
@@ -209,6 +235,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const float* __restric
             const f32x4 a = *(const f32x4*)(qr + d), b = *(const f32x4*)(kr + d);
             s += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
         }
+        if (rel) s += qpe[min(max(j - qp, -left), right) + left];
         s *= scale;
         const float nm = fmaxf(m_run, s);
         const float al = expf(m_run - nm), p = expf(s - nm);
@@ -357,17 +384,37 @@ extern "C" int itts_tok_statspool_forward(const float* x, float* out, int n, int
     return ITTS_OK;
 }
 
-extern "C" int itts_attention_forward(const float* q, const float* k, const float* v, float* out, const int32_t* kstart, const int32_t* klen,
-                                      int n_q, int heads, int dq, int dv, float scale, void* stream) {
+static int attention_launch(const float* q, const float* k, const float* v, float* out, const int32_t* kstart, const int32_t* klen, int n_q,
+                            int heads, int dq, int dv, float scale, const float* rel, const int32_t* qpos, int left, int right, void* stream) {
     if (!q || !k || !v || !out || !kstart || !klen || heads < 1 || dq < 4 || dv < 4 || (dq & 3) || (dv & 3) || dv > 128) {
         itts_set_error("attention_forward: need non-null tensors, dq %% 4 == 0, dv %% 4 == 0, dv <= 128");
         return ITTS_ERR_ARG;
     }
+    if (rel && (!qpos || left < 0 || right < 0 || left + right + 1 > ATTN_REL_MAX)) {
+        itts_set_error("attention_relkey_forward: need qpos and 0 <= left + right < %d", ATTN_REL_MAX);
+        return ITTS_ERR_ARG;
+    }
     if (n_q <= 0) return ITTS_OK;
-    if (dv <= 64) hipLaunchKernelGGL(attn_generic_kernel<16>, dim3(n_q, heads), dim3(64), 0, (hipStream_t)stream, q, k, v, out, kstart, klen, heads, dq, dv, scale);
-    else hipLaunchKernelGGL(attn_generic_kernel<32>, dim3(n_q, heads), dim3(64), 0, (hipStream_t)stream, q, k, v, out, kstart, klen, heads, dq, dv, scale);
+    if (dv <= 64)
+        hipLaunchKernelGGL(attn_generic_kernel<16>, dim3(n_q, heads), dim3(64), 0, (hipStream_t)stream, q, k, v, out, kstart, klen, heads, dq, dv, scale,
+                           rel, qpos, left, right);
+    else
+        hipLaunchKernelGGL(attn_generic_kernel<32>, dim3(n_q, heads), dim3(64), 0, (hipStream_t)stream, q, k, v, out, kstart, klen, heads, dq, dv, scale,
+                           rel, qpos, left, right);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
+}
+
+extern "C" int itts_attention_forward(const float* q, const float* k, const float* v, float* out, const int32_t* kstart, const int32_t* klen,
+                                      int n_q, int heads, int dq, int dv, float scale, void* stream) {
+    return attention_launch(q, k, v, out, kstart, klen, n_q, heads, dq, dv, scale, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int itts_attention_relkey_forward(const float* q, const float* k, const float* v, float* out, const int32_t* kstart, const int32_t* klen,
+                                             const int32_t* qpos, const float* dist_emb, int left, int right, int n_q, int heads, int dq, int dv,
+                                             float scale, void* stream) {
+    if (!dist_emb) { itts_set_error("attention_relkey_forward: null distance embedding"); return ITTS_ERR_ARG; }
+    return attention_launch(q, k, v, out, kstart, klen, n_q, heads, dq, dv, scale, dist_emb, qpos, left, right, stream);
 }
 
 extern "C" int itts_tok_glu_forward(const float* x, float* out, int n, int C, int mode, void* stream) {

@@ -429,6 +429,9 @@ class IndexTTS2:
         return out
 
 
+W2V_TAP_LAYER = 17                    # `hidden_states[17]` of the w2v-bert-2.0 encoder (infer_v2_5.py:288)
+
+
 class ReferenceFrontend(Frontend):
     """Prompt / text stages on the reference's own PyTorch modules.
 
@@ -473,6 +476,23 @@ class ReferenceFrontend(Frontend):
             except NotImplementedError:
                 self.campplus = None
 
+        # likewise the w2v-bert-2.0 feature encoder (indextts_amd/w2vbert.py): only the 17 layers below the tapped hidden state
+        self.w2v = None
+        sm = getattr(ref, "semantic_model", None)
+        if sm is not None and hasattr(sm, "config") and torch.cuda.is_available() and str(device).startswith("cuda"):
+            try:
+                from .w2vbert import Wav2Vec2BertModel
+                c = sm.config
+                self.w2v = Wav2Vec2BertModel(
+                    hidden_size=c.hidden_size, num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                    intermediate_size=c.intermediate_size, feature_projection_input_dim=c.feature_projection_input_dim,
+                    position_embeddings_type=c.position_embeddings_type, left_max_position_embeddings=c.left_max_position_embeddings,
+                    right_max_position_embeddings=c.right_max_position_embeddings, conv_depthwise_kernel_size=c.conv_depthwise_kernel_size,
+                    hidden_act=c.hidden_act, layer_norm_eps=c.layer_norm_eps, add_adapter=c.add_adapter, device=device,
+                ).load_state_dict(sm.state_dict(), n_layers=W2V_TAP_LAYER)
+            except NotImplementedError:
+                self.w2v = None
+
     # ---- the reference's own state dicts, for the engine stages (IndexTTS2.__init__ loads them when none are injected) --------
     def engine_state_dicts(self):
         return dict(semantic_codec=self.ref.semantic_codec.state_dict(), cfm=self.ref.s2mel.models["cfm"].state_dict(),
@@ -483,6 +503,8 @@ class ReferenceFrontend(Frontend):
     def _w2v(self, audio_16k):
         r = self.ref
         inputs = r.extract_features(audio_16k, sampling_rate=16000, return_tensors="pt")
+        if self.w2v is not None:
+            return self.w2v.get_emb(inputs["input_features"], inputs["attention_mask"], r.semantic_mean, r.semantic_std, layer=W2V_TAP_LAYER)
         return r.get_emb(inputs["input_features"].to(self.device), inputs["attention_mask"].to(self.device))
 
     @torch.no_grad()
