@@ -39,6 +39,11 @@ def test_relkey_attention_and_causal_dwconv_vs_torch():
         ref = (torch.softmax(sc, -1) @ vv).transpose(0, 1).reshape(T, H * dh)
         assert float((out[s0:s0 + T] - ref).abs().max()) <= 2e-5
         s0 += T
+    from indextts_amd.gpt import layernorm
+    for D in (160, 36):                                           # widths off the 64-lane grid (the 160-wide stacked fbank rows)
+        xx, gg, bb = torch.randn(77, D, generator=g) * 3 + 1, torch.randn(D, generator=g), torch.randn(D, generator=g)
+        y = layernorm(xx.to(DEV), gg.to(DEV), bb.to(DEV), eps=1e-5).cpu()
+        assert float((y - F.layer_norm(xx, (D,), gg, bb, 1e-5)).abs().max()) <= 1e-5
     C, kk = 48, 7
     x, w = torch.randn(n, C, generator=g), torch.randn(C, kk, generator=g)
     y = ops.dwconv_causal(x.to(DEV), w.to(DEV), tok_seq, tok_t, Tt, kk).cpu()
