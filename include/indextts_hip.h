@@ -55,6 +55,17 @@ int itts_conv1d_forward(const float* x, const float* wpk, const float* bias, con
                         float* y, int B, int Cin, int Cout, int T, int k, int dilation, const int32_t* lens,
                         int len_mult, int acc_mode, float div, void* stream);
 
+/* Opt-in second mode of the resblock Conv1d's (same arithmetic contract as itts_conv1d_forward, `same` zero padding, odd k):
+ * the f32 operands are split into two f16 parts each (x = xh + 2^-11 xl, 22 significand bits) and the conv runs as three
+ * v_mfma_f32_16x16x32_f16 products per fragment pair with exact f32 accumulation (the xl*wl term, 2^-22 relative, is dropped).
+ * C_in % 32 == 0.  wp3 = itts_pack_conv1d_h3_weight output on the device; scratch = itts_conv1d_h3_scratch_bytes device bytes.
+ * replaces: the same nn.Conv1d calls of AMPBlock1 (bigvgan.py:96-141) as itts_conv1d_forward. */
+size_t itts_conv1d_h3_packed_bytes(int Cout, int Cin, int k);
+int itts_pack_conv1d_h3_weight(const float* w, int Cout, int Cin, int k, void* out);        /* host -> host */
+size_t itts_conv1d_h3_scratch_bytes(int B, int Cin, int T);
+int itts_conv1d_h3_forward(const float* x, const void* wp3, const float* bias, const float* res, float* y, int B, int Cin, int Cout,
+                           int T, int k, int dilation, const int32_t* lens, int len_mult, int acc_mode, float div, void* scratch,
+                           void* stream);
 /* replaces: torch.nn.ConvTranspose1d forward of the upsamplers (bigvgan.py:300-316,366-367); k == 2*u,
  * padding (k-u)/2.  wpk_phases: u packed 2-tap weights back to back (itts_pack_convT_weight, phase 0..u-1). */
 int itts_conv_transpose1d_forward(const float* x, const float* wpk_phases, const float* bias, const float* bias_b,
@@ -85,7 +96,11 @@ typedef struct itts_bigvgan itts_bigvgan;
  *   (indextts/s2mel/modules/bigvgan/bigvgan.py:266-358,388-492; v1 indextts/BigVGAN/models.py).
  * Tensors are given by their reference state-dict names (weight-norm already folded), host f32 pointers. */
 int itts_bigvgan_create(const itts_bigvgan_config* cfg, itts_bigvgan** out);
-int itts_bigvgan_device(const itts_bigvgan* h);   /* device index the handle is bound to */
+int itts_bigvgan_device(const itts_bigvgan* h);   /* Conv mode of the generator's resblock convs, to be chosen BEFORE the weights are loaded: 0 = exact f32 MFMA (default; the parity
+ * mode), 1 = f16 x 3 split operands (itts_conv1d_h3_forward) for the resblocks with >= min_channels channels (0 = default 96);
+ * everything else (conv_pre / upsamplers / conv_post / activations) is unchanged. */
+int itts_bigvgan_set_conv_mode(itts_bigvgan* h, int mode, int min_channels);
+/* device index the handle is bound to */
 int itts_bigvgan_load_tensor(itts_bigvgan* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
 int itts_bigvgan_finalize(itts_bigvgan* h);       /* checks every required tensor arrived */
 void itts_bigvgan_destroy(itts_bigvgan* h);

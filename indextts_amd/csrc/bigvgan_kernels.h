@@ -25,3 +25,21 @@ int launch_conv_post(const float* x, float* y, const float* w, const float* bias
                      const int* lens, int len_mult, int use_tanh, hipStream_t st);
 int launch_cond_bias(const float* spk, const float* w, const float* bias, float* out, int B, int Cout, int cond_dim,
                      hipStream_t st);
+
+// ---- opt-in f16 x 3 split-operand mode of the resblock convs (bigvgan_h3.hip) ----------------------------------------------
+struct ConvH3Args {
+    const void* xh; const void* xl;   // [B][T][Cin] f16: f16(x) and f16(2^11 (x - f16(x))), frames >= the row length zeroed
+    const void* wp;                   // conv_h3_pack output
+    const float* bias;                // [Cout] or null
+    const float* res;                 // [B][Cout][T] or null
+    float* y;                         // [B][Cout][T]
+    const void* zero_row;             // >= 16 zero bytes
+    const int* lens; int len_mult;    // row b is min(lens[b] * len_mult, T) frames long (null: T)
+    int B, Cin, Cout, T, k, dil;
+    int acc_mode; float div;          // as ConvArgs
+    int n_mt, n_co;                   // filled by the launcher
+};
+size_t conv_h3_packed_bytes(int Cout, int Cin, int k);
+int conv_h3_pack(const float* w, int Cout, int Cin, int k, void* out);
+int launch_split_tm(const float* x, void* xh, void* xl, int B, int C, int T, const int* lens, int len_mult, hipStream_t st);
+int launch_conv_h3(const ConvH3Args& a, hipStream_t st);

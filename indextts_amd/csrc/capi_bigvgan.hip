@@ -109,6 +109,28 @@ extern "C" int itts_conv1d_forward(const float* x, const float* wpk, const float
                        acc_mode, div, (hipStream_t)stream);
 }
 
+// ---- f16 x 3 split-operand conv as a unit op (tests / microbenchmarks; the model path packs at load time) ----------------------
+extern "C" size_t itts_conv1d_h3_packed_bytes(int Cout, int Cin, int k) { return (Cin > 0 && Cin % 32 == 0 && Cout > 0 && k > 0) ? conv_h3_packed_bytes(Cout, Cin, k) : 0; }
+extern "C" int itts_pack_conv1d_h3_weight(const float* w, int Cout, int Cin, int k, void* out) { return conv_h3_pack(w, Cout, Cin, k, out); }
+extern "C" size_t itts_conv1d_h3_scratch_bytes(int B, int Cin, int T) { return (size_t)B * T * Cin * 4 + 512; }
+extern "C" int itts_conv1d_h3_forward(const float* x, const void* wp3, const float* bias, const float* res, float* y, int B, int Cin, int Cout,
+                                      int T, int k, int dilation, const int32_t* lens, int len_mult, int acc_mode, float div, void* scratch,
+                                      void* stream) {
+    if (!x || !wp3 || !y || !scratch || B < 0 || T < 0 || acc_mode < 0 || acc_mode > 2) { itts_set_error("conv1d_h3_forward: bad args"); return ITTS_ERR_ARG; }
+    if (B == 0 || T == 0) return ITTS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    const size_t half = (size_t)B * T * Cin * 2;
+    void* zr = base + half * 2;                           // the zero row lives behind the two halves
+    HIP_TRY(hipMemsetAsync(zr, 0, 64, st));
+    int rc = launch_split_tm(x, base, base + half, B, Cin, T, lens, len_mult < 1 ? 1 : len_mult, st);
+    if (rc) return rc;
+    ConvH3Args g{};
+    g.xh = base; g.xl = base + half; g.wp = wp3; g.bias = bias; g.res = res; g.y = y; g.zero_row = zr; g.lens = lens; g.len_mult = len_mult < 1 ? 1 : len_mult;
+    g.B = B; g.Cin = Cin; g.Cout = Cout; g.T = T; g.k = k; g.dil = dilation; g.acc_mode = acc_mode; g.div = div;
+    return launch_conv_h3(g, st);
+}
+
 static int convT_impl(const float* x, const float* wpk_phases, const float* bias, const float* bias_b, float* y, int B,
                       int Cin, int Cout, int Tin, int k, int u, const int* lens, int len_mult_in, hipStream_t st) {
     const int p = (k - u) / 2, ntaps = k / u;
@@ -147,6 +169,7 @@ struct ConvL {
     int Cin = 0, Cout = 0, k = 0;
     DevBuf w, b;
     bool has_w = false, has_b = false;
+    void* w3 = nullptr;                 // f16 x 3 mode: split weight fragments (conv_h3_pack), resblock convs with enough channels only
 };
 struct ActL {
     int C = 0;
@@ -176,6 +199,10 @@ struct itts_bigvgan {
     std::vector<Rec> recs;      // one per launch of the last forward; events 2i, 2i+1
     hipStream_t prof_stream = nullptr;
     int device = -1;            // device current at itts_bigvgan_create: owns the weights and profiling events
+    // opt-in conv mode (itts_bigvgan_set_conv_mode): 0 = exact f32 MFMA (default, the parity mode), 1 = f16 x 3 split operands for
+    // the resblock convs with >= h3_min_c channels
+    int conv_mode = 0, h3_min_c = 96;
+    void* zero_row = nullptr;
 };
 
 // profiling classes
@@ -267,6 +294,23 @@ extern "C" int itts_bigvgan_create(const itts_bigvgan_config* cfg, itts_bigvgan*
 
 extern "C" int itts_bigvgan_device(const itts_bigvgan* h) { return h ? h->device : -1; }
 
+extern "C" int itts_bigvgan_set_conv_mode(itts_bigvgan* h, int mode, int min_channels) {
+    if (!h || mode < 0 || mode > 1) { itts_set_error("bigvgan_set_conv_mode: mode 0 (exact f32) or 1 (f16 x 3 split operands)"); return ITTS_ERR_ARG; }
+    for (const ConvL& L : h->convs1)
+        if (L.has_w) { itts_set_error("bigvgan_set_conv_mode: call before loading the weights"); return ITTS_ERR_STATE; }
+    ItDevGuard dg(h->device);
+    h->conv_mode = mode;
+    if (min_channels > 0) h->h3_min_c = min_channels;
+    if (mode == 1 && !h->zero_row) {
+        void* z = nullptr;
+        HIP_TRY(hipMalloc(&z, 256));
+        HIP_TRY(hipMemset(z, 0, 256));
+        h->owned.push_back((float*)z);
+        h->zero_row = z;
+    }
+    return ITTS_OK;
+}
+
 extern "C" void itts_bigvgan_destroy(itts_bigvgan* h) {
     if (!h) return;
     ItDevGuard dg(h->device);
@@ -289,7 +333,7 @@ static bool eat(const char*& s, const char* lit) {
 }
 
 static int load_conv(itts_bigvgan* h, ConvL* L, const char* what, const float* data, const int64_t* shape, int ndim,
-                     int Cout, int Cin, int k) {
+                     int Cout, int Cin, int k, bool resblock = false) {
     if (!strcmp(what, "weight")) {
         if (ndim != 3 || shape[0] != Cout || shape[1] != Cin || shape[2] != k) {
             itts_set_error("conv weight shape mismatch: got [%lld,%lld,%lld] want [%d,%d,%d]", (long long)shape[0],
@@ -300,6 +344,17 @@ static int load_conv(itts_bigvgan* h, ConvL* L, const char* what, const float* d
         int rc = itts_pack_conv1d_weight(data, Cout, Cin, k, pk.data());
         if (rc) return rc;
         L->Cin = Cin; L->Cout = Cout; L->k = k; L->has_w = true;
+        L->w3 = nullptr;
+        if (resblock && h->conv_mode == 1 && Cin % 32 == 0 && Cin >= h->h3_min_c) {
+            std::vector<char> p3(conv_h3_packed_bytes(Cout, Cin, k));
+            rc = conv_h3_pack(data, Cout, Cin, k, p3.data());
+            if (rc) return rc;
+            void* d = nullptr;
+            HIP_TRY(hipMalloc(&d, p3.size()));
+            h->owned.push_back((float*)d);
+            HIP_TRY(hipMemcpy(d, p3.data(), p3.size(), hipMemcpyHostToDevice));
+            L->w3 = d;
+        }
         return upload(h, pk.data(), pk.size(), &L->w);
     }
     if (!strcmp(what, "bias")) {
@@ -377,11 +432,11 @@ extern "C" int itts_bigvgan_load_tensor(itts_bigvgan* h, const char* name, const
         const int k = c.resblock_kernel_sizes[i % c.num_kernels];
         if (eat(s, "convs1.")) {
             if (!parse_idx(s, &d) || d >= c.num_dilations || !eat(s, ".")) { itts_set_error("bad name %s", name); return ITTS_ERR_ARG; }
-            return load_conv(h, &h->convs1[(size_t)i * c.num_dilations + d], s, data, shape, ndim, ch, ch, k);
+            return load_conv(h, &h->convs1[(size_t)i * c.num_dilations + d], s, data, shape, ndim, ch, ch, k, true);
         }
         if (eat(s, "convs2.")) {
             if (!parse_idx(s, &d) || d >= c.num_dilations || !eat(s, ".")) { itts_set_error("bad name %s", name); return ITTS_ERR_ARG; }
-            return load_conv(h, &h->convs2[(size_t)i * c.num_dilations + d], s, data, shape, ndim, ch, ch, k);
+            return load_conv(h, &h->convs2[(size_t)i * c.num_dilations + d], s, data, shape, ndim, ch, ch, k, true);
         }
         if (eat(s, "activations.")) {
             if (!parse_idx(s, &j) || j >= 2 * c.num_dilations || !eat(s, ".")) { itts_set_error("bad name %s", name); return ITTS_ERR_ARG; }
@@ -507,7 +562,7 @@ extern "C" size_t itts_bigvgan_workspace_bytes(const itts_bigvgan* h, int B, int
         cond = align256((size_t)B * c.upsample_initial_channel * 4);
         for (int i = 0; i < c.num_upsamples; ++i) cond += align256((size_t)B * stage_channels(c, i) * 4);
     }
-    return 7 * align256(max_stage_floats(h, B, T) * sizeof(float)) + cond + 256;
+    return (size_t)(h->conv_mode == 1 ? 8 : 7) * align256(max_stage_floats(h, B, T) * sizeof(float)) + cond + 256;
 }
 
 extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32_t* lens, const float* spk, float* wav,
@@ -533,9 +588,11 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
     hipStream_t st = (hipStream_t)stream;
     const size_t bufsz = align256(max_stage_floats(h, B, T) * sizeof(float));
     char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    float* buf[7];
-    for (int i = 0; i < 7; ++i) buf[i] = (float*)(base + bufsz * i);
-    char* condp = base + bufsz * 7;
+    const int nbuf = h->conv_mode == 1 ? 8 : 7;
+    float* buf[8];
+    for (int i = 0; i < 8; ++i) buf[i] = (float*)(base + bufsz * (i < nbuf ? i : 0));
+    char* condp = base + bufsz * nbuf;
+    float* SP = buf[7];                                  // f16 x 3 mode: the token-major (hi, lo) halves of the conv input
     float *P = buf[0], *X = buf[1], *XS = buf[2], *T1 = buf[3], *T2 = buf[4], *RA = buf[5], *RB = buf[6];
     const int ND = c.num_dilations;
     int rc;
@@ -569,6 +626,20 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
                      7, 1, lens, 1, 0, 1.f, st); }
     if (rc) return rc;
 
+    // a resblock conv: exact f32 MFMA, or (opt-in) the activation split into token-major f16 (hi, lo) + the f16 x 3 kernel
+    auto res_conv = [&](const ConvL& L, const float* xin, const float* res, float* yout, int ch_, int t_, int kk_, int dil_, int mult_, int mode_,
+                        float div_) -> int {
+        if (!L.w3) return conv1d_impl(xin, L.w.p, L.b.p, nullptr, res, yout, B, ch_, ch_, t_, kk_, dil_, lens, mult_, mode_, div_, st);
+        void* sh = SP;
+        void* sl = (char*)SP + (size_t)B * t_ * ch_ * 2;
+        int rc2 = launch_split_tm(xin, sh, sl, B, ch_, t_, lens, mult_, st);
+        if (rc2) return rc2;
+        ConvH3Args g{};
+        g.xh = sh; g.xl = sl; g.wp = L.w3; g.bias = L.b.p; g.res = res; g.y = yout; g.zero_row = h->zero_row; g.lens = lens; g.len_mult = mult_;
+        g.B = B; g.Cin = ch_; g.Cout = ch_; g.T = t_; g.k = kk_; g.dil = dil_; g.acc_mode = mode_; g.div = div_;
+        return launch_conv_h3(g, st);
+    };
+
     int t_cur = T, mult = 1;
     for (int i = 0; i < c.num_upsamples; ++i) {
         const int Cin = c.upsample_initial_channel >> i, ch = stage_channels(c, i);
@@ -591,7 +662,7 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
                   rc = launch_aa_act(cur, T1, a1.alpha.p, a1.beta.p, a1.fu.p, a1.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st); }
                 if (rc) return rc;
                 { ProfScope ps(h, st, PC_CONV, conv_flops(ch, ch, kk, t_cur), tensor_bytes(2 * ch, t_cur));
-                  rc = conv1d_impl(T1, c1.w.p, c1.b.p, nullptr, nullptr, T2, B, ch, ch, t_cur, kk, c.resblock_dilations[j][d], lens, mult, 0, 1.f, st); }
+                  rc = res_conv(c1, T1, nullptr, T2, ch, t_cur, kk, c.resblock_dilations[j][d], mult, 0, 1.f); }
                 if (rc) return rc;
                 { ProfScope ps(h, st, PC_ACT, 0, tensor_bytes(2 * ch, t_cur));
                   rc = launch_aa_act(T2, T1, a2.alpha.p, a2.beta.p, a2.fu.p, a2.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st); }
@@ -599,7 +670,7 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
                 if (d < ND - 1) {
                     float* nxt = (cur == RA) ? RB : RA;
                     { ProfScope ps(h, st, PC_CONV, conv_flops(ch, ch, kk, t_cur), tensor_bytes(3 * ch, t_cur));
-                      rc = conv1d_impl(T1, c2.w.p, c2.b.p, nullptr, cur, nxt, B, ch, ch, t_cur, kk, 1, lens, mult, 0, 1.f, st); }
+                      rc = res_conv(c2, T1, cur, nxt, ch, t_cur, kk, 1, mult, 0, 1.f); }
                     if (rc) return rc;
                     cur = nxt;
                 } else {
@@ -607,7 +678,7 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
                     int mode = (j == 0) ? 0 : 1;
                     if (j == c.num_kernels - 1) mode = (c.num_kernels == 1) ? 0 : 2;
                     { ProfScope ps(h, st, PC_CONV, conv_flops(ch, ch, kk, t_cur), tensor_bytes((mode ? 4 : 3) * ch, t_cur));
-                      rc = conv1d_impl(T1, c2.w.p, c2.b.p, nullptr, cur, XS, B, ch, ch, t_cur, kk, 1, lens, mult, mode, (float)c.num_kernels, st); }
+                      rc = res_conv(c2, T1, cur, XS, ch, t_cur, kk, 1, mult, mode, (float)c.num_kernels); }
                     if (rc) return rc;
                 }
             }
