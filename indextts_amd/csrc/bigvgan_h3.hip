@@ -1,6 +1,7 @@
 // Opt-in second vocoder mode: the resblock Conv1d's on the f16 matrix cores with SPLIT f32 operands ("f16 x 3").
 //
-//   x = xh + 2^-11 xl,  xh = f16(x),  xl = f16(2^11 (x - xh))          (22 significand bits; the scale keeps xl a normal f16)
+//   x = xh + 2^-11 xl,  xh = f16(x) (0 where that would be an f16 subnormal),  xl = f16(2^11 (x - xh))
+//                                      (22 significand bits; the scale keeps xl a normal f16 down to |x| = 3e-8)
 //   w = wh + 2^-11 wl,  likewise (packed once at load time)
 //   y = sum xh wh  +  2^-11 ( sum xh wl + sum xl wh )                   (the xl wl term, 2^-22 relative, is dropped)
 //
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void split_tm_kernel(const float* __restrict__
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const float f = tile[cb + 2 * e + s][tid >> 2];
-                const _Float16 h = (_Float16)f;
+                const _Float16 h = fabsf(f) < 6.103515625e-05f ? (_Float16)0.0f : (_Float16)f;     // no subnormal high part: xl carries it
                 const _Float16 l = (_Float16)((f - (float)h) * 2048.0f);
                 hh |= (uint32_t)__builtin_bit_cast(u16, h) << (16 * s);
                 ll |= (uint32_t)__builtin_bit_cast(u16, l) << (16 * s);
@@ -89,12 +90,11 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(ConvH3Args a) {
     const int ntiles = (a.Cout + 15) >> 4;
     const int pad = (a.k - 1) / 2 * a.dil;
 
-    // ---- staging sources.  A chunk = 16 frames x 64 bytes, held as 8 lines of 128 bytes (two frames per line) with the 16-byte
-    // pieces of a line XOR-swizzled so that a fragment read (16 frames x 4 k-groups) is conflict-free for every ds_read_b128
-    // lane group: piece' = (((frame & 1) << 2) | kgroup) ^ (((line >> 2) & 1) << 1).  The swizzle is applied on the source side.
-    const int line = lane >> 3;
-    const int p = (lane & 7) ^ (((line >> 2) & 1) << 1);
-    const int srow = line * 2 + (p >> 2), skp = p & 3;
+    // ---- staging sources.  A chunk = 16 frames x 64 bytes, held K-GROUP MAJOR: piece (frame r, k-group q) at q * 256 + r * 16.
+    // A ds_read_b128 lane group takes 8 frames of one k-group and the other 8 frames of its neighbour ({0-3, 12-15} / {4-11}),
+    // and bank = frame mod 16 -> conflict-free, also when the 16 frames start at any row offset (the window kernel's taps).
+    // The DMA writes lane l to byte 16 l of the chunk, so lane l fetches (frame l & 15, k-group l >> 4).
+    const int srow = lane & 15, skp = lane >> 4;
     int arow[2];
     const char* bsrc_h[2];
     const char* bsrc_l[2];
@@ -140,9 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(ConvH3Args a) {
 
     // fragment read offsets
     const int row16 = lane & 15, kg = lane >> 4;
-    const int fline = row16 >> 1;
-    const int fp = ((((row16 & 1) << 2) | kg) ^ (((fline >> 2) & 1) << 1));
-    const int a_off = wr * 4 * 1024 + fline * 128 + fp * 16;
+    const int a_off = wr * 4 * 1024 + kg * 256 + row16 * 16;
     const int b_off = 16384 + wc * 4 * 1024 + lane * 16;
 
     issue(0, 0);
@@ -220,6 +218,177 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(ConvH3Args a) {
     }
 }
 
+// ---- second kernel: 256 frames x 128 channels per block (8 waves), the A operand held as a WINDOW -------------------------------
+// For one 32-channel chunk kc every tap reads the same frames shifted by j * dil, so the (hi, lo) rows of frames
+// m0 - pad .. m0 + 255 + pad are staged ONCE per chunk (double-buffered) and a tap's fragments are read at a row offset; only the
+// weights stream per (tap, chunk) K tile, through a 4-deep ring so a tile is requested three K tiles (~4 600 cycles) before it is
+// used -- the two-stage pipeline of conv_h3_kernel had one tile of lookahead (~770 cycles) against ~1 500 of L2 latency.
+// DMA bytes per 128 frames and chunk at k = 11: 107 KB against 352 KB.  Needs (k - 1) * dil <= 48 (19 row chunks).
+#define H3W_BM 256
+#define H3W_ACH 19                         // 16-row chunks of the window: 256 + 48
+#define H3W_ABUF (2 * H3W_ACH * 1024)      // hi + lo
+#define H3W_WST 16384                      // one K tile of weights: hi 8 KiB | lo 8 KiB
+#define H3W_LDS (2 * H3W_ABUF + 4 * H3W_WST)
+
+template <int N>
+__device__ __forceinline__ void h3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h3w_kernel(ConvH3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int L = blockIdx.x;
+    const int xcd = L & 7, slot = L >> 3;
+    const int tile = (slot / a.n_co) * 8 + xcd;
+    if (tile >= a.n_mt * a.B) return;
+    const int b = tile / a.n_mt;
+    const int m0 = (tile - b * a.n_mt) * H3W_BM;
+    const int co0 = (slot % a.n_co) * H3_BN;
+    const int len = a.lens ? min(a.lens[b] * a.len_mult, a.T) : a.T;
+    if (m0 >= len) return;
+    const int nkc = a.Cin / H3_BK, G = a.k * nkc;
+    const int ntiles = (a.Cout + 15) >> 4;
+    const int pad = (a.k - 1) / 2 * a.dil;
+    const int nach = (H3W_BM + 2 * pad + 15) >> 4;                      // row chunks of the window actually needed
+
+    const int srow = lane & 15, skp = lane >> 4;                        // k-group-major chunks, as in conv_h3_kernel
+    const char* xh_b = (const char*)a.xh + ((size_t)b * a.T * a.Cin + skp * 8) * 2;
+    const char* xl_b = (const char*)a.xl + ((size_t)b * a.T * a.Cin + skp * 8) * 2;
+    const char* zr = (const char*)a.zero_row;
+    // three window chunks per wave and stream (a wave past the end repeats the last chunk: same bytes to the same place), so every
+    // wave issues the same number of DMA instructions and the counted waits below hold for all of them
+    auto issue_a = [&](int kc, int buf) {
+        char* base = sm + buf * H3W_ABUF;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int c = w + 8 * i;
+            c = c < nach ? c : nach - 1;
+            const int t = m0 - pad + c * 16 + srow;
+            const bool ok = (unsigned)t < (unsigned)a.T;
+            const size_t o = ((size_t)(ok ? t : 0) * a.Cin + kc * H3_BK) * 2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? xh_b + o : zr),
+                                             (__attribute__((address_space(3))) void*)(base + c * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? xl_b + o : zr),
+                                             (__attribute__((address_space(3))) void*)(base + (H3W_ACH + c) * 1024), 16, 0, 0);
+        }
+    };
+    int ntw = (co0 >> 4) + w;                                           // this wave's n-tile of the weight stage (8 per K tile)
+    ntw = ntw < ntiles ? ntw : ntiles - 1;
+    const char* wsrc_h = (const char*)a.wp + (size_t)ntw * G * 1024 + lane * 16;
+    const char* wsrc_l = wsrc_h + (size_t)ntiles * G * 1024;
+    auto issue_w = [&](int g) {                                         // K tile g = (chunk g / k, tap g % k); packed index tap * nkc + chunk
+        const int kc = g / a.k, j = g - kc * a.k;
+        const size_t kt = (size_t)j * nkc + kc;
+        char* base = sm + 2 * H3W_ABUF + (g & 3) * H3W_WST;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc_h + kt * 1024),
+                                         (__attribute__((address_space(3))) void*)(base + w * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc_l + kt * 1024),
+                                         (__attribute__((address_space(3))) void*)(base + 8192 + w * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc_h[4][4], acc_l[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) { acc_h[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_l[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int row16 = lane & 15, kg = lane >> 4;
+    const int b_off = wc * 4 * 1024 + lane * 16;
+
+    issue_a(0, 0);
+    issue_w(0);
+    if (G > 1) issue_w(1);
+    if (G > 2) issue_w(2);
+    for (int g = 0; g < G; ++g) {
+        const int kc = g / a.k, j = g - kc * a.k;
+        // wait for weight tile g (and the window of its chunk): everything issued after it may stay in flight
+        const int later_w = (G - 1 - g) < 2 ? (G - 1 - g) : 2;
+        const bool a_recent = (g >= 1 && (g - 1) % a.k == 0 && (g - 1) / a.k + 1 < nkc) || (g >= 2 && (g - 2) % a.k == 0 && (g - 2) / a.k + 1 < nkc);
+        const int allow = 2 * later_w + (a_recent ? 6 : 0);
+        switch (allow) {
+            case 0: h3_wait_vm<0>(); break;
+            case 2: h3_wait_vm<2>(); break;
+            case 4: h3_wait_vm<4>(); break;
+            case 6: h3_wait_vm<6>(); break;
+            case 8: h3_wait_vm<8>(); break;
+            default: h3_wait_vm<10>(); break;
+        }
+        __syncthreads();
+        if (g + 3 < G) issue_w(g + 3);
+        if (j == 0 && kc + 1 < nkc) issue_a(kc + 1, (kc + 1) & 1);
+        const char* abase = sm + (kc & 1) * H3W_ABUF;
+        const char* wbase = sm + 2 * H3W_ABUF + (g & 3) * H3W_WST;
+        v4u32 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int rr = (wr * 4 + mt) * 16 + row16 + j * a.dil;      // window row of this lane's frame for tap j
+            const int off = (rr >> 4) * 1024 + kg * 256 + (rr & 15) * 16;
+            ah[mt] = *(const v4u32*)(abase + off);
+            al[mt] = *(const v4u32*)(abase + H3W_ACH * 1024 + off);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            bh[nt] = *(const v4u32*)(wbase + b_off + nt * 1024);
+            bl[nt] = *(const v4u32*)(wbase + 8192 + b_off + nt * 1024);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc_h[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bh[nt]),
+                                                                       acc_h[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc_l[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bl[nt]),
+                                                                       acc_l[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc_l[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[mt]), __builtin_bit_cast(f16x8, bh[nt]),
+                                                                       acc_l[mt][nt], 0, 0, 0);
+    }
+
+    const bool vec = (a.T & 3) == 0;
+    float* yb = a.y + (size_t)b * a.Cout * a.T;
+    const float* rb = a.res ? a.res + (size_t)b * a.Cout * a.T : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int co = co0 + (wc * 4 + nt) * 16 + (lane & 15);
+        if (co >= a.Cout) continue;
+        const float bias = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int t = m0 + (wr * 4 + mt) * 16 + (lane >> 4) * 4;
+            if (t >= len) continue;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc_h[mt][nt][r] + acc_l[mt][nt][r] * (1.0f / 2048.0f) + bias;
+            const size_t o = (size_t)co * a.T + t;
+            if (vec && t + 3 < len) {
+                if (rb) { const f32x4 rv = *(const f32x4*)(rb + o); v += rv; }
+                if (a.acc_mode != 0) {
+                    const f32x4 yo = *(const f32x4*)(yb + o);
+                    v = yo + v;
+                    if (a.acc_mode == 2) v = v / a.div;
+                }
+                *(f32x4*)(yb + o) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (t + r >= len) break;
+                    float s = v[r];
+                    if (rb) s += rb[o + r];
+                    if (a.acc_mode != 0) { s = yb[o + r] + s; if (a.acc_mode == 2) s = s / a.div; }
+                    yb[o + r] = s;
+                }
+            }
+        }
+    }
+}
+
 size_t conv_h3_packed_bytes(int Cout, int Cin, int k) {
     return (size_t)2 * ((Cout + 15) / 16) * ((size_t)k * (Cin / H3_BK)) * 1024;
 }
@@ -242,7 +411,7 @@ int conv_h3_pack(const float* w, int Cout, int Cin, int k, void* out) {
                     for (int e = 0; e < 8; ++e) {
                         const int co = nt * 16 + (lane & 15), ci = kc * H3_BK + (lane >> 4) * 8 + e;
                         const float f = co < Cout ? w[((size_t)co * Cin + ci) * k + j] : 0.f;
-                        const _Float16 h = (_Float16)f;
+                        const _Float16 h = (f < 6.103515625e-05f && f > -6.103515625e-05f) ? (_Float16)0.0f : (_Float16)f;
                         const _Float16 l = (_Float16)((f - (float)h) * 2048.0f);
                         if (!(f - f == 0.f) || !((float)h - (float)h == 0.f)) {
                             itts_set_error("conv_h3_pack: weight %g is outside the f16 range", (double)f);
@@ -267,14 +436,22 @@ int launch_conv_h3(const ConvH3Args& a0, hipStream_t st) {
     if (a0.B <= 0 || a0.T <= 0) return ITTS_OK;
     if (a0.Cin % H3_BK || !(a0.k & 1) || a0.Cout < 1) { itts_set_error("conv_h3: need C_in %% 32 == 0 and odd k"); return ITTS_ERR_ARG; }
     if ((long long)a0.Cout * a0.T >= (1ll << 31) || (long long)a0.Cin * a0.T >= (1ll << 31)) { itts_set_error("conv_h3: row plane too large"); return ITTS_ERR_ARG; }
-    HIP_TRY(hipFuncSetAttribute((const void*)conv_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS));
+    // ITTS_H3_KERNEL: 0 = the 128-frame two-stage kernel everywhere, 1 (default) = the 256-frame window kernel where the taps fit
+    static const int which = [] { const char* e = getenv("ITTS_H3_KERNEL"); return e ? atoi(e) : 1; }();
+    const bool win = which != 0 && a0.k >= 3 && (a0.k - 1) * a0.dil <= 48;     // the counted waits need the window requested >= 3 K tiles ahead
     ConvH3Args a = a0;
-    a.n_mt = ceil_div(a.T, H3_BM);
+    a.n_mt = ceil_div(a.T, win ? H3W_BM : H3_BM);
     a.n_co = ceil_div(a.Cout, H3_BN);
     const long long tiles8 = ((long long)a.n_mt * a.B + 7) / 8 * 8;
     const long long nblocks = tiles8 * a.n_co;
     if (nblocks > 2147483647ll) { itts_set_error("conv_h3: grid too large"); return ITTS_ERR_ARG; }
-    hipLaunchKernelGGL(conv_h3_kernel, dim3((unsigned)nblocks), dim3(256), H3_LDS, st, a);
+    if (win) {
+        HIP_TRY(hipFuncSetAttribute((const void*)conv_h3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H3W_LDS));
+        hipLaunchKernelGGL(conv_h3w_kernel, dim3((unsigned)nblocks), dim3(512), H3W_LDS, st, a);
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void*)conv_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS));
+        hipLaunchKernelGGL(conv_h3_kernel, dim3((unsigned)nblocks), dim3(256), H3_LDS, st, a);
+    }
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }

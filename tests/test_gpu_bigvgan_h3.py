@@ -25,7 +25,10 @@ H3_CASES = [
     (192, 192, 11, 3, 260, 1),     # 1.5 co tiles of 128
     (96, 96, 7, 5, 515, 2),        # 4+ frame tiles, dilated taps reaching 15 frames out
     (32, 48, 3, 1, 77, 3),         # fewer n-tiles than a block stages (clamped), one K tile per tap
-    (384, 384, 7, 1, 128, 1),      # exactly one frame tile
+    (384, 384, 7, 1, 128, 1),      # exactly one frame tile of the 128-frame kernel
+    (64, 64, 11, 5, 300, 2),       # taps reach 25 frames out: beyond the window kernel's 48-frame span -> the 128-frame kernel
+    (64, 64, 1, 1, 100, 1),        # k = 1 -> the 128-frame kernel
+    (128, 128, 3, 3, 1000, 1),     # four 256-frame tiles of the window kernel, ragged last one
 ]
 
 
