@@ -100,6 +100,9 @@ int itts_bigvgan_device(const itts_bigvgan* h);   /* Conv mode of the generator'
  * mode), 1 = f16 x 3 split operands (itts_conv1d_h3_forward) for the resblocks with >= min_channels channels (0 = default 96);
  * everything else (conv_pre / upsamplers / conv_post / activations) is unchanged. */
 int itts_bigvgan_set_conv_mode(itts_bigvgan* h, int mode, int min_channels);
+/* f16 x 3 mode only: 1 if a forward since the last call met an activation that is not finite or not below 65504 in magnitude (that
+ * forward's output is invalid -- use mode 0), else 0; synchronises the device and clears the flag; < 0 on error. */
+int itts_bigvgan_range_check(itts_bigvgan* h);
 /* device index the handle is bound to */
 int itts_bigvgan_load_tensor(itts_bigvgan* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
 int itts_bigvgan_finalize(itts_bigvgan* h);       /* checks every required tensor arrived */

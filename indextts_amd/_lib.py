@@ -65,6 +65,7 @@ SIGNATURES = {
     "itts_bigvgan_device": (C.c_int, [vp]),
     "itts_bigvgan_load_tensor": (C.c_int, [vp, C.c_char_p, vp, c_i64p, C.c_int]),
     "itts_bigvgan_set_conv_mode": (C.c_int, [vp, C.c_int, C.c_int]),
+    "itts_bigvgan_range_check": (C.c_int, [vp]),
     "itts_conv1d_h3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "itts_pack_conv1d_h3_weight": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "itts_conv1d_h3_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -229,6 +229,11 @@ class BigVGAN:
         rc = _lib.lib().itts_bigvgan_forward(self._h, _lib.ptr(x), _lib.ptr(lens_t), _lib.ptr(spk), _lib.ptr(wav), B, T,
                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
         _lib.check(rc, "itts_bigvgan_forward")
+        if self.conv_mode:                              # the split mode cannot represent values outside the f16 range: fail, never garble
+            bad = _lib.lib().itts_bigvgan_range_check(self._h)
+            if bad:
+                raise _lib.HipEngineError("BigVGAN(conv_mode='f16x3'): an activation was not finite or outside the f16 range "
+                                          "(|x| >= 65504); use the exact f32 mode for this model / input")
         return (wav, None) if v1 else wav
 
     __call__ = forward

@@ -30,8 +30,9 @@ typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 #define H3_LDS (2 * H3_STAGE)
 
 // f32 [B][C][T] -> (hi, lo) f16 [B][T][C]; frames >= the row's length are written as zeros (the conv's zero padding on the right)
+// *range_flag (optional) is set when a value is not finite or outside the f16 range (the mode cannot represent it: the caller fails)
 __global__ __launch_bounds__(256) void split_tm_kernel(const float* __restrict__ x, u16* __restrict__ xh, u16* __restrict__ xl, int C, int T,
-                                                       const int* __restrict__ lens, int len_mult) {
+                                                       const int* __restrict__ lens, int len_mult, int* __restrict__ range_flag) {
     __shared__ float tile[64][65];
     const int b = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -43,8 +44,13 @@ __global__ __launch_bounds__(256) void split_tm_kernel(const float* __restrict__
         const int c = c0 + w * 16 + i, t = t0 + lane;
         v[i] = (c < C && t < len) ? xb[(size_t)c * T + t] : 0.f;
     }
+    bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tile[w * 16 + i][lane] = v[i];
+    for (int i = 0; i < 16; ++i) {
+        tile[w * 16 + i][lane] = v[i];
+        bad |= !(fabsf(v[i]) < 65504.0f);
+    }
+    if (range_flag && __any(bad) && lane == 0) atomicOr(range_flag, 1);
     __syncthreads();
     const int t = t0 + (tid >> 2), cq = tid & 3;
     if (t >= T) return;
@@ -424,10 +430,10 @@ int conv_h3_pack(const float* w, int Cout, int Cin, int k, void* out) {
     return ITTS_OK;
 }
 
-int launch_split_tm(const float* x, void* xh, void* xl, int B, int C, int T, const int* lens, int len_mult, hipStream_t st) {
+int launch_split_tm(const float* x, void* xh, void* xl, int B, int C, int T, const int* lens, int len_mult, int* range_flag, hipStream_t st) {
     if (B <= 0 || C <= 0 || T <= 0) return ITTS_OK;
     if (C % 8) { itts_set_error("split_tm: C %% 8 != 0"); return ITTS_ERR_ARG; }
-    hipLaunchKernelGGL(split_tm_kernel, dim3(ceil_div(T, 64), ceil_div(C, 64), B), dim3(256), 0, st, x, (u16*)xh, (u16*)xl, C, T, lens, len_mult);
+    hipLaunchKernelGGL(split_tm_kernel, dim3(ceil_div(T, 64), ceil_div(C, 64), B), dim3(256), 0, st, x, (u16*)xh, (u16*)xl, C, T, lens, len_mult, range_flag);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }

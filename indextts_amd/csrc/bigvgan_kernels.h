@@ -41,5 +41,5 @@ struct ConvH3Args {
 };
 size_t conv_h3_packed_bytes(int Cout, int Cin, int k);
 int conv_h3_pack(const float* w, int Cout, int Cin, int k, void* out);
-int launch_split_tm(const float* x, void* xh, void* xl, int B, int C, int T, const int* lens, int len_mult, hipStream_t st);
+int launch_split_tm(const float* x, void* xh, void* xl, int B, int C, int T, const int* lens, int len_mult, int* range_flag, hipStream_t st);
 int launch_conv_h3(const ConvH3Args& a, hipStream_t st);

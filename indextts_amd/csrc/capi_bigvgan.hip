@@ -123,7 +123,7 @@ extern "C" int itts_conv1d_h3_forward(const float* x, const void* wp3, const flo
     const size_t half = (size_t)B * T * Cin * 2;
     void* zr = base + half * 2;                           // the zero row lives behind the two halves
     HIP_TRY(hipMemsetAsync(zr, 0, 64, st));
-    int rc = launch_split_tm(x, base, base + half, B, Cin, T, lens, len_mult < 1 ? 1 : len_mult, st);
+    int rc = launch_split_tm(x, base, base + half, B, Cin, T, lens, len_mult < 1 ? 1 : len_mult, nullptr, st);
     if (rc) return rc;
     ConvH3Args g{};
     g.xh = base; g.xl = base + half; g.wp = wp3; g.bias = bias; g.res = res; g.y = y; g.zero_row = zr; g.lens = lens; g.len_mult = len_mult < 1 ? 1 : len_mult;
@@ -309,6 +309,18 @@ extern "C" int itts_bigvgan_set_conv_mode(itts_bigvgan* h, int mode, int min_cha
         h->zero_row = z;
     }
     return ITTS_OK;
+}
+
+// f16 x 3 mode: 1 if a forward since the last call met an activation that is not finite or outside the f16 range (the result of
+// that forward is invalid), else 0; synchronises the device and clears the flag.  < 0 on error.
+extern "C" int itts_bigvgan_range_check(itts_bigvgan* h) {
+    if (!h) return -1;
+    if (!h->zero_row) return 0;
+    ItDevGuard dg(h->device);
+    int v = 0;
+    if (hipMemcpy(&v, (char*)h->zero_row + 128, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (v && hipMemset((char*)h->zero_row + 128, 0, 4) != hipSuccess) return -1;
+    return v ? 1 : 0;
 }
 
 extern "C" void itts_bigvgan_destroy(itts_bigvgan* h) {
@@ -632,7 +644,7 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
         if (!L.w3) return conv1d_impl(xin, L.w.p, L.b.p, nullptr, res, yout, B, ch_, ch_, t_, kk_, dil_, lens, mult_, mode_, div_, st);
         void* sh = SP;
         void* sl = (char*)SP + (size_t)B * t_ * ch_ * 2;
-        int rc2 = launch_split_tm(xin, sh, sl, B, ch_, t_, lens, mult_, st);
+        int rc2 = launch_split_tm(xin, sh, sl, B, ch_, t_, lens, mult_, (int*)((char*)h->zero_row + 128), st);
         if (rc2) return rc2;
         ConvH3Args g{};
         g.xh = sh; g.xl = sl; g.wp = L.w3; g.bias = L.b.p; g.res = res; g.y = yout; g.zero_row = h->zero_row; g.lens = lens; g.len_mult = mult_;

@@ -108,3 +108,17 @@ def test_generator_f16x3_ragged_rows_equal_solo():
     for b, n in enumerate(lens):
         solo = m(mel[b:b + 1, :, :n].to(DEV)).cpu()
         assert float((wav[b, ..., : n * 256] - solo[0]).abs().max()) <= 1e-6
+
+
+def test_generator_f16x3_out_of_range_activation_raises():
+    from indextts_amd import _lib, bigvgan as bv
+    h = dict(O.V2_HPARAMS, upsample_initial_channel=512)
+    sd = O.synth_weights(h, seed=11)
+    m = bv.BigVGAN(h, conv_mode="f16x3", h3_min_channels=32)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    mel = torch.randn(1, 80, 12, generator=torch.Generator().manual_seed(3))
+    m(mel.to(DEV))                                               # in range: fine
+    with pytest.raises(_lib.HipEngineError):
+        m((mel * 1e7).to(DEV))                                   # drives the resblock inputs beyond 65504
+    m(mel.to(DEV))                                               # the flag was cleared: the model keeps working
