@@ -2,7 +2,7 @@
 # full validation of the round: every GPU test, smoke(), the default bench line, and a rocprofv3 kernel-stats pass of one bench step
 set -u
 cd "$(dirname "$0")/.."
-O=gpurun_out/r03a
+O=gpurun_out/r02zf
 mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" > $O/status.txt
 tail -4 $O/pytest_gpu.log > $O/pytest_gpu_tail.txt
