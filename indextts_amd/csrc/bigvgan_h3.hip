@@ -224,22 +224,39 @@ __global__ __launch_bounds__(256, 2) void conv_h3_kernel(ConvH3Args a) {
     }
 }
 
-// ---- second kernel: 256 frames x 128 channels per block (8 waves), the A operand held as a WINDOW -------------------------------
+// ---- second kernel: (64 MT) frames x (32 NT) channels per block (8 waves as 4 x 2), the A operand held as a WINDOW ----------------
 // For one 32-channel chunk kc every tap reads the same frames shifted by j * dil, so the (hi, lo) rows of frames
-// m0 - pad .. m0 + 255 + pad are staged ONCE per chunk (double-buffered) and a tap's fragments are read at a row offset; only the
+// m0 - pad .. m0 + BM - 1 + pad are staged ONCE per chunk (double-buffered) and a tap's fragments are read at a row offset; only the
 // weights stream per (tap, chunk) K tile, through a 4-deep ring so a tile is requested three K tiles (~4 600 cycles) before it is
 // used -- the two-stage pipeline of conv_h3_kernel had one tile of lookahead (~770 cycles) against ~1 500 of L2 latency.
-// DMA bytes per 128 frames and chunk at k = 11: 107 KB against 352 KB.  Needs (k - 1) * dil <= 48 (19 row chunks).
-#define H3W_BM 256
-#define H3W_ACH 19                         // 16-row chunks of the window: 256 + 48
-#define H3W_ABUF (2 * H3W_ACH * 1024)      // hi + lo
-#define H3W_WST 16384                      // one K tile of weights: hi 8 KiB | lo 8 KiB
-#define H3W_LDS (2 * H3W_ABUF + 4 * H3W_WST)
-
+// DMA bytes per 128 frames and chunk at k = 11 (256 x 128 tile): 107 KB against 352 KB.  Needs 3 <= k and (k - 1) * dil <= 48.
+// Tile shapes: <4,4> 256 x 128 (the wide stages), <3,6> 192 x 192 and <4,3> 256 x 96 so that 192 / 96 output channels fill the tile.
 template <int N>
 __device__ __forceinline__ void h3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int WI>     // DMA instructions per wave and weight stage
+__device__ __forceinline__ void h3_wait_allow(int later_w, bool a_recent) {
+    if (!a_recent) {
+        if (later_w == 0) h3_wait_vm<0>(); else if (later_w == 1) h3_wait_vm<WI>(); else h3_wait_vm<2 * WI>();
+    } else {
+        if (later_w == 0) h3_wait_vm<6>(); else if (later_w == 1) h3_wait_vm<WI + 6>(); else h3_wait_vm<2 * WI + 6>();
+    }
+}
+
+template <int MT, int NT>
+struct H3W {
+    static constexpr int BM = 64 * MT, BN = 32 * NT;
+    static constexpr int ACH = (BM + 48) / 16;              // 16-row chunks of the window
+    static constexpr int ABUF = 2 * ACH * 1024;             // hi + lo
+    static constexpr int NWT = 2 * NT;                      // n-tiles of a weight stage
+    static constexpr int WPW = (NWT + 7) / 8;               // n-tiles a wave stages per stream
+    static constexpr int WST = 2 * NWT * 1024;              // hi | lo
+    static constexpr int LDS = 2 * ABUF + 4 * WST;
+};
+
+template <int MT, int NT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_h3w_kernel(ConvH3Args a) {
+    using S = H3W<MT, NT>;
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = w >> 1, wc = w & 1;
@@ -248,14 +265,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tile = (slot / a.n_co) * 8 + xcd;
     if (tile >= a.n_mt * a.B) return;
     const int b = tile / a.n_mt;
-    const int m0 = (tile - b * a.n_mt) * H3W_BM;
-    const int co0 = (slot % a.n_co) * H3_BN;
+    const int m0 = (tile - b * a.n_mt) * S::BM;
+    const int co0 = (slot % a.n_co) * S::BN;
     const int len = a.lens ? min(a.lens[b] * a.len_mult, a.T) : a.T;
     if (m0 >= len) return;
     const int nkc = a.Cin / H3_BK, G = a.k * nkc;
     const int ntiles = (a.Cout + 15) >> 4;
     const int pad = (a.k - 1) / 2 * a.dil;
-    const int nach = (H3W_BM + 2 * pad + 15) >> 4;                      // row chunks of the window actually needed
+    const int nach = (S::BM + 2 * pad + 15) >> 4;                       // row chunks of the window actually needed
 
     const int srow = lane & 15, skp = lane >> 4;                        // k-group-major chunks, as in conv_h3_kernel
     const char* xh_b = (const char*)a.xh + ((size_t)b * a.T * a.Cin + skp * 8) * 2;
@@ -263,111 +280,120 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const char* zr = (const char*)a.zero_row;
     // three window chunks per wave and stream (a wave past the end repeats the last chunk: same bytes to the same place), so every
     // wave issues the same number of DMA instructions and the counted waits below hold for all of them
-    auto issue_a = [&](int kc, int buf) {
-        char* base = sm + buf * H3W_ABUF;
+    auto issue_a = [&](int kc_, int buf) {
+        char* base = sm + buf * S::ABUF;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             int c = w + 8 * i;
             c = c < nach ? c : nach - 1;
             const int t = m0 - pad + c * 16 + srow;
             const bool ok = (unsigned)t < (unsigned)a.T;
-            const size_t o = ((size_t)(ok ? t : 0) * a.Cin + kc * H3_BK) * 2;
+            const size_t o = ((size_t)(ok ? t : 0) * a.Cin + kc_ * H3_BK) * 2;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? xh_b + o : zr),
                                              (__attribute__((address_space(3))) void*)(base + c * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? xl_b + o : zr),
-                                             (__attribute__((address_space(3))) void*)(base + (H3W_ACH + c) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + (S::ACH + c) * 1024), 16, 0, 0);
         }
     };
-    int ntw = (co0 >> 4) + w;                                           // this wave's n-tile of the weight stage (8 per K tile)
-    ntw = ntw < ntiles ? ntw : ntiles - 1;
-    const char* wsrc_h = (const char*)a.wp + (size_t)ntw * G * 1024 + lane * 16;
-    const char* wsrc_l = wsrc_h + (size_t)ntiles * G * 1024;
+    const char* wsrc_h[S::WPW];
+    int wslot[S::WPW];
+#pragma unroll
+    for (int i = 0; i < S::WPW; ++i) {
+        int ntl = w + 8 * i;                                            // n-tile of the stage (a wave past the end repeats the last one)
+        ntl = ntl < S::NWT ? ntl : S::NWT - 1;
+        int ntg = (co0 >> 4) + ntl;
+        ntg = ntg < ntiles ? ntg : ntiles - 1;
+        wslot[i] = ntl * 1024;
+        wsrc_h[i] = (const char*)a.wp + (size_t)ntg * G * 1024 + lane * 16;
+    }
+    const size_t wstream = (size_t)ntiles * G * 1024;
     auto issue_w = [&](int g) {                                         // K tile g = (chunk g / k, tap g % k); packed index tap * nkc + chunk
-        const int kc = g / a.k, j = g - kc * a.k;
-        const size_t kt = (size_t)j * nkc + kc;
-        char* base = sm + 2 * H3W_ABUF + (g & 3) * H3W_WST;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc_h + kt * 1024),
-                                         (__attribute__((address_space(3))) void*)(base + w * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc_l + kt * 1024),
-                                         (__attribute__((address_space(3))) void*)(base + 8192 + w * 1024), 16, 0, 0);
+        const int kc_ = g / a.k, j_ = g - kc_ * a.k;
+        const size_t kt = (size_t)j_ * nkc + kc_;
+        char* base = sm + 2 * S::ABUF + (g & 3) * S::WST;
+#pragma unroll
+        for (int i = 0; i < S::WPW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc_h[i] + kt * 1024),
+                                             (__attribute__((address_space(3))) void*)(base + wslot[i]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc_h[i] + wstream + kt * 1024),
+                                             (__attribute__((address_space(3))) void*)(base + S::NWT * 1024 + wslot[i]), 16, 0, 0);
+        }
     };
 
-    f32x4 acc_h[4][4], acc_l[4][4];
+    f32x4 acc_h[MT][NT], acc_l[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn) { acc_h[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_l[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int jn = 0; jn < NT; ++jn) { acc_h[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_l[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const int row16 = lane & 15, kg = lane >> 4;
-    const int b_off = wc * 4 * 1024 + lane * 16;
+    const int b_off = wc * NT * 1024 + lane * 16;
 
     issue_a(0, 0);
     issue_w(0);
     if (G > 1) issue_w(1);
     if (G > 2) issue_w(2);
+    // (kc, j) of K tile g, and how many iterations ago a window was requested (3 = not within the last two), kept incrementally
+    int kc = 0, j = 0, a_age = 3;
     for (int g = 0; g < G; ++g) {
-        const int kc = g / a.k, j = g - kc * a.k;
         // wait for weight tile g (and the window of its chunk): everything issued after it may stay in flight
-        const int later_w = (G - 1 - g) < 2 ? (G - 1 - g) : 2;
-        const bool a_recent = (g >= 1 && (g - 1) % a.k == 0 && (g - 1) / a.k + 1 < nkc) || (g >= 2 && (g - 2) % a.k == 0 && (g - 2) / a.k + 1 < nkc);
-        const int allow = 2 * later_w + (a_recent ? 6 : 0);
-        switch (allow) {
-            case 0: h3_wait_vm<0>(); break;
-            case 2: h3_wait_vm<2>(); break;
-            case 4: h3_wait_vm<4>(); break;
-            case 6: h3_wait_vm<6>(); break;
-            case 8: h3_wait_vm<8>(); break;
-            default: h3_wait_vm<10>(); break;
-        }
+        h3_wait_allow<2 * S::WPW>((G - 1 - g) < 2 ? (G - 1 - g) : 2, a_age <= 2);
         __syncthreads();
-        if (g + 3 < G) issue_w(g + 3);
-        if (j == 0 && kc + 1 < nkc) issue_a(kc + 1, (kc + 1) & 1);
-        const char* abase = sm + (kc & 1) * H3W_ABUF;
-        const char* wbase = sm + 2 * H3W_ABUF + (g & 3) * H3W_WST;
-        v4u32 ah[4], al[4], bh[4], bl[4];
+        const char* abase = sm + (kc & 1) * S::ABUF;
+        const char* wbase = sm + 2 * S::ABUF + (g & 3) * S::WST;
+        v4u32 ah[MT], al[MT], bh[NT], bl[NT];
+        const int rbase = wr * MT * 16 + row16 + j * a.dil;             // window row of this lane's first frame for tap j
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int rr = (wr * 4 + mt) * 16 + row16 + j * a.dil;      // window row of this lane's frame for tap j
-            const int off = (rr >> 4) * 1024 + kg * 256 + (rr & 15) * 16;
-            ah[mt] = *(const v4u32*)(abase + off);
-            al[mt] = *(const v4u32*)(abase + H3W_ACH * 1024 + off);
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rr = rbase + mt * 16;
+            ah[mt] = *(const v4u32*)(abase + (rr >> 4) * 1024 + kg * 256 + (rr & 15) * 16);
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            bh[nt] = *(const v4u32*)(wbase + b_off + nt * 1024);
-            bl[nt] = *(const v4u32*)(wbase + 8192 + b_off + nt * 1024);
+        for (int nt = 0; nt < NT; ++nt) bh[nt] = *(const v4u32*)(wbase + b_off + nt * 1024);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bl[nt] = *(const v4u32*)(wbase + S::NWT * 1024 + b_off + nt * 1024);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int rr = rbase + mt * 16;
+            al[mt] = *(const v4u32*)(abase + S::ACH * 1024 + (rr >> 4) * 1024 + kg * 256 + (rr & 15) * 16);
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 acc_h[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bh[nt]),
                                                                        acc_h[mt][nt], 0, 0, 0);
+        // the prefetches go out behind the first MFMA group: their address arithmetic runs in the matrix pipe's shadow instead of
+        // between the barrier and the fragment reads
+        if (g + 3 < G) issue_w(g + 3);
+        a_age = a_age < 3 ? a_age + 1 : 3;
+        if (j == 0 && kc + 1 < nkc) { issue_a(kc + 1, (kc + 1) & 1); a_age = 1; }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 acc_l[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bl[nt]),
                                                                        acc_l[mt][nt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 acc_l[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, al[mt]), __builtin_bit_cast(f16x8, bh[nt]),
                                                                        acc_l[mt][nt], 0, 0, 0);
+        if (++j == a.k) { j = 0; ++kc; }
     }
 
     const bool vec = (a.T & 3) == 0;
     float* yb = a.y + (size_t)b * a.Cout * a.T;
     const float* rb = a.res ? a.res + (size_t)b * a.Cout * a.T : nullptr;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int co = co0 + (wc * 4 + nt) * 16 + (lane & 15);
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = co0 + (wc * NT + nt) * 16 + (lane & 15);
         if (co >= a.Cout) continue;
         const float bias = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int t = m0 + (wr * 4 + mt) * 16 + (lane >> 4) * 4;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int t = m0 + (wr * MT + mt) * 16 + (lane >> 4) * 4;
             if (t >= len) continue;
             f32x4 v;
 #pragma unroll
@@ -393,6 +419,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
+}
+
+template <int MT, int NT>
+static int launch_h3w(ConvH3Args a, hipStream_t st) {
+    using S = H3W<MT, NT>;
+    a.n_mt = ceil_div(a.T, S::BM);
+    a.n_co = ceil_div(a.Cout, S::BN);
+    const long long tiles8 = ((long long)a.n_mt * a.B + 7) / 8 * 8;
+    const long long nblocks = tiles8 * a.n_co;
+    if (nblocks > 2147483647ll) { itts_set_error("conv_h3: grid too large"); return ITTS_ERR_ARG; }
+    HIP_TRY(hipFuncSetAttribute((const void*)conv_h3w_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS));
+    hipLaunchKernelGGL((conv_h3w_kernel<MT, NT>), dim3((unsigned)nblocks), dim3(512), S::LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
 }
 
 size_t conv_h3_packed_bytes(int Cout, int Cin, int k) {
@@ -442,22 +482,29 @@ int launch_conv_h3(const ConvH3Args& a0, hipStream_t st) {
     if (a0.B <= 0 || a0.T <= 0) return ITTS_OK;
     if (a0.Cin % H3_BK || !(a0.k & 1) || a0.Cout < 1) { itts_set_error("conv_h3: need C_in %% 32 == 0 and odd k"); return ITTS_ERR_ARG; }
     if ((long long)a0.Cout * a0.T >= (1ll << 31) || (long long)a0.Cin * a0.T >= (1ll << 31)) { itts_set_error("conv_h3: row plane too large"); return ITTS_ERR_ARG; }
-    // ITTS_H3_KERNEL: 0 = the 128-frame two-stage kernel everywhere, 1 (default) = the 256-frame window kernel where the taps fit
+    // ITTS_H3_KERNEL: 0 = the 128-frame two-stage kernel everywhere, 1 (default) = the window kernel where the taps fit, with the
+    // co tile (128 / 192 / 96 wide) that wastes the fewest columns; 2 = the window kernel with the 128-wide tile only
     static const int which = [] { const char* e = getenv("ITTS_H3_KERNEL"); return e ? atoi(e) : 1; }();
     const bool win = which != 0 && a0.k >= 3 && (a0.k - 1) * a0.dil <= 48;     // the counted waits need the window requested >= 3 K tiles ahead
+    if (win) {
+        auto padded = [&](int bn) { return (long long)ceil_div(a0.Cout, bn) * bn; };
+        int best = 128;
+        if (which == 1) {
+            if (padded(192) < padded(best)) best = 192;
+            if (padded(96) < padded(best)) best = 96;
+        }
+        if (best == 192) return launch_h3w<3, 6>(a0, st);
+        if (best == 96) return launch_h3w<4, 3>(a0, st);
+        return launch_h3w<4, 4>(a0, st);
+    }
     ConvH3Args a = a0;
-    a.n_mt = ceil_div(a.T, win ? H3W_BM : H3_BM);
+    a.n_mt = ceil_div(a.T, H3_BM);
     a.n_co = ceil_div(a.Cout, H3_BN);
     const long long tiles8 = ((long long)a.n_mt * a.B + 7) / 8 * 8;
     const long long nblocks = tiles8 * a.n_co;
     if (nblocks > 2147483647ll) { itts_set_error("conv_h3: grid too large"); return ITTS_ERR_ARG; }
-    if (win) {
-        HIP_TRY(hipFuncSetAttribute((const void*)conv_h3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H3W_LDS));
-        hipLaunchKernelGGL(conv_h3w_kernel, dim3((unsigned)nblocks), dim3(512), H3W_LDS, st, a);
-    } else {
-        HIP_TRY(hipFuncSetAttribute((const void*)conv_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS));
-        hipLaunchKernelGGL(conv_h3_kernel, dim3((unsigned)nblocks), dim3(256), H3_LDS, st, a);
-    }
+    HIP_TRY(hipFuncSetAttribute((const void*)conv_h3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS));
+    hipLaunchKernelGGL(conv_h3_kernel, dim3((unsigned)nblocks), dim3(256), H3_LDS, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
