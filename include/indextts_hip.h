@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 4
+#define ITTS_ABI_VERSION 5
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -385,6 +385,43 @@ int itts_tok_ctxpool_forward(const float* h, float* out, int n, int C, int seg_l
 int itts_tok_gate_forward(float* y, const float* g, size_t n, void* stream);
 /* replaces: StatsPool (mean | unbiased std over time, layers.py statistics_pooling): x [n][C] -> out [2C] */
 int itts_tok_statspool_forward(const float* x, float* out, int n, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * prompt-audio front end (the DSP half; once per speaker prompt): resampling and the three framed-spectrum
+ * feature kinds of indextts/infer_v2_5.py:626-648; indextts_amd/audio.py builds the filter banks / windows / twiddles and mirrors the
+ * reference callables (mel_spectrogram, kaldi.fbank, SeamlessM4TFeatureExtractor, Resample).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t frame_length;   /* samples per frame (<= n_fft; the frame sits at the start of the zero-padded FFT buffer) */
+    int32_t hop;            /* frame shift */
+    int32_t n_fft;          /* power of two, 64 .. 2048 */
+    int32_t n_mels;
+    int32_t pad;            /* > 0: the waveform is reflect-padded by this much on both sides (mel_spectrogram: (n_fft - hop) / 2);
+                               0: Kaldi snip_edges framing */
+    int32_t remove_dc;      /* subtract the frame mean (Kaldi remove_dc_offset) */
+    int32_t power;          /* 2: |X|^2;  1: sqrt(|X|^2 + mag_eps) */
+    int32_t take_log;       /* natural log after the floor */
+    int32_t layout;         /* 0: out [frames][ld_out >= n_mels];  1: out [n_mels][ld_out >= frames] */
+    float preemphasis;      /* y[i] = x[i] - c x[i-1], y[0] = (1 - c) x[0];  0 = none */
+    float mag_eps;
+    float floor;            /* mel energies are floored here before the log (Kaldi: FLT_EPSILON; mel_spectrogram: 1e-5) */
+    float scale;            /* multiplies the samples first (SeamlessM4T: 32768) */
+} itts_fbank_config;
+/* frames the configuration yields for n_samples (0 when shorter than one frame; < 0 on a bad configuration) */
+int itts_fbank_frames(const itts_fbank_config* cfg, int n_samples);
+/* replaces: mel_spectrogram (indextts/s2mel/modules/audio.py:43-83: reflect pad + torch.stft + magnitude + mel basis + log clamp),
+ *   torchaudio.compliance.kaldi.fbank (indextts/infer_v2_5.py:644-647) and transformers' SeamlessM4TFeatureExtractor._extract_fbank_features
+ *   (infer_v2_5.py:174,631), by configuration.  wave [B][n_samples] (row stride wave_stride), window [frame_length],
+ *   twiddle [n_fft / 2][2] = (cos, -sin)(2 pi m / n_fft), mel [n_mels][n_fft / 2 + 1], out per `layout` (batch stride out_stride). */
+int itts_fbank_forward(const float* wave, int B, int n_samples, int64_t wave_stride, const itts_fbank_config* cfg, const float* window,
+                       const float* twiddle, const float* mel, float* out, int ld_out, int64_t out_stride, void* stream);
+/* replaces: torchaudio.transforms.Resample.forward (infer_v2_5.py:627-628,642; functional._apply_sinc_resample_kernel): x [B][L_in],
+ *   kernel [new_rate][2 width + orig] (rates already divided by their gcd), y [B][L_out], L_out = ceil(new_rate L_in / orig) */
+int itts_resample_forward(const float* x, const float* kernel, float* y, int B, int L_in, int64_t x_stride, int L_out, int64_t y_stride,
+                          int orig, int new_rate, int width, void* stream);
+/* replaces: `feat - feat.mean(dim=0)` (mode 0, infer_v2_5.py:648) and the per-mel-bin normalisation of SeamlessM4TFeatureExtractor
+ *   (mode 1: (x - mean) / sqrt(var(ddof) + eps)); x [n][C] -> out [n][ld_out >= C] */
+int itts_tok_colnorm_forward(const float* x, float* out, int n, int C, int ld_out, int mode, int ddof, float eps, void* stream);
 
 #ifdef __cplusplus
 }

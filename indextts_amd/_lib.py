@@ -31,13 +31,19 @@ class S2MelConfig(C.Structure):
                 ("wavenet_dilation_rate", C.c_int32), ("precision", C.c_int32), ("norm_eps", C.c_float)]
 
 
+class FbankConfig(C.Structure):
+    _fields_ = [("frame_length", C.c_int32), ("hop", C.c_int32), ("n_fft", C.c_int32), ("n_mels", C.c_int32), ("pad", C.c_int32),
+                ("remove_dc", C.c_int32), ("power", C.c_int32), ("take_log", C.c_int32), ("layout", C.c_int32),
+                ("preemphasis", C.c_float), ("mag_eps", C.c_float), ("floor", C.c_float), ("scale", C.c_float)]
+
+
 class GPTConfig(C.Structure):
     _fields_ = [("layers", C.c_int32), ("model_dim", C.c_int32), ("heads", C.c_int32), ("vocab", C.c_int32),
                 ("n_mel_pos", C.c_int32), ("precision", C.c_int32), ("start_mel_token", C.c_int32),
                 ("stop_mel_token", C.c_int32), ("ln_eps", C.c_float)]
 
 
-ABI_VERSION = 4          # include/indextts_hip.h ITTS_ABI_VERSION
+ABI_VERSION = 5          # include/indextts_hip.h ITTS_ABI_VERSION
 
 
 class GenParams(C.Structure):
@@ -133,6 +139,10 @@ SIGNATURES = {
     "itts_tok_groupnorm_mish_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "itts_gemm_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "itts_layernorm_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    "itts_fbank_frames": (C.c_int, [C.POINTER(FbankConfig), C.c_int]),
+    "itts_fbank_forward": (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(FbankConfig), vp, vp, vp, vp, C.c_int, C.c_int64, vp]),
+    "itts_resample_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp]),
+    "itts_tok_colnorm_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
 }
 
 _lib = None

@@ -469,7 +469,7 @@ class ReferenceFrontend(Frontend):
         # the reference's own module stays in place only when its configuration is not the shipped one
         self.campplus = None
         cm = getattr(ref, "campplus_model", None)
-        if cm is not None and torch.cuda.is_available() and str(device).startswith("cuda"):
+        if cm is not None and hasattr(cm, "state_dict") and torch.cuda.is_available() and str(device).startswith("cuda"):
             try:
                 from .campplus import CAMPPlus
                 self.campplus = CAMPPlus(feat_dim=80, embedding_size=192, device=device).load_state_dict(cm.state_dict())
@@ -493,6 +493,25 @@ class ReferenceFrontend(Frontend):
             except NotImplementedError:
                 self.w2v = None
 
+        # and the DSP in front of them (indextts_amd/audio.py: resampling, SeamlessM4T features, prompt log-mel, Kaldi fbank): the engine
+        # versions take over when the s2mel spectrogram parameters are the ones the kernel supports (win_length == n_fft, center=False)
+        self.audio = None
+        if torch.cuda.is_available() and str(device).startswith("cuda"):
+            try:
+                from . import audio as A
+                sp = cfg["s2mel"]["preprocess_params"]
+                spect = sp["spect_params"]
+                fmax = spect.get("fmax", "None") if hasattr(spect, "get") else "None"
+                self._mel_args = dict(n_fft=int(spect["n_fft"]), win_size=int(spect["win_length"]), hop_size=int(spect["hop_length"]),
+                                      num_mels=int(spect["n_mels"]), sampling_rate=int(sp["sr"]),
+                                      fmin=spect.get("fmin", 0) if hasattr(spect, "get") else 0,
+                                      fmax=None if fmax == "None" else 8000, center=False)          # infer_v2_5.py:256-265
+                if self._mel_args["win_size"] == self._mel_args["n_fft"]:
+                    self.audio = A
+                    self._features = A.SeamlessM4TFeatureExtractor(device=device)
+            except (KeyError, TypeError, AttributeError):
+                self.audio = None
+
     # ---- the reference's own state dicts, for the engine stages (IndexTTS2.__init__ loads them when none are injected) --------
     def engine_state_dicts(self):
         return dict(semantic_codec=self.ref.semantic_codec.state_dict(), cfm=self.ref.s2mel.models["cfm"].state_dict(),
@@ -502,22 +521,31 @@ class ReferenceFrontend(Frontend):
     @torch.no_grad()
     def _w2v(self, audio_16k):
         r = self.ref
-        inputs = r.extract_features(audio_16k, sampling_rate=16000, return_tensors="pt")
+        inputs = (self._features if self.audio is not None else r.extract_features)(audio_16k, sampling_rate=16000, return_tensors="pt")
         if self.w2v is not None:
             return self.w2v.get_emb(inputs["input_features"], inputs["attention_mask"], r.semantic_mean, r.semantic_std, layer=W2V_TAP_LAYER)
         return r.get_emb(inputs["input_features"].to(self.device), inputs["attention_mask"].to(self.device))
 
     @torch.no_grad()
     def speaker_bundle(self, spk_audio_prompt):
-        import torchaudio
         r = self.ref
         audio, sr = r._load_and_cut_audio(spk_audio_prompt, 15, False)
-        audio_22k = torchaudio.transforms.Resample(sr, 22050)(audio)
-        audio_16k = torchaudio.transforms.Resample(sr, 16000)(audio)
-        spk_cond_emb = self._w2v(audio_16k)
-        ref_mel = r.mel_fn(audio_22k.to(spk_cond_emb.device).float())
-        feat = torchaudio.compliance.kaldi.fbank(audio_16k.to(ref_mel.device), num_mel_bins=80, dither=0, sample_frequency=16000)
-        style = (self.campplus or r.campplus_model)((feat - feat.mean(dim=0, keepdim=True)).unsqueeze(0))
+        if self.audio is not None:                                   # DSP on the engine (indextts_amd/audio.py)
+            A = self.audio
+            audio_22k = A.Resample(sr, 22050, device=self.device)(audio)
+            audio_16k = A.Resample(sr, 16000, device=self.device)(audio)
+            spk_cond_emb = self._w2v(audio_16k)
+            ref_mel = A.mel_spectrogram(audio_22k, **self._mel_args)
+            feat = A.subtract_mean(A.fbank(audio_16k, num_mel_bins=80, dither=0, sample_frequency=16000))
+        else:
+            import torchaudio
+            audio_22k = torchaudio.transforms.Resample(sr, 22050)(audio)
+            audio_16k = torchaudio.transforms.Resample(sr, 16000)(audio)
+            spk_cond_emb = self._w2v(audio_16k)
+            ref_mel = r.mel_fn(audio_22k.to(spk_cond_emb.device).float())
+            feat = torchaudio.compliance.kaldi.fbank(audio_16k.to(ref_mel.device), num_mel_bins=80, dither=0, sample_frequency=16000)
+            feat = feat - feat.mean(dim=0, keepdim=True)
+        style = (self.campplus or r.campplus_model)(feat.unsqueeze(0))
         prompt_condition = r.s2mel.models["length_regulator"](spk_cond_emb, ylens=torch.LongTensor([ref_mel.size(2)]).to(ref_mel.device),
                                                               n_quantizers=3, f0=None)[0]
         return dict(style=style, spk_cond_emb=spk_cond_emb, ref_mel=ref_mel, prompt_condition=prompt_condition)
