@@ -324,6 +324,13 @@ int itts_s2mel_attention_forward(const float* qkv, const float* rope, const int3
  *   (indextts/codec/amphion_codec/quantize/factorized_vector_quantize.py:99-127); codes int64 [n] -> out [n][H] */
 int itts_vq_project_forward(const int64_t* codes, const float* codebook, const float* w, const float* bias, float* out, int n,
                             int n_codes, int cd, int H, void* stream);
+/* replaces: FVQ.forward up to the indices (eval mode; indextts/codec/amphion_codec/quantize/factorized_vector_quantize.py:52-118, reached
+ *   from EnhancedCodec.quantize, indextts/codec/models.py:179-199 <- indextts/infer_v2.py:465): the weight-normed 1x1 in_project
+ *   (w_in [cd][H], b_in [cd]), L2 normalisation, nearest row of the L2-normalised codebook cb_norm [n_codes][cd] (cb_sq [n_codes] = its
+ *   squared row norms) by the reference's distance expression; h [n][H] -> idx int64 [n] (first index on ties); cd <= 16.
+ *   itts_vq_project_forward on idx then gives the quantized features. */
+int itts_vq_search_forward(const float* h, const float* w_in, const float* b_in, const float* cb_norm, const float* cb_sq, int64_t* idx,
+                           int n, int H, int n_codes, int cd, void* stream);
 /* replaces: F.interpolate(mode="nearest") + the im2col of a "same" zero-padded Conv1d that follows it
  *   (indextts/codec/models.py:226-229 `up`; indextts/s2mel/modules/length_regulator.py:121-125; vocos.py:770 `embed`):
  *   col [n_dst][k*C], the GEMM with the [k*C][C_out] matrix of the conv weight finishes the conv. */

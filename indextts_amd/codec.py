@@ -93,7 +93,8 @@ class _TokOps:
 
 
 class EnhancedCodec:
-    """The decode half of the reference's semantic codec (quantize / encode stay with the prompt-side PyTorch modules)."""
+    """The reference's semantic codec on the engine: `decode` / `vq2emb` (codes -> features) and, when the checkpoint carries the
+    encoder half, `quantize` (features -> codes + quantized features; the v2 pipeline's prompt side)."""
 
     def __init__(self, codebook_size=8192, hidden_size=1024, codebook_dim=8, vocos_dim=384, vocos_intermediate_dim=2048,
                  vocos_num_layers=12, device="cuda:0", **_unused):
@@ -115,21 +116,53 @@ class EnhancedCodec:
         p["codebook"] = f(sd[Q + "codebook.weight"])
         w = sd[Q + "out_project.weight"]
         p["out_w"], p["out_b"] = f(w.reshape(w.shape[0], -1)), f(sd[Q + "out_project.bias"])
-        p["embed_w"], p["embed_b"] = pk(_conv_matrix(sd["decoder.0.embed.weight"])), f(sd["decoder.0.embed.bias"])
-        p["norm_g"], p["norm_b"] = f(sd["decoder.0.norm.weight"]), f(sd["decoder.0.norm.bias"])
-        for i in range(self.vocos_num_layers):
-            c = f"decoder.0.convnext.{i}."
-            dw = sd[c + "dwconv.weight"]
-            p[f"dw_w{i}"], p[f"dw_b{i}"] = f(dw.reshape(dw.shape[0], -1)), f(sd[c + "dwconv.bias"])
-            p[f"ln_g{i}"], p[f"ln_b{i}"] = f(sd[c + "norm.weight"]), f(sd[c + "norm.bias"])
-            p[f"pw1_w{i}"], p[f"pw1_b{i}"] = pk(sd[c + "pwconv1.weight"].t()), f(sd[c + "pwconv1.bias"])
-            p[f"pw2_w{i}"], p[f"pw2_b{i}"] = pk(sd[c + "pwconv2.weight"].t()), f(sd[c + "pwconv2.bias"])
-            p[f"gamma{i}"] = f(sd[c + "gamma"])
-        p["fln_g"], p["fln_b"] = f(sd["decoder.0.final_layer_norm.weight"]), f(sd["decoder.0.final_layer_norm.bias"])
-        p["dec1_w"], p["dec1_b"] = pk(sd["decoder.1.weight"].t()), f(sd["decoder.1.bias"])
+        self._load_backbone(sd, "decoder.", "", f, pk)
         p["up_w"], p["up_b"] = pk(_conv_matrix(sd["up.weight"])), f(sd["up.bias"])
+        # the quantize half (stride-2 down conv, Vocos encoder, FVQ in_project + search), when the checkpoint carries it
+        self._has_encoder = all(k in sd for k in ("down.weight", "encoder.0.embed.weight", Q + "in_project.weight"))
+        if self._has_encoder:
+            if self.codebook_dim > 16:
+                raise ValueError("EnhancedCodec.quantize (HIP engine): codebook_dim <= 16")
+            p["down_w"], p["down_b"] = pk(_conv_matrix(sd["down.weight"])), f(sd["down.bias"])
+            self._load_backbone(sd, "encoder.", "enc.", f, pk)
+            wi = sd[Q + "in_project.weight"]
+            p["in_w"], p["in_b"] = f(wi.reshape(wi.shape[0], -1)), f(sd[Q + "in_project.bias"])
+            cbn = torch.nn.functional.normalize(sd[Q + "codebook.weight"].detach().float().cpu())        # F.normalize(codebook), decode_latents
+            p["cb_norm"], p["cb_sq"] = f(cbn), f(cbn.pow(2).sum(1))
         self._loaded = True
-        return [k for k in sd if not (k.startswith("decoder.") or k.startswith("up.") or k.startswith(Q))]
+        used = ("decoder.", "up.", Q) + (("encoder.", "down.") if self._has_encoder else ())
+        return [k for k in sd if not k.startswith(used)]
+
+    def _load_backbone(self, sd, ref_prefix: str, key: str, f, pk):
+        """VocosBackbone + the Linear after it (`decoder` / `encoder` of the reference module) under parameter keys `key` + name"""
+        p, b = self._p, ref_prefix + "0."
+        p[key + "embed_w"], p[key + "embed_b"] = pk(_conv_matrix(sd[b + "embed.weight"])), f(sd[b + "embed.bias"])
+        p[key + "norm_g"], p[key + "norm_b"] = f(sd[b + "norm.weight"]), f(sd[b + "norm.bias"])
+        for i in range(self.vocos_num_layers):
+            c = f"{b}convnext.{i}."
+            dw = sd[c + "dwconv.weight"]
+            p[f"{key}dw_w{i}"], p[f"{key}dw_b{i}"] = f(dw.reshape(dw.shape[0], -1)), f(sd[c + "dwconv.bias"])
+            p[f"{key}ln_g{i}"], p[f"{key}ln_b{i}"] = f(sd[c + "norm.weight"]), f(sd[c + "norm.bias"])
+            p[f"{key}pw1_w{i}"], p[f"{key}pw1_b{i}"] = pk(sd[c + "pwconv1.weight"].t()), f(sd[c + "pwconv1.bias"])
+            p[f"{key}pw2_w{i}"], p[f"{key}pw2_b{i}"] = pk(sd[c + "pwconv2.weight"].t()), f(sd[c + "pwconv2.bias"])
+            p[f"{key}gamma{i}"] = f(sd[c + "gamma"])
+        p[key + "fln_g"], p[key + "fln_b"] = f(sd[b + "final_layer_norm.weight"]), f(sd[b + "final_layer_norm.bias"])
+        p[key + "dec1_w"], p[key + "dec1_b"] = pk(sd[ref_prefix + "1.weight"].t()), f(sd[ref_prefix + "1.bias"])
+
+    def _backbone(self, key: str, e: torch.Tensor, tabs, n: int) -> torch.Tensor:
+        """e [n][hidden] packed rows -> [n][hidden]: embed conv (k 7), LayerNorm, ConvNeXt blocks, final LayerNorm, Linear (vocos.py:770-782)"""
+        tok_seq, tok_t, start, Tt = tabs
+        p, ops, D = self._p, _TokOps(self.device), self.vocos_dim
+        x = ops.conv(e, (tok_seq, tok_t), n, start, Tt, Tt, 7, p[key + "embed_w"], p[key + "embed_b"], D)
+        x = engine_layernorm(x, p[key + "norm_g"], p[key + "norm_b"], eps=1e-6)
+        for i in range(self.vocos_num_layers):                                                             # ConvNeXtBlock
+            y = ops.dwconv(x, p[f"{key}dw_w{i}"], p[f"{key}dw_b{i}"], tok_seq, tok_t, Tt, 7)
+            y = engine_layernorm(y, p[f"{key}ln_g{i}"], p[f"{key}ln_b{i}"], eps=1e-6)
+            y = ops.gelu_(ops.linear(y, p[f"{key}pw1_w{i}"], p[f"{key}pw1_b{i}"], self.vocos_intermediate_dim))
+            y = ops.linear(y, p[f"{key}pw2_w{i}"], p[f"{key}pw2_b{i}"], D)
+            ops.scale_residual_(x, y, p[f"{key}gamma{i}"])
+        x = engine_layernorm(x, p[key + "fln_g"], p[key + "fln_b"], eps=1e-6)
+        return ops.linear(x, p[key + "dec1_w"], p[key + "dec1_b"], self.hidden_size)
 
     def eval(self):
         return self
@@ -157,6 +190,50 @@ class EnhancedCodec:
                            "itts_vq_project_forward")
         return e.reshape(B, T, self.hidden_size).transpose(1, 2)
 
+    @torch.no_grad()
+    def quantize(self, x: torch.Tensor, lens: Optional[Sequence[int]] = None):
+        """`EnhancedCodec.quantize` (indextts/codec/models.py:179-199; `_, S_ref = semantic_codec.quantize(spk_cond_emb)`, indextts/infer_v2.py:465):
+        x (B, T, hidden) features -> (indices, quantized (B, T', hidden)), T' = (T - 1) // 2 + 1; indices are (B, T') int64 -- for B == 1
+        the reference's squeeze of the quantizer axis leaves the same (1, T').  With `lens` each row is encoded at its own length (rows of
+        the outputs beyond (len - 1) // 2 + 1 are zero)."""
+        if not self._loaded or not self._has_encoder:
+            raise RuntimeError("EnhancedCodec.quantize: load a state dict that carries the encoder half (down.*, encoder.*, in_project) first")
+        dev, p, ops, H, L = self.device, self._p, _TokOps(self.device), self.hidden_size, _lib.lib()
+        B, T = x.shape[0], x.shape[1]
+        lens = [T] * B if lens is None else [int(v) for v in lens]
+        olens = [(v - 1) // 2 + 1 if v > 0 else 0 for v in lens]
+        Tq = (T - 1) // 2 + 1 if T > 0 else 0
+        idx = torch.zeros(B, Tq, dtype=torch.int64, device=dev)
+        q = torch.zeros(B, Tq, H, dtype=torch.float32, device=dev)
+        tabs, n = _tables(olens, dev)
+        if n == 0:
+            return idx, q
+        # stride-2, k = 3, padding 1 conv as a row gather (data movement) + GEMM: output t reads input rows 2t - 1, 2t, 2t + 1 of its own sequence
+        xd = x.to(dev, torch.float32)
+        cols = []
+        for b in range(B):
+            if olens[b] == 0:
+                continue
+            xp = torch.nn.functional.pad(xd[b, : lens[b]], (0, 0, 1, 2))                  # one zero row in front, two behind (even lengths read one)
+            t = torch.arange(olens[b], device=dev) * 2
+            cols.append(torch.cat([xp[t], xp[t + 1], xp[t + 2]], dim=1))
+        col = torch.cat(cols, 0).contiguous()
+        h = ops.gelu_(ops.linear(col, p["down_w"], p["down_b"], H))
+        h = self._backbone("enc.", h, tabs, n).contiguous()
+        flat = torch.empty(n, dtype=torch.int64, device=dev)
+        qf = torch.empty(n, H, dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            st = _lib.stream_ptr(dev)
+            _lib.check(L.itts_vq_search_forward(_lib.ptr(h), _lib.ptr(p["in_w"]), _lib.ptr(p["in_b"]), _lib.ptr(p["cb_norm"]), _lib.ptr(p["cb_sq"]),
+                                                _lib.ptr(flat), n, H, self.codebook_size, self.codebook_dim, st), "itts_vq_search_forward")
+            _lib.check(L.itts_vq_project_forward(_lib.ptr(flat), _lib.ptr(p["codebook"]), _lib.ptr(p["out_w"]), _lib.ptr(p["out_b"]), _lib.ptr(qf),
+                                                 n, self.codebook_size, self.codebook_dim, H, st), "itts_vq_project_forward")
+        o = 0
+        for b in range(B):
+            idx[b, : olens[b]], q[b, : olens[b]] = flat[o:o + olens[b]], qf[o:o + olens[b]]
+            o += olens[b]
+        return idx, q
+
     @property
     def quantizer(self):
         return self                                                    # `semantic_codec.quantizer.vq2emb(...)` call sites
@@ -183,16 +260,7 @@ class EnhancedCodec:
             _lib.check(L.itts_vq_project_forward(_lib.ptr(flat), _lib.ptr(p["codebook"]), _lib.ptr(p["out_w"]), _lib.ptr(p["out_b"]),
                                                  _lib.ptr(e), n, self.codebook_size, self.codebook_dim, H, _lib.stream_ptr(dev)),
                        "itts_vq_project_forward")
-        x = ops.conv(e, (tok_seq, tok_t), n, start, Tt, Tt, 7, p["embed_w"], p["embed_b"], D)            # VocosBackbone.embed
-        x = engine_layernorm(x, p["norm_g"], p["norm_b"], eps=1e-6)
-        for i in range(self.vocos_num_layers):                                                             # ConvNeXtBlock
-            y = ops.dwconv(x, p[f"dw_w{i}"], p[f"dw_b{i}"], tok_seq, tok_t, Tt, 7)
-            y = engine_layernorm(y, p[f"ln_g{i}"], p[f"ln_b{i}"], eps=1e-6)
-            y = ops.gelu_(ops.linear(y, p[f"pw1_w{i}"], p[f"pw1_b{i}"], self.vocos_intermediate_dim))
-            y = ops.linear(y, p[f"pw2_w{i}"], p[f"pw2_b{i}"], D)
-            ops.scale_residual_(x, y, p[f"gamma{i}"])
-        x = engine_layernorm(x, p["fln_g"], p["fln_b"], eps=1e-6)
-        x = ops.linear(x, p["dec1_w"], p["dec1_b"], H)
+        x = self._backbone("", e, (tok_seq, tok_t, start, Tt), n)                                        # VocosBackbone + Linear
         (tseq2, tt2, start2, T2), n2 = _tables([2 * v for v in lens], dev)                                 # x2 nearest + up conv
         y = ops.conv(x, (tseq2, tt2), n2, start, Tt, T2, 3, p["up_w"], p["up_b"], H)
         o = 0

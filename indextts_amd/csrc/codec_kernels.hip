@@ -6,6 +6,7 @@
 //   FVQ decode_code / vq2emb, weight-normed 1x1 out_project   indextts/codec/amphion_codec/quantize/factorized_vector_quantize.py:99-127
 //   ConvNeXtBlock, VocosBackbone                              indextts/codec/kmeans/vocos.py:468-526,719-782
 //   EnhancedCodec.decode (interpolate x2 + up conv)           indextts/codec/models.py:205-231
+//   EnhancedCodec.quantize: FVQ in_project + nearest code      indextts/codec/models.py:179-199, factorized_vector_quantize.py:52-118
 //   InterpolateRegulator.forward                              indextts/s2mel/modules/length_regulator.py:90-141
 //
 // The stage is ~40 GFLOP per utterance (the flow-matching decoder after it is ~37 TFLOP), so everything runs in f32: the dense
@@ -33,6 +34,70 @@ __global__ __launch_bounds__(256) void vq_project_kernel(const long long* __rest
         float acc = 0.f;
         for (int d = 0; d < cd; ++d) acc = fmaf(w[d], e[d], acc);
         out[i] = acc + bias[h];
+    }
+}
+
+// FVQ search of one row per block (factorized_vector_quantize.py:52-118, eval): z_e = W_in h + b (the weight-normed 1x1 in_project,
+// H -> cd <= 16), e = z_e / max(|z_e|, 1e-12), index = argmax_k -((|e|^2 - 2 e . c_k) + |c_k|^2) over the L2-normalised codebook rows c_k
+// (normalised once at load time, |c_k|^2 passed alongside); the first index wins a tie, as torch.max does.
+#define VQ_MAX_CD 16
+__global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict__ h, const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                        const float* __restrict__ cbn, const float* __restrict__ c2, long long* __restrict__ idx,
+                                                        int H, int K, int cd) {
+    __shared__ float part[4][VQ_MAX_CD];
+    __shared__ float ze[VQ_MAX_CD];
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* row = h + (size_t)blockIdx.x * H;
+    float acc[VQ_MAX_CD];
+#pragma unroll
+    for (int d = 0; d < VQ_MAX_CD; ++d) acc[d] = 0.f;
+    for (int c = tid; c < H; c += 256) {
+        const float x = row[c];
+#pragma unroll
+        for (int d = 0; d < VQ_MAX_CD; ++d)
+            if (d < cd) acc[d] = fmaf(w_in[(size_t)d * H + c], x, acc[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < VQ_MAX_CD; ++d) {
+        const float s = wave_sum(acc[d]);
+        if (lane == 0) part[wv][d] = s;
+    }
+    __syncthreads();
+    if (tid < cd) ze[tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + b_in[tid];
+    __syncthreads();
+    float en[VQ_MAX_CD];
+    float n2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < VQ_MAX_CD; ++d) { en[d] = d < cd ? ze[d] : 0.f; n2 = fmaf(en[d], en[d], n2); }
+    const float inv = 1.f / fmaxf(sqrtf(n2), 1e-12f);
+    float e2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < VQ_MAX_CD; ++d) { en[d] *= inv; e2 = fmaf(en[d], en[d], e2); }
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int k = tid; k < K; k += 256) {
+        const float* c = cbn + (size_t)k * cd;
+        float dot = 0.f;
+#pragma unroll
+        for (int d = 0; d < VQ_MAX_CD; ++d)
+            if (d < cd) dot = fmaf(en[d], c[d], dot);
+        const float v = -((e2 - 2.f * dot) + c2[k]);
+        if (v > best) { best = v; besti = k; }                 // k ascends per thread: the first maximum stays
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) { bv[wv] = best; bi[wv] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 1; q < 4; ++q)
+            if (bv[q] > best || (bv[q] == best && bi[q] < besti)) { best = bv[q]; besti = bi[q]; }
+        idx[blockIdx.x] = besti;
     }
 }
 
@@ -141,6 +206,18 @@ extern "C" int itts_vq_project_forward(const int64_t* codes, const float* codebo
     if (n == 0) return ITTS_OK;
     hipLaunchKernelGGL(vq_project_kernel, dim3(grid_for((size_t)n * H)), dim3(256), 0, (hipStream_t)stream, (const long long*)codes, codebook, w,
                        bias, out, n, n_codes, cd, H);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+extern "C" int itts_vq_search_forward(const float* h, const float* w_in, const float* b_in, const float* cb_norm, const float* cb_sq, int64_t* idx,
+                                      int n, int H, int n_codes, int cd, void* stream) {
+    if (!h || !w_in || !b_in || !cb_norm || !cb_sq || !idx || n < 0 || H < 1 || n_codes < 1 || cd < 1 || cd > VQ_MAX_CD) {
+        itts_set_error("vq_search: bad args (1 <= codebook_dim <= %d)", VQ_MAX_CD);
+        return ITTS_ERR_ARG;
+    }
+    if (n == 0) return ITTS_OK;
+    hipLaunchKernelGGL(vq_search_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, h, w_in, b_in, cb_norm, cb_sq, (long long*)idx, H, n_codes, cd);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }

@@ -8,7 +8,8 @@ Differences from the v2.5 pipeline (`indextts_amd/infer_v2_5.py`, whose batching
   * after decoding, the teacher-forced latent pass `self.gpt(...)` (infer_v2.py:636-651) runs on the engine
     (`itts_gpt_forward_latent`) and its output goes through `s2mel.models['gpt_layer']`;
   * the content features are `semantic_codec.quantizer.vq2emb(codes) + latent` (no Vocos decode), the mel length is
-    `(code_lens * 1.72).long()` (:659-662).
+    `(code_lens * 1.72).long()` (:659-662);
+  * the speaker prompt's content condition goes through the codec's `quantize` half first (`prompt_condition`, :465-479).
 """
 import time
 import warnings
@@ -82,6 +83,16 @@ class IndexTTS2(_IndexTTS2V25):
         t4 = time.perf_counter()
         self.last_timing = dict(gpt=t1 - t0, gpt_forward=t2 - t1, s2mel=t3 - t2, bigvgan=t4 - t3)
         return out
+
+    @torch.no_grad()
+    def prompt_condition(self, spk_cond_emb: torch.Tensor, ref_mel_frames: int) -> torch.Tensor:
+        """The speaker prompt's content condition of IndexTTS-2 (infer_v2.py:465-479) on the engine: `_, S_ref = semantic_codec.quantize(
+        spk_cond_emb)` (down conv, Vocos encoder, FVQ search + out_project) -> `length_regulator(S_ref, ylens=[ref_mel.size(2)])`.
+        spk_cond_emb (1, T, 1024) w2v-bert features -> (1, ref_mel_frames, 512).  (v2.5 regulates spk_cond_emb directly, infer_v2_5.py:651-656.)"""
+        if self.s2mel is None or self.semantic_codec is None:
+            raise RuntimeError("prompt_condition needs the engine's semantic codec and s2mel stages")
+        _, S_ref = self.semantic_codec.quantize(spk_cond_emb)
+        return self.s2mel.models["length_regulator"](S_ref, ylens=torch.tensor([int(ref_mel_frames)]), n_quantizers=3, f0=None)[0]
 
     def codes_latent_to_mel(self, codes, code_lens, latent, bundle, diffusion_steps: int = 25, inference_cfg_rate: float = 0.7,
                             noise=None):

@@ -111,3 +111,66 @@ def test_ragged_batch_equals_per_utterance(golden_dir):
         with torch.no_grad():
             ref, _ = O.length_regulator(rsd, rc, refs[b], torch.tensor([ylens[b]]))
         assert float((cond[b:b + 1, : ylens[b]].cpu() - ref).abs().max()) <= TOL
+
+
+def test_quantize_vs_reference_class(golden_dir):
+    """`EnhancedCodec.quantize` on the engine (stride-2 down conv, Vocos encoder, FVQ search, out_project) vs tests/golden/codec_quantize.npz =
+    the reference's own class on the oracle's seeded weights (tools/make_golden_codec_quantize.py).  Indices must be identical wherever the
+    oracle's search margin (best minus second-best negative distance) exceeds 1e-4 -- every position of the fixture (smallest margin 6e-3);
+    quantized features within 1e-4 where the index agrees."""
+    from indextts_amd import codec
+    from tools.make_golden_codec_quantize import CFG, LENGTHS, SEED
+    z = np.load(os.path.join(golden_dir, "codec_quantize.npz"))
+    sd = O.synth_codec_weights(CFG, SEED)
+    sd.update(O.synth_codec_encoder_weights(CFG, SEED + 1))
+    c = codec.EnhancedCodec(codebook_size=CFG.codebook_size, hidden_size=CFG.hidden_size, codebook_dim=CFG.codebook_dim, vocos_dim=CFG.vocos_dim,
+                            vocos_intermediate_dim=CFG.vocos_intermediate_dim, vocos_num_layers=CFG.vocos_num_layers, device=DEV)
+    assert c.load_state_dict(sd) == []
+    for i, T in enumerate(LENGTHS):
+        x = torch.from_numpy(z[f"x{i}"])
+        idx, q = c.quantize(x.to(DEV))
+        _, _, margin = O.codec_quantize(sd, CFG, x)
+        idx, q = idx.cpu(), q.cpu()
+        same = idx == torch.from_numpy(z[f"idx{i}"])
+        print(f"quantize T={T}: {int(same.sum())}/{same.numel()} indices equal the reference's, smallest margin {float(margin.min()):.2e}, "
+              f"quantized max|d| {float((q - torch.from_numpy(z[f'q{i}']))[same].abs().max()):.2e}")
+        assert idx.shape == z[f"idx{i}"].shape and idx.dtype == torch.int64 and bool(same[margin > 1e-4].all())
+        assert float((q - torch.from_numpy(z[f"q{i}"]))[same].abs().max()) <= TOL
+    # batch 1 keeps the (1, T') index shape of the reference's squeeze; ragged rows equal the rows run alone
+    idx1, q1 = c.quantize(torch.from_numpy(z["x_b1"]).to(DEV))
+    assert idx1.shape == z["idx_b1"].shape and torch.equal(idx1.cpu(), torch.from_numpy(z["idx_b1"]))
+    assert float((q1.cpu() - torch.from_numpy(z["q_b1"])).abs().max()) <= TOL
+    x = torch.from_numpy(z["x1"])
+    idx_r, q_r = c.quantize(x.to(DEV), lens=[34, 21])
+    ia, qa = c.quantize(x[1:2, :21].to(DEV))
+    assert torch.equal(idx_r[1, :11], ia[0]) and float((q_r[1, :11] - qa[0]).abs().max()) <= 1e-6 and float(q_r[1, 11:].abs().max()) == 0.0
+    # a decode-only checkpoint refuses quantize loudly
+    d = codec.EnhancedCodec(codebook_size=CFG.codebook_size, hidden_size=CFG.hidden_size, codebook_dim=CFG.codebook_dim, vocos_dim=CFG.vocos_dim,
+                            vocos_intermediate_dim=CFG.vocos_intermediate_dim, vocos_num_layers=CFG.vocos_num_layers, device=DEV)
+    d.load_state_dict(O.synth_codec_weights(CFG, SEED))
+    with pytest.raises(RuntimeError):
+        d.quantize(x.to(DEV))
+
+
+def test_v2_prompt_condition_chain(golden_dir):
+    """IndexTTS-2's prompt content condition (indextts/infer_v2.py:465-479): quantize(spk_cond_emb) -> length_regulator, engine vs the oracle chain."""
+    from indextts_amd import codec
+    from tools.make_golden_codec_quantize import CFG, SEED
+    z = np.load(os.path.join(golden_dir, "codec_quantize.npz"))
+    sd = O.synth_codec_weights(CFG, SEED)
+    sd.update(O.synth_codec_encoder_weights(CFG, SEED + 1))
+    rc = O.RegulatorConfig(channels=64, in_channels=CFG.hidden_size, n_layers=4, groups=1, codebook_size=64)
+    rsd = O.synth_regulator_weights(rc, SEED + 5)
+    c = codec.EnhancedCodec(codebook_size=CFG.codebook_size, hidden_size=CFG.hidden_size, codebook_dim=CFG.codebook_dim, vocos_dim=CFG.vocos_dim,
+                            vocos_intermediate_dim=CFG.vocos_intermediate_dim, vocos_num_layers=CFG.vocos_num_layers, device=DEV)
+    c.load_state_dict(sd)
+    r = codec.InterpolateRegulator(channels=rc.channels, sampling_ratios=(1,) * rc.n_layers, is_discrete=False, in_channels=rc.in_channels,
+                                   codebook_size=rc.codebook_size, device=DEV)
+    r.load_state_dict(rsd)
+    x = torch.from_numpy(z["x_b1"])
+    ylens = torch.tensor([23])
+    _, S_ref = c.quantize(x.to(DEV))
+    cond = r(S_ref, ylens=ylens, n_quantizers=3, f0=None)[0].cpu()
+    _, q_o, _ = O.codec_quantize(sd, CFG, x)
+    ref, _ = O.length_regulator(rsd, rc, q_o, ylens)
+    assert cond.shape == ref.shape == (1, 23, 64) and float((cond - ref).abs().max()) <= TOL

@@ -1,5 +1,5 @@
 """Oracle for the second "next" row (EnhancedCodec.decode + InterpolateRegulator) vs the fixture minted
-from the reference's own classes (tools/make_golden_codec.py).  No HIP path for this row yet: these tests pin the oracle."""
+from the reference's own classes (tools/make_golden_codec.py).  These tests pin the oracle; the HIP path is tested in tests/test_gpu_codec.py."""
 import os
 
 import numpy as np
@@ -33,3 +33,18 @@ def test_length_regulator_matches_reference(golden_dir):
     np.testing.assert_allclose(cond.numpy(), z["cond"], rtol=0, atol=1e-5)
     assert olens.tolist() == ylens.tolist()
     assert float(cond[1, int(ylens[1]):].abs().max()) == 0.0              # rows are zeroed beyond their own target length
+
+
+def test_quantize_equals_reference_class(golden_dir):
+    """oracle `codec_quantize` vs tests/golden/codec_quantize.npz = the reference's own EnhancedCodec.quantize (tools/make_golden_codec_quantize.py):
+    identical indices, quantized features to f32 rounding."""
+    from tools.make_golden_codec_quantize import CFG, LENGTHS, SEED
+    z = np.load(os.path.join(golden_dir, "codec_quantize.npz"))
+    sd = C.synth_codec_weights(CFG, SEED)
+    sd.update(C.synth_codec_encoder_weights(CFG, SEED + 1))
+    for i, T in enumerate(LENGTHS):
+        idx, q, margin = C.codec_quantize(sd, CFG, torch.from_numpy(z[f"x{i}"]))
+        assert idx.shape == (2, (T - 1) // 2 + 1) and np.array_equal(idx.numpy(), z[f"idx{i}"])
+        assert float((q - torch.from_numpy(z[f"q{i}"])).abs().max()) <= 2e-6 and float(margin.min()) > 0
+    idx, q, _ = C.codec_quantize(sd, CFG, torch.from_numpy(z["x_b1"]))
+    assert np.array_equal(idx.numpy(), z["idx_b1"]) and idx.shape == (1, 5) and float((q - torch.from_numpy(z["q_b1"])).abs().max()) <= 2e-6
