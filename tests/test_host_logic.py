@@ -156,3 +156,21 @@ def test_v1_pad_tokens_cat_matches_reference(golden_dir):
         t = _v1_shell(case["version"])
         res = t.pad_tokens_cat([torch.tensor(x) for x in case["tokens"]])
         assert res.tolist() == case["out"]
+
+
+def test_golden_tools_import_without_the_reference():
+    """tests import constants (shapes, seeds) from tools/make_golden_*.py; /root/reference does not exist on the GPU box, so importing those
+    modules must not touch the reference package -- only their main() may."""
+    import glob
+    import re
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    used = set()
+    for f in glob.glob(os.path.join(root, "tests", "*.py")):
+        used.update(re.findall(r"from tools\.(make_golden_\w+) import", open(f).read()))
+    assert used
+    code = "import sys; sys.modules['indextts'] = None; sys.path[:] = [p for p in sys.path if 'reference' not in p]\n" + \
+           "\n".join(f"import tools.{m}" for m in sorted(used)) + "\nassert not any('reference' in p for p in sys.path), sys.path"
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -10,11 +10,6 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(HERE, ".."))
-import ref_shim_s2mel as R  # noqa: E402
-
-R.install()
-from indextts.codec.models import EnhancedCodec  # noqa: E402
-
 from oracle import codec_oracle as C  # noqa: E402
 
 GOLD = os.path.join(HERE, "..", "tests", "golden")
@@ -30,6 +25,9 @@ def weights():
 
 
 def main():
+    import ref_shim_s2mel as R          # the reference is imported only when minting (tests import CFG / LENGTHS / SEED from this module)
+    R.install()
+    from indextts.codec.models import EnhancedCodec
     sd = weights()
     codec = EnhancedCodec(codebook_size=CFG.codebook_size, hidden_size=CFG.hidden_size, codebook_dim=CFG.codebook_dim, vocos_dim=CFG.vocos_dim,
                           vocos_intermediate_dim=CFG.vocos_intermediate_dim, vocos_num_layers=CFG.vocos_num_layers).eval()
