@@ -156,8 +156,12 @@ class Resample:
         if self.orig_freq == self.new_freq:
             return waveform
         dev = _device_of(waveform, self.device)
-        kern, width, o, n = sinc_kernel(self.orig_freq, self.new_freq, self.lowpass_filter_width, self.rolloff)
-        (kd,) = _cached(("sinc", self.orig_freq, self.new_freq, self.lowpass_filter_width, self.rolloff), dev, lambda: (kern,))
+        g = math.gcd(self.orig_freq, self.new_freq)
+        o, n = self.orig_freq // g, self.new_freq // g
+        width = int(math.ceil(self.lowpass_filter_width * o / (min(o, n) * self.rolloff)))
+        (kd,) = _cached(("sinc", self.orig_freq, self.new_freq, self.lowpass_filter_width, self.rolloff), dev,
+                        lambda: (sinc_kernel(self.orig_freq, self.new_freq, self.lowpass_filter_width, self.rolloff)[0],))
+        assert kd.shape == (n, 2 * width + o)
         lead = tuple(waveform.shape[:-1])
         x = _as_rows(waveform, dev)
         length = x.shape[1]

@@ -205,6 +205,33 @@ def codec_weights(c: dict = CODEC_V2, seed: int = 1234) -> Dict[str, torch.Tenso
     return sd
 
 
+def codec_encoder_weights(c: dict = CODEC_V2, seed: int = 4321) -> Dict[str, torch.Tensor]:
+    """The `quantize` half of the semantic codec (stride-2 down conv, Vocos encoder, FVQ in_project) under the reference names;
+    merge into `codec_weights(...)` to get a state dict `EnhancedCodec.quantize` accepts."""
+    g = torch.Generator().manual_seed(seed)
+    D, H, I = c["vocos_dim"], c["hidden_size"], c["vocos_intermediate_dim"]
+    rn = lambda *s_, fan: torch.randn(*s_, generator=g) / math.sqrt(fan)
+    sd = {"down.weight": rn(H, H, 3, fan=3 * H), "down.bias": torch.randn(H, generator=g) * 0.05,
+          "encoder.0.embed.weight": rn(D, H, 7, fan=7 * H), "encoder.0.embed.bias": torch.randn(D, generator=g) * 0.05,
+          "encoder.0.norm.weight": 1 + 0.1 * torch.randn(D, generator=g), "encoder.0.norm.bias": 0.05 * torch.randn(D, generator=g)}
+    for i in range(c["vocos_num_layers"]):
+        p = f"encoder.0.convnext.{i}."
+        sd[p + "gamma"] = 0.3 + 0.1 * torch.randn(D, generator=g)
+        sd[p + "dwconv.weight"] = rn(D, 1, 7, fan=7)
+        sd[p + "dwconv.bias"] = 0.05 * torch.randn(D, generator=g)
+        sd[p + "norm.weight"] = 1 + 0.1 * torch.randn(D, generator=g)
+        sd[p + "norm.bias"] = 0.05 * torch.randn(D, generator=g)
+        sd[p + "pwconv1.weight"], sd[p + "pwconv1.bias"] = rn(I, D, fan=D), 0.05 * torch.randn(I, generator=g)
+        sd[p + "pwconv2.weight"], sd[p + "pwconv2.bias"] = rn(D, I, fan=I), 0.05 * torch.randn(D, generator=g)
+    sd["encoder.0.final_layer_norm.weight"] = 1 + 0.1 * torch.randn(D, generator=g)
+    sd["encoder.0.final_layer_norm.bias"] = 0.05 * torch.randn(D, generator=g)
+    sd["encoder.1.weight"], sd["encoder.1.bias"] = rn(H, D, fan=D), 0.05 * torch.randn(H, generator=g)
+    Q = "quantizer.quantizers.0."
+    sd[Q + "in_project.weight"] = rn(c["codebook_dim"], H, 1, fan=H)                            # weight-norm already folded
+    sd[Q + "in_project.bias"] = 0.05 * torch.randn(c["codebook_dim"], generator=g)
+    return sd
+
+
 def regulator_weights(c: dict = REGULATOR_V2, seed: int = 1234) -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
     Cc, n = c["channels"], len(c["sampling_ratios"])
