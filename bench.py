@@ -203,11 +203,23 @@ class HipEngine:
 
     def step(self, text, langs, mel, bundle, n_gen, record):
         """-> int16 waveforms (b, T*256) of this rank's utterances"""
-        B = text.shape[0]
-        style, emo_vec = bundle["style"], bundle["emo_vec"]
-        codes, _ = self.model.inference_speech(None, text, langs=langs, emo_vec=emo_vec, campplus_embedding=style,
+        return self.render(self.decode(text, langs, bundle, n_gen, record), mel, bundle, n_gen, record)
+
+    def decode(self, text, langs, bundle, n_gen, record):
+        """GPT stage: text ids -> speech codes (b, n_gen), on torch's CURRENT stream (host-blocking: the device loop reports back
+        every 8 tokens)"""
+        codes, _ = self.model.inference_speech(None, text, langs=langs, emo_vec=bundle["emo_vec"], campplus_embedding=bundle["style"],
                                                max_generate_length=n_gen, **self.gen_kw)
-        assert codes.shape == (B, n_gen), codes.shape
+        assert codes.shape == (text.shape[0], n_gen), codes.shape
+        if record:
+            for k in ("prefill_ms", "decode_ms", "steps"):
+                self.gpt_t[k] += self.model.last_timing[k]
+        return codes
+
+    def render(self, codes, mel, bundle, n_gen, record):
+        """codes -> codec decode -> length regulator -> 25-step CFG flow matching -> BigVGAN -> int16, on torch's current stream"""
+        B = codes.shape[0]
+        style = bundle["style"]
         if self.s2 is not None:
             # codes -> content features -> 25-step CFG flow matching -> mel (indextts/infer_v2_5.py:830-846), all on the engine
             from indextts_amd import s2mel
@@ -245,9 +257,6 @@ class HipEngine:
                     a = self.prof_acc.setdefault(k, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
                     for kk in a:
                         a[kk] += v[kk]
-        if record:
-            for k in ("prefill_ms", "decode_ms", "steps"):
-                self.gpt_t[k] += self.model.last_timing[k]
         wav = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
         return torch.clamp(32767.0 * wav[:, 0], -32767.0, 32767.0).to(torch.int16)      # infer_v2_5.py:855, :897-898
 
@@ -313,9 +322,13 @@ class StubEngine:
         self.prof_acc, self.gpt_t = {}, {"prefill_ms": 0.0, "decode_ms": 0.0, "steps": 0}
 
     def step(self, text, langs, mel, bundle, n_gen, record):
-        b, t = text.shape[0], mel.shape[-1] * HOP
-        base = (text[:, :1].to(torch.int64) % 97).to(torch.int16)           # a value that identifies the utterance
-        return base.expand(b, t).contiguous() + int(bundle["style"].double().sum() * 0)
+        return self.render(self.decode(text, langs, bundle, n_gen, record), mel, bundle, n_gen, record)
+
+    def decode(self, text, langs, bundle, n_gen, record):
+        return (text[:, :1].to(torch.int64) % 97).to(torch.int16) + int(bundle["style"].double().sum() * 0)   # identifies the utterance
+
+    def render(self, codes, mel, bundle, n_gen, record):
+        return codes.expand(codes.shape[0], mel.shape[-1] * HOP).contiguous()
 
 
 def main():
@@ -337,6 +350,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = all usable cores)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed beam-3 / f32-mode decode measurements")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="software-pipeline consecutive steps: the GPT decode of step k + 1 (latency-bound, "
+                    "small grids) runs on a second, high-priority HIP stream from its own host thread while step k's codec / flow "
+                    "matching / vocoder kernels (compute-bound) run on the main stream; every step still completes inside the timed region")
     ap.add_argument("--engine", default="hip", choices=["hip", "stub"], help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -417,10 +433,69 @@ def main():
             torch.cuda.synchronize()
         if rank == 0:
             log(f"[bench] warmup step {i}: {time.perf_counter() - tw:.2f}s")
+    def steps_overlapped(n_steps):
+        """The same n_steps steps as a two-stage software pipeline.  Stage 1 (decode of step k + 1) runs on `s_dec` from a worker thread
+        -- the device decode loop blocks its host thread, and HIP's current device / torch's current stream are per thread -- stage 2
+        (render of step k) on the main stream; the hand-over is an event the main stream waits on.  Nothing is skipped: n_steps decodes
+        and n_steps renders complete before the closing barrier; with n_steps = 1 this degenerates to the sequential step."""
+        import threading
+        s_dec = None if stub else torch.cuda.Stream(device=dev, priority=-1)
+        slot = {}
+
+        def decode_worker(k, bundle):
+            try:
+                if stub:
+                    slot[k] = (eng.decode(text, langs, bundle, n_gen, True), None)
+                    return
+                torch.cuda.set_device(dev)
+                tw = time.perf_counter()
+                with torch.cuda.stream(s_dec):
+                    codes = eng.decode(text, langs, bundle, n_gen, True)
+                    ev = torch.cuda.Event()
+                    ev.record(s_dec)
+                slot[k] = (codes, ev)
+                if rank == 0:
+                    log(f"[bench] overlap: decode of step {k} took {time.perf_counter() - tw:.2f}s of host wall time")
+            except BaseException as e:      # surfaced by the main thread
+                slot[k] = e
+
+        def start(k):
+            # the speaker bundle of step k is broadcast by the main thread (the only thread that issues collectives), then handed over
+            bundle = D.broadcast_speaker_bundle(bundle0, src=0, device=dev) if dist is not None else bundle0
+            if not stub:
+                torch.cuda.current_stream().synchronize()
+            th = threading.Thread(target=decode_worker, args=(k, bundle), name=f"decode-{k}")
+            th.start()
+            return th, bundle
+
+        out = None
+        th, bundle = start(0)
+        for k in range(n_steps):
+            th.join()
+            got = slot.pop(k)
+            if isinstance(got, BaseException):
+                raise got
+            codes, ev = got
+            cur_bundle = bundle
+            if k + 1 < n_steps:
+                th, bundle = start(k + 1)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+                codes.record_stream(torch.cuda.current_stream())
+            tw = time.perf_counter()
+            wav16 = eng.render(codes, mel, cur_bundle, n_gen, True)
+            out = D.gather_waveform_tensor(wav16, mine, n_total, dst=0) if dist is not None else wav16
+            if rank == 0 and not stub:
+                log(f"[bench] overlap: render of step {k} enqueued / finished on the host after {time.perf_counter() - tw:.2f}s")
+        return out
+
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wavs = one_step(True)
+    if args.overlap and args.steps > 1:
+        wavs = steps_overlapped(args.steps)
+    else:
+        for _ in range(args.steps):
+            wavs = one_step(True)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -454,7 +529,8 @@ def main():
                                       f"{world} GPU(s); prompt encoders / text front end not included"),
                        "global_batch": n_total, "per_gpu_batch": B, "text_tokens": n_text, "gen_tokens": n_gen,
                        "mel_frames": t_mel, "audio_seconds_per_utt": t_mel * HOP / SR, "parallelism": f"utterance-dp{world}",
-                       "use_hipgraph": not args.no_graph},
+                       "use_hipgraph": not args.no_graph,
+                       "step_overlap": bool(args.overlap and args.steps > 1)},
         }
         if stub:       # launcher test: every utterance of the batch reached rank 0, in utterance order
             out["stub_rows_ok"] = bool(torch.equal(wavs[:, 0].to(torch.int64), text_all[:, 0].to(torch.int64) % 97))

@@ -43,3 +43,12 @@ def test_world_size_mismatch_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "stub", "--gpus", "4"], capture_output=True,
                        text=True, timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_overlapped_steps_two_ranks():
+    """`--overlap`: the two-stage software pipeline (decode of step k + 1 on a worker thread, render of step k on the main thread; collectives
+    only from the main thread) delivers the same rows as the sequential loop, on one rank and on two."""
+    j = _run(["--gpus", "2", "--utts", "6", "--overlap"])
+    assert j["n_gpus"] == 2 and j["stub_rows_ok"] is True and j["config"]["step_overlap"] is True and j["steps"] == 2
+    j1 = _run(["--gpus", "1", "--utts", "5", "--overlap"])
+    assert j1["stub_rows_ok"] is True and j1["config"]["step_overlap"] is True
