@@ -108,12 +108,19 @@ class DynamicBatcher:
             _, _, emo_alpha, lang, gen = key
             self.batches.append(len(reqs))
             try:
-                res = self.tts.infer_batch(spk, [r.text for r in reqs], lang, emo_audio_prompt=emo, emo_alpha=emo_alpha, **dict(gen))
+                res = list(self.tts.infer_batch(spk, [r.text for r in reqs], lang, emo_audio_prompt=emo, emo_alpha=emo_alpha, **dict(gen)))
+                if len(res) != len(reqs):
+                    raise RuntimeError(f"infer_batch returned {len(res)} results for {len(reqs)} requests")
                 for r, out in zip(reqs, res):
-                    r.future.set_result(out)
+                    if r.future.set_running_or_notify_cancel():      # a caller may have cancelled while the batch ran
+                        r.future.set_result(out)
             except Exception as e:                    # noqa: BLE001 -- delivered to the callers of this batch
                 for r in reqs:
-                    r.future.set_exception(e)
+                    if not r.future.done():
+                        try:
+                            r.future.set_exception(e)
+                        except Exception:             # noqa: BLE001 -- cancelled in between: nobody is waiting
+                            pass
 
 
 def synthesize_tasks(tts, tasks: List[Dict[str, Any]], lang=None, max_batch: int = 64, **generation_kwargs) -> List[str]:

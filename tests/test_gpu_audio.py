@@ -156,3 +156,29 @@ def test_reference_frontend_runs_the_dsp_on_the_engine(gold):
     k = k - k.mean(dim=0, keepdim=True)
     assert seen["fbank"].shape == (1,) + tuple(k.shape) and float((seen["fbank"][0] - k).abs().max()) <= 1e-2
     assert b["prompt_condition"].shape == (1, mel.shape[2], 512) and b["style"].shape == (1, 192)
+
+
+def test_full_length_prompt_chain_vs_oracle():
+    """The longest prompt the pipeline keeps (15 s, infer_v2_5.py:627) at 24 kHz through the whole DSP chain, engine vs oracle: resample to
+    16 / 22.05 kHz, SeamlessM4T features (749 stacked frames), prompt log-mel (1291 frames), mean-normalised Kaldi fbank (1498 frames)."""
+    from indextts_amd import audio as A
+    from tools.make_golden_audio import speechlike
+    x = torch.from_numpy(speechlike(15 * 24000, 24000, 77))[None]
+    a16, a22 = A.Resample(24000, 16000, device=DEV)(x), A.Resample(24000, 22050, device=DEV)(x)
+    o16, o22 = AO.resample(x, 24000, 16000), AO.resample(x, 24000, 22050)
+    assert a16.shape == o16.shape == (1, 240000) and a22.shape == o22.shape == (1, 330750)
+    assert float((a16.cpu() - o16).abs().max()) <= 1e-5 and float((a22.cpu() - o22).abs().max()) <= 1e-5
+    f = A.SeamlessM4TFeatureExtractor(device=DEV)(a16, sampling_rate=16000)
+    fo, mo = AO.seamless_features(o16[0].numpy())
+    err_f = float((f["input_features"].cpu() - torch.from_numpy(fo)).abs().max())
+    assert f["input_features"].shape == fo.shape == (1, 749, 160) and np.array_equal(f["attention_mask"].cpu().numpy(), mo) and err_f <= 5e-3
+    mel = A.mel_spectrogram(a22, n_fft=1024, num_mels=80, sampling_rate=22050, hop_size=256, win_size=1024, fmin=0, fmax=None, center=False)
+    err_m = float((mel.cpu() - AO.mel_spectrogram(o22)).abs().max())
+    assert mel.shape == (1, 80, 1291) and err_m <= 2e-4
+    k = A.subtract_mean(A.fbank(a16, num_mel_bins=80, dither=0, sample_frequency=16000)).cpu()
+    ko = AO.kaldi_fbank(o16, dtype=torch.float64)
+    ko = (ko - ko.mean(dim=0, keepdim=True)).float()
+    loud = ko > ko.max() - 12.0
+    err_k = (k - ko).abs()
+    print(f"15 s prompt: SeamlessM4T {err_f:.2e}, log-mel {err_m:.2e}, fbank {float(err_k.max()):.2e} (loud bins {float(err_k[loud].max()):.2e})")
+    assert k.shape == (1498, 80) and float(err_k[loud].max()) <= 2e-4 and float(err_k.max()) <= 1e-2
