@@ -1,0 +1,110 @@
+"""GPU test of `EngineFrontend` (indextts_amd/frontend.py): the prompt side of `IndexTTS2` built from a checkpoint DIRECTORY without the
+reference package -- w2v-bert-2.0 (config.json + safetensors), its statistics, CAMPPlus, the s2mel checkpoint's length regulator, the
+emotion / speaker matrices, a WAV prompt -- every network and DSP step on the engine.  A synthetic directory with the reference's file
+layout and names is written here (small w2v-bert / regulator widths, the real CAMPPlus architecture, oracle-seeded weights) and the speaker
+bundle is compared with the ORACLE chain on the same file: resample -> SeamlessM4T features -> w2v-bert hidden state -> (x - mean) / std;
+log-mel; Kaldi fbank -> CAMPPlus; length regulator."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio_oracle as AO
+from oracle import campplus_oracle as CO
+from oracle import codec_oracle as KO
+from oracle import w2vbert_oracle as WO
+from tools.make_golden_audio import speechlike
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+WCFG = WO.W2VBertCfg(hidden_size=64, num_hidden_layers=4, num_attention_heads=2, intermediate_size=128, feature_projection_input_dim=160,
+                     left_max_position_embeddings=6, right_max_position_embeddings=2, conv_depthwise_kernel_size=7)
+RCFG = KO.RegulatorConfig(channels=64, in_channels=64, n_layers=4, groups=1, codebook_size=64)
+
+
+def write_checkpoint_dir(d):
+    from safetensors.torch import save_file
+    from scipy.io import wavfile
+    g = torch.Generator().manual_seed(5)
+    wdir = d / "hf_cache" / "w2v-bert-2.0"
+    wdir.mkdir(parents=True)
+    (wdir / "config.json").write_text(json.dumps(dict(
+        hidden_size=WCFG.hidden_size, num_hidden_layers=WCFG.num_hidden_layers, num_attention_heads=WCFG.num_attention_heads,
+        intermediate_size=WCFG.intermediate_size, feature_projection_input_dim=WCFG.feature_projection_input_dim,
+        position_embeddings_type="relative_key", left_max_position_embeddings=WCFG.left_max_position_embeddings,
+        right_max_position_embeddings=WCFG.right_max_position_embeddings, conv_depthwise_kernel_size=WCFG.conv_depthwise_kernel_size,
+        hidden_act="swish", layer_norm_eps=WCFG.layer_norm_eps, add_adapter=False, model_type="wav2vec2-bert", vocab_size=None)))
+    wsd = WO.synth_weights(WCFG)
+    save_file({k: v.contiguous() for k, v in wsd.items()}, str(wdir / "model.safetensors"))
+    stats = {"mean": 0.3 * torch.randn(WCFG.hidden_size, generator=g), "var": 0.5 + torch.rand(WCFG.hidden_size, generator=g)}
+    torch.save(stats, d / "wav2vec2bert_stats.pt")
+    csd = CO.synth_weights()
+    torch.save(csd, d / "hf_cache" / "campplus_cn_common.bin")
+    rsd = KO.synth_regulator_weights(RCFG, 9)
+    torch.save({"net": {"cfm": {"module.placeholder": torch.zeros(1)}, "length_regulator": {"module." + k: v for k, v in rsd.items()}}}, d / "s2mel.pth")
+    emo, spk = torch.randn(5, 32, generator=g), torch.randn(5, 192, generator=g)
+    torch.save(emo, d / "emo.pt")
+    torch.save({"model": {"up.bias": torch.zeros(4)}}, d / "codec.pth")
+    torch.save(spk, d / "spk.pt")
+    wave = speechlike(48000, 24000, 61)                                   # 2 s at 24 kHz -> 198 Kaldi frames at 16 kHz (even: no padded pair)
+    pcm = np.round(wave * 32767.0).astype(np.int16)
+    wavfile.write(str(d / "prompt.wav"), 24000, pcm)
+    cfg = {"w2v_stat": "wav2vec2bert_stats.pt", "s2mel_checkpoint": "s2mel.pth", "emo_matrix": "emo.pt", "spk_matrix": "spk.pt", "emo_num": [2, 3],
+           "s2mel": {"length_regulator": {"channels": RCFG.channels, "sampling_ratios": [1, 1, 1, 1], "is_discrete": False,
+                                          "in_channels": RCFG.in_channels, "content_codebook_size": RCFG.codebook_size},
+                     "preprocess_params": {"sr": 22050, "spect_params": {"n_fft": 1024, "win_length": 1024, "hop_length": 256, "n_mels": 80,
+                                                                         "fmin": 0, "fmax": "None"}}}}
+    return cfg, dict(wsd=wsd, stats=stats, csd=csd, rsd=rsd, emo=emo, spk=spk, pcm=pcm)
+
+
+def test_speaker_bundle_from_checkpoint_directory_vs_oracle_chain(tmp_path):
+    from indextts_amd.frontend import EngineFrontend, load_wav
+    d = tmp_path / "ckpt"
+    cfg, w = write_checkpoint_dir(d)
+    fe = EngineFrontend(cfg, str(d), DEV)
+    x, sr = load_wav(str(d / "prompt.wav"))
+    assert sr == 24000 and x.shape == (1, 48000) and torch.equal(x[0], torch.from_numpy(w["pcm"].astype(np.float32) / 32768.0))
+    b = fe.speaker_bundle(str(d / "prompt.wav"))
+    # the oracle chain on the same samples (infer_v2_5.py:626-656; the file arrives at 22.05 kHz like librosa.load's default)
+    a22 = AO.resample(x, 24000, 22050)
+    a16 = AO.resample(a22, 22050, 16000)
+    feats, mask = AO.seamless_features(a16[0].numpy())
+    assert feats.shape[1] == 99 and int(mask.sum()) == 99
+    emb = WO.get_emb(w["wsd"], WCFG, torch.from_numpy(feats), torch.from_numpy(mask).long(), w["stats"]["mean"], torch.sqrt(w["stats"]["var"]),
+                     layer=WCFG.num_hidden_layers)
+    mel = AO.mel_spectrogram(a22)
+    fb = AO.kaldi_fbank(a16)
+    style = CO.campplus(w["csd"], (fb - fb.mean(dim=0, keepdim=True))[None])
+    cond, _ = KO.length_regulator(w["rsd"], RCFG, emb, torch.tensor([mel.shape[2]]))
+    err = {k: float((b[k].cpu() - v).abs().max()) for k, v in (("spk_cond_emb", emb), ("ref_mel", mel), ("style", style), ("prompt_condition", cond))}
+    print("EngineFrontend.speaker_bundle vs the oracle chain, max|d|:", {k: f"{v:.2e}" for k, v in err.items()},
+          "| scales:", f"emb {float(emb.abs().max()):.1f}, style {float(style.abs().max()):.1f}, cond {float(cond.abs().max()):.1f}")
+    assert b["spk_cond_emb"].shape == emb.shape == (1, 99, 64) and b["ref_mel"].shape == mel.shape and b["style"].shape == (1, 192)
+    assert b["prompt_condition"].shape == cond.shape == (1, mel.shape[2], 64)
+    # every stage sees the float32 DSP's rounding of the stage before it (quiet fbank bins differ by up to 1e-3, test_gpu_audio.py): the bars are
+    # relative to each output's scale -- 1e-4 of the largest value for the three network outputs (measured 1e-6 .. 1e-5), 5e-4 absolute on the log-mel (1e-5)
+    assert err["ref_mel"] <= 5e-4
+    assert err["spk_cond_emb"] <= 1e-4 * float(emb.abs().max()) and err["style"] <= 1e-4 * float(style.abs().max())
+    assert err["prompt_condition"] <= 1e-4 * float(cond.abs().max())
+    # emotion prompt: the same file at 16 kHz directly (librosa.load(path, sr=16000), :687)
+    e = fe.emo_cond(str(d / "prompt.wav"))
+    f16, m16 = AO.seamless_features(AO.resample(x, 24000, 16000)[0].numpy())
+    e_o = WO.get_emb(w["wsd"], WCFG, torch.from_numpy(f16), torch.from_numpy(m16).long(), w["stats"]["mean"], torch.sqrt(w["stats"]["var"]),
+                     layer=WCFG.num_hidden_layers)
+    valid = torch.from_numpy(m16[0]).bool()
+    assert e.shape == e_o.shape and float((e.cpu() - e_o)[0, valid].abs().max()) <= 1e-4 * float(e_o.abs().max())
+    # emotion-vector mixing (:669-680): nearest speaker row per emotion group by cosine similarity, weighted sum of the emotion rows
+    vec = [0.3, 0.5]
+    mat, wsum = fe.emo_vector_mix(vec, b["style"], use_random=False)
+    q = b["style"].cpu().float()
+    groups_s, groups_e = torch.split(w["spk"], [2, 3]), torch.split(w["emo"], [2, 3])
+    idx = [int(torch.argmax(torch.nn.functional.cosine_similarity(q, m, dim=1))) for m in groups_s]
+    ref = sum(v * ge[i] for v, ge, i in zip(vec, groups_e, idx))[None]
+    assert float((mat.cpu() - ref).abs().max()) <= 1e-6 and abs(float(wsum) - 0.8) <= 1e-6
+    sds = fe.engine_state_dicts()
+    assert set(sds) == {"semantic_codec", "cfm", "length_regulator"} and "placeholder" in sds["cfm"] and "up.bias" in sds["semantic_codec"]
+    with pytest.raises(RuntimeError):
+        fe.text_segments("no text front end was injected", "en", 120, True, 600)
+    with pytest.raises(RuntimeError):
+        fe.merge_emovec(b["spk_cond_emb"], e, 1.0)
