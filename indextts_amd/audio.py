@@ -5,6 +5,7 @@ pipeline applies to the speaker / emotion prompt before any network runs (indext
     mel_spectrogram(y, n_fft, num_mels, sampling_rate, ...)      indextts/s2mel/modules/audio.py:43-83        :266, :640
     fbank(waveform, num_mel_bins=80, dither=0, ...)              torchaudio.compliance.kaldi.fbank            :644-647
     SeamlessM4TFeatureExtractor()(audio, sampling_rate=16000)    transformers (w2v-bert-2.0 preprocessor)     :174, :631, :687
+    MelSpectrogramFeatures()(audio)                              indextts/utils/feature_extractors.py:24-51   indextts/infer.py:318,535 (v1 / v1.5)
 
 with the reference's argument names and result shapes.  The host side builds the constant tables in float64 (filter banks, windows,
 FFT twiddles, the windowed-sinc resampling kernel) exactly as the published definitions give them and uploads them once per
@@ -65,6 +66,22 @@ def mel_banks_kaldi(n_mels: int = 80, n_fft: int = 512, sr: float = 16000.0, low
     for m in range(n_mels):
         left, centre, right = m_lo + m * step, m_lo + (m + 1) * step, m_lo + (m + 2) * step
         bank[m, : n_fft // 2] = np.clip(np.minimum((bin_mel - left) / (centre - left), (right - bin_mel) / (right - centre)), 0.0, None)
+    return bank.astype(np.float32)
+
+
+def mel_banks_htk(sr: int, n_fft: int, n_mels: int, f_min: float = 0.0, f_max: Optional[float] = None) -> np.ndarray:
+    """HTK-scale triangular bank without area normalisation (mel = 2595 log10(1 + f / 700); n_mels + 2 edges equally spaced in mel between
+    f_min and f_max, triangles in Hz over the n_fft / 2 + 1 bin frequencies): what torchaudio's MelScale(norm=None, mel_scale="htk") applies
+    -> float32 [n_mels][n_fft / 2 + 1]"""
+    top = float(sr // 2) if f_max is None else float(f_max)
+    mel_of = lambda hz: 2595.0 * math.log10(1.0 + hz / 700.0)
+    edges_mel = np.linspace(mel_of(float(f_min)), mel_of(top), n_mels + 2)
+    edges = 700.0 * (np.power(10.0, edges_mel / 2595.0) - 1.0)
+    bins = np.linspace(0, sr // 2, n_fft // 2 + 1)
+    bank = np.zeros((n_mels, bins.size))
+    for m in range(n_mels):
+        lo, mid, hi = edges[m], edges[m + 1], edges[m + 2]
+        bank[m] = np.clip(np.minimum((bins - lo) / (mid - lo), (hi - bins) / (hi - mid)), 0.0, None)
     return bank.astype(np.float32)
 
 
@@ -194,6 +211,37 @@ def mel_spectrogram(y: torch.Tensor, n_fft: int, num_mels: int, sampling_rate: i
     cfg = _lib.FbankConfig(frame_length=n_fft, hop=hop_size, n_fft=n_fft, n_mels=num_mels, pad=pad, remove_dc=0, power=1, take_log=1, layout=1,
                            preemphasis=0.0, mag_eps=1e-9, floor=1e-5, scale=1.0)
     return _fbank(rows, cfg, window, tw, basis)
+
+
+class MelSpectrogramFeatures:
+    """indextts/utils/feature_extractors.py:24-51 -- the conditioning mel of IndexTTS-1 / 1.5 (`MelSpectrogramFeatures()(audio)`,
+    indextts/infer.py:318,535): torchaudio MelSpectrogram(power=1, HTK bank, no normalisation) + log(clip(., 1e-7)).
+    audio (B, L) -> (B, n_mels, frames); "center": reflect padding n_fft / 2, frames = 1 + L // hop."""
+
+    def __init__(self, sample_rate=24000, n_fft=1024, hop_length=256, win_length=None, n_mels=100, mel_fmin=0, mel_fmax=None, normalize=False,
+                 padding="center", device=None):
+        if padding not in ("center", "same"):
+            raise ValueError("Padding must be 'center' or 'same'.")
+        if normalize or (win_length not in (None, n_fft)):
+            raise NotImplementedError("MelSpectrogramFeatures (HIP engine): normalize=False and win_length == n_fft (the pipeline's defaults)")
+        self.sample_rate, self.n_fft, self.hop_length, self.n_mels = int(sample_rate), int(n_fft), int(hop_length), int(n_mels)
+        self.mel_fmin, self.mel_fmax, self.padding = mel_fmin, mel_fmax, padding
+        self.device = None if device is None else torch.device(device)
+
+    def __call__(self, audio: torch.Tensor, **kwargs) -> torch.Tensor:
+        dev = _device_of(audio, self.device)
+        window, tw, bank = _cached(("htk", self.n_fft, self.n_mels, self.sample_rate, self.mel_fmin, self.mel_fmax), dev,
+                                   lambda: (window_hann_periodic(self.n_fft), twiddles(self.n_fft),
+                                            mel_banks_htk(self.sample_rate, self.n_fft, self.n_mels, self.mel_fmin, self.mel_fmax)))
+        rows = _as_rows(audio, dev)
+        pad = self.n_fft // 2 if self.padding == "center" else (self.n_fft - self.hop_length) // 2
+        if rows.shape[1] <= pad:
+            raise ValueError(f"MelSpectrogramFeatures: reflect padding of {pad} needs more than {pad} samples (got {rows.shape[1]})")
+        cfg = _lib.FbankConfig(frame_length=self.n_fft, hop=self.hop_length, n_fft=self.n_fft, n_mels=self.n_mels, pad=pad, remove_dc=0, power=1,
+                               take_log=1, layout=1, preemphasis=0.0, mag_eps=0.0, floor=1e-7, scale=1.0)
+        return _fbank(rows, cfg, window, tw, bank)
+
+    forward = __call__
 
 
 def _kaldi_cfg(sample_frequency, frame_length, frame_shift, num_mel_bins, preemphasis_coefficient, remove_dc_offset, scale):

@@ -186,3 +186,28 @@ class EngineFrontend(Frontend):
         if self.text is None:
             raise RuntimeError("EngineFrontend has no text front end: pass text_frontend=")
         return int(self.text.lang_id(lang))
+
+
+class EngineFrontendV1:
+    """Prompt side of the v1 / v1.5 pipeline (`indextts_amd.infer.IndexTTS`, `FrontendV1` protocol) on the engine: the conditioning mel of
+    indextts/infer.py:303-323,529-537 -- load, channel mean, `torchaudio.transforms.Resample(sr, 24000)`, truncation, `MelSpectrogramFeatures`
+    -- with the WAV decoded by scipy (the reference uses `torchaudio.load`) and both DSP steps in `indextts_amd.audio`.  The text side
+    (`tokenizer`) is injected; `conditioning` is the engine GPT's own `get_conditioning` (indextts_amd/cond.py)."""
+
+    def __init__(self, device, gpt_engine=None, tokenizer=None, audio_loader: Optional[Callable[[str], Tuple[torch.Tensor, int]]] = None):
+        self.device, self.gpt, self.tokenizer = torch.device(device), gpt_engine, tokenizer
+        self.load_audio = audio_loader or load_wav
+        self.mel = A.MelSpectrogramFeatures(device=self.device)
+
+    @torch.no_grad()
+    def cond_mel(self, audio_prompt, truncate_seconds: Optional[float] = None) -> torch.Tensor:
+        audio, sr = self.load_audio(audio_prompt)                       # (1, L) mono: torch.mean(audio, dim=0, keepdim=True)
+        audio = A.Resample(sr, 24000, device=self.device)(audio.to(self.device))
+        if truncate_seconds:
+            audio = audio[:, : int(truncate_seconds * 24000)]
+        return self.mel(audio)
+
+    def conditioning(self, cond_mel: torch.Tensor, cond_mel_lengths: torch.Tensor) -> torch.Tensor:
+        if self.gpt is None:
+            raise RuntimeError("EngineFrontendV1.conditioning needs the engine GPT (gpt_engine=)")
+        return self.gpt.get_conditioning(cond_mel, cond_mel_lengths)

@@ -22,6 +22,12 @@ What it restates, and what pins each piece:
                                  scaled by 2^15, per-mel-bin mean / unbiased-variance normalisation, zero padding to an even frame count,
                                  pairs of frames stacked to 160 features, attention mask of the odd frames.  Pinned to the installed
                                  transformers class (exact algorithm, float64 inside like its numpy code).
+  mel_spectrogram_features       indextts/utils/feature_extractors.py:24-51 (`MelSpectrogramFeatures`, the conditioning mel of IndexTTS-1 / 1.5,
+                                 indextts/infer.py:318,535): torchaudio.transforms.MelSpectrogram(24 kHz, n_fft 1024, hop 256, power 1, 100 HTK
+                                 mel bins without normalisation, centred reflect padding) + safe_log (clip 1e-7).  torchaudio is absent: the
+                                 transform is restated from its published definition (Spectrogram = torch.stft with a periodic Hann window;
+                                 MelScale = `melscale_fbanks(norm=None, mel_scale="htk")`), the bank anchored on transformers'
+                                 `mel_filter_bank(norm=None, mel_scale="htk")`.  **Parity unpinned** beyond that anchor.
 Golden vectors: tests/golden/audio.npz (tools/make_golden_audio.py).
 """
 import math
@@ -60,6 +66,20 @@ def slaney_mel_basis(sr, n_fft, n_mels, fmin=0.0, fmax=None):
         w[i] = np.maximum(0.0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
     w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
     return w.astype(np.float32)
+
+
+def htk_mel_banks(sr, n_fft, n_mels, f_min=0.0, f_max=None):
+    """torchaudio.functional.melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sr, norm=None, mel_scale="htk"), transposed
+    -> float32 [n_mels][n_fft / 2 + 1]"""
+    f_max = float(sr // 2) if f_max is None else float(f_max)
+    to_mel = lambda f: 2595.0 * np.log10(1.0 + np.asarray(f, dtype=np.float64) / 700.0)
+    to_hz = lambda m: 700.0 * (10.0 ** (np.asarray(m, dtype=np.float64) / 2595.0) - 1.0)
+    all_freqs = np.linspace(0, sr // 2, n_fft // 2 + 1)
+    f_pts = to_hz(np.linspace(to_mel(f_min), to_mel(f_max), n_mels + 2))
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down, up = -slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]
+    return np.maximum(0.0, np.minimum(down, up)).T.astype(np.float32)
 
 
 def kaldi_mel_banks(n_mels=80, n_fft=512, sr=16000.0, low=20.0, high=0.0):
@@ -125,6 +145,18 @@ def mel_spectrogram(y: torch.Tensor, n_fft=1024, num_mels=80, sampling_rate=2205
                                          center=center, pad_mode="reflect", normalized=False, onesided=True, return_complex=True))
     spec = torch.sqrt(spec.pow(2).sum(-1) + 1e-9)
     return torch.log(torch.clamp(torch.matmul(basis, spec), min=1e-5))
+
+
+def mel_spectrogram_features(audio: torch.Tensor, sample_rate=24000, n_fft=1024, hop_length=256, n_mels=100, mel_fmin=0, mel_fmax=None,
+                             padding="center") -> torch.Tensor:
+    """audio (B, L) -> (B, n_mels, frames) log-mel, indextts/utils/feature_extractors.py:24-51"""
+    if padding == "same":
+        pad = n_fft - hop_length
+        audio = torch.nn.functional.pad(audio.unsqueeze(1), (pad // 2, pad // 2), mode="reflect").squeeze(1)
+    spec = torch.stft(audio, n_fft, hop_length=hop_length, win_length=n_fft, window=torch.hann_window(n_fft), center=padding == "center",
+                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs()
+    mel = torch.matmul(torch.from_numpy(htk_mel_banks(sample_rate, n_fft, n_mels, mel_fmin, mel_fmax)), spec)
+    return torch.log(torch.clip(mel, min=1e-7))
 
 
 def kaldi_fbank(wave: torch.Tensor, num_mel_bins=80, sample_frequency=16000.0, frame_length_ms=25.0, frame_shift_ms=10.0,

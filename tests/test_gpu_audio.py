@@ -182,3 +182,19 @@ def test_full_length_prompt_chain_vs_oracle():
     err_k = (k - ko).abs()
     print(f"15 s prompt: SeamlessM4T {err_f:.2e}, log-mel {err_m:.2e}, fbank {float(err_k.max()):.2e} (loud bins {float(err_k[loud].max()):.2e})")
     assert k.shape == (1498, 80) and float(err_k[loud].max()) <= 2e-4 and float(err_k.max()) <= 1e-2
+
+
+def test_v1_conditioning_mel_vs_oracle(gold):
+    """`MelSpectrogramFeatures` (IndexTTS-1 / 1.5 conditioning mel, indextts/utils/feature_extractors.py:24-51): 24 kHz, centred reflect padding,
+    100 HTK bins on the magnitude spectrum, log clip 1e-7 -- engine vs the torch.stft restatement (torchaudio absent: parity unpinned beyond
+    the bank's agreement with transformers' HTK bank, tests/test_host_audio.py)."""
+    from indextts_amd.audio import MelSpectrogramFeatures
+    x = torch.from_numpy(np.stack([gold["wave22k_1"][:26000], gold["wave22k_1"][4000:30000]]))
+    for padding in ("center", "same"):
+        m = MelSpectrogramFeatures(padding=padding, device=DEV)(x)
+        ref = AO.mel_spectrogram_features(x, padding=padding)
+        err = float((m.cpu() - ref).abs().max())
+        print(f"v1 conditioning mel ({padding}): {tuple(m.shape)}, max|d| vs the oracle {err:.2e} (range {float(ref.min()):.1f}..{float(ref.max()):.1f})")
+        assert m.shape == ref.shape and err <= 5e-4
+    with pytest.raises(NotImplementedError):
+        MelSpectrogramFeatures(normalize=True)

@@ -108,3 +108,21 @@ def test_speaker_bundle_from_checkpoint_directory_vs_oracle_chain(tmp_path):
         fe.text_segments("no text front end was injected", "en", 120, True, 600)
     with pytest.raises(RuntimeError):
         fe.merge_emovec(b["spk_cond_emb"], e, 1.0)
+
+
+def test_v1_conditioning_mel_from_a_wav_file(tmp_path):
+    """`EngineFrontendV1.cond_mel` (indextts/infer.py:303-323): WAV -> mono -> 24 kHz -> truncation -> MelSpectrogramFeatures, vs the oracle chain."""
+    from scipy.io import wavfile
+    from indextts_amd.frontend import EngineFrontendV1
+    wave = speechlike(30000, 22050, 62)
+    stereo = np.stack([wave, 0.5 * wave[::-1]], axis=1)
+    wavfile.write(str(tmp_path / "v1.wav"), 22050, stereo.astype(np.float32))
+    fe = EngineFrontendV1(DEV)
+    mono = torch.from_numpy(stereo.astype(np.float32).mean(axis=1))[None]
+    a24 = AO.resample(mono, 22050, 24000)
+    for trunc in (None, 1.0):
+        m = fe.cond_mel(str(tmp_path / "v1.wav"), truncate_seconds=trunc)
+        ref = AO.mel_spectrogram_features(a24 if trunc is None else a24[:, :24000])
+        assert m.shape == ref.shape and m.shape[1] == 100 and float((m.cpu() - ref).abs().max()) <= 5e-4
+    with pytest.raises(RuntimeError):
+        fe.conditioning(m, torch.tensor([m.shape[-1]]))

@@ -63,6 +63,9 @@ def test_tables_match_oracle_and_transformers():
     assert np.abs(audio.mel_banks_kaldi() - kb).max() <= 1e-7
     assert np.abs(audio.window_povey(400) - window_function(400, "povey", periodic=False)).max() <= 1e-7
     assert np.array_equal(audio.window_hann_periodic(1024), torch.hann_window(1024).numpy())
+    hb = mel_filter_bank(num_frequency_bins=513, num_mel_filters=100, min_frequency=0.0, max_frequency=12000.0, sampling_rate=24000, norm=None,
+                         mel_scale="htk").T
+    assert np.abs(audio.mel_banks_htk(24000, 1024, 100) - hb).max() <= 1e-7 and np.abs(AO.htk_mel_banks(24000, 1024, 100) - hb).max() <= 1e-7
     tw = audio.twiddles(512)
     ref = np.exp(-2j * np.pi * np.arange(256) / 512)
     assert np.abs(tw[:, 0] + 1j * tw[:, 1] - ref).max() <= 1e-7
@@ -207,3 +210,9 @@ def test_host_paths_on_an_emulated_library(gold, monkeypatch):
         assert y.shape == ref.shape == (1, math.ceil(new * x.numel() / orig)) and float((y - ref).abs().max()) <= 1e-5
     two = torch.stack([x[:5000], x[5000:10000]])
     assert float((audio.Resample(24000, 16000)(two) - AO.resample(two, 24000, 16000)).abs().max()) <= 1e-5
+    # v1 / v1.5 conditioning mel: centred reflect padding, 100 HTK bins, magnitude, log clip 1e-7
+    for padding in ("center", "same"):
+        m = audio.MelSpectrogramFeatures(padding=padding)(two)
+        ref = AO.mel_spectrogram_features(two, padding=padding)
+        assert m.shape == ref.shape == (2, 100, 1 + 5000 // 256 if padding == "center" else 1 + (5000 + 768 - 1024) // 256)
+        assert float((m - ref).abs().max()) <= 5e-4
