@@ -211,3 +211,37 @@ class EngineFrontendV1:
         if self.gpt is None:
             raise RuntimeError("EngineFrontendV1.conditioning needs the engine GPT (gpt_engine=)")
         return self.gpt.get_conditioning(cond_mel, cond_mel_lengths)
+
+
+class EngineFrontendV2(EngineFrontend):
+    """IndexTTS-2 (`indextts/infer_v2.py`) prompt side: as `EngineFrontend`, plus the semantic codec with its encoder half
+    (`build_semantic_codec(cfg.semantic_codec)` + `safetensors.torch.load_model(..., aux_paths["semantic_codec"])`, infer_v2.py:138-142) so
+    that the prompt's content condition is `length_regulator(quantize(spk_cond_emb)[1])` (:465-479) instead of v2.5's
+    `length_regulator(spk_cond_emb)`.  `self.codec` is an `indextts_amd.codec.EnhancedCodec` holding both halves: hand it to the pipeline as
+    `IndexTTS2(..., frontend=fe, semantic_codec=fe.codec)` so the weights live on the GPU once."""
+
+    def __init__(self, cfg, model_dir: str, device, gpt_engine=None, text_frontend=None, audio_loader=None, semantic_codec_path: Optional[str] = None):
+        super().__init__(cfg, model_dir, device, gpt_engine=gpt_engine, text_frontend=text_frontend, audio_loader=audio_loader)
+        from safetensors.torch import load_file
+        from .codec import EnhancedCodec
+        path = semantic_codec_path or os.path.join(model_dir, "hf_cache", "semantic_codec", "model.safetensors")
+        self._codec_sd = load_file(path)
+        sc = _get(cfg, "semantic_codec")
+        keys = ("codebook_size", "hidden_size", "codebook_dim", "vocos_dim", "vocos_intermediate_dim", "vocos_num_layers")
+        self.codec = EnhancedCodec(**{k: int(_get(sc, k)) for k in keys if _get(sc, k) is not None}, device=self.device)
+        self.codec.load_state_dict(self._codec_sd)
+        if not self.codec._has_encoder:
+            raise RuntimeError(f"{path} does not carry the codec's encoder half (down.*, encoder.*, in_project): quantize() is unavailable")
+
+    def engine_state_dicts(self):
+        out = dict(semantic_codec=self._codec_sd, cfm=self._net["cfm"], length_regulator=self._net["length_regulator"])
+        if "gpt_layer" in self._net:
+            out["gpt_layer"] = self._net["gpt_layer"]
+        return out
+
+    @torch.no_grad()
+    def speaker_bundle(self, spk_audio_prompt) -> Dict[str, torch.Tensor]:
+        b = super().speaker_bundle(spk_audio_prompt)
+        _, S_ref = self.codec.quantize(b["spk_cond_emb"])
+        b["prompt_condition"] = self.regulator(S_ref, ylens=torch.tensor([b["ref_mel"].size(2)]), n_quantizers=3, f0=None)[0]
+        return b

@@ -126,3 +126,37 @@ def test_v1_conditioning_mel_from_a_wav_file(tmp_path):
         assert m.shape == ref.shape and m.shape[1] == 100 and float((m.cpu() - ref).abs().max()) <= 5e-4
     with pytest.raises(RuntimeError):
         fe.conditioning(m, torch.tensor([m.shape[-1]]))
+
+
+def test_v2_frontend_prompt_condition_goes_through_quantize(tmp_path):
+    """`EngineFrontendV2` (indextts/infer_v2.py:138-142,465-479): the semantic codec read from safetensors with its encoder half; prompt_condition =
+    length_regulator(quantize(spk_cond_emb)) vs the oracle chain; the other bundle entries equal the v2.5 frontend's."""
+    from safetensors.torch import save_file
+    from indextts_amd.frontend import EngineFrontend, EngineFrontendV2
+    from tools.make_golden_codec_quantize import CFG as QCFG, SEED as QSEED
+    d = tmp_path / "ckpt"
+    cfg, w = write_checkpoint_dir(d)
+    csd = KO.synth_codec_weights(QCFG, QSEED)
+    csd.update(KO.synth_codec_encoder_weights(QCFG, QSEED + 1))
+    (d / "hf_cache" / "semantic_codec").mkdir(parents=True)
+    save_file({k: v.contiguous() for k, v in csd.items()}, str(d / "hf_cache" / "semantic_codec" / "model.safetensors"))
+    cfg = dict(cfg, semantic_codec=dict(codebook_size=QCFG.codebook_size, hidden_size=QCFG.hidden_size, codebook_dim=QCFG.codebook_dim,
+                                        vocos_dim=QCFG.vocos_dim, vocos_intermediate_dim=QCFG.vocos_intermediate_dim,
+                                        vocos_num_layers=QCFG.vocos_num_layers))
+    assert QCFG.hidden_size == WCFG.hidden_size == RCFG.in_channels
+    fe2 = EngineFrontendV2(cfg, str(d), DEV)
+    b2 = fe2.speaker_bundle(str(d / "prompt.wav"))
+    b = EngineFrontend(cfg, str(d), DEV).speaker_bundle(str(d / "prompt.wav"))
+    for k in ("spk_cond_emb", "ref_mel", "style"):
+        assert torch.equal(b2[k], b[k])
+    idx_o, q_o, margin = KO.codec_quantize(csd, QCFG, b["spk_cond_emb"].cpu())
+    idx_e, q_e = fe2.codec.quantize(b["spk_cond_emb"])
+    same = idx_e.cpu() == idx_o
+    assert bool(same[margin > 1e-4].all()) and same.float().mean() > 0.9
+    cond_o, _ = KO.length_regulator(w["rsd"], RCFG, q_e.cpu(), torch.tensor([b["ref_mel"].shape[2]]))       # regulator on the engine's own codes
+    err = float((b2["prompt_condition"].cpu() - cond_o).abs().max())
+    print(f"v2 prompt_condition: {int(same.sum())}/{same.numel()} codes equal the oracle's (smallest margin {float(margin.min()):.1e}), "
+          f"regulator max|d| {err:.2e}")
+    assert b2["prompt_condition"].shape == b["prompt_condition"].shape and err <= 1e-4 * float(cond_o.abs().max()) + 1e-5
+    assert float((b2["prompt_condition"] - b["prompt_condition"]).abs().max()) > 1e-3           # not the v2.5 path
+    assert set(fe2.engine_state_dicts()) == {"semantic_codec", "cfm", "length_regulator"}
