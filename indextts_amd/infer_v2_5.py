@@ -452,7 +452,9 @@ class ReferenceFrontend(Frontend):
                 from indextts.infer_v2_5 import IndexTTS2 as RefIndexTTS2
             except Exception as e:                                   # loud: there is no fallback
                 raise ImportError("ReferenceFrontend needs the reference `indextts` package and its prompt-side dependencies "
-                                  f"(torchaudio, librosa, transformers, ...): {e!r}.  Inject frontend= instead.") from e
+                                  f"(torchaudio, librosa, transformers, ...): {e!r}.  Inject frontend= instead, e.g. "
+                                  "indextts_amd.frontend.EngineFrontend(cfg, model_dir, device, text_frontend=...), which reads the "
+                                  "checkpoint directory itself and needs no reference package.") from e
             ref = RefIndexTTS2(cfg_path=cfg_path or os.path.join(model_dir, "config.yaml"), model_dir=model_dir, use_bf16=False,
                                device=device, use_cuda_kernel=False)
             for name in ("bigvgan",):                                # replaced by the engine
