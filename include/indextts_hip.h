@@ -372,7 +372,7 @@ int itts_tok_dwconv_causal_forward(const float* x, const float* w, const float* 
                                    const int32_t* seq_T, int n, int C, int k, void* stream);
 /* replaces: F.glu (mode 0, conformer_encoder.py:147) / GEGLU (mode 1, perceiver.py): x [n][2C] -> out [n][C] */
 int itts_tok_glu_forward(const float* x, float* out, int n, int C, int mode, void* stream);
-/* replaces: ReLU (mode 0, subsampling.py:150) / SiLU (mode 1, conformer activation), in place */
+/* replaces: ReLU (mode 0, subsampling.py:150) / SiLU (mode 1, conformer activation) / tanh (mode 2, ECAPA attention), in place */
 int itts_tok_act_forward(float* x, size_t n, int mode, void* stream);
 /* replaces: perceiver.py RMSNorm (F.normalize(x) * sqrt(dim) * gamma), in place */
 int itts_tok_l2norm_forward(float* x, const float* gamma, int n, int C, float scale, void* stream);
@@ -390,6 +390,10 @@ int itts_tok_affine_forward(const float* x, int ld_x, const float* scale, const 
 int itts_tok_ctxpool_forward(const float* h, float* out, int n, int C, int seg_len, void* stream);
 /* replaces: y * sigmoid(linear2(...)) of CAMLayer.forward, in place on y */
 int itts_tok_gate_forward(float* y, const float* g, size_t n, void* stream);
+/* replaces: AttentiveStatisticsPooling._compute_statistics (indextts/BigVGAN/ECAPA_TDNN.py:282-338, the speaker encoder inside the v1 / v1.5
+ *   vocoder, models.py:191,202): per channel, weights softmax over the n frames of logit [n][C] (NULL: uniform, the global-context statistics);
+ *   x [n][C] -> out [2C] = weighted mean | sqrt(max(weighted variance, eps)) */
+int itts_tok_attnstats_forward(const float* x, const float* logit, float* out, int n, int C, float eps, void* stream);
 /* replaces: StatsPool (mean | unbiased std over time, layers.py statistics_pooling): x [n][C] -> out [2C] */
 int itts_tok_statspool_forward(const float* x, float* out, int n, int C, void* stream);
 

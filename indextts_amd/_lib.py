@@ -135,6 +135,7 @@ SIGNATURES = {
     "itts_tok_affine_forward": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "itts_tok_ctxpool_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "itts_tok_gate_forward": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "itts_tok_attnstats_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "itts_tok_statspool_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "itts_tok_scale_residual_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "itts_tok_groupnorm_mish_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),

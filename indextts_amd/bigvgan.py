@@ -5,8 +5,9 @@ Reference interface mirrored (same names / argument meaning):
     `BigVGAN.from_pretrained(dir)`, `.remove_weight_norm()`, `.eval()`, `.to(device)`, `model(mel) -> (B,1,T*256)`
     (call site `indextts/infer_v2_5.py:224-233,850`).
   * v1 / v1.5: `indextts/BigVGAN/models.py::BigVGAN` -- `model(latent (B,T,D), mel_ref^T) -> (wav, None)`
-    (call site `indextts/infer.py:647`).  The ECAPA-TDNN speaker encoder stays a PyTorch module supplied by the
-    caller (`speaker_encoder=`); its embedding is cached per reference clip instead of being recomputed per call.
+    (call site `indextts/infer.py:647`).  The ECAPA-TDNN speaker encoder runs on the engine too (indextts_amd/ecapa.py, built from the
+    checkpoint's `speaker_encoder.*` tensors; `speaker_encoder=` injects another callable); its embedding is cached per reference clip instead
+    of being recomputed per call.
 Extra (not in the reference): `lens=` for ragged batches -- every row is bounded at its own length so the result
 per row equals the reference run at B=1.
 """
@@ -142,7 +143,23 @@ class BigVGAN:
                 continue
             host[name] = t.detach().to("cpu", torch.float32).contiguous()
         self._sd_host = host
+        # v1 / v1.5 checkpoints carry the ECAPA-TDNN speaker encoder under `speaker_encoder.` (models.py:191): kept on the host and built on the
+        # engine (indextts_amd/ecapa.py) at the first speaker_embedding() call, unless a speaker_encoder= was injected
+        self._spk_sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()
+                        if k.startswith("speaker_encoder.") and not k.endswith("num_batches_tracked")}
         return skipped + self._upload(strict)
+
+    def _build_speaker_encoder(self):
+        from .ecapa import ECAPA_TDNN
+        sd, P = self._spk_sd, "speaker_encoder."
+        w0 = sd[P + "blocks.0.conv.conv.weight"]
+        C = int(w0.shape[0])
+        scale = 1 + len({k.split(".")[5] for k in sd if k.startswith(P + "blocks.1.res2net_block.blocks.")})
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        enc = ECAPA_TDNN(int(w0.shape[1]), device=dev, lin_neurons=int(sd[P + "fc.conv.weight"].shape[0]), channels=[C] * 4 + [3 * C],
+                         attention_channels=int(sd[P + "asp.tdnn.conv.conv.weight"].shape[0]),
+                         se_channels=int(sd[P + "blocks.1.se_block.conv1.conv.weight"].shape[0]), res2net_scale=scale)
+        return enc.load_state_dict(sd, prefix=P)
 
     @classmethod
     def from_pretrained(cls, model_dir: str, use_cuda_kernel: bool = False, **kw):
@@ -186,8 +203,10 @@ class BigVGAN:
 
     def speaker_embedding(self, mel_ref: torch.Tensor, lens=None, key=None) -> torch.Tensor:
         """v1: ECAPA-TDNN embedding of the reference mel (models.py:202), cached per `key`."""
+        if self.speaker_encoder is None and getattr(self, "_spk_sd", None):
+            self.speaker_encoder = self._build_speaker_encoder()
         if self.speaker_encoder is None:
-            raise RuntimeError("this BigVGAN was built without a speaker_encoder; pass speaker_embedding=")
+            raise RuntimeError("this BigVGAN was built without a speaker_encoder and its checkpoint carried none; pass speaker_embedding=")
         if key is not None and key in self._spk_cache:
             return self._spk_cache[key]
         with torch.no_grad():

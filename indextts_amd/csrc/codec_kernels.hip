@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void glu_kernel(const float* __restrict__ x, f
 __global__ __launch_bounds__(256) void act_kernel(float* __restrict__ x, size_t n, int mode) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float v = x[i];
-        x[i] = mode == 0 ? fmaxf(v, 0.f) : v / (1.0f + expf(-v));
+        x[i] = mode == 0 ? fmaxf(v, 0.f) : (mode == 1 ? v / (1.0f + expf(-v)) : tanhf(v));
     }
 }
 
@@ -427,6 +427,44 @@ __global__ __launch_bounds__(64) void statspool_kernel(const float* __restrict__
     for (int t = lane; t < n; t += 64) { const float d = x[(size_t)t * C + c] - mean; q += d * d; }
     q = wave_sum(q);
     if (lane == 0) { out[c] = mean; out[C + c] = sqrtf(q / (float)(n - 1)); }
+}
+
+// Attentive statistics pooling (ECAPA_TDNN.py AttentiveStatisticsPooling._compute_statistics): per channel c over the n frames, weights
+// a_t = softmax_t(logit[t][c]) (logit == NULL: uniform 1 / n -- the global-context statistics): out[c] = sum_t a_t x[t][c],
+// out[C + c] = sqrt(max(sum_t a_t (x[t][c] - mean)^2, eps)).  One wave per channel, like statspool_kernel.
+__global__ __launch_bounds__(64) void attnstats_kernel(const float* __restrict__ x, const float* __restrict__ logit, float* __restrict__ out, int n,
+                                                       int C, float eps) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float mx = 0.f, den = (float)n;
+    if (logit) {
+        mx = -INFINITY;
+        for (int t = lane; t < n; t += 64) mx = fmaxf(mx, logit[(size_t)t * C + c]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int t = lane; t < n; t += 64) s += expf(logit[(size_t)t * C + c] - mx);
+        den = wave_sum(s);
+    }
+    float m = 0.f;
+    for (int t = lane; t < n; t += 64) {
+        const float a = logit ? expf(logit[(size_t)t * C + c] - mx) : 1.f;
+        m = fmaf(a, x[(size_t)t * C + c], m);
+    }
+    const float mean = wave_sum(m) / den;
+    float q = 0.f;
+    for (int t = lane; t < n; t += 64) {
+        const float a = logit ? expf(logit[(size_t)t * C + c] - mx) : 1.f;
+        const float d = x[(size_t)t * C + c] - mean;
+        q = fmaf(a * d, d, q);
+    }
+    q = wave_sum(q) / den;
+    if (lane == 0) { out[c] = mean; out[C + c] = sqrtf(fmaxf(q, eps)); }
+}
+
+extern "C" int itts_tok_attnstats_forward(const float* x, const float* logit, float* out, int n, int C, float eps, void* stream) {
+    if (!x || !out || C < 1 || n < 1) { itts_set_error("tok_attnstats: bad args"); return ITTS_ERR_ARG; }
+    hipLaunchKernelGGL(attnstats_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, x, logit, out, n, C, eps);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
 }
 
 extern "C" int itts_tok_affine_forward(const float* x, int ld_x, const float* scale, const float* shift, float* out, int n, int C, int relu,
@@ -503,7 +541,7 @@ extern "C" int itts_tok_glu_forward(const float* x, float* out, int n, int C, in
 }
 
 extern "C" int itts_tok_act_forward(float* x, size_t n, int mode, void* stream) {
-    if (!x || mode < 0 || mode > 1) { itts_set_error("tok_act: bad args"); return ITTS_ERR_ARG; }
+    if (!x || mode < 0 || mode > 2) { itts_set_error("tok_act: bad args"); return ITTS_ERR_ARG; }
     if (n == 0) return ITTS_OK;
     hipLaunchKernelGGL(act_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, mode);
     HIP_TRY(hipGetLastError());
