@@ -12,7 +12,7 @@ def test_load_wav_scales_and_mixes_down(tmp_path):
     x = (g.rand(1000, 2) * 2 - 1).astype(np.float32) * 0.9
     cases = {"f32": x, "i16": np.round(x * 32767).astype(np.int16), "i32": np.round(x.astype(np.float64) * (2 ** 31 - 1)).astype(np.int32),
              "u8": np.round((x + 1) * 127.5).astype(np.uint8)}
-    tol = {"f32": 0.0, "i16": 2.0 / 32768, "i32": 1e-6, "u8": 1.0 / 127}
+    tol = {"f32": 0.0, "i16": 2.0 / 32768, "i32": 1e-6, "u8": 2.0 / 127}
     for tag, data in cases.items():
         p = tmp_path / f"{tag}.wav"
         wavfile.write(str(p), 22050, data)
