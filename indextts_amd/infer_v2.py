@@ -21,6 +21,8 @@ from .infer_v2_5 import PCM16_MAX, Frontend, IndexTTS2 as _IndexTTS2V25  # noqa:
 
 
 class IndexTTS2(_IndexTTS2V25):
+    USE_GPT_LATENT = True
+
     def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", use_fp16=False, device=None, use_cuda_kernel=None,
                  use_deepspeed=False, use_accel=False, use_torch_compile=False, use_qwen_emo=True, aux_paths=None, *, frontend=None,
                  gpt=None, bigvgan=None, cfg=None, semantic_codec=None, s2mel=None):

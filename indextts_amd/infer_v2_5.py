@@ -72,6 +72,8 @@ class Frontend:
 
 
 class IndexTTS2:
+    USE_GPT_LATENT = False                 # the s2mel stage of IndexTTS-2 carries the GPT-latent projector `gpt_layer` (subclass sets it)
+
     def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", use_bf16=False, device=None,
                  use_cuda_kernel=None, use_deepspeed=False, use_accel=False, use_torch_compile=False, use_qwen_emo=False,
                  *, frontend: Optional[Frontend] = None, gpt=None, bigvgan=None, cfg: Optional[dict] = None,
@@ -118,16 +120,26 @@ class IndexTTS2:
         if frontend is None:
             frontend = ReferenceFrontend(cfg, model_dir, self.device, self.gpt, cfg_path=cfg_path)
         self.frontend = frontend
-        if self.s2mel is None and self.semantic_codec is None and hasattr(frontend, "engine_state_dicts") and "s2mel" in cfg \
+        if (self.s2mel is None or self.semantic_codec is None) and hasattr(frontend, "engine_state_dicts") and "s2mel" in cfg \
                 and "semantic_codec" in cfg:
-            # codes -> mel on the engine, weights taken from the modules the reference loaded (codec.pth / s2mel.pth)
+            # codes -> mel on the engine, weights from the state dicts the frontend read (the reference's modules, or codec.pth / s2mel.pth
+            # themselves); a stage that was injected is kept
             from .codec import EnhancedCodec
             from .s2mel import MyModel
             sds = frontend.engine_state_dicts()
-            self.semantic_codec = EnhancedCodec(**dict(cfg["semantic_codec"]), device=self.device)
-            self.semantic_codec.load_state_dict(sds["semantic_codec"])
-            self.s2mel = MyModel(cfg["s2mel"], precision="bf16" if self.use_bf16 else "fp32", device=self.device)
-            self.s2mel.load_state_dict({"cfm": sds["cfm"], "length_regulator": sds["length_regulator"]})
+            if self.semantic_codec is None:
+                self.semantic_codec = EnhancedCodec(**dict(cfg["semantic_codec"]), device=self.device)
+                self.semantic_codec.load_state_dict(sds["semantic_codec"])
+            if self.s2mel is None:
+                net = {"cfm": sds["cfm"], "length_regulator": sds["length_regulator"]}
+                if self.USE_GPT_LATENT:                   # IndexTTS-2: MyModel(cfg.s2mel, use_gpt_latent=True), infer_v2.py:145
+                    if "gpt_layer" not in sds:
+                        raise RuntimeError("IndexTTS-2 needs the s2mel checkpoint's `gpt_layer` (latent projector): this frontend's "
+                                           "engine_state_dicts() has none -- use indextts_amd.frontend.EngineFrontendV2 or inject s2mel=")
+                    net["gpt_layer"] = sds["gpt_layer"]
+                self.s2mel = MyModel(cfg["s2mel"], use_gpt_latent=self.USE_GPT_LATENT, precision="bf16" if self.use_bf16 else "fp32",
+                                     device=self.device)
+                self.s2mel.load_state_dict(net)
         self.tokenizer = getattr(frontend, "tokenizer", None)
         # reference cache attributes (:269-279)
         self.cache_spk_cond = None

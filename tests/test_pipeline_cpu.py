@@ -136,3 +136,58 @@ def test_v2_pipeline_control_flow():
     assert set(tts.last_timing) == {"gpt", "gpt_forward", "s2mel", "bigvgan"}
     res = tts.infer_batch("spk.wav", ["a. b", "c"], "en", num_beams=1)
     assert len(res) == 2 and all(r[0] == 22050 for r in res)
+
+
+def test_engine_stages_are_built_from_the_frontends_state_dicts(monkeypatch):
+    """`IndexTTS2.__init__` builds the codes -> mel engine stages from `frontend.engine_state_dicts()` when the config describes them: a stage
+    that was injected is kept; IndexTTS-2 (`USE_GPT_LATENT`) builds `MyModel(use_gpt_latent=True)` and loads `gpt_layer`, and refuses a frontend
+    whose dicts lack it.  The engine classes are replaced by recorders (their real constructors need a GPU)."""
+    from indextts_amd import codec as codec_mod, s2mel as s2mel_mod
+    from indextts_amd.infer_v2 import IndexTTS2 as V2
+    made = []
+
+    class RecCodec:
+        def __init__(self, **kw):
+            self.kw, self.loaded = kw, None
+            made.append(("codec", kw))
+
+        def load_state_dict(self, sd):
+            self.loaded = sd
+
+    class RecS2:
+        def __init__(self, args, use_gpt_latent=False, precision="bf16", device="cuda:0"):
+            self.args, self.use_gpt_latent, self.precision, self.net = args, use_gpt_latent, precision, None
+            made.append(("s2mel", use_gpt_latent, precision))
+
+        def load_state_dict(self, net):
+            self.net = net
+
+    monkeypatch.setattr(codec_mod, "EnhancedCodec", RecCodec)
+    monkeypatch.setattr(s2mel_mod, "MyModel", RecS2)
+
+    class FE(StubFrontend):
+        def __init__(self, with_gpt_layer):
+            super().__init__(64)
+            self.with_gpt_layer = with_gpt_layer
+
+        def engine_state_dicts(self):
+            d = dict(semantic_codec={"c": 1}, cfm={"f": 2}, length_regulator={"r": 3})
+            if self.with_gpt_layer:
+                d["gpt_layer"] = {"g": 4}
+            return d
+
+    cfg = {"gpt": {"stop_mel_token": 8193}, "s2mel": {"x": 1}, "semantic_codec": {"hidden_size": 64}}
+    tts = IndexTTS2(cfg=cfg, device="cpu", frontend=FE(False), gpt=FakeGPT(), bigvgan=FakeVoc())
+    assert made == [("codec", {"hidden_size": 64, "device": "cpu"}), ("s2mel", False, "fp32")]
+    assert tts.semantic_codec.loaded == {"c": 1} and tts.s2mel.net == {"cfm": {"f": 2}, "length_regulator": {"r": 3}}
+    made.clear()
+    mine = object()
+    tts = V2(cfg=dict(cfg, version=2.0), device="cpu", frontend=FE(True), gpt=FakeGPTV2(), bigvgan=FakeVoc(), semantic_codec=mine, use_fp16=True)
+    assert tts.semantic_codec is mine and made == [("s2mel", True, "bf16")]                     # the injected codec is kept
+    assert tts.s2mel.net == {"cfm": {"f": 2}, "length_regulator": {"r": 3}, "gpt_layer": {"g": 4}}
+    import pytest
+    with pytest.raises(RuntimeError, match="gpt_layer"):
+        V2(cfg=dict(cfg, version=2.0), device="cpu", frontend=FE(False), gpt=FakeGPTV2(), bigvgan=FakeVoc())
+    made.clear()
+    IndexTTS2(cfg=cfg, device="cpu", frontend=FE(False), gpt=FakeGPT(), bigvgan=FakeVoc(), semantic_codec=mine, s2mel=mine)
+    assert made == []                                                                            # both injected: nothing is built
