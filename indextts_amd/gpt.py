@@ -53,6 +53,11 @@ class UnifiedVoice:
         self.use_graph = True
         self.n_mel_pos = max_mel_tokens + 2 + max_conditioning_inputs
         self.n_text_pos = max_text_tokens + 2
+        # `tts.gpt.text_pos_embedding.emb.num_embeddings` is read by the reference's text splitter (indextts/infer_v2_5.py:428) and
+        # `mel_pos_embedding` likewise by callers sizing generation: attribute paths kept
+        from types import SimpleNamespace
+        self.text_pos_embedding = SimpleNamespace(emb=SimpleNamespace(num_embeddings=self.n_text_pos))
+        self.mel_pos_embedding = SimpleNamespace(emb=SimpleNamespace(num_embeddings=self.n_mel_pos))
         cfg = _lib.GPTConfig()
         cfg.layers, cfg.model_dim, cfg.heads = layers, model_dim, heads
         cfg.vocab, cfg.n_mel_pos, cfg.precision = number_mel_codes, self.n_mel_pos, self.precision
