@@ -13,7 +13,7 @@ configuration and device; the waveform work runs in `audio_kernels.hip` through 
 `itts_fbank_forward`, `itts_tok_colnorm_forward`).  There is no CPU path: without the HIP library the calls raise.
 """
 import math
-from typing import Dict, List, Optional, Sequence, Tuple, Union
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
