@@ -306,7 +306,11 @@ class ConditioningEncoders:
 
     @staticmethod
     def _run(pair, feats, lens):
-        x, t_out, _ = pair[0].forward_packed(feats, [int(v) for v in lens])
+        # the reference passes the feature WIDTH (1024) as the "length" (infer_v2_5.py:760-765, infer_v2.py:643-648, model_v2.py:761;
+        # SURVEY.md section 9 item 9) and its padding mask compares frame index < length, so a length above T simply means "every frame
+        # is valid": clamp instead of rejecting it
+        T = int(feats.shape[1])
+        x, t_out, _ = pair[0].forward_packed(feats, [min(int(v), T) for v in lens])
         return pair[1].forward_packed(x, t_out)
 
     def get_conditioning(self, speech_conditioning_input: torch.Tensor, cond_mel_lengths) -> torch.Tensor:

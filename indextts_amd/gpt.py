@@ -277,6 +277,7 @@ class UnifiedVoice:
         attention_mask (B,s+1).  Returns generated ids (B, n) (what `output[:, trunc_index:]` is in the reference)."""
         if not self._loaded:
             raise RuntimeError("UnifiedVoice: load_state_dict() first")
+        self._check_idle("generate")
         if num_beams != 1:
             return self._generate_beam(inputs_embeds, attention_mask, max_new_tokens, do_sample, num_beams, top_p, top_k,
                                        temperature, repetition_penalty, length_penalty, uniforms, seed, typical_mass)
@@ -338,6 +339,24 @@ class UnifiedVoice:
             raise NotImplementedError("generate_chunks streams num_beams=1 (a beam's prefix is not final until the search ends)")
         if not self._loaded:
             raise RuntimeError("UnifiedVoice: load_state_dict() first")
+        # the suspended loop's state (KV cache in the workspace, the persistent `codes` buffer) is shared with generate(): another
+        # generation on this object while a stream is open would corrupt it -> refuse until the stream is exhausted / closed
+        self._check_idle("generate_chunks")
+        self._stream_open = True
+        try:
+            yield from self._generate_chunks_body(inputs_embeds, attention_mask, max_new_tokens, chunk_size, overlap_size, stride, do_sample,
+                                                  top_p, top_k, temperature, repetition_penalty, length_penalty, uniforms, seed, typical_mass)
+        finally:
+            self._stream_open = False
+
+    def _check_idle(self, who: str):
+        if getattr(self, "_stream_open", False):
+            raise RuntimeError(f"UnifiedVoice.{who}: a chunked generation (generate_chunks / infer_stream) is open on this engine; its "
+                               "KV cache and code buffer live in the shared workspace.  Exhaust or close() that generator first, or use "
+                               "a second UnifiedVoice for concurrent requests.")
+
+    def _generate_chunks_body(self, inputs_embeds, attention_mask, max_new_tokens, chunk_size, overlap_size, stride, do_sample, top_p, top_k,
+                              temperature, repetition_penalty, length_penalty, uniforms, seed, typical_mass):
         dev = self.device
         B, s, D = inputs_embeds.shape
         start = (self._emb["mel_embedding.weight"][self.start_mel_token] + self._emb["mel_pos_embedding.emb.weight"][0])
@@ -499,8 +518,9 @@ class UnifiedVoice:
             else:                                                   # IndexTTS-2 (model_v2.py:761,767-773)
                 if speech_condition.ndim == 2:
                     speech_condition = speech_condition.unsqueeze(0)
-                if cond_lengths is None:
-                    cond_lengths = torch.tensor([speech_condition.shape[-1]], device=speech_condition.device)
+                if cond_lengths is None:       # model_v2.py:761 passes the feature width; = "all frames valid" (clamped to the frame count)
+                    cond_lengths = torch.tensor([min(int(speech_condition.shape[-1]), int(speech_condition.shape[1]))],
+                                                device=speech_condition.device)
                 spk_lat = self.get_conditioning(speech_condition.transpose(1, 2), cond_lengths)
                 conds_latent = self.conds_latent_v2(spk_lat, emo_vec)
                 langs = None
@@ -538,6 +558,7 @@ class UnifiedVoice:
     # ---- teacher-forced latent pass (model_v2.py:596-646) ----------------------------------------------------------
     def forward_latent(self, conds: torch.Tensor, text_inputs: torch.Tensor, text_lengths: torch.Tensor,
                        mel_codes: torch.Tensor, mel_codes_lengths: torch.Tensor) -> torch.Tensor:
+        self._check_idle("forward_latent")
         dev = self.device
         text = text_inputs.to(dev).long().clone()
         mel = mel_codes.to(dev).long().clone()

@@ -22,19 +22,55 @@ from .infer_v2_5 import PCM16_MAX, Frontend, IndexTTS2 as _IndexTTS2V25  # noqa:
 
 class IndexTTS2(_IndexTTS2V25):
     USE_GPT_LATENT = True
+    SPK_COND_MODE = "conformer"            # infer_v2.py:98: `UnifiedVoice(**cfg.gpt)`, the default conditioning mode (no spk_emb_proj.*)
+
+    @staticmethod
+    def _bigvgan_dir(model_dir, aux_paths=None):
+        """infer_v2.py:176-177: `aux_paths["bigvgan"]`; `ensure_models_available(model_dir)` (utils/model_download.py:213-214) places it
+        at `<model_dir>/hf_cache/bigvgan`, which is where it is looked for when no `aux_paths` is given (no downloads here)."""
+        import os
+        if aux_paths and "bigvgan" in aux_paths:
+            return aux_paths["bigvgan"]
+        return os.path.join(model_dir, "hf_cache", "bigvgan")
 
     def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", use_fp16=False, device=None, use_cuda_kernel=None,
                  use_deepspeed=False, use_accel=False, use_torch_compile=False, use_qwen_emo=True, aux_paths=None, *, frontend=None,
-                 gpt=None, bigvgan=None, cfg=None, semantic_codec=None, s2mel=None):
+                 gpt=None, bigvgan=None, cfg=None, semantic_codec=None, s2mel=None, codes_to_mel="auto"):
         """infer_v2.py:37-41.  `use_fp16` selects the engine's reduced-precision (bf16) GPT mode; QwenEmotion (text -> emotion
         vector) is a prompt-side LLM: when no frontend providing it is injected, `use_emo_text` raises like the reference does
         without the model."""
         super().__init__(cfg_path=cfg_path, model_dir=model_dir, use_bf16=use_fp16, device=device, use_cuda_kernel=use_cuda_kernel,
                          use_deepspeed=use_deepspeed, use_accel=use_accel, use_torch_compile=use_torch_compile, use_qwen_emo=False,
-                         frontend=frontend, gpt=gpt, bigvgan=bigvgan, cfg=cfg, semantic_codec=semantic_codec, s2mel=s2mel)
+                         frontend=frontend, gpt=gpt, bigvgan=bigvgan, cfg=cfg, semantic_codec=semantic_codec, s2mel=s2mel,
+                         aux_paths=aux_paths, codes_to_mel=codes_to_mel)
         self.use_fp16 = bool(use_fp16)
         self.aux_paths = aux_paths
         self.model_version = (cfg or self.cfg).get("version", 2.0)
+
+    # ---- API: the reference v2 signatures (infer_v2.py:371-400) -- no `lang`, `duration_factor`, `text_normalization` -------------
+    def infer(self, spk_audio_prompt, text, output_path, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None, use_emo_text=False,
+              emo_text=None, use_random=False, interval_silence=200, verbose=False, max_text_tokens_per_segment=120,
+              stream_return=False, more_segment_before=0, **generation_kwargs):
+        gen = self.infer_generator(spk_audio_prompt, text, output_path, emo_audio_prompt, emo_alpha, emo_vector, use_emo_text, emo_text,
+                                   use_random, interval_silence, verbose, max_text_tokens_per_segment, stream_return,
+                                   more_segment_before, **generation_kwargs)
+        if stream_return:
+            return gen
+        try:
+            return list(gen)[0]
+        except IndexError:
+            return None
+
+    def infer_generator(self, spk_audio_prompt, text, output_path, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None,
+                        use_emo_text=False, emo_text=None, use_random=False, interval_silence=200, verbose=False,
+                        max_text_tokens_per_segment=120, stream_return=False, quick_streaming_tokens=0, **generation_kwargs):
+        yield from self._infer_impl(spk_audio_prompt, text, output_path, None, emo_audio_prompt, emo_alpha, emo_vector, use_emo_text,
+                                    emo_text, use_random, interval_silence, verbose, max_text_tokens_per_segment, stream_return, 1.0,
+                                    True, generation_kwargs)
+
+    def infer_stream(self, *a, **kw):
+        raise NotImplementedError("IndexTTS-2 streaming needs the teacher-forced latent pass per chunk; the chunked path "
+                                  "(infer_stream) is built for the v2.5 pipeline only")
 
     def _synthesize(self, segment_tokens: List[torch.Tensor], lang_ids, bundle, emovec, duration_factor, generation_kwargs,
                     max_text_tokens_per_segment) -> List[torch.Tensor]:
@@ -50,13 +86,24 @@ class IndexTTS2(_IndexTTS2V25):
         B = len(segment_tokens)
         L = max(int(t.numel()) for t in segment_tokens)
         text = torch.full((B, L), 1, dtype=torch.int32)                 # stop_text_token right padding
-        text_lens = torch.tensor([int(t.numel()) for t in segment_tokens])
+        # The teacher-forced pass sees `[start, ids, stop]` (infer_v2.py:558-560,639-642: the v2 reference tokenises a segment WITHOUT a
+        # trailing stop id and `forward` pads one on).  The Frontend protocol appends stop id 1 to every segment (the v2.5 convention,
+        # infer_v2_5.py:726); it is not part of the text, so the length handed to the latent pass excludes trailing stop ids.
+        text_lens = []
         for i, t in enumerate(segment_tokens):
-            text[i, : t.numel()] = t.reshape(-1).to(torch.int32)
+            flat = t.reshape(-1).to(torch.int32)
+            text[i, : flat.numel()] = flat
+            n = int(flat.numel())
+            while n > 0 and int(flat[n - 1]) == 1:
+                n -= 1
+            text_lens.append(n)
+        text_lens = torch.tensor(text_lens)
         spk_cond_emb, emo_cond_emb = bundle["spk_cond_emb"], bundle.get("emo_cond_emb", bundle["spk_cond_emb"])
         t0 = time.perf_counter()
-        # one batch of B segments: the speaker latents are the same for every row (one speaker prompt)
-        lat1 = self.gpt.get_conditioning(spk_cond_emb.transpose(1, 2), torch.tensor([spk_cond_emb.shape[-1]], device=spk_cond_emb.device))
+        # one batch of B segments: the speaker latents are the same for every row (one speaker prompt).  The reference hands the
+        # feature WIDTH over as the length (infer_v2.py:646, model_v2.py:761): "every frame valid" for prompts under 1024 frames
+        n_spk = min(int(spk_cond_emb.shape[-1]), int(spk_cond_emb.shape[1]))
+        lat1 = self.gpt.get_conditioning(spk_cond_emb.transpose(1, 2), torch.tensor([n_spk], device=spk_cond_emb.device))
         conds = self.gpt.conds_latent_v2(lat1.expand(B, -1, -1), emovec)
         codes, speech_conditioning_latent = self.gpt.inference_speech(
             spk_cond_emb, text.to(dev), emo_cond_emb, emo_vec=emovec, conds_latent=conds, do_sample=True, top_p=top_p, top_k=top_k,

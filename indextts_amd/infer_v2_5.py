@@ -73,11 +73,26 @@ class Frontend:
 
 class IndexTTS2:
     USE_GPT_LATENT = False                 # the s2mel stage of IndexTTS-2 carries the GPT-latent projector `gpt_layer` (subclass sets it)
+    SPK_COND_MODE = "campplus"             # `UnifiedVoice(..., spk_cond_mode=)` of this version (infer_v2_5.py:106; v2: the default, conformer)
+
+    @staticmethod
+    def _bigvgan_dir(model_dir, aux_paths=None):
+        """infer_v2_5.py:224-228: `<model_dir>/hf_cache/bigvgan`, else the pre-downloaded `aux_paths["bigvgan"]`."""
+        d = os.path.join(model_dir, "hf_cache", "bigvgan")
+        if not os.path.isdir(d) and aux_paths and "bigvgan" in aux_paths:
+            d = aux_paths["bigvgan"]
+        return d
 
     def __init__(self, cfg_path="checkpoints/config.yaml", model_dir="checkpoints", use_bf16=False, device=None,
                  use_cuda_kernel=None, use_deepspeed=False, use_accel=False, use_torch_compile=False, use_qwen_emo=False,
                  *, frontend: Optional[Frontend] = None, gpt=None, bigvgan=None, cfg: Optional[dict] = None,
-                 semantic_codec=None, s2mel=None):
+                 semantic_codec=None, s2mel=None, aux_paths=None, codes_to_mel="auto"):
+        """`codes_to_mel`: where codes -> mel runs.  "engine": the HIP codec / length regulator / CFM stages (given as
+        `semantic_codec=` / `s2mel=` or built from the frontend's state dicts) -- raises if they cannot be built; "frontend": the
+        frontend's PyTorch `codes_to_mel` (north_star keeps s2mel on PyTorch as a legitimate integration mode); "auto" (default):
+        the engine when its stages are available, else the frontend, and the choice is recorded in `self.codes_to_mel_mode`."""
+        if codes_to_mel not in ("auto", "engine", "frontend"):
+            raise ValueError(f"codes_to_mel must be 'auto', 'engine' or 'frontend', got {codes_to_mel!r}")
         if device is not None:
             self.device = device
         elif torch.cuda.is_available():
@@ -97,13 +112,15 @@ class IndexTTS2:
         self.stop_mel_token = gcfg.get("stop_mel_token", 8193)
         self.model_version = cfg.get("version", None)
         self.gr_progress = None
+        self.low_vram = False                  # infer_v2_5.py:124-131 turns it on below 10 GB of device memory; callers may set it
         self.qwen_emo = None
         if use_qwen_emo:
             raise NotImplementedError("QwenEmotion (text -> emotion vector) is a prompt-side LLM; run it with the reference "
                                       "package and pass emo_vector= instead")
         if gpt is None:
             from .gpt import UnifiedVoice
-            gpt = UnifiedVoice(**gcfg, spk_cond_mode="campplus", precision="bf16" if self.use_bf16 else "fp32",
+            gcfg.pop("spk_cond_mode", None)
+            gpt = UnifiedVoice(**gcfg, spk_cond_mode=self.SPK_COND_MODE, precision="bf16" if self.use_bf16 else "fp32",
                                device=self.device)
             ck = torch.load(os.path.join(model_dir, cfg["gpt_checkpoint"]), map_location="cpu")
             gpt.load_state_dict(ck["model"] if "model" in ck else ck)
@@ -111,7 +128,7 @@ class IndexTTS2:
         self.gpt = gpt
         if bigvgan is None:
             from .bigvgan import BigVGAN
-            bigvgan = BigVGAN.from_pretrained(os.path.join(model_dir, "hf_cache", "bigvgan")).to(self.device)
+            bigvgan = BigVGAN.from_pretrained(self._bigvgan_dir(model_dir, aux_paths)).to(self.device)
         self.bigvgan = bigvgan
         # codes -> mel on the HIP engine when both stages are given (indextts_amd.codec.EnhancedCodec, indextts_amd.s2mel.MyModel);
         # otherwise the frontend's codes_to_mel (the reference's PyTorch modules) is used
@@ -120,7 +137,9 @@ class IndexTTS2:
         if frontend is None:
             frontend = ReferenceFrontend(cfg, model_dir, self.device, self.gpt, cfg_path=cfg_path)
         self.frontend = frontend
-        if (self.s2mel is None or self.semantic_codec is None) and hasattr(frontend, "engine_state_dicts") and "s2mel" in cfg \
+        if codes_to_mel == "frontend":
+            self.semantic_codec = self.s2mel = None
+        elif (self.s2mel is None or self.semantic_codec is None) and hasattr(frontend, "engine_state_dicts") and "s2mel" in cfg \
                 and "semantic_codec" in cfg:
             # codes -> mel on the engine, weights from the state dicts the frontend read (the reference's modules, or codec.pth / s2mel.pth
             # themselves); a stage that was injected is kept
@@ -140,6 +159,10 @@ class IndexTTS2:
                 self.s2mel = MyModel(cfg["s2mel"], use_gpt_latent=self.USE_GPT_LATENT, precision="bf16" if self.use_bf16 else "fp32",
                                      device=self.device)
                 self.s2mel.load_state_dict(net)
+        if codes_to_mel == "engine" and (self.s2mel is None or self.semantic_codec is None):
+            raise RuntimeError("codes_to_mel='engine': the HIP codec / s2mel stages were neither injected (semantic_codec=, s2mel=) nor "
+                               "buildable from this frontend (it needs engine_state_dicts() and cfg['s2mel'] / cfg['semantic_codec'])")
+        self.codes_to_mel_mode = "engine" if (self.s2mel is not None and self.semantic_codec is not None) else "frontend"
         self.tokenizer = getattr(frontend, "tokenizer", None)
         # reference cache attributes (:269-279)
         self.cache_spk_cond = None
@@ -215,10 +238,68 @@ class IndexTTS2:
         return emovec
 
     # ---- API -------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def split_text_by_punctuation(text, max_chars=40):
+        """infer_v2_5.py:466-487: pieces of at most `max_chars` characters cut after punctuation; a piece with no punctuation
+        stays whole (no mid-word cut)."""
+        import re
+        pieces, cur = [], ""
+        for part in re.split(r'(?<=[\uff0c\u3002\uff01\uff1f\u3001\uff1b\uff1a,\.!\?;:\n])', text):
+            if not part:
+                continue
+            if len(cur) + len(part) <= max_chars:
+                cur += part
+            else:
+                if cur:
+                    pieces.append(cur)
+                cur = part
+        if cur:
+            pieces.append(cur)
+        return pieces
+
+    def _infer_low_vram(self, run_piece, text, output_path, interval_silence, verbose):
+        """The `low_vram` branch of `infer()` (infer_v2_5.py:510-547; a < 10 GB device there, never an MI355X: `self.low_vram` is False
+        unless the caller sets it): the text is cut at punctuation into <= 40-character pieces, each synthesised by its own
+        `infer_generator` call with no inner silence, the int16 results joined with `interval_silence` ms of zeros."""
+        pieces = self.split_text_by_punctuation(text, max_chars=40)
+        if verbose:
+            print(f">> Low-VRAM: split into {len(pieces)} segments: {pieces}")
+        sr, wavs = 22050, []
+        for piece in pieces:
+            result = None
+            for result in run_piece(piece):
+                pass
+            if result is not None and isinstance(result, tuple):
+                wavs.append(torch.from_numpy(result[1].T).to(torch.int16))
+        if not wavs:
+            return None
+        sil = torch.zeros(1, int(sr * interval_silence / 1000), dtype=torch.int16)
+        parts = []
+        for i, w in enumerate(wavs):
+            parts.append(w)
+            if i < len(wavs) - 1:
+                parts.append(sil)
+        wav = torch.cat(parts, dim=1)
+        if output_path:
+            if os.path.isfile(output_path):
+                os.remove(output_path)
+            if os.path.dirname(output_path) != "":
+                os.makedirs(os.path.dirname(output_path), exist_ok=True)
+            save_pcm_wav(output_path, wav, sr)
+            return output_path
+        return (sr, wav.numpy().T)
+
     def infer(self, spk_audio_prompt, text, output_path, lang, emo_audio_prompt=None, emo_alpha=1.0, emo_vector=None,
               use_emo_text=False, emo_text=None, use_random=False, interval_silence=200, verbose=False,
               max_text_tokens_per_segment=120, stream_return=False, more_segment_before=0, duration_factor=1.0,
               text_normalization=True, **generation_kwargs):
+        if getattr(self, "low_vram", False) and not stream_return and len(text) > 40:
+            return self._infer_low_vram(
+                lambda piece: self.infer_generator(spk_audio_prompt, piece, None, lang, emo_audio_prompt, emo_alpha, emo_vector,
+                                                   use_emo_text, emo_text, use_random, 0, verbose, max_text_tokens_per_segment, False, 0,
+                                                   duration_factor=duration_factor, text_normalization=text_normalization,
+                                                   **generation_kwargs),
+                text, output_path, interval_silence, verbose)
         gen = self.infer_generator(spk_audio_prompt, text, output_path, lang, emo_audio_prompt, emo_alpha, emo_vector,
                                    use_emo_text, emo_text, use_random, interval_silence, verbose,
                                    max_text_tokens_per_segment, stream_return, more_segment_before, duration_factor,
@@ -234,6 +315,15 @@ class IndexTTS2:
                         emo_vector=None, use_emo_text=False, emo_text=None, use_random=False, interval_silence=200,
                         verbose=False, max_text_tokens_per_segment=120, stream_return=False, quick_streaming_tokens=0,
                         duration_factor=1.0, text_normalization=True, **generation_kwargs):
+        yield from self._infer_impl(spk_audio_prompt, text, output_path, lang, emo_audio_prompt, emo_alpha, emo_vector, use_emo_text,
+                                    emo_text, use_random, interval_silence, verbose, max_text_tokens_per_segment, stream_return,
+                                    duration_factor, text_normalization, generation_kwargs)
+
+    def _infer_impl(self, spk_audio_prompt, text, output_path, lang, emo_audio_prompt, emo_alpha, emo_vector, use_emo_text, emo_text,
+                    use_random, interval_silence, verbose, max_text_tokens_per_segment, stream_return, duration_factor,
+                    text_normalization, generation_kwargs):
+        """Body of `infer_generator` (infer_v2_5.py:570-899; infer_v2.py:396-720 has the same flow without `lang`, `duration_factor`
+        and `text_normalization`: the v2 subclass passes lang=None, 1.0, True)."""
         start_time = time.perf_counter()
         self._set_gr_progress(0, "starting inference...")
         if use_emo_text:
@@ -254,7 +344,8 @@ class IndexTTS2:
         if not segments:
             return
         sr = 22050
-        wavs = self._synthesize(segments, [self.frontend.lang_id(lang)] * len(segments), bundle, emovec, duration_factor,
+        lang_id = self.frontend.lang_id(lang) if lang is not None else 0
+        wavs = self._synthesize(segments, [lang_id] * len(segments), bundle, emovec, duration_factor,
                                 generation_kwargs, max_text_tokens_per_segment)
         silence = None
         if stream_return:
@@ -383,7 +474,10 @@ class IndexTTS2:
             wav = self.bigvgan(mel.float(), lens=mel_lens)
             return [wav[i, 0, : int(mel_lens[i]) * up].float().cpu().numpy() for i in range(wav.shape[0])]
 
-        dec = StreamingDecoder(self.gpt, codes_to_audio, chunk_size=chunk_size, overlap_size=overlap_size)
+        # the cross-fade spans the samples the overlapping codes render to: int(2 * n * 1.72 * duration_factor) frames for n codes here
+        # (infer_v2_5.py:833), not the reference decoder's fixed 1.72 frames per code of IndexTTS-2
+        dec = StreamingDecoder(self.gpt, codes_to_audio, chunk_size=chunk_size, overlap_size=overlap_size,
+                               frames_per_code=2 * 1.72 * float(duration_factor))
         self.last_stream = dec
         yield from dec.generate(inputs_embeds, attention_mask, max_new, **hf)
 

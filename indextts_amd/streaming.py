@@ -22,9 +22,10 @@ PCM16_MAX = 32767
 TAIL_FADE_SAMPLES = 512
 
 
-def overlap_samples(n_codes: int) -> int:
-    """samples covered by `n_codes` codes (streaming.py:13-14)"""
-    return int(n_codes * MEL_CODE_TO_FRAME_RATIO) * HOP_SIZE
+def overlap_samples(n_codes: int, frames_per_code: float = MEL_CODE_TO_FRAME_RATIO) -> int:
+    """samples covered by `n_codes` codes (streaming.py:13-14; the reference's ratio is IndexTTS-2's 1.72 frames per code -- the v2.5
+    pipeline renders int(2 * n * 1.72 * duration_factor) frames for n codes, infer_v2_5.py:833, and passes that ratio)"""
+    return int(n_codes * frames_per_code) * HOP_SIZE
 
 
 def crossfade(tail: np.ndarray, head: np.ndarray) -> np.ndarray:
@@ -52,9 +53,13 @@ class StreamingDecoder:
     """gpt_engine: an object with `generate_chunks(...)` yielding `(codes, is_last, batch_done, code_lens)` (UnifiedVoice);
     codes_to_audio_fn(codes, code_lens) -> list of float32 arrays in [-1, 1], one per row, covering that chunk's codes."""
 
-    def __init__(self, gpt_engine, codes_to_audio_fn: Callable, chunk_size: int = 100, overlap_size: int = 20, verbose: bool = False):
+    def __init__(self, gpt_engine, codes_to_audio_fn: Callable, chunk_size: int = 100, overlap_size: int = 20, verbose: bool = False,
+                 frames_per_code: float = MEL_CODE_TO_FRAME_RATIO):
         if overlap_size >= chunk_size:
             raise ValueError(f"overlap_size ({overlap_size}) must be less than chunk_size ({chunk_size})")
+        if not frames_per_code > 0:
+            raise ValueError(f"frames_per_code must be positive, got {frames_per_code}")
+        self.frames_per_code = float(frames_per_code)     # mel frames codes_to_audio_fn renders per code: sizes the cross-fade
         self.gpt_engine, self.codes_to_audio_fn = gpt_engine, codes_to_audio_fn
         self.chunk_size, self.overlap_size = int(chunk_size), int(overlap_size)
         self.stride = self.chunk_size - self.overlap_size
@@ -63,7 +68,7 @@ class StreamingDecoder:
 
     def generate(self, inputs_embeds, attention_mask, max_new_tokens: int = 1500, **generation_kwargs):
         B = inputs_embeds.shape[0]
-        ovlp = overlap_samples(self.overlap_size)
+        ovlp = overlap_samples(self.overlap_size, self.frames_per_code)
         tails: List[Optional[np.ndarray]] = [None] * B      # a row's samples still waiting for the next chunk's head
         finished = [False] * B
         t0 = time.perf_counter()
