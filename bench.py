@@ -6,7 +6,10 @@ One "step" = one pass of the hot path over the synthetic 64-utterance batch (BAS
     -> GPT speech-token decode of this rank's utterances (prefill + 560 sampled tokens each, top-k 30 / top-p 0.8 / T 0.8 /
        repetition penalty 10, bf16 weights + KV)
     -> codes -> mel: semantic-codec decode, length regulator, 25-step classifier-free-guidance flow matching over
-       [speaker prompt | int(2 * n_tokens * 1.72) target frames] (indextts/infer_v2_5.py:830-846), bf16 GEMMs / attention
+       [speaker prompt | int(2 * n_tokens * 1.72) target frames] (indextts/infer_v2_5.py:830-846) in `--s2mel-precision`: fp32 by
+       default -- the reference runs this stage with autocast off even in its bf16 mode (infer_v2_5.py:827-828) -- so `value` is the
+       fp32-CFM line; the bf16 mode (bf16 GEMM operands / attention, f32 accumulation) is timed right after on the same inputs and
+       printed beside it (`value_by_s2mel_precision`), with its measured waveform error cited from tests/test_gpu_fullsize.py
        (`--no-s2mel` vocodes a synthetic mel of that length instead: the round-1 hot-path-only measurement)
     -> BigVGAN (80-band mel -> 22.05 kHz wave, fp32) -> int16 -> waveforms gathered on rank 0.
 Scaling is STRONG by default: the 64 utterances are LPT-sharded over the N ranks (`indextts_amd.dist.shard_utterances`),
@@ -180,30 +183,48 @@ class HipEngine:
         self.voc = bigvgan.BigVGAN(self.bh, device=dev)
         self.voc.load_state_dict(self.bsd)
         self.voc.to(dev)
-        self.voc.set_profiling(True)
         self.prof_acc = {}
+        self.n_prof = 0                    # timed steps that carried per-launch HIP-event profiling (the stage split's denominator)
         self.gpt_t = {"prefill_ms": 0.0, "decode_ms": 0.0, "steps": 0}
         self.s2 = None
-        self.s2_t = {"codec_regulator_ms": 0.0, "cfm_ms": 0.0, "gemm_ms": 0.0, "gemm_flops": 0.0, "attention_ms": 0.0,
-                     "attention_flops": 0.0, "estimator_ms": 0.0, "launches": 0}
+        self.s2_t = self.new_stage_acc()
         if not args.no_s2mel:
-            from indextts_amd import codec, s2mel
+            from indextts_amd import codec
             self.codec = codec.EnhancedCodec(**synth.CODEC_V2, device=dev)
             self.codec.load_state_dict(synth.codec_weights(seed=1234))
             self.s2_args = dict(synth.S2MEL_V2, length_regulator=synth.REGULATOR_V2)
-            self.s2 = s2mel.MyModel(self.s2_args, precision=args.precision, device=dev)
-            self.s2.models["cfm"].load_state_dict(synth.s2mel_weights(seed=1234))
-            self.s2.models["length_regulator"].load_state_dict(synth.regulator_weights(seed=1234))
-            self.s2.models["cfm"].set_profiling(True)
+            self.s2 = self.build_s2(args.s2mel_precision)
             self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         self.gen_kw = dict(do_sample=True, top_p=0.8, top_k=30, temperature=0.8, num_beams=1, repetition_penalty=10.0,
                            length_penalty=0.0)
         if rank == 0:
             log(f"[bench] weights synthesised + packed + uploaded in {time.perf_counter() - t_load:.1f}s")
 
+    def build_s2(self, precision):
+        from indextts_amd import s2mel, synth
+        s2 = s2mel.MyModel(self.s2_args, precision=precision, device=self.dev)
+        s2.models["cfm"].load_state_dict(synth.s2mel_weights(seed=1234))
+        s2.models["length_regulator"].load_state_dict(synth.regulator_weights(seed=1234))
+        return s2
+
+    def set_profiling(self, on):
+        """Per-launch HIP events around every vocoder launch and every CFM GEMM / attention launch (a few thousand pairs per step):
+        switched on for the first `--profile-steps` timed steps only, so the headline does not pay for its own instrumentation."""
+        self.voc.set_profiling(bool(on))
+        if self.s2 is not None:
+            self.s2.models["cfm"].set_profiling(bool(on))
+
+    def new_stage_acc(self):
+        return {"codec_regulator_ms": 0.0, "cfm_ms": 0.0, "gemm_ms": 0.0, "gemm_flops": 0.0, "attention_ms": 0.0,
+                "attention_flops": 0.0, "estimator_ms": 0.0, "launches": 0}
+
     def step(self, text, langs, mel, bundle, n_gen, record):
         """-> int16 waveforms (b, T*256) of this rank's utterances"""
-        return self.render(self.decode(text, langs, bundle, n_gen, record), mel, bundle, n_gen, record)
+        # record: True = a timed step with per-launch profiling, "gpt" = a timed step without it (only the GPT stage's own timers,
+        # which cost nothing, are accumulated), False = warmup
+        if record is True:
+            self.n_prof += 1
+        return self.render(self.decode(text, langs, bundle, n_gen, bool(record)), mel, bundle, n_gen, record is True)
 
     def decode(self, text, langs, bundle, n_gen, record):
         """GPT stage: text ids -> speech codes (b, n_gen), on torch's CURRENT stream (host-blocking: the device loop reports back
@@ -216,19 +237,20 @@ class HipEngine:
                 self.gpt_t[k] += self.model.last_timing[k]
         return codes
 
-    def render(self, codes, mel, bundle, n_gen, record):
-        """codes -> codec decode -> length regulator -> 25-step CFG flow matching -> BigVGAN -> int16, on torch's current stream"""
+    def render(self, codes, mel, bundle, n_gen, record, s2=None, acc=None):
+        """codes -> codec decode -> length regulator -> 25-step CFG flow matching -> BigVGAN -> int16, on torch's current stream.
+        s2 / acc: another s2mel engine (the second precision) and the stage accumulator its profile goes to"""
         B = codes.shape[0]
         style = bundle["style"]
-        if self.s2 is not None:
+        s2 = s2 if s2 is not None else self.s2
+        if s2 is not None:
             # codes -> content features -> 25-step CFG flow matching -> mel (indextts/infer_v2_5.py:830-846), all on the engine
-            from indextts_amd import s2mel
-            cfm = self.s2.models["cfm"]
+            cfm = s2.models["cfm"]
             self._ev[0].record()
             S_infer = self.codec.decode(codes, code_lens=[n_gen] * B)
             target = [int(2 * n_gen * 1.72)] * B
-            cond = self.s2.models["length_regulator"](S_infer, ylens=torch.tensor(target), n_quantizers=3, f0=None,
-                                                      xlens=[2 * n_gen] * B, frame_lens=target)[0]
+            cond = s2.models["length_regulator"](S_infer, ylens=torch.tensor(target), n_quantizers=3, f0=None,
+                                                 xlens=[2 * n_gen] * B, frame_lens=target)[0]
             self._ev[1].record()
             Tp = int(bundle["prompt_condition"].shape[1])
             cat = torch.cat([bundle["prompt_condition"].expand(B, -1, -1), cond], dim=1)
@@ -239,7 +261,7 @@ class HipEngine:
             assert mel.shape == (B, 80, target[0]), mel.shape
             if record:
                 pr = cfm.profile()                                 # synchronises the launch stream
-                t = self.s2_t
+                t = acc if acc is not None else self.s2_t
                 t["codec_regulator_ms"] += self._ev[0].elapsed_time(self._ev[1])
                 t["cfm_ms"] += self._ev[1].elapsed_time(self._ev[2])
                 t["gemm_ms"] += pr["gemm"]["ms"]
@@ -252,7 +274,7 @@ class HipEngine:
         outs = []
         for b0 in range(0, B, chunk):
             outs.append(self.voc(mel[b0:b0 + chunk]))
-            if record:
+            if record and acc is None:
                 for k, v in self.voc.profile().items():
                     a = self.prof_acc.setdefault(k, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
                     for kk in a:
@@ -341,7 +363,15 @@ def main():
     ap.add_argument("--weak", action="store_true", help="weak scaling: --utts utterances PER GPU")
     ap.add_argument("--text-tokens", type=int, default=128)
     ap.add_argument("--gen-tokens", type=int, default=560)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"], help="GPT precision (bf16 = the reference's own GPU mode)")
+    ap.add_argument("--s2mel-precision", default="fp32", choices=["fp32", "bf16"],
+                    help="precision of the flow-matching stage in the timed steps.  fp32 (default) is what the reference computes "
+                         "(autocast off around s2mel, infer_v2_5.py:827-828) and carries `value`; the other mode is timed after the "
+                         "headline on the same inputs and printed beside it")
+    ap.add_argument("--profile-steps", type=int, default=1, help="timed steps that carry per-launch HIP-event profiling (stage split, "
+                    "roofline); the remaining timed steps run without the instrumentation")
+    ap.add_argument("--alt-steps", type=int, default=3, help="timed steps of the second s2mel precision (after the headline)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the timed lines of BASELINE.json's other configs")
     ap.add_argument("--bigvgan-chunk", type=int, default=0, help="utterances per BigVGAN launch group (0 = all)")
     ap.add_argument("--no-s2mel", action="store_true", help="skip codes -> mel (codec, length regulator, 25-step CFM) and vocode a "
                                                            "synthetic mel instead (the round-1 hot-path-only measurement)")
@@ -489,15 +519,27 @@ def main():
                 log(f"[bench] overlap: render of step {k} enqueued / finished on the host after {time.perf_counter() - tw:.2f}s")
         return out
 
+    step_ev = [] if stub else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    n_prof = 0 if stub else max(0, min(args.profile_steps, args.steps))
     barrier()
     t0 = time.perf_counter()
     if args.overlap and args.steps > 1:
+        if not stub:
+            eng.set_profiling(True)
+            eng.n_prof = args.steps
         wavs = steps_overlapped(args.steps)
     else:
-        for _ in range(args.steps):
-            wavs = one_step(True)
+        for k in range(args.steps):
+            if not stub:
+                if k == 0 or k == n_prof:
+                    eng.set_profiling(k < n_prof)
+                step_ev[k][0].record()
+            wavs = one_step(True if k < n_prof else "gpt")
+            if not stub:
+                step_ev[k][1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = [] if (stub or (args.overlap and args.steps > 1)) else [a.elapsed_time(b) for a, b in step_ev]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -513,8 +555,12 @@ def main():
             "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None,
-            "dtype": ("bf16 (GPT and s2mel GEMM operands / K,V / attention probabilities; f32 accumulate, residual streams, norms) + "
-                      "f32 (codec decode, length regulator, BigVGAN)") if args.precision == "bf16" else "f32",
+            "dtype": (("bf16 (GPT GEMM operands / KV cache; f32 accumulate, residual stream, norms: the reference's own GPU mode) + "
+                       if args.precision == "bf16" else "f32 (GPT) + ")
+                      + ("f32 (codec decode, length regulator, flow matching, BigVGAN: the reference runs these with autocast off)"
+                         if args.s2mel_precision == "fp32" or args.no_s2mel else
+                         "bf16 (s2mel GEMM operands / K,V / attention probabilities; f32 accumulate, residual streams, norms) + "
+                         "f32 (codec decode, length regulator, BigVGAN)")),
             "data": "synthetic (seeded random-init weights of the IndexTTS-2.5 architecture; synthetic text ids, conditioning "
                     "vectors, prompt mel / prompt condition" + ("" if not args.no_s2mel else " and mel") +
                     "; EOS suppressed so every row decodes all tokens)",
@@ -523,12 +569,13 @@ def main():
             "config": {"workload": (f"IndexTTS-2.5 codes-to-waveform path, {n_total} utterances x {n_text} text tokens -> GPT decode of "
                                     f"{n_gen} speech tokens (top-k 30, top-p 0.8, T 0.8, rep-penalty 10, num_beams 1) -> "
                                     + (f"semantic-codec decode + length regulator + 25-step CFG flow matching (DiT 13 x 512, "
-                                       f"{args.prompt_frames}-frame speaker prompt) -> " if not args.no_s2mel else
+                                       f"{args.prompt_frames}-frame speaker prompt, {args.s2mel_precision}) -> " if not args.no_s2mel else
                                        "[s2mel skipped: synthetic mel] -> ")
                                     + f"BigVGAN-v2 22 kHz on {t_mel}-frame mels (BASELINE.json configs[2]), {B} utterances on each of "
                                       f"{world} GPU(s); prompt encoders / text front end not included"),
                        "global_batch": n_total, "per_gpu_batch": B, "text_tokens": n_text, "gen_tokens": n_gen,
                        "mel_frames": t_mel, "audio_seconds_per_utt": t_mel * HOP / SR, "parallelism": f"utterance-dp{world}",
+                       "gpt_precision": args.precision, "s2mel_precision": None if args.no_s2mel else args.s2mel_precision,
                        "use_hipgraph": not args.no_graph,
                        "step_overlap": bool(args.overlap and args.steps > 1)},
         }
@@ -536,7 +583,32 @@ def main():
             out["stub_rows_ok"] = bool(torch.equal(wavs[:, 0].to(torch.int64), text_all[:, 0].to(torch.int64) % 97))
         if not stub:
             out.update(gpu_report(args, eng, B, n_text, n_gen, t_mel))
+            out["step_ms"] = step_ms            # per timed step (HIP events): the first --profile-steps carry the per-launch instrumentation
+            st = out["stages"]
+            if step_ms and len(step_ms) > eng.n_prof > 0:
+                st["profiled_step_ms"] = sum(step_ms[:eng.n_prof]) / eng.n_prof
+                st["unprofiled_step_ms"] = sum(step_ms[eng.n_prof:]) / (len(step_ms) - eng.n_prof)
+            # the two north_star hot paths alone (GPT + BigVGAN, both at the reference's precision), from the stage timers
+            hot_ms = st["gpt_prefill_ms_per_step"] + st["gpt_decode_ms_per_step"] + st["bigvgan_ms_per_step"]
+            out["value_north_star_paths"] = {"value": audio_per_step / (hot_ms * 1e-3), "ms_per_step": hot_ms,
+                                             "what": "GPT decode + BigVGAN only (the two hot paths north_star names), from the stage timers"}
+            if not args.no_s2mel:
+                out["value_by_s2mel_precision"] = {args.s2mel_precision: {"value": value, "ms_per_step": out["ms_per_step"], "steps": args.steps}}
             log("[bench] GPU result:", json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline", "stages")}))
+            if not args.no_s2mel and not args.no_extras and world == 1 and args.alt_steps > 0 and not (args.overlap and args.steps > 1):
+                # the other s2mel precision on the same inputs: --alt-steps timed steps (one of them profiled), outside the headline's timed region
+                t_x = time.perf_counter()
+                try:
+                    alt = "bf16" if args.s2mel_precision == "fp32" else "fp32"
+                    out["value_by_s2mel_precision"][alt] = alt_precision_leg(args, eng, alt, text, langs, mel, bundle0, n_gen, audio_per_step, st)
+                except Exception as e:
+                    out["value_by_s2mel_precision"]["error"] = repr(e)
+                log(f"[bench] second s2mel precision took {time.perf_counter() - t_x:.1f}s")
+                out["s2mel_precision_note"] = (
+                    "`value` is the line with the flow-matching stage in " + args.s2mel_precision + "; the reference computes it in fp32 "
+                    "(indextts/infer_v2_5.py:827-828).  The bf16 mode's error at this shape after the full 25 steps (mel and BigVGAN "
+                    "waveform RMS vs the f32 mode) is measured by tests/test_gpu_fullsize.py::test_cfm_bf16_error_after_25_steps_mel_and_waveform "
+                    "and recorded in DESIGN.md section 9; it is above north_star's 1e-4 waveform bar, so the bf16 line is not the headline")
             if not args.no_extras and world == 1:
                 t_x = time.perf_counter()
                 try:
@@ -548,6 +620,14 @@ def main():
                 except Exception as e:
                     out["stages"]["extras_error"] = repr(e)
                 log(f"[bench] extra modes (beam-3, f32) took {time.perf_counter() - t_x:.1f}s")
+            if not args.no_extras and not args.no_configs and not args.no_s2mel and world == 1:
+                t_x = time.perf_counter()
+                try:
+                    eng.set_profiling(False)
+                    out["stages"]["configs"] = configs_leg(args, eng, bundle0, dev)
+                except Exception as e:
+                    out["stages"]["configs"] = {"error": repr(e)}
+                log(f"[bench] other BASELINE configs took {time.perf_counter() - t_x:.1f}s")
             if not args.no_cpu_baseline and world == 1:
                 t_cpu = time.perf_counter()
                 try:
@@ -564,9 +644,157 @@ def main():
         dist.destroy_process_group()
 
 
+def configs_leg(args, eng, bundle0, dev):
+    """Timed lines of BASELINE.json's OTHER configs and of the one published comparison point (single-utterance RTF), through the
+    PRODUCT pipeline classes' own `_synthesize` (GPT batch -> stop-token trim -> codes -> mel -> ragged BigVGAN batch -> float waveforms
+    on the host), with this process's engines: untimed extras beside the headline (`stages.configs`), one warm call + one timed call
+    each; EOS is suppressed, so every row decodes `gen_tokens`.  s2mel runs in the headline's precision (--s2mel-precision).
+      configs[1]  IndexTTS-2.5, 8 utterances x 64 text tokens, reference-default 3-beam beam-sample (top-p 0.8 / top-k 30 / T 0.8), 350 codes
+      configs[3]  IndexTTS-2, 16 utterances x 64 text tokens at 24 x 1280: emotion path (merge_emovec: two Conformer + Perceiver passes
+                  over 15 s prompts), speaker latents, 34 conditioning tokens, 700 codes (50 / s), teacher-forced latent pass,
+                  gpt_layer + vq2emb -> regulator -> CFM -> BigVGAN
+      configs[4]  IndexTTS-2.5 long-form: 2 000 characters = 17 segments of <= 120 text tokens decoded as ONE batch, duration_factor 1.5,
+                  plus the vocoder alone as an exact overlap-save stream (256-frame chunks, receptive-field halo) over the same mels
+      b1_rtf      one utterance, 40 text tokens (~80 characters) -> 200 codes (8 s): beside the reference README's RTF table (other hardware)
+    """
+    import warnings
+    from indextts_amd import gpt, infer_v2, infer_v2_5, s2mel, synth
+    out = {}
+
+    class NoFrontend:                      # `_synthesize` takes token tensors and a speaker bundle: no prompt / text front end involved
+        pass
+
+    def segments(n_seg, n_text, seed):
+        g = torch.Generator().manual_seed(seed)
+        return [torch.cat([torch.randint(2, 12000, (n_text,), generator=g).to(torch.int32), torch.ones(1, dtype=torch.int32)])
+                for _ in range(n_seg)]
+
+    def timed(tts, segs, bundle, emovec, df, gen):
+        res = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")                  # "generation stopped due to exceeding max_mel_tokens": EOS is suppressed
+                wavs = tts._synthesize(segs, [3] * len(segs), bundle, emovec, df, dict(gen), 120)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            audio = sum(int(w.shape[-1]) for w in wavs) / SR
+            res = {"ms": dt * 1e3, "audio_seconds": audio, "audio_seconds_per_sec": audio / dt, "rtf_per_stream": dt / (audio / len(wavs)),
+                   "stage_seconds": {k: round(float(v), 4) for k, v in tts.last_timing.items()}}
+        return res
+
+    style, emo_vec = bundle0["style"], bundle0["emo_vec"]
+    bundle = dict(bundle0, spk_cond_emb=torch.zeros(1, 4, 1024, device=dev))
+    tts = infer_v2_5.IndexTTS2(cfg={"gpt": {"stop_mel_token": 8193}, "version": 2.5}, device=str(dev), frontend=NoFrontend(), gpt=eng.model,
+                               bigvgan=eng.voc, semantic_codec=eng.codec, s2mel=eng.s2, codes_to_mel="engine")
+    sample = dict(top_p=0.8, top_k=30, temperature=0.8, repetition_penalty=10.0)
+    try:
+        r = timed(tts, segments(8, 64, 301), bundle, emo_vec, 1.0, dict(sample, num_beams=3, max_mel_tokens=350))
+        out["config1_v25_b8_beam3"] = dict(r, batch=8, text_tokens=64, gen_tokens=350, num_beams=3, mel_frames=int(2 * 350 * 1.72))
+    except Exception as e:
+        out["config1_v25_b8_beam3"] = {"error": repr(e)}
+    try:
+        r = timed(tts, segments(1, 40, 302), bundle, emo_vec, 1.0, dict(sample, num_beams=1, max_mel_tokens=200))
+        r3 = timed(tts, segments(1, 40, 302), bundle, emo_vec, 1.0, dict(sample, num_beams=3, max_mel_tokens=200))
+        out["b1_rtf"] = dict(r, batch=1, text_tokens=40, gen_tokens=200, num_beams=1, rtf_beam3=r3["rtf_per_stream"],
+                             published_context={"reference README.md:474-483 (RTX 4090, IndexTTS-2, fp16)": 0.2065,
+                                                "backends/trt/README.md:63-76 (TensorRT, RTX 4090)": 0.1365,
+                                                "note": "other hardware, real checkpoints, prompt encoders included there: context, not a baseline"})
+    except Exception as e:
+        out["b1_rtf"] = {"error": repr(e)}
+    try:
+        segs = segments(17, 118, 303)                              # 2 000 chars -> ceil(tokens / 120) ~ 17 segments
+        r = timed(tts, segs, bundle, emo_vec, 1.5, dict(sample, num_beams=1, max_mel_tokens=480))
+        t_mel = int(2 * 480 * 1.72 * 1.5)
+        mel = (torch.randn(1, 80, t_mel, generator=torch.Generator().manual_seed(9)) * 2 - 4).to(dev)
+        eng.voc.forward_chunked(mel, chunk_frames=256)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(17):
+            eng.voc.forward_chunked(mel, chunk_frames=256)
+        torch.cuda.synchronize()
+        out["config4_v25_longform"] = dict(r, segments=17, text_tokens=118, gen_tokens=480, duration_factor=1.5, mel_frames=t_mel,
+                                           vocoder_streamed_ms=(time.perf_counter() - t0) * 1e3,
+                                           vocoder_streamed_what="17 segments, each vocoded alone as an exact overlap-save stream of 256-frame chunks")
+    except Exception as e:
+        out["config4_v25_longform"] = {"error": repr(e)}
+    try:                                                           # configs[3]: IndexTTS-2
+        cfg2 = dict(synth.GPT_V2)
+        sd2 = dict(eng.gsd)
+        sd2.update(synth.cond_weights(cfg2))
+        for k in ("spk_emb_proj.weight", "spk_emb_proj.bias", "lang_embedding.weight"):
+            sd2.pop(k, None)
+        m2 = gpt.UnifiedVoice(**cfg2, precision=args.precision, device=str(dev))
+        m2.load_state_dict(sd2)
+        m2.post_init_gpt2_config(kv_cache=True, half=args.precision == "bf16")
+        s2v2 = s2mel.MyModel(eng.s2_args, use_gpt_latent=True, precision=args.s2mel_precision, device=dev)
+        s2v2.load_state_dict({"cfm": synth.s2mel_weights(seed=1234), "length_regulator": synth.regulator_weights(seed=1234),
+                              "gpt_layer": synth.gpt_layer_weights()})
+        tts2 = infer_v2.IndexTTS2(cfg={"gpt": {"stop_mel_token": 8193}, "version": 2.0}, device=str(dev), frontend=NoFrontend(), gpt=m2,
+                                  bigvgan=eng.voc, semantic_codec=eng.codec, s2mel=s2v2, codes_to_mel="engine")
+        g = torch.Generator().manual_seed(304)
+        spk_feat = torch.randn(1, 750, 1024, generator=g).to(dev)                 # 15 s of w2v-bert features (50 / s)
+        emo_feat = torch.randn(1, 750, 1024, generator=g).to(dev)
+        b2 = dict(bundle0, spk_cond_emb=spk_feat, emo_cond_emb=emo_feat)
+        ev = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev = m2.merge_emovec(spk_feat, emo_feat, torch.tensor([750]), torch.tensor([750]), alpha=0.7)
+            torch.cuda.synchronize()
+            t_emo = time.perf_counter() - t0
+        r = timed(tts2, segments(16, 64, 305), b2, ev, 1.0, dict(sample, num_beams=1, max_mel_tokens=700))
+        out["config3_v2_emotion_b16"] = dict(r, batch=16, text_tokens=64, gen_tokens=700, cond_tokens=34, mel_frames=int(700 * 1.72),
+                                             emotion_path_ms=t_emo * 1e3,
+                                             emotion_path_what="merge_emovec: emotion Conformer (4 blocks) + Perceiver over two 750-frame prompts")
+        del tts2, m2, s2v2
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["config3_v2_emotion_b16"] = {"error": repr(e)}
+    return out
+
+
+def alt_precision_leg(args, eng, precision, text, langs, mel, bundle, n_gen, audio_per_step, stages):
+    """--alt-steps full steps with the flow-matching stage in the OTHER precision (same GPT, codec, vocoder, inputs), after the headline:
+    one untimed warmup, then the timed steps, the first of them with per-launch profiling for its own stage split."""
+    s2 = eng.build_s2(precision)
+    cfm = s2.models["cfm"]
+    acc = eng.new_stage_acc()
+    eng.set_profiling(False)
+    eng.render(eng.decode(text, langs, bundle, n_gen, False), mel, bundle, n_gen, False, s2=s2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.alt_steps):
+        cfm.set_profiling(k == 0)
+        eng.render(eng.decode(text, langs, bundle, n_gen, False), mel, bundle, n_gen, k == 0, s2=s2, acc=acc)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    stages["s2mel_" + precision] = s2_stage(acc, 1, args.prompt_frames, precision)
+    del s2
+    torch.cuda.empty_cache()
+    return {"value": audio_per_step * args.alt_steps / el, "ms_per_step": el / args.alt_steps * 1e3, "steps": args.alt_steps}
+
+
+def s2_stage(t, n_prof, prompt_frames, precision):
+    """stage split of the flow-matching stage from the HIP-event records of `n_prof` profiled steps"""
+    n = max(1, n_prof)
+    peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_F32_MFMA_TFLOPS
+    gemm_tf = t["gemm_flops"] / max(1e-9, t["gemm_ms"] * 1e-3) / 1e12
+    attn_tf = t["attention_flops"] / max(1e-9, t["attention_ms"] * 1e-3) / 1e12
+    return {"precision": precision, "codec_regulator_ms_per_step": t["codec_regulator_ms"] / n,
+            "cfm_ms_per_step": t["cfm_ms"] / n,                 # 25 Euler steps x CFG batch-2 estimator, host prep included
+            "cfm_estimator_ms_per_step": t["estimator_ms"] / n, "cfm_gemm_ms_per_step": t["gemm_ms"] / n,
+            "cfm_gemm_tflops": gemm_tf, "cfm_gemm_mfma_frac": gemm_tf / peak, "cfm_gemm_launches_per_step": t["launches"] // n,
+            "cfm_attention_ms_per_step": t["attention_ms"] / n, "cfm_attention_tflops": attn_tf, "cfm_attention_mfma_frac": attn_tf / peak,
+            "cfm_elementwise_ms_per_step": (t["estimator_ms"] - t["gemm_ms"] - t["attention_ms"]) / n,
+            "mfma_peak_tflops": peak, "prompt_frames": prompt_frames, "euler_steps": EULER_STEPS, "cfg_rate": 0.7}
+
+
 def gpu_report(args, eng, B, n_text, n_gen, t_mel):
-    """roofline (dominant kernel) + stage split from rank 0's HIP-event records of the timed steps."""
+    """roofline (dominant kernel) + stage split from rank 0's HIP-event records of the profiled timed steps."""
     prof_acc, gpt_t, gcfg = eng.prof_acc, eng.gpt_t, eng.gcfg
+    n_prof = max(1, eng.n_prof)
     conv = prof_acc.get("conv1d_mfma", dict(ms=1e-9, launches=1, flops=0.0, bytes=0.0))
     achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
     # HBM traffic of the same kernel: PMC counters cannot be read from inside this process, so the figure comes from
@@ -588,6 +816,7 @@ def gpu_report(args, eng, B, n_text, n_gen, t_mel):
     prefill_flops = 2.0 * (12 * D * D * L) * B * s_pre + 4.0 * L * D * s_pre * s_pre * B / 2 + 2.0 * D * V * B
     prefill_tflops = prefill_flops / (gpt_t["prefill_ms"] / args.steps * 1e-3) / 1e12
     stages = {
+        "profiled_steps": eng.n_prof,
         "gpt_prefill_ms_per_step": gpt_t["prefill_ms"] / args.steps,
         "gpt_prefill_tflops": prefill_tflops,          # whole prefill pass (GEMMs + attention + LayerNorms) per wall time
         "gpt_prefill_mfma_frac": prefill_tflops / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
@@ -595,30 +824,47 @@ def gpu_report(args, eng, B, n_text, n_gen, t_mel):
         "gpt_decode_ms_per_token": ms_tok,
         "gpt_decode_algorithmic_GBps": bytes_step / (ms_tok * 1e-3) / 1e9,
         "gpt_decode_hbm_frac": bytes_step / (ms_tok * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-        "s2mel": None if eng.s2 is None else {
-            "codec_regulator_ms_per_step": eng.s2_t["codec_regulator_ms"] / args.steps,
-            "cfm_ms_per_step": eng.s2_t["cfm_ms"] / args.steps,        # 25 Euler steps x CFG batch-2 estimator, host prep included
-            "cfm_estimator_ms_per_step": eng.s2_t["estimator_ms"] / args.steps,
-            "cfm_gemm_ms_per_step": eng.s2_t["gemm_ms"] / args.steps,
-            "cfm_gemm_tflops": eng.s2_t["gemm_flops"] / max(1e-9, eng.s2_t["gemm_ms"] * 1e-3) / 1e12,
-            "cfm_gemm_mfma_frac": eng.s2_t["gemm_flops"] / max(1e-9, eng.s2_t["gemm_ms"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-            "cfm_attention_ms_per_step": eng.s2_t["attention_ms"] / args.steps,
-            "cfm_attention_tflops": eng.s2_t["attention_flops"] / max(1e-9, eng.s2_t["attention_ms"] * 1e-3) / 1e12,
-            "cfm_elementwise_ms_per_step": (eng.s2_t["estimator_ms"] - eng.s2_t["gemm_ms"] - eng.s2_t["attention_ms"]) / args.steps,
-            "prompt_frames": args.prompt_frames, "euler_steps": 25, "cfg_rate": 0.7},
-        "bigvgan_ms_per_step": sum(v["ms"] for v in prof_acc.values()) / args.steps,
-        "bigvgan_kernels": {k: dict(ms_per_step=v["ms"] / args.steps, launches_per_step=v["launches"] // args.steps,
+        "s2mel": None if eng.s2 is None else s2_stage(eng.s2_t, eng.n_prof, args.prompt_frames, args.s2mel_precision),
+        "bigvgan_ms_per_step": sum(v["ms"] for v in prof_acc.values()) / n_prof,
+        "bigvgan_kernels": {k: dict(ms_per_step=v["ms"] / n_prof, launches_per_step=v["launches"] // n_prof,
                                     tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
                                     GBps=(v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0))
                             for k, v in prof_acc.items()},
     }
-    roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel (BigVGAN Conv1d implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
-                "launches_per_step": conv["launches"] // max(1, args.steps),
-                "avg_launch_ms": conv["ms"] / max(1, conv["launches"])}
-    return {"roofline": roofline, "stages": stages}
+    conv_roof = {"bound": "mfma", "kernel": "conv_mfma_kernel (BigVGAN Conv1d implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                 "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
+                 "launches_per_step": conv["launches"] // n_prof, "avg_launch_ms": conv["ms"] / max(1, conv["launches"]),
+                 "ms_per_step": conv["ms"] / n_prof}
+    roofline, other = conv_roof, None
+    st = stages["s2mel"]
+    if st is not None and st["cfm_gemm_ms_per_step"] > conv_roof["ms_per_step"]:
+        # the flow-matching GEMMs are the step's dominant kernel (always so with the f32 CFM): all epilogue instantiations of the tile
+        # kernel of that precision, algorithmic FLOPs 2 M N K per launch, durations from the HIP events around every launch
+        f32 = args.s2mel_precision == "fp32"
+        # traffic: PMC passes of the same solve (tools/pmc_s2mel_traffic.sh -> profiles/s2mel_gemm_traffic.json), if the shape matches
+        tr, tr_src, alg = None, None, None
+        tp2 = os.path.join(ROOT, "profiles", "s2mel_gemm_traffic.json")
+        if os.path.exists(tp2):
+            tj = json.load(open(tp2))
+            if tj.get("B") == B and tj.get("mel_frames") == t_mel and tj.get("precision") == args.s2mel_precision:
+                tr, tr_src, alg = tj["hbm_bytes_per_gemm_launch"], tj.get("source"), tj.get("algorithmic_bytes_per_gemm_launch")
+        gemm_roof = {"bound": "mfma",
+                     "kernel": ("gemm_prefill_kernel<EPI, CONV, VEC, F32 = true> (s2mel DiT / WaveNet GEMMs, v_mfma_f32_16x16x4_f32, every "
+                                "epilogue instantiation)" if f32 else
+                                "gemm_tile256_kernel / gemm_prefill_kernel (s2mel DiT / WaveNet GEMMs, v_mfma_f32_16x16x32_bf16, every "
+                                "epilogue instantiation)"),
+                     "achieved": st["cfm_gemm_tflops"], "peak": st["mfma_peak_tflops"], "unit": "TFLOP/s", "frac": st["cfm_gemm_mfma_frac"],
+                     "traffic": tr, "traffic_unit": "bytes/launch", "traffic_source": tr_src, "algorithmic_bytes_per_launch": alg,
+                     "launches_per_step": st["cfm_gemm_launches_per_step"],
+                     "avg_launch_ms": st["cfm_gemm_ms_per_step"] / max(1, st["cfm_gemm_launches_per_step"]),
+                     "ms_per_step": st["cfm_gemm_ms_per_step"]}
+        roofline, other = gemm_roof, conv_roof
+    out = {"roofline": roofline, "stages": stages}
+    if other is not None:
+        out["roofline_second_kernel"] = other
+    return out
 
 
 if __name__ == "__main__":

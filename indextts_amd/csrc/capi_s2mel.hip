@@ -19,12 +19,14 @@
 #include "gpt_kernels.h"
 #include "s2mel_kernels.h"
 
-// bf16: element-wise stages live in the GEMM epilogues (no f32 round trip of the wide intermediates) and the paired weights are
-// packed tile-interleaved for them; the f32 parity mode keeps separate kernels.  ITTS_S2MEL_FUSED=0 (read once, before the
-// weights are packed) forces the separate kernels in bf16 too -- the A/B switch of tests/test_gpu_s2mel.py.
+// Element-wise stages live in the GEMM epilogues (no f32 round trip of the wide intermediates) and the paired weights are packed
+// tile-interleaved for them -- in both precisions: the f32 mode (what the reference computes: autocast is off around the s2mel
+// stage, infer_v2_5.py:827-828) runs the same fused structure on the f32-MFMA instantiations of the tile kernel.
+// ITTS_S2MEL_FUSED=0 (read once, before the weights are packed) forces the separate element-wise kernels -- the A/B switch of
+// tests/test_gpu_s2mel.py.
 static bool s2_fused(int precision) {
     static const bool env = [] { const char* e = getenv("ITTS_S2MEL_FUSED"); return !e || atoi(e) != 0; }();
-    return precision == PREC_BF16 && env;
+    return (precision == PREC_BF16 || precision == PREC_F32) && env;
 }
 
 struct S2Layer {
@@ -189,7 +191,7 @@ struct Fin {
         return kn;
     }
     // [K][N] with N = two halves -> n-tiles interleaved (tile 2j: first half's columns 16j.., tile 2j+1: second half's 16j..): the
-    // layout the bf16 tile kernel's pair epilogues (EPI_SWIGLU / EPI_GATE) expect; identity in the f32 parity mode
+    // layout the tile kernel's pair epilogues (EPI_SWIGLU / EPI_GATE) expect; identity with the separate element-wise kernels
     std::vector<float> pair_tiles(const std::vector<float>& kn, int K, int N) const {
         if (!s2_fused(h->cfg.precision)) return kn;
         const int half = N / 2;

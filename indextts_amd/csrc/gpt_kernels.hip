@@ -599,6 +599,15 @@ __device__ __forceinline__ v2u_t pf_cvt4(f32x4 v) { return v2u_t{pf_cvt2(v[0], v
 // expf + an IEEE division per element made the SwiGLU / gate epilogues as long as a K = 512 main loop.
 __device__ __forceinline__ float pf_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float pf_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+// F32 instantiations of the tile kernel (the s2mel f32 mode: the reference runs this stage with autocast off, infer_v2_5.py:827-828):
+// activations, shadows and the K / V^T images are f32, and the gate functions are the libm ones the separate f32 kernels use
+// (swiglu_kernel<false>, wn_gate_kernel<false>) -- the main loop is 8x longer per byte than the bf16 one, the epilogue hides under it.
+template <bool F32> __device__ __forceinline__ float pf_sigmoid_t(float x) { if constexpr (F32) return 1.0f / (1.0f + expf(-x)); else return pf_sigmoid(x); }
+template <bool F32> __device__ __forceinline__ float pf_tanh_t(float x) { if constexpr (F32) return tanhf(x); else return pf_tanh(x); }
+template <bool F32> __device__ __forceinline__ void pf_store_act4(void* base, size_t idx, f32x4 v) {      // 4 consecutive act-dtype elements
+    if constexpr (F32) *(f32x4*)((float*)base + idx) = v;
+    else *(v2u_t*)((u16*)base + idx) = pf_cvt4(v);
+}
 
 // Row metadata of a tile region for the epilogues that need the row's (sequence, frame): staged ONCE per region into LDS (meta[row],
 // meta[ROWS + row]) by pf_stage_meta -- read per chunk from global they were two dependent L2 round trips in front of every RoPE
@@ -617,7 +626,7 @@ __device__ __forceinline__ void pf_stage_meta(const GemmArgs& a, int* meta, int 
     }
 }
 
-template <int EPI, int ROWS, int NT>            // ROWS x 128 columns of the tile, stored by NT threads (tid < NT)
+template <int EPI, int ROWS, int NT, bool F32 = false>            // ROWS x 128 columns of the tile, stored by NT threads (tid < NT)
 __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct, const int* meta, int m0, int n0, int tid) {
     constexpr bool PAIR = (EPI == EPI_SWIGLU || EPI == EPI_GATE);
     constexpr int CH = PAIR ? 16 : 32;                              // 4-column chunks per tile row
@@ -657,31 +666,32 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
             f32x4 o;
             if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = va[q] * pf_sigmoid(va[q]) * vb[q];                       // silu(w1 x) * (w3 x)
+                for (int q = 0; q < 4; ++q) o[q] = va[q] * pf_sigmoid_t<F32>(va[q]) * vb[q];                       // silu(w1 x) * (w3 x)
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = pf_tanh(va[q] + b1[q]) * pf_sigmoid(vb[q] + b2[q]);      // commons.py:133-141
+                for (int q = 0; q < 4; ++q) o[q] = pf_tanh_t<F32>(va[q] + b1[q]) * pf_sigmoid_t<F32>(vb[q] + b2[q]);      // commons.py:133-141
             }
-            *(v2u_t*)((u16*)a.out_act + (size_t)m * half + n) = pf_cvt4(o);
+            pf_store_act4<F32>(a.out_act, (size_t)m * half + n, o);
         } else {
             f32x4 v = *(const f32x4*)(ct + row * 128 + (ca ^ sw));
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] += b1[q];
             if constexpr (EPI == EPI_STORE_F32) {
                 *(f32x4*)(a.out_f32 + (size_t)m * a.ldo + n) = v;
-                if (a.out_act2) *(v2u_t*)((u16*)a.out_act2 + (size_t)m * a.ldo + n) = pf_cvt4(v);      // bf16 shadow: the next GEMM's A operand
+                if (a.out_act2) pf_store_act4<F32>(a.out_act2, (size_t)m * a.ldo + n, v);      // act-dtype shadow: the next GEMM's A operand
             } else if constexpr (EPI == EPI_RESIDUAL) {
                 f32x4* o = (f32x4*)(a.out_f32 + (size_t)m * a.ldo + n);
                 const f32x4 old = *o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] += old[q];
                 *o = v;
-                if (a.out_act2) *(v2u_t*)((u16*)a.out_act2 + (size_t)m * a.ldo + n) = pf_cvt4(v);
+                if (a.out_act2) pf_store_act4<F32>(a.out_act2, (size_t)m * a.ldo + n, v);
             } else if constexpr (EPI == EPI_GELU_ACT) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = gelu_new_f(v[q]);
-                *(v2u_t*)((u16*)a.out_act + (size_t)m * a.ldo + n) = v2u_t{(uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
-                                                                          (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)};
+                if constexpr (F32) *(f32x4*)((float*)a.out_act + (size_t)m * a.ldo + n) = v;
+                else *(v2u_t*)((u16*)a.out_act + (size_t)m * a.ldo + n) = v2u_t{(uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
+                                                                               (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)};
             } else if constexpr (EPI == EPI_WN_RS) {
                 if (a.wn_last || n >= a.D) {
                     f32x4* o = (f32x4*)(a.out2 + (size_t)m * a.D + (a.wn_last ? n : n - a.D));
@@ -698,7 +708,7 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = (old[q] + v[q]) * mask;
                     *o = v;
-                    if (a.out_act2) *(v2u_t*)((u16*)a.out_act2 + (size_t)m * a.D + n) = pf_cvt4(v);
+                    if (a.out_act2) pf_store_act4<F32>(a.out_act2, (size_t)m * a.D + n, v);
                 }
             } else if constexpr (EPI == EPI_QKV) {                    // GPT prefill: q f32, K / V appended to the bf16 cache
                 if (which == 0) {
@@ -707,7 +717,8 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
                     const int b = m / a.S, si = m - b * a.S;
                     const int pos = *a.pos_ptr + si;
                     const size_t o = (((size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1) * a.H + hd) * a.Tmax + pos) * 64 + d;
-                    *(v2u_t*)((u16*)(which == 1 ? a.kcache : a.vcache) + o) =
+                    if constexpr (F32) *(f32x4*)((float*)(which == 1 ? a.kcache : a.vcache) + o) = v;
+                    else *(v2u_t*)((u16*)(which == 1 ? a.kcache : a.vcache) + o) =
                         v2u_t{(uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16), (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)};
                 }
             } else {                                                   // EPI_QKV_ROPE (s2mel): both RoPE pairs of the chunk are in-thread
@@ -715,9 +726,13 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
                 if (which < 2) {
                     const f32x4 cs = *(const f32x4*)(a.rope + ((size_t)t * 32 + (d >> 1)) * 2);       // (cos, sin) of pairs d/2, d/2 + 1
                     const f32x4 y{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
-                    if (which == 0) *(v2u_t*)((u16*)a.out_act + (size_t)m * a.D + c) = pf_cvt4(y);
-                    else *(v2u_t*)((u16*)a.kcache + (((size_t)sq * a.H + hd) * a.Tmax + t) * 64 + d) = pf_cvt4(y);
-                } else {                                               // only when D % 128 != 0 (else pf_store_vt takes the V regions)
+                    if (which == 0) pf_store_act4<F32>(a.out_act, (size_t)m * a.D + c, y);
+                    else pf_store_act4<F32>(a.kcache, (((size_t)sq * a.H + hd) * a.Tmax + t) * 64 + d, y);
+                } else if constexpr (F32) {                            // only when D % 128 != 0 (else pf_store_vt takes the V regions)
+                    float* vt = (float*)a.vcache + (((size_t)sq * a.H + hd) * 64 + d) * a.Tmax + t;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) vt[(size_t)q * a.Tmax] = v[q];
+                } else {
                     u16* vt = (u16*)a.vcache + (((size_t)sq * a.H + hd) * 64 + d) * a.Tmax + t;
                     const v2u_t pk = pf_cvt4(v);
                     vt[0] = (u16)(pk.x & 0xffffu);
@@ -735,7 +750,7 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
 // a thread owns 4 consecutive frames of one (head, d) row of V^T and a wave's stores walk along t: 8-byte stores when the frame
 // run is 4-aligned, 2-byte stores into shared lines otherwise.  (Read from the row-major image the same stores were one 2-byte
 // element per line per lane: the wqkv GEMM ran at 425 TFLOP/s against 790 for the SwiGLU GEMM of the same K.)
-template <int ROWS, int NT>
+template <int ROWS, int NT, bool F32 = false>
 __device__ __forceinline__ void pf_store_vt(const GemmArgs& a, const float* ctT, int m0, int n0, int tid) {
     constexpr int RQ = ROWS / 4, CSTEP = NT / RQ;                   // a thread keeps its 4-frame run and walks over the columns
     const int rq = tid % RQ, col0 = tid / RQ;
@@ -762,6 +777,18 @@ __device__ __forceinline__ void pf_store_vt(const GemmArgs& a, const float* ctT,
             for (int q = 0; q < 4; ++q) v[q] += b;
         }
         const int c = n - 2 * a.D, hd = c >> 6, d = c & 63;
+        if constexpr (F32) {                                       // f32 V^T image: 16-byte stores along t when the run is 4-aligned
+            if (run) {
+                float* vt = (float*)a.vcache + (((size_t)s0 * a.H + hd) * 64 + d) * a.Tmax + t0;
+                if (wide) *(f32x4*)vt = v;
+                else { vt[0] = v[0]; vt[1] = v[1]; vt[2] = v[2]; vt[3] = v[3]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (m + q < a.M) ((float*)a.vcache)[(((size_t)sq[q] * a.H + hd) * 64 + d) * a.Tmax + tq[q]] = v[q];
+            }
+            continue;
+        }
         const v2u_t pk = pf_cvt4(v);
         if (run) {
             u16* vt = (u16*)a.vcache + (((size_t)s0 * a.H + hd) * 64 + d) * a.Tmax + t0;
@@ -779,8 +806,17 @@ __device__ __forceinline__ void pf_store_vt(const GemmArgs& a, const float* ctT,
     }
 }
 
-template <int EPI, bool CONV = false, bool VEC = true>      // VEC: the LDS-transposed vector epilogue (N, ldo, D multiples of 4)
+// F32 = true: the same kernel on v_mfma_f32_16x16x4_f32 (exact f32: the s2mel f32 mode and the GPT parity mode's prefill).  A K tile is
+// 32 f32 = the same 128 bytes per row, the packed f32 weights ([N/16][K/16][64 lanes][16 B]) give the same 2 KiB per n-tile and K tile,
+// so the LDS images, the DMA issue and the fragment read offsets are byte-identical; a 16-byte fragment piece now holds 4 k-values =
+// 4 MFMAs (lane group kg supplies k = 16 s2 + 4 kg + j to MFMA j), issued j-outer so consecutive MFMAs never chain on one accumulator
+// (40-cycle dependent latency vs 32-cycle issue).  Per output element the accumulation order equals gemm_kernel<false>'s (k-blocks
+// ascending, MFMAs x, y, z, w) -> bitwise the same results.  Per K tile a wave issues 128 MFMAs x 32 cycles against 16 fragment reads
+// and 32 KiB of DMA per block: MFMA-bound (157 TFLOP/s peak).
+template <int EPI, bool CONV = false, bool VEC = true, bool F32 = false>      // VEC: the LDS-transposed vector epilogue (N, ldo, D multiples of 4)
 __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
+    constexpr int ES = F32 ? 4 : 2;                                   // operand element size
+    constexpr int BK = 128 / ES;                                      // K tile: 128 bytes per row (64 bf16 / 32 f32)
     extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB | W 16 KiB]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 1, wc = w & 1;
@@ -793,7 +829,7 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     const int r = t - g * PF_GM * n_nt;
     const int bn = r / gm, bm = first_m + (r - bn * gm);
     const int m0 = bm * PF_BM, nt0 = bn * (PF_BN / 16);
-    const int nkb = a.K >> 5, nk = a.K / PF_BK;
+    const int nkb = F32 ? a.K >> 4 : a.K >> 5, nk = a.K / BK;
     const int ntiles = (a.N + 15) >> 4;
 
     // staging sources of this lane: 4 A chunks (rows) and 4 W chunks per wave per K tile
@@ -802,7 +838,7 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     int cv_t[4], cv_T[4];
     const char* cv_base[4];
     const char* cv_zero[4];
-    const int cv_kpt = CONV ? a.conv_W / PF_BK : 1;            // K tiles per tap
+    const int cv_kpt = CONV ? a.conv_W / BK : 1;               // K tiles per tap
     const int cv_left = CONV ? (a.conv_taps - 1) * a.conv_dil - ((a.conv_taps - 1) * a.conv_dil) / 2 : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -811,12 +847,12 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
         const int piece = (lane & 7) ^ ((row16 >> 1) & 7);
         int m = m0 + row_t;
         m = m < a.M ? m : a.M - 1;
-        asrc[i] = (const char*)a.A + ((size_t)m * a.lda + piece * 8) * 2;
+        asrc[i] = (const char*)a.A + (size_t)m * a.lda * ES + piece * 16;
         if constexpr (CONV) {                                  // implicit im2col: remember the row's frame and sequence extent
             const int sq = a.tok_seq[m];
             cv_t[i] = a.tok_t[m];
             cv_T[i] = a.seq_T[sq];
-            cv_base[i] = (const char*)a.A + ((size_t)a.seq_start[sq] * a.lda + piece * 8) * 2;
+            cv_base[i] = (const char*)a.A + (size_t)a.seq_start[sq] * a.lda * ES + piece * 16;
             cv_zero[i] = (const char*)a.zero_row + piece * 16;
         }
         const int nblk = w * 2 + (i >> 1), kb = i & 1;          // W chunk (n-block, k-block of the pair)
@@ -830,7 +866,7 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
         if constexpr (CONV) { tap = kt / cv_kpt; rem = kt - tap * cv_kpt; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const char* ap = asrc[i] + (size_t)kt * (PF_BK * 2);
+            const char* ap = asrc[i] + (size_t)kt * 128;
             if constexpr (CONV) {
                 const int maxpad = cv_left;                                        // left >= right
                 const int Tv = cv_T[i] <= maxpad ? maxpad + 1 : cv_T[i];           // zero-extended length of very short inputs
@@ -838,7 +874,7 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
                 p = p < 0 ? -p : p;
                 p = p >= Tv ? 2 * (Tv - 1) - p : p;
                 const bool ok = p >= 0 && p < cv_T[i];
-                ap = ok ? cv_base[i] + ((size_t)p * a.lda + (size_t)rem * PF_BK) * 2 : cv_zero[i];
+                ap = ok ? cv_base[i] + ((size_t)p * a.lda + (size_t)rem * BK) * ES : cv_zero[i];
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap,
                                              (__attribute__((address_space(3))) void*)(base + (w * 4 + i) * 1024), 16, 0, 0);
@@ -882,19 +918,41 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
         for (int mt = 0; mt < 4; ++mt) af1[mt] = *(const v4u*)(base + a_wave + mt * 2048 + a_off[1]);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) bf1[nt] = *(const v4u*)(base + b_wave + (nt * 2 + 1) * 1024);
+        if constexpr (F32) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af0[mt]),
-                                                                      __builtin_bit_cast(bf16x8_t, bf0[nt]), acc[mt][nt], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af1[mt]),
-                                                                      __builtin_bit_cast(bf16x8_t, bf1[nt]), acc[mt][nt], 0, 0, 0);
-        if (PF_SCHED) {
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float((s2 ? af1 : af0)[mt][j]),
+                                                                               __uint_as_float((s2 ? bf1 : bf0)[nt][j]), acc[mt][nt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af0[mt]),
+                                                                          __builtin_bit_cast(bf16x8_t, bf0[nt]), acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af1[mt]),
+                                                                          __builtin_bit_cast(bf16x8_t, bf1[nt]), acc[mt][nt], 0, 0, 0);
+        }
+        if (PF_SCHED && F32) {                                      // f32: 8 MFMAs (256 cycles) per read of the second k-step's fragments
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+        }
+        if (PF_SCHED && !F32) {
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // 8 DS reads: the first k-step's fragments
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -917,7 +975,7 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) *(f32x4*)(ct + (wc * 64 + nt * 16 + c16) * 132 + wr * 64 + mt * 16 + g * 4) = acc[mt][nt];
             __syncthreads();
-            pf_store_vt<128, 256>(a, ct, m0, nt0 * 16, threadIdx.x);
+            pf_store_vt<128, 256, F32>(a, ct, m0, nt0 * 16, threadIdx.x);
             return;
         }
 #pragma unroll
@@ -930,8 +988,9 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
         int* meta = (int*)(pf_sm + 65536);                          // 1 KiB of the slack above the 64 KiB row-major image
         pf_stage_meta<EPI, 128>(a, meta, m0, threadIdx.x);
         __syncthreads();
-        pf_store_tile<EPI, 128, 256>(a, ct, meta, m0, nt0 * 16, threadIdx.x);
+        pf_store_tile<EPI, 128, 256, F32>(a, ct, meta, m0, nt0 * 16, threadIdx.x);
     } else {
+        static_assert(!F32, "the f32 tile kernel has the vector epilogue only");
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -1425,6 +1484,45 @@ static int launch_gemm_prefill(const GemmArgs& a, hipStream_t st) {
     }
 }
 
+// f32 instantiations of the 128 x 128 tile kernel (vector epilogue only: N, ldo, D multiples of 4).  Two blocks fit a CU (66 KiB of
+// LDS each, 64 accumulator registers), so one block's epilogue overlaps the other's main loop.
+template <int EPI, bool CONV = false>
+static int launch_gemm_prefill_f32_e(const GemmArgs& a, hipStream_t st) {
+    const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
+    const int per = ceil_div(n_mt * n_nt, 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_prefill_kernel<EPI, CONV, true, true>), dim3(per * 8), dim3(256), PF_LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+static bool pf_f32_ok(const GemmArgs& a) {
+    return a.K % 32 == 0 && a.lda % 4 == 0 && a.nsplit == 1 && a.epi != EPI_PARTIAL && pf_vec_ok(a) && (((uintptr_t)a.A) & 15) == 0;
+}
+
+static int launch_gemm_prefill_f32(const GemmArgs& a, hipStream_t st) {
+    if (a.epi == EPI_GATE && a.conv_taps > 0 &&
+        (a.conv_W % 32 || a.K != a.conv_taps * a.conv_W || a.lda != a.conv_W || !a.tok_seq || !a.tok_t || !a.seq_start || !a.seq_T || !a.zero_row)) {
+        itts_set_error("gemm tap mode (f32): need conv_W %% 32 == 0, K == taps * conv_W, lda == conv_W and the sequence tables");
+        return ITTS_ERR_ARG;
+    }
+    switch (a.epi) {
+        case EPI_STORE_F32: return launch_gemm_prefill_f32_e<EPI_STORE_F32>(a, st);
+        case EPI_RESIDUAL: return launch_gemm_prefill_f32_e<EPI_RESIDUAL>(a, st);
+        case EPI_GELU_ACT: return launch_gemm_prefill_f32_e<EPI_GELU_ACT>(a, st);
+        case EPI_QKV: return launch_gemm_prefill_f32_e<EPI_QKV>(a, st);
+        case EPI_SWIGLU: return launch_gemm_prefill_f32_e<EPI_SWIGLU>(a, st);
+        case EPI_GATE: return a.conv_taps > 0 ? launch_gemm_prefill_f32_e<EPI_GATE, true>(a, st) : launch_gemm_prefill_f32_e<EPI_GATE>(a, st);
+        case EPI_QKV_ROPE: return launch_gemm_prefill_f32_e<EPI_QKV_ROPE>(a, st);
+        case EPI_WN_RS: return launch_gemm_prefill_f32_e<EPI_WN_RS>(a, st);
+        default: itts_set_error("gemm prefill (f32): unsupported epilogue %d", a.epi); return ITTS_ERR_ARG;
+    }
+}
+
 // ================================================================================================================
 // Decode GEMM, bf16, 16 / 32 / 64 activation rows per block (MT m-tiles; 64-row slices of larger batches).
 //   Same decomposition as gemm_kernel<true,4,1,true> -- one 16-column n-tile per block, the block's K slice (<= 1280)
@@ -1684,7 +1782,14 @@ static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
         // bf16, K a multiple of the 64-deep K tile, 16-byte aligned rows: the LDS-DMA tile kernel; else the direct-load one
         static const bool old_path = [] { const char* e = getenv("ITTS_PREFILL_GEMM"); return e && atoi(e) == 0; }();
         if (BF16 && !old_path && a.K % PF_BK == 0 && a.lda % 8 == 0 && a.nsplit == 1 && a.epi != EPI_PARTIAL) return launch_gemm_prefill(a, st);
-        if (a.epi > EPI_QKV || a.out_act2) { itts_set_error("gemm: epilogue %d / bf16 shadow output needs the bf16 tile kernel (K %% 64 == 0, lda %% 8 == 0)", a.epi); return ITTS_ERR_ARG; }
+        if constexpr (!BF16) {
+            // f32: the LDS-DMA tile kernel on the f32 MFMA (bitwise the register-path kernel's results; ITTS_F32_TILE=0 forces the
+            // latter for the plain epilogues -- the A/B switch of tests/test_gpu_gpt.py / test_gpu_s2mel.py)
+            static const bool f32_reg = [] { const char* e = getenv("ITTS_F32_TILE"); return e && atoi(e) == 0; }();
+            const bool fused = a.epi > EPI_QKV || a.out_act2 != nullptr;
+            if (pf_f32_ok(a) && (fused || !f32_reg)) return launch_gemm_prefill_f32(a, st);
+        }
+        if (a.epi > EPI_QKV || a.out_act2) { itts_set_error("gemm: epilogue %d / shadow output needs a tile kernel (bf16: K %% 64 == 0, lda %% 8 == 0; f32: K %% 32 == 0, lda %% 4 == 0, N / ldo / D %% 4 == 0)", a.epi); return ITTS_ERR_ARG; }
         return launch_gemm_cfg<BF16, 8, 2, false>(a, st);
     }
     if constexpr (BF16) {

@@ -151,8 +151,8 @@ int launch_cast_pad(const float* in, void* out, int rows, int src_rows, int C_in
 
 // ================================================================================================================
 // RoPE (interleaved pairs) + split of the fused QKV output.  Block = 4 consecutive frames of one sequence.
-//   Q -> [n_tok][H] act;  K -> [seq][head][t_pad][64] act;  V -> bf16: V^T [seq][head][64][t_pad] (4 frames = one 8-byte
-//   store per channel; the flash kernel's PV product wants 8 consecutive KEYS per lane), f32: [seq][head][t_pad][64].
+//   Q -> [n_tok][H] act;  K -> [seq][head][t_pad][64] act;  V -> V^T [seq][head][64][t_pad] act (4 frames = one 8- / 16-byte
+//   store per channel; the flash kernels' PV product wants consecutive KEYS per lane).
 // ================================================================================================================
 template <bool BF16>
 __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict__ qkv, const float* __restrict__ rope,
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict
         if constexpr (BF16) {
             const v2u pk{pack_bf16x2(val[0], val[1]), pack_bf16x2(val[2], val[3])};      // frames past T stay 0
             *(v2u*)((u16*)v + ((size_t)(s * heads + h) * 64 + d) * t_pad + t0) = pk;
-        } else {
-            for (int tt = 0; tt < nt; ++tt) ((float*)v)[((size_t)(s * heads + h) * t_pad + t0 + tt) * 64 + d] = val[tt];
+        } else {                                                                          // f32: the same V^T image (t0 % 4 == 0, t_pad % 64 == 0)
+            *(f32x4*)((float*)v + ((size_t)(s * heads + h) * 64 + d) * t_pad + t0) = f32x4{val[0], val[1], val[2], val[3]};
         }
     }
 }
@@ -206,7 +206,9 @@ int launch_rope_split(const float* qkv, const float* rope, void* q, void* k, voi
 }
 
 // ================================================================================================================
-// Non-causal attention, parity (f32) mode: one wave per (query, head); 16 lanes per key, 4 keys per step, online softmax.
+// Non-causal attention, f32, scalar form: one wave per (query, head); 16 lanes per key, 4 keys per step, online softmax with libm expf.
+// Kept as the independent A/B reference of flash_attn_f32_kernel below (ITTS_F32_ATTN=scalar; tests/test_gpu_s2mel.py): 25 TFLOP/s-class,
+// 335 ms per Euler step at 8 x 2443 frames (profiles/r03b).  V is the V^T image [seq][head][64][t_pad].
 // ================================================================================================================
 __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                                                       float* __restrict__ O, SeqTab tab, int heads, int t_pad) {
@@ -215,14 +217,16 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
     const int H = heads * 64, sub = lane & 15, grp = lane >> 4;
     const f32x4 q = *(const f32x4*)(Q + (size_t)m * H + h * 64 + sub * 4);
     const float* Kb = K + ((size_t)(s * heads + h) * t_pad) * 64;
-    const float* Vb = V + ((size_t)(s * heads + h) * t_pad) * 64;
+    const float* Vb = V + ((size_t)(s * heads + h) * 64) * t_pad;
     float m_run = -INFINITY, l_run = 0.f;
     f32x4 acc{0.f, 0.f, 0.f, 0.f};
     for (int t0 = 0; t0 < len; t0 += 4) {
         const int t = t0 + grp;
         const bool ok = t < len;
         const int tc = ok ? t : len - 1;
-        const f32x4 kf = *(const f32x4*)(Kb + (size_t)tc * 64 + sub * 4), vf = *(const f32x4*)(Vb + (size_t)tc * 64 + sub * 4);
+        const f32x4 kf = *(const f32x4*)(Kb + (size_t)tc * 64 + sub * 4);
+        const f32x4 vf{Vb[(size_t)(sub * 4 + 0) * t_pad + tc], Vb[(size_t)(sub * 4 + 1) * t_pad + tc], Vb[(size_t)(sub * 4 + 2) * t_pad + tc],
+                       Vb[(size_t)(sub * 4 + 3) * t_pad + tc]};
         float sc = (q[0] * kf[0] + q[1] * kf[1]) + (q[2] * kf[2] + q[3] * kf[3]);
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) sc += __shfl_xor(sc, o, 64);
@@ -497,6 +501,147 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
     }
 }
 
+// ================================================================================================================
+// Non-causal flash attention in exact f32 on v_mfma_f32_16x16x4_f32 (the s2mel f32 mode: the reference runs the DiT with autocast off,
+// infer_v2_5.py:827-828; gpt_fast/model.py:262-307).  Block = 64 queries of one (sequence, head), 4 waves x 16 queries; key tiles of 64.
+//   S^T = K Q^T   : A = K fragment (lane (g, r): key row 16 kt + r, d = 16 ks + 4 g + j -- one 16-byte LDS read feeds MFMAs j = 0..3),
+//                   B = Q^T from registers (lane (g, q): the same four d of its query) -> C: lane (g, q) holds keys 16 kt + 4 g + r.
+//   O^T = V^T P^T : A = V^T fragment (lane (g, r): row d = 16 dt + r, keys 16 kt + 4 g + j: again one 16-byte read per four MFMAs),
+//                   B = P^T = the S^T accumulators themselves: MFMA j of key sub-tile kt contracts over the keys {16 kt + 4 g + j}_g,
+//                   and lane (g, q) holds exactly that key's probability in st[kt][j] -- no transpose, no LDS round trip.
+//   MFMAs are issued j-outer over four independent accumulators (dependent latency 40 cycles, issue 32).  Per key tile and wave:
+//   128 MFMAs (4096 cycles) against 32 fragment reads and ~60 VALU softmax instructions: matrix-pipe bound (157 TFLOP/s peak).
+//   K tile [64 keys][64 d] and V^T tile [64 d][64 keys] f32 = 16 KiB each, two stages (64 KiB: two blocks per CU), filled by LDS-DMA
+//   (global_load_lds_dwordx4: a wave instruction writes four 256-byte rows lane-linearly); the sixteen 16-byte pieces of row r are
+//   XOR-permuted by r & 15 on the SOURCE side, so a fragment read (piece 4 ks + g of rows 16 kt + r) is conflict-free under
+//   ds_read_b128's real lane groups ({0-3, 12-15, 20-27}, ...: aligned pairs / quads of r within one g, MI355X guide).
+//   softmax in the exp2 domain on the raw scores (f32 v_exp_f32, ~1 ulp), running max across the query's four lanes by permlane swaps.
+// ================================================================================================================
+#define FA32_STAGE 32768
+#define FA32_LDS (2 * FA32_STAGE)
+__global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
+                                                                float* __restrict__ O, SeqTab tab, int heads, int t_pad, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char fa32_sm[];     // [2][K 16 KiB | V^T 16 KiB]
+    const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int T = tab.seq_T[s], len = tab.seq_len[s];
+    if (q0 >= T) return;
+    const int H = heads * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const size_t row0 = (size_t)tab.seq_start[s];
+    int qi = q0 + w * 16 + c16;
+    const bool q_ok = qi < T;
+    qi = q_ok ? qi : T - 1;
+    f32x4 qf[4];
+    {
+        const float* qrow = Q + (row0 + qi) * H + h * 64 + g * 4;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f32x4*)(qrow + ks * 16);
+    }
+    const float* Kb = K + ((size_t)(s * heads + h) * t_pad) * 64;
+    const float* Vb = Vt + ((size_t)(s * heads + h) * 64) * t_pad;
+    // DMA sources of this lane: wave w stages 1 KiB chunks 4 w .. 4 w + 3 of each operand = rows 16 w + 4 i + (lane >> 4)
+    const float* ksrc[4];
+    const float* vsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 16 * w + 4 * i + g;
+        const int piece = c16 ^ (r & 15);
+        ksrc[i] = Kb + (size_t)r * 64 + piece * 4;
+        vsrc[i] = Vb + (size_t)r * t_pad + piece * 4;
+    }
+    auto issue = [&](int k0, int buf) {
+        char* base = fa32_sm + buf * FA32_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc[i] + (size_t)k0 * 64),
+                                             (__attribute__((address_space(3))) void*)(base + (w * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + 16384 + (w * 4 + i) * 1024), 16, 0, 0);
+        }
+    };
+    // fragment read offsets: row (16 x + c16) * 256 B + slot ((4 y + g) ^ c16) * 16 B; x = sub-tile (kt / dt), y = k-step (ks / kt)
+    int f_off[4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y) f_off[y] = c16 * 256 + (((4 * y + g) ^ c16) << 4);
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    issue(0, 0);
+    int it = 0;
+    for (int k0 = 0; k0 < len; k0 += 64, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                               // tile `it` is in LDS; everybody is done with tile it - 1
+        if (k0 + 64 < len) issue(k0 + 64, (it + 1) & 1);               // block-uniform; in flight under this tile's MFMAs
+        const char* kt_s = fa32_sm + (it & 1) * FA32_STAGE;
+        const char* vt_s = kt_s + 16384;
+        f32x4 st[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f32x4 a[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) a[kt] = *(const f32x4*)(kt_s + kt * 4096 + f_off[ks]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kt][j], qf[ks][j], st[kt], 0, 0, 0);
+        }
+        if (k0 + 64 > len) {                                           // block-uniform: only the last tile holds masked keys
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + 16 * kt + 4 * g + r >= len) st[kt][r] = -INFINITY;
+        }
+        const float t0 = fa_max3(st[0][0], st[0][1], st[0][2]), t1 = fa_max3(st[1][0], st[1][1], st[1][2]);
+        const float t2 = fa_max3(st[2][0], st[2][1], st[2][2]), t3 = fa_max3(st[3][0], st[3][1], st[3][2]);
+        const float u0 = fa_max3(t0, t1, st[0][3]), u1 = fa_max3(t2, t3, st[1][3]);
+        const float m_new = fa_colmax(fa_max3(u0, u1, fa_max3(st[2][3], st[3][3], m_run)));      // >= m_run, finite (key 0 is valid)
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);             // exp2(-inf) = 0 on the first tile
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+            l_run *= alpha;
+            m_run = m_new;
+        }
+        const float off = -m_new * scale_log2e;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], scale_log2e, off));
+                st[kt][r] = p;
+                psum += p;
+            }
+        l_run += psum;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 a[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) a[dt] = *(const f32x4*)(vt_s + dt * 4096 + f_off[kt]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[dt][j], st[kt][j], o[dt], 0, 0, 0);
+        }
+    }
+    float ls = l_run;                                                  // the four key groups' shares of the row sum
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    if (q_ok) {
+        const float inv = ls > 0.f ? 1.0f / ls : 0.f;
+        float* orow = O + (row0 + qi) * H + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) *(f32x4*)(orow + dt * 16) = f32x4{o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+    }
+}
+
 int launch_s2mel_attention(const void* q, const void* k, const void* v, void* out, const SeqTab& tab, int heads, int t_pad, int prec,
                            hipStream_t st) {
     if (tab.n_tok <= 0) return ITTS_OK;
@@ -512,7 +657,19 @@ int launch_s2mel_attention(const void* q, const void* k, const void* v, void* ou
         if (qs >= 4) FA_LAUNCH(4); else if (qs == 2) FA_LAUNCH(2); else FA_LAUNCH(1);
 #undef FA_LAUNCH
     } else {
-        hipLaunchKernelGGL(attn_f32_kernel, dim3(tab.n_tok, heads), dim3(64), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, tab, heads, t_pad);
+        static const bool scalar = [] { const char* e = getenv("ITTS_F32_ATTN"); return e && e[0] == 's'; }();      // "scalar": the A/B reference
+        if (scalar) {
+            hipLaunchKernelGGL(attn_f32_kernel, dim3(tab.n_tok, heads), dim3(64), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, tab, heads, t_pad);
+        } else {
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FA32_LDS));
+                attr_set = true;
+            }
+            const float scale_log2e = 0.125f * 1.4426950408889634f;
+            hipLaunchKernelGGL(flash_attn_f32_kernel, dim3(ceil_div(tab.t_max, 64), heads, tab.n_seq), dim3(256), FA32_LDS, st, (const float*)q,
+                               (const float*)k, (const float*)v, (float*)out, tab, heads, t_pad, scale_log2e);
+        }
     }
     HIP_TRY(hipGetLastError());
     return ITTS_OK;

@@ -245,3 +245,76 @@ def regulator_weights(c: dict = REGULATOR_V2, seed: int = 1234) -> Dict[str, tor
     sd[f"model.{3 * n}.weight"] = torch.randn(Cc, Cc, 1, generator=g) / math.sqrt(Cc)
     sd[f"model.{3 * n}.bias"] = 0.05 * torch.randn(Cc, generator=g)
     return sd
+
+
+# ---- IndexTTS-2 (BASELINE.json configs[3]): conditioning encoders, speed embedding, GPT-latent projector --------------------------
+# the published IndexTTS-2 config's sections (checkpoints/config.yaml `gpt.condition_module` / `gpt.emo_condition_module`)
+COND_V2 = dict(output_size=512, linear_units=2048, attention_heads=8, num_blocks=6, input_layer="conv2d2", perceiver_mult=2)
+EMO_COND_V2 = dict(output_size=512, linear_units=1024, attention_heads=4, num_blocks=4, input_layer="conv2d2", perceiver_mult=2)
+GPT_V2 = dict(GPT_V25, condition_type="conformer_perceiver", condition_module=COND_V2, emo_condition_module=EMO_COND_V2)
+
+
+def _conformer_weights(pre: str, cm: dict, g, input_size: int = 1024, cnn_kernel: int = 15) -> Dict[str, torch.Tensor]:
+    """ConformerEncoder parameters (indextts/gpt/conformer_encoder.py) by name and shape, fan-in scaled."""
+    D, H, U = cm["output_size"], cm["attention_heads"], cm["linear_units"]
+    f_out = (input_size - 1) // 2
+    w = lambda *shape: torch.randn(*shape, generator=g) / math.sqrt(max(1, int(torch.tensor(shape[1:]).prod())))
+    b = lambda n: 0.05 * torch.randn(n, generator=g)
+    gain = lambda n: 1.0 + 0.1 * torch.randn(n, generator=g)
+    sd = {pre + "embed.conv.0.weight": w(D, 1, 3, 3), pre + "embed.conv.0.bias": b(D), pre + "embed.out.0.weight": 2.0 * w(D, D * f_out),
+          pre + "embed.out.0.bias": b(D), pre + "after_norm.weight": gain(D), pre + "after_norm.bias": b(D)}
+    shapes = {"self_attn.linear_q": (D, D), "self_attn.linear_k": (D, D), "self_attn.linear_v": (D, D), "self_attn.linear_out": (D, D),
+              "feed_forward.w_1": (U, D), "feed_forward.w_2": (D, U), "conv_module.pointwise_conv1": (2 * D, D, 1),
+              "conv_module.depthwise_conv": (D, 1, cnn_kernel), "conv_module.pointwise_conv2": (D, D, 1)}
+    for i in range(cm["num_blocks"]):
+        p = f"{pre}encoders.{i}."
+        for name, shape in shapes.items():
+            sd[p + name + ".weight"], sd[p + name + ".bias"] = w(*shape), b(shape[0])
+        sd[p + "self_attn.linear_pos.weight"] = w(D, D)
+        sd[p + "self_attn.pos_bias_u"] = 0.3 * torch.randn(H, D // H, generator=g)
+        sd[p + "self_attn.pos_bias_v"] = 0.3 * torch.randn(H, D // H, generator=g)
+        for n in ("conv_module.norm", "norm_ff", "norm_mha", "norm_conv", "norm_final"):
+            sd[p + n + ".weight"], sd[p + n + ".bias"] = gain(D), b(D)
+    return sd
+
+
+def _perceiver_weights(pre: str, dim: int, dim_context: int, heads: int, ff_mult: float, num_latents: int, g, depth: int = 2,
+                       dim_head: int = 64) -> Dict[str, torch.Tensor]:
+    """PerceiverResampler parameters (indextts/gpt/perceiver.py) by name and shape."""
+    inner, ffi = dim_head * heads, int(dim * ff_mult * 2 / 3)
+    w = lambda o, i: torch.randn(o, i, generator=g) / math.sqrt(i)
+    sd = {pre + "latents": 0.5 * torch.randn(num_latents, dim, generator=g), pre + "norm.gamma": 1.0 + 0.1 * torch.randn(dim, generator=g)}
+    if dim_context != dim:
+        sd[pre + "proj_context.weight"], sd[pre + "proj_context.bias"] = w(dim, dim_context), 0.05 * torch.randn(dim, generator=g)
+    for i in range(depth):
+        p = f"{pre}layers.{i}."
+        sd[p + "0.to_q.weight"], sd[p + "0.to_kv.weight"], sd[p + "0.to_out.weight"] = w(inner, dim), w(2 * inner, dim), w(dim, inner)
+        sd[p + "1.0.weight"], sd[p + "1.0.bias"] = w(2 * ffi, dim), 0.05 * torch.randn(2 * ffi, generator=g)
+        sd[p + "1.2.weight"], sd[p + "1.2.bias"] = w(dim, ffi), 0.05 * torch.randn(dim, generator=g)
+    return sd
+
+
+def cond_weights(cfg: dict = GPT_V2, seed: int = 4242, cond_num: int = 32) -> Dict[str, torch.Tensor]:
+    """What an IndexTTS-2 `gpt.pth` holds beside the GPT-2 stack: the speaker / emotion Conformer + Perceiver encoders
+    (model_v2.py:358-384), `emovec_layer`, `emo_layer` and the speed embedding."""
+    g = torch.Generator().manual_seed(seed)
+    D, cm, em = cfg["model_dim"], cfg["condition_module"], cfg["emo_condition_module"]
+    sd = {}
+    sd.update(_conformer_weights("conditioning_encoder.", cm, g))
+    sd.update(_perceiver_weights("perceiver_encoder.", D, cm["output_size"], cm["attention_heads"], cm["perceiver_mult"], cond_num, g))
+    sd.update(_conformer_weights("emo_conditioning_encoder.", em, g))
+    sd.update(_perceiver_weights("emo_perceiver_encoder.", 1024, em["output_size"], em["attention_heads"], em["perceiver_mult"], 1, g))
+    sd["emovec_layer.weight"], sd["emovec_layer.bias"] = torch.randn(D, 1024, generator=g) / 32.0, 0.02 * torch.randn(D, generator=g)
+    sd["emo_layer.weight"], sd["emo_layer.bias"] = torch.randn(D, D, generator=g) / math.sqrt(D) * 0.3, 0.02 * torch.randn(D, generator=g)
+    sd["speed_emb.weight"] = 0.3 * torch.randn(2, D, generator=g)
+    return sd
+
+
+def gpt_layer_weights(dims=(1280, 256, 128, 1024), seed: int = 77) -> Dict[str, torch.Tensor]:
+    """`s2mel.models['gpt_layer']` of IndexTTS-2 (s2mel/modules/commons.py:413): three Linear layers on the GPT latents."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for i in range(len(dims) - 1):
+        sd[f"{i}.weight"] = torch.randn(dims[i + 1], dims[i], generator=g) / math.sqrt(dims[i])
+        sd[f"{i}.bias"] = 0.02 * torch.randn(dims[i + 1], generator=g)
+    return sd

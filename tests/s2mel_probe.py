@@ -1,5 +1,5 @@
-"""Helper for test_gpu_s2mel.py::test_tile_gemm_kernels_agree: runs the bf16 s2mel solve at the shipped widths on three ragged
-utterances and prints a digest of the raw output.  ITTS_TILE256 (read once per process) selects the tile GEMM kernel: 0 = the
+"""Helper for test_gpu_s2mel.py::test_tile_gemm_kernels_agree / test_f32_fast_path_vs_separate_kernels: runs the s2mel solve (PROBE_PREC,
+default bf16) at the shipped widths on three ragged utterances and prints a digest of the raw output (PROBE_SAVE: also saves it).  ITTS_TILE256 (read once per process) selects the tile GEMM kernel: 0 = the
 128 x 128 kernel, 1 = the 256 x 256 eight-wave kernel, 2 = the 256 x 128 four-wave kernel, for every shape -- hence one process per setting."""
 import hashlib
 import os
@@ -14,7 +14,7 @@ from test_gpu_s2mel import engine  # noqa: E402
 
 cfg = S.S2MelConfig(depth=3, wavenet_layers=2, wavenet_dilation_rate=int(os.environ.get("PROBE_DIL", "1")))
 sd = S.synth_weights(cfg, 5)
-m = engine(cfg, sd, "bf16")
+m = engine(cfg, sd, os.environ.get("PROBE_PREC", "bf16"))
 g = torch.Generator().manual_seed(6)
 T, Tp = [391, 97, 258], [40, 33, 1]          # 2 x 746 rows: three 256-row tiles, the last one ragged; sequences straddle tiles
 Tm = max(T)
@@ -26,4 +26,6 @@ h = hashlib.sha256()
 for rep in range(int(os.environ.get("PROBE_REPS", "3"))):          # repeated: a race between LDS-DMA and fragment reads is intermittent
     y = m.solve_euler(x.clone(), torch.tensor(T), prompt, mu, style, None, torch.linspace(0, 1, 3), 0.7, prompt_lens=Tp, frame_lens=T)
     h.update(y.float().cpu().numpy().tobytes())
+if os.environ.get("PROBE_SAVE"):
+    torch.save(y.float().cpu(), os.environ["PROBE_SAVE"])
 print("DIGEST", h.hexdigest(), float(y.float().abs().mean()), tuple(y.shape))

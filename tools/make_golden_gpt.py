@@ -317,12 +317,53 @@ def main():
                                 cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens,
                                               cfg.max_mel_tokens, cfg.number_text_tokens]))
 
+    if only is not None and "fullsize" in only:            # minutes of CPU: only on request (`make_golden_gpt.py fullsize`)
+        make_fullsize()
     if only is None or "v1" in only:
         make_v1()
     if only is None or "bf16" in only:
         make_bf16()
     if only is None or "v2" in only:
         make_v2()
+
+
+def make_fullsize():
+    """The benchmarked GPT at the benchmarked context: the full-size stack (24 x 1280 x 20 heads) decoding
+    560 greedy tokens from 128-token texts, i.e. context 134 + 560 = 694 -- BASELINE configs[2]'s shape, two rows (one ragged).
+    The REFERENCE's own classes run it here on CPU (minutes); the fixture holds their ids plus the oracle's top-2 margins of the
+    processed scores per step (the oracle's ids must equal the reference's), so the GPU test needs no CPU decode."""
+    cfg = G.GPTConfig(max_text_tokens=140, max_mel_tokens=600)
+    seed, B, L, n = 1234, 2, 128, 560
+    sd = G.synth_weights(cfg, seed=seed)
+    sd["mel_head.bias"][cfg.stop_mel_token] -= 1e4                # fixed-length decode (bench.py does the same)
+    g = torch.Generator().manual_seed(692)          # text seed chosen for a comfortable minimum greedy margin (1.1e-3)
+    lens = [128, 97]
+    text = ragged_text(g, B, L, cfg.number_text_tokens, lens)
+    style = torch.randn(1, 192, generator=g)
+    emo_vec = torch.randn(1, cfg.model_dim, generator=g) * 0.1
+    langs = torch.randint(0, cfg.n_langs, (B,), generator=g)
+    gk = dict(do_sample=False, num_beams=1, repetition_penalty=10.0)
+    import time
+    t0 = time.time()
+    uv = build_reference(sd, cfg, kv_cache=True)
+    with torch.no_grad():
+        codes, _ = uv.inference_speech(torch.zeros(1, 4, 2), text, langs=langs, emo_vec=emo_vec, campplus_embedding=style,
+                                       max_generate_length=n, **gk)
+    t1 = time.time()
+    trace = {}
+    with torch.no_grad():
+        oc = G.inference_speech(sd, cfg, G.conds_latent_campplus(sd, style, emo_vec), text, langs,
+                                G.GenParams(max_generate_length=n, **gk), kv_cache=True, trace=trace)
+    t2 = time.time()
+    same = codes.shape == oc.shape and bool((codes == oc).all())
+    margins = np.stack([(lambda t: (t[:, 0] - t[:, 1]).numpy())(torch.topk(l, 2, dim=-1).values) for l in trace["scores"]], 1)
+    print(f"fullsize: reference ids {tuple(codes.shape)} in {t1 - t0:.0f}s, oracle in {t2 - t1:.0f}s, oracle==reference: {same}; "
+          f"min top-2 margin of the processed scores {margins.min():.3e} (row/step {np.unravel_index(margins.argmin(), margins.shape)})")
+    assert same
+    np.savez_compressed(os.path.join(GOLD, "gpt_fullsize_ctx694.npz"), text=text.numpy(), lens=np.array(lens), style=style.numpy(),
+                        emo_vec=emo_vec.numpy(), langs=langs.numpy(), codes=codes.numpy(), margins=margins.astype(np.float32),
+                        seed=np.int64(seed), n=np.int64(n),
+                        cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens, cfg.max_mel_tokens, cfg.number_text_tokens]))
 
 
 def make_v1():
