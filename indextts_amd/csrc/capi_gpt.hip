@@ -9,18 +9,46 @@
 
 // ---- host-side weight packing ----------------------------------------------------------------------------------
 extern "C" size_t itts_packed_gemm_bytes(int K, int N, int precision) {
+    if (precision == PREC_F32X3) return (size_t)((N + 15) / 16) * (K / 32) * 3 * 64 * 16;       // three bf16 planes per 32-deep k-block
     const int KB = precision == PREC_BF16 ? 32 : 16;
     return (size_t)((N + 15) / 16) * (K / KB) * 64 * 16;
 }
 
 // w: [K][N] row-major (HF Conv1D) when transposed == 0, [N][K] (nn.Linear) when transposed != 0
 extern "C" int itts_pack_gemm_weight(const float* w, int K, int N, int transposed, int precision, void* out) {
-    const int KB = precision == PREC_BF16 ? 32 : 16;
+    const int KB = precision == PREC_F32 ? 16 : 32;
     if (!w || !out || K <= 0 || N <= 0 || K % KB) {
         itts_set_error("pack_gemm: K=%d must be a positive multiple of %d", K, KB);
         return ITTS_ERR_ARG;
     }
+    if (precision != PREC_F32 && precision != PREC_BF16 && precision != PREC_F32X3) { itts_set_error("pack_gemm: precision %d", precision); return ITTS_ERR_ARG; }
     const int ntiles = (N + 15) / 16, nkb = K / KB, per = KB / 4;   // per = k elements per lane
+    if (precision == PREC_F32X3) {
+        // [N/16][K/32][3 planes][64 lanes][8 bf16]: x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (exact: 24 bits);
+        // lane (kg, n) element j holds k = 32 kb + 4 kg + j (j < 4) or 32 kb + 16 + 4 kg + (j - 4): the two 16-byte pieces of the
+        // f32 activation row that gemm_x3_kernel's lane reads
+        auto b2f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+        for (int nt = 0; nt < ntiles; ++nt)
+            for (int kb = 0; kb < nkb; ++kb)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int n = nt * 16 + (lane & 15), kg = lane >> 4;
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = kb * 32 + (j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4));
+                        float v = 0.f;
+                        if (n < N) v = transposed ? w[(size_t)n * K + k] : w[(size_t)k * N + n];
+                        const uint16_t h = host_f32_to_bf16(v);
+                        const float r1 = v - b2f(h);
+                        const uint16_t m = host_f32_to_bf16(r1);
+                        const float r2 = r1 - b2f(m);
+                        const uint16_t l = host_f32_to_bf16(r2);
+                        const size_t blk = ((size_t)nt * nkb + kb) * 3;
+                        ((u16*)out)[((blk + 0) * 64 + lane) * 8 + j] = h;
+                        ((u16*)out)[((blk + 1) * 64 + lane) * 8 + j] = m;
+                        ((u16*)out)[((blk + 2) * 64 + lane) * 8 + j] = l;
+                    }
+                }
+        return ITTS_OK;
+    }
     for (int nt = 0; nt < ntiles; ++nt)
         for (int kb = 0; kb < nkb; ++kb)
             for (int lane = 0; lane < 64; ++lane) {

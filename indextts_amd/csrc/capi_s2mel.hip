@@ -26,6 +26,7 @@
 // tests/test_gpu_s2mel.py.
 static bool s2_fused(int precision) {
     static const bool env = [] { const char* e = getenv("ITTS_S2MEL_FUSED"); return !e || atoi(e) != 0; }();
+    if (precision == PREC_F32X3) return true;                   // the f32x3 GEMM kernel exists with the fused epilogues only
     return (precision == PREC_BF16 || precision == PREC_F32) && env;
 }
 
@@ -99,7 +100,7 @@ extern "C" int itts_s2mel_create(const itts_s2mel_config* cfg, itts_s2mel** out)
     const itts_s2mel_config& c = *cfg;
     if (c.hidden_dim != c.num_heads * 64 || c.hidden_dim % 64 || c.depth < 1 || c.in_channels < 1 || c.in_channels % 4 || c.wavenet_hidden % 64 ||
         c.wavenet_layers < 1 || c.wavenet_kernel < 1 || (c.wavenet_kernel & 1) == 0 || c.wavenet_dilation_rate < 1 ||
-        (c.precision != PREC_F32 && c.precision != PREC_BF16)) {
+        (c.precision != PREC_F32 && c.precision != PREC_BF16 && c.precision != PREC_F32X3)) {
         itts_set_error("s2mel_create: unsupported config (hidden=%d heads=%d: head_dim must be 64; wavenet=%d x %d k=%d; prec=%d)", c.hidden_dim,
                        c.num_heads, c.wavenet_hidden, c.wavenet_layers, c.wavenet_kernel, c.precision);
         return ITTS_ERR_ARG;

@@ -2,7 +2,9 @@
 #pragma once
 #include "common.h"
 
-enum { PREC_F32 = 0, PREC_BF16 = 1 };
+enum { PREC_F32 = 0, PREC_BF16 = 1,
+       PREC_F32X3 = 2 };   // f32 activations; GEMMs on the bf16 matrix pipe with every f32 operand carried exactly as three bf16 planes
+                           // (gpt_kernels.hip::gemm_x3_kernel).  Everything that is not a GEMM runs its f32 code.
 
 // ---- LayerNorm with fused split-K reduce / bias / residual update ---------------------------------------------
 struct LnArgs {

@@ -1524,6 +1524,219 @@ static int launch_gemm_prefill_f32(const GemmArgs& a, hipStream_t st) {
 }
 
 // ================================================================================================================
+// f32-accurate GEMM on the bf16 matrix pipe ("f32x3"): every f32 operand is carried EXACTLY as three bf16 planes
+//   x = xh + xm + xl,  xh = bf16(x), xm = bf16(x - xh), xl = bf16(x - xh - xm)        (8 + 8 + 8 significand bits, no bit dropped)
+// and an f32 product is the sum of the plane products, each of them exact in the f32 accumulator of v_mfma_f32_16x16x32_bf16:
+//   NPROD = 8: every term down to 2^-24 |a b| (hh, hm, mh, mm, hl, lh, ml, lm; only ll, 2^-32, is dropped) -- closer to the exact
+//              product than one f32 rounding;  NPROD = 6: without ml / lm (2^-24 |a b| each).
+// Accumulation stays f32.  The native f32 MFMA runs at 1/16 of the bf16 rate, so 8 bf16 MFMAs per K = 32 tile pair replace 8 f32
+// MFMAs of twice the issue time: 2x the native-f32 matrix rate (2.67x with 6 products) -- tests/test_gpu_gemm_x3.py holds the
+// result to an f64 GEMM and compares its error with the native f32 kernel's on the same operands.
+//   Activations stay f32 in HBM and LDS: the A tile is DMA'd exactly like the f32 tile kernel's ([128 rows][32 k] f32, same image and
+//   swizzle) and each wave splits its fragments in registers (12 VALU ops per pair of values, issued in the shadow of the MFMAs).  The
+//   lane's eight k-values are the two 16-byte pieces the f32 kernel reads (k = 4 kg + j and 16 + 4 kg + j): conflict-free, and the
+//   weights are packed with the same k permutation.  Weights are split once on the host (itts_pack_gemm_weight, precision 2):
+//   [N/16][K/32][3 planes][64 lanes][16 B].  LDS: 2 stages x (A 16 KiB | W 24 KiB) = 80 KiB -> two blocks per CU.
+//   Epilogues: the f32 tile kernel's (pf_store_tile / pf_store_vt with F32 = true).
+// ================================================================================================================
+#define X3_STAGE 40960
+#define X3_LDS (2 * X3_STAGE)
+
+__device__ __forceinline__ void x3_split8(const f32x4 p0, const f32x4 p1, v4u& H, v4u& M, v4u& L) {
+    const float x[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const uint32_t h = pf_cvt2(a, b);
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);      // exact
+        const uint32_t m = pf_cvt2(ra, rb);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);    // exact
+        H[i] = h; M[i] = m; L[i] = pf_cvt2(sa, sb);
+    }
+}
+
+template <int EPI, bool CONV = false, int NPROD = 8>
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB | W 24 KiB]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int n_mt = (a.M + PF_BM - 1) / PF_BM, n_nt = (a.N + PF_BN - 1) / PF_BN;
+    const int total = n_mt * n_nt, per = (total + 7) >> 3;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= total) return;
+    const int g0 = t / (PF_GM * n_nt), first_m = g0 * PF_GM;
+    const int gm = (n_mt - first_m) < PF_GM ? (n_mt - first_m) : PF_GM;
+    const int r = t - g0 * PF_GM * n_nt;
+    const int bn = r / gm, bm = first_m + (r - bn * gm);
+    const int m0 = bm * PF_BM, nt0 = bn * (PF_BN / 16);
+    const int nk = a.K >> 5;                                           // K tiles of 32
+    const int ntiles = (a.N + 15) >> 4;
+
+    const char* asrc[4];
+    const char* bsrc[6];
+    int cv_t[4], cv_T[4];
+    const char* cv_base[4];
+    const char* cv_zero[4];
+    const int cv_kpt = CONV ? a.conv_W / 32 : 1;
+    const int cv_left = CONV ? (a.conv_taps - 1) * a.conv_dil - ((a.conv_taps - 1) * a.conv_dil) / 2 : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = w * 4 + i;                               // A chunk: tile rows c*8 .. c*8+7
+        const int row_t = c * 8 + (lane >> 3), row16 = row_t & 15;
+        const int piece = (lane & 7) ^ ((row16 >> 1) & 7);
+        int m = m0 + row_t;
+        m = m < a.M ? m : a.M - 1;
+        asrc[i] = (const char*)a.A + (size_t)m * a.lda * 4 + piece * 16;
+        if constexpr (CONV) {
+            const int sq = a.tok_seq[m];
+            cv_t[i] = a.tok_t[m];
+            cv_T[i] = a.seq_T[sq];
+            cv_base[i] = (const char*)a.A + (size_t)a.seq_start[sq] * a.lda * 4 + piece * 16;
+            cv_zero[i] = (const char*)a.zero_row + piece * 16;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = w * 6 + i, nblk = c / 3, plane = c - nblk * 3;       // W chunk (n-block of the tile, plane)
+        int nt = nt0 + nblk;
+        nt = nt < ntiles ? nt : ntiles - 1;
+        bsrc[i] = (const char*)a.Wp + ((size_t)nt * nk * 3 + plane) * 1024 + lane * 16;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = pf_sm + buf * X3_STAGE;
+        int tap = 0, rem = kt;
+        if constexpr (CONV) { tap = kt / cv_kpt; rem = kt - tap * cv_kpt; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* ap = asrc[i] + (size_t)kt * 128;
+            if constexpr (CONV) {
+                const int maxpad = cv_left;
+                const int Tv = cv_T[i] <= maxpad ? maxpad + 1 : cv_T[i];
+                int p = cv_t[i] + tap * a.conv_dil - cv_left;
+                p = p < 0 ? -p : p;
+                p = p >= Tv ? 2 * (Tv - 1) - p : p;
+                const bool ok = p >= 0 && p < cv_T[i];
+                ap = ok ? cv_base[i] + ((size_t)p * a.lda + (size_t)rem * 32) * 4 : cv_zero[i];
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap,
+                                             (__attribute__((address_space(3))) void*)(base + (w * 4 + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (size_t)kt * 3072),
+                                             (__attribute__((address_space(3))) void*)(base + 16384 + (w * 6 + i) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int row16 = lane & 15, kg = lane >> 4;
+    int a_off[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int pos = (s2 * 4 + kg) ^ ((row16 >> 1) & 7);
+        a_off[s2] = (row16 >> 3) * 1024 + ((row16 & 7) * 8 + pos) * 16;
+    }
+    const int a_wave = wr * 4 * 2048;
+    const int b_wave = 16384 + wc * 4 * 3072 + lane * 16;
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* base = pf_sm + (kt & 1) * X3_STAGE;
+        v4u bw[4][3];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bw[nt][p] = *(const v4u*)(base + b_wave + (nt * 3 + p) * 1024);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 p0 = *(const f32x4*)(base + a_wave + mt * 2048 + a_off[0]);
+            const f32x4 p1 = *(const f32x4*)(base + a_wave + mt * 2048 + a_off[1]);
+            v4u ap[3];
+            x3_split8(p0, p1, ap[0], ap[1], ap[2]);
+            // plane pairs, smallest terms first; four independent accumulators between two MFMAs on the same one
+            constexpr int PA[8] = {2, 1, 2, 0, 1, 1, 0, 0};
+            constexpr int PB[8] = {1, 2, 0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 8 - NPROD; q < 8; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ap[PA[q]]),
+                                                                          __builtin_bit_cast(bf16x8_t, bw[nt][PB[q]]), acc[mt][nt], 0, 0, 0);
+        }
+    }
+    // epilogue: the f32 tile kernel's vector path
+    __syncthreads();
+    float* ct = (float*)pf_sm;
+    const int g = lane >> 4, c16 = lane & 15;
+    if (EPI == EPI_QKV_ROPE && a.D % 128 == 0 && nt0 * 16 >= 2 * a.D) {       // block-uniform: a V tile
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) *(f32x4*)(ct + (wc * 64 + nt * 16 + c16) * 132 + wr * 64 + mt * 16 + g * 4) = acc[mt][nt];
+        __syncthreads();
+        pf_store_vt<128, 256, true>(a, ct, m0, nt0 * 16, threadIdx.x);
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                ct[(wr * 64 + mt * 16 + g * 4 + rr) * 128 + ((wc * 64 + nt * 16 + c16) ^ (g << 4))] = acc[mt][nt][rr];
+    int* meta = (int*)(pf_sm + 65536);
+    pf_stage_meta<EPI, 128>(a, meta, m0, threadIdx.x);
+    __syncthreads();
+    pf_store_tile<EPI, 128, 256, true>(a, ct, meta, m0, nt0 * 16, threadIdx.x);
+}
+
+template <int EPI, bool CONV = false>
+static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
+    const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
+    const int per = ceil_div(n_mt * n_nt, 8);
+    static const int nprod = [] { const char* e = getenv("ITTS_X3_PRODUCTS"); const int v = e ? atoi(e) : 8; return v == 6 ? 6 : 8; }();
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
+        attr_set = true;
+    }
+    if (nprod == 6) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6>), dim3(per * 8), dim3(256), X3_LDS, st, a);
+    else hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8>), dim3(per * 8), dim3(256), X3_LDS, st, a);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+static int launch_gemm_x3(const GemmArgs& a, hipStream_t st) {
+    if (!pf_f32_ok(a)) {
+        itts_set_error("gemm (f32x3): needs K %% 32 == 0, lda %% 4 == 0, N / ldo / D %% 4 == 0, 16-byte aligned rows, no split-K (M=%d N=%d K=%d lda=%d epi=%d)",
+                       a.M, a.N, a.K, a.lda, a.epi);
+        return ITTS_ERR_ARG;
+    }
+    if (a.epi == EPI_GATE && a.conv_taps > 0 &&
+        (a.conv_W % 32 || a.K != a.conv_taps * a.conv_W || a.lda != a.conv_W || !a.tok_seq || !a.tok_t || !a.seq_start || !a.seq_T || !a.zero_row)) {
+        itts_set_error("gemm tap mode (f32x3): need conv_W %% 32 == 0, K == taps * conv_W, lda == conv_W and the sequence tables");
+        return ITTS_ERR_ARG;
+    }
+    switch (a.epi) {
+        case EPI_STORE_F32: return launch_gemm_x3_e<EPI_STORE_F32>(a, st);
+        case EPI_RESIDUAL: return launch_gemm_x3_e<EPI_RESIDUAL>(a, st);
+        case EPI_SWIGLU: return launch_gemm_x3_e<EPI_SWIGLU>(a, st);
+        case EPI_GATE: return a.conv_taps > 0 ? launch_gemm_x3_e<EPI_GATE, true>(a, st) : launch_gemm_x3_e<EPI_GATE>(a, st);
+        case EPI_QKV_ROPE: return launch_gemm_x3_e<EPI_QKV_ROPE>(a, st);
+        case EPI_WN_RS: return launch_gemm_x3_e<EPI_WN_RS>(a, st);
+        default: itts_set_error("gemm (f32x3): unsupported epilogue %d", a.epi); return ITTS_ERR_ARG;
+    }
+}
+
+// ================================================================================================================
 // Decode GEMM, bf16, 16 / 32 / 64 activation rows per block (MT m-tiles; 64-row slices of larger batches).
 //   Same decomposition as gemm_kernel<true,4,1,true> -- one 16-column n-tile per block, the block's K slice (<= 1280)
 //   split over the 4 waves by k-block (w, w+4, ...), LDS reduce, shared epilogue -- but the activation slab no longer
@@ -1809,12 +2022,13 @@ static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
 
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return ITTS_OK;
-    const int KB = prec == PREC_BF16 ? 32 : 16;
+    const int KB = prec == PREC_F32 ? 16 : 32;
     if (a.K % KB || a.nsplit < 1 || (a.K / KB) < a.nsplit) {
         itts_set_error("gemm: K=%d must be a multiple of %d and >= nsplit=%d blocks", a.K, KB, a.nsplit);
         return ITTS_ERR_ARG;
     }
     if (a.nsplit > 1 && a.epi != EPI_PARTIAL) { itts_set_error("gemm: split-K needs EPI_PARTIAL"); return ITTS_ERR_ARG; }
+    if (prec == PREC_F32X3) return launch_gemm_x3(a, st);           // f32 operands as three bf16 planes (weights packed for it): no other kernel reads that image
     return prec == PREC_BF16 ? launch_gemm_t<true>(a, prefill, st) : launch_gemm_t<false>(a, prefill, st);
 }
 

@@ -68,7 +68,11 @@ class CFM:
         self.rope_base = 10000.0
         self.norm_eps = 1e-5
         self.device = torch.device(device)
-        self.precision = {"bf16": 1, "bfloat16": 1, "fp32": 0, "float32": 0, "f32": 0}[precision]
+        # "fp32x3": f32 activations, GEMMs on the bf16 matrix pipe with every f32 operand carried exactly as three bf16 planes
+        # (gemm_x3_kernel); attention, norms and every element-wise stage run their f32 code
+        self.precision = {"bf16": 1, "bfloat16": 1, "fp32": 0, "float32": 0, "f32": 0, "fp32x3": 2, "f32x3": 2}[precision]
+        # the once-per-solve projections of the step-invariant inputs (K = 784 is not a multiple of the x3 kernel's 32-deep tile) run f32
+        self._host_prec = 0 if self.precision == 2 else self.precision
         cfg = _lib.S2MelConfig()
         cfg.hidden_dim, cfg.num_heads, cfg.depth, cfg.in_channels = self.hidden_dim, self.num_heads, self.depth, self.in_channels
         cfg.wavenet_hidden, cfg.wavenet_layers = self.wavenet_hidden, self.wavenet_layers
@@ -130,12 +134,12 @@ class CFM:
         self._k_rest_pad = (k_rest + 63) // 64 * 64
         w_rest = torch.zeros(self._k_rest_pad, H)
         w_rest[:k_rest] = wm[:, Cc:].t().cpu()
-        self._w_rest = pack_gemm_weight(w_rest, self.precision).to(self.device)
+        self._w_rest = pack_gemm_weight(w_rest, self._host_prec).to(self.device)
         cd = self.content_dim
         self._cd_pad = (cd + 63) // 64 * 64
         w_cp = torch.zeros(self._cd_pad, H)
         w_cp[:cd] = self._p["cond_projection.weight"].t().cpu()
-        self._w_cp = pack_gemm_weight(w_cp, self.precision).to(self.device)
+        self._w_cp = pack_gemm_weight(w_cp, self._host_prec).to(self.device)
         self._loaded = True
         return ignored
 
@@ -211,17 +215,17 @@ class CFM:
         n = mu_rows.shape[0]
         a = torch.zeros(n, self._cd_pad, device=self.device)
         a[:, : self.content_dim] = mu_rows
-        cond = engine_gemm(self._act(a), self._w_cp, p["cond_projection.bias"], H, self.precision, prefill_tiles=True)
+        cond = engine_gemm(self._act(a), self._w_cp, p["cond_projection.bias"], H, self._host_prec, prefill_tiles=True)
         rest = torch.zeros(n, self._k_rest_pad, device=self.device)
         Cc = self.in_channels
         rest[:, :Cc] = prompt_x_rows
         rest[:, Cc:Cc + H] = cond
         rest[:, Cc + H:Cc + H + self.style_dim] = style_rows
-        cin = engine_gemm(self._act(rest), self._w_rest, p["cond_x_merge_linear.bias"], H, self.precision, prefill_tiles=True)
+        cin = engine_gemm(self._act(rest), self._w_rest, p["cond_x_merge_linear.bias"], H, self._host_prec, prefill_tiles=True)
         if n_null_rows:
             null = torch.zeros(1, self._k_rest_pad, device=self.device)
             null[:, Cc:Cc + H] = p["cond_projection.bias"]
-            nrow = engine_gemm(self._act(null), self._w_rest, p["cond_x_merge_linear.bias"], H, self.precision, prefill_tiles=True)
+            nrow = engine_gemm(self._act(null), self._w_rest, p["cond_x_merge_linear.bias"], H, self._host_prec, prefill_tiles=True)
             cin = torch.cat([cin, nrow.expand(n_null_rows, -1)], 0)
         return cin.contiguous()
 

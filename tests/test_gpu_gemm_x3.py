@@ -1,0 +1,64 @@
+"""GPU: the f32x3 GEMM (`gemm_x3_kernel`: every f32 operand carried exactly as three bf16 planes, the plane products summed in the f32
+accumulator of the bf16 MFMA) -- is it f32-accurate?  Measured against an f64 GEMM, beside the native f32-MFMA kernel on the same
+operands; then the s2mel solve in that mode against the reference-minted goldens at the f32 mode's tolerance."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _errors(M, N, K, seed, scale=1.0):
+    from indextts_amd import gpt
+    g = torch.Generator().manual_seed(seed)
+    # wide dynamic range per row / column: exercises all three planes of both operands
+    a = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g)) * scale
+    w = torch.randn(K, N, generator=g) * torch.exp(0.5 * torch.randn(1, N, generator=g)) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    ref = (a.double() @ w.double() + b.double())
+    out = {}
+    for name, prec in (("f32", 0), ("f32x3", 2)):
+        wp = gpt.pack_gemm_weight(w, prec).to(DEV)
+        y = gpt.gemm(a.to(DEV), wp, b.to(DEV), N, prec, prefill_tiles=True).cpu().double()
+        out[name] = float((y - ref).abs().max() / ref.abs().max()), float(((y - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 512), (129, 3072, 512), (257, 512, 1536), (200, 80, 512), (64, 1024, 2560)])
+def test_x3_gemm_is_at_least_as_accurate_as_native_f32(M, N, K):
+    e = _errors(M, N, K, seed=M + N + K)
+    print(f"GEMM {M} x {N} x {K} vs f64: native f32 MFMA max-rel {e['f32'][0]:.3e} rms-rel {e['f32'][1]:.3e}; "
+          f"f32x3 (8 products) max-rel {e['f32x3'][0]:.3e} rms-rel {e['f32x3'][1]:.3e}")
+    assert e["f32x3"][1] <= 1.5 * e["f32"][1] + 1e-9 and e["f32x3"][0] <= 2.0 * e["f32"][0] + 1e-9
+    assert e["f32x3"][1] <= 3e-7
+
+
+def test_x3_six_products_error_reported():
+    """ITTS_X3_PRODUCTS=6 drops the two 2^-24-relative cross terms (ml, lm): reported beside the 8-product default."""
+    code = ("import sys; sys.path.insert(0, %r); from tests import test_gpu_gemm_x3 as T; "
+            "e = T._errors(300, 512, 512, 9); print('X3SIX', e['f32'][1], e['f32x3'][1])") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ITTS_X3_PRODUCTS="6"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    f32, six = [float(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("X3SIX")][-1].split()[1:]]
+    print(f"6-product variant: rms-rel error {six:.3e} vs native f32 {f32:.3e}")
+    assert six <= 1e-6
+
+
+def test_s2mel_solve_in_x3_mode_vs_reference(golden_dir):
+    """The 4-step CFG Euler solve with every DiT / WaveNet GEMM on the f32x3 kernel (attention, norms, gates: the f32 code) against
+    the outputs of the reference's own CFM class, at the f32 mode's tolerance."""
+    from tests.test_gpu_s2mel import engine, load, utt
+    z, cfg, sd = load(golden_dir)
+    m = engine(cfg, sd, "fp32x3")
+    n_steps, rate = int(z["n_steps"]), float(z["cfg_rate"])
+    for u in range(2):
+        x, prompt, mu, style, x_lens = utt(z, u)
+        y = m.solve_euler(x.clone(), x_lens, prompt, mu, style, None, torch.linspace(0, 1, n_steps + 1), rate).cpu()
+        err = float((y - torch.from_numpy(z[f"euler_out{u}"])).abs().max())
+        print(f"solve_euler f32x3 utt {u}: max|d| vs reference = {err:.3e}")
+        assert err <= 1e-4
