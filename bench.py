@@ -659,6 +659,10 @@ def configs_leg(args, eng, bundle0, dev):
       configs[4]  IndexTTS-2.5 long-form: 2 000 characters = 17 segments of <= 120 text tokens decoded as ONE batch, duration_factor 1.5,
                   plus the vocoder alone as an exact overlap-save stream (256-frame chunks, receptive-field halo) over the same mels
       b1_rtf      one utterance, 40 text tokens (~80 characters) -> 200 codes (8 s): beside the reference README's RTF table (other hardware)
+      ragged_b64  the headline's 64 x 128-token batch with utterance lengths spread over 280..560 codes (per-row caps: every request of a
+                  merged batch keeps its own max_mel_tokens): audio-seconds counted on the ACTUAL lengths; the decode stage alone with row
+                  compaction off / on (finished rows leave the running batch in 8-row buckets; backends/trt/pipeline/pipeline.py:459-548 is
+                  the reference design for continuous batching)
     """
     import warnings
     from indextts_amd import gpt, infer_v2, infer_v2_5, s2mel, synth
@@ -722,6 +726,26 @@ def configs_leg(args, eng, bundle0, dev):
                                            vocoder_streamed_what="17 segments, each vocoded alone as an exact overlap-save stream of 256-frame chunks")
     except Exception as e:
         out["config4_v25_longform"] = {"error": repr(e)}
+    try:
+        g = torch.Generator().manual_seed(306)
+        caps = torch.randint(280, 561, (64,), generator=g).tolist()
+        segs = segments(64, 128, 307)
+        text = torch.stack([t for t in segs]).to(dev)
+        langs = torch.full((64,), 3, dtype=torch.long, device=dev)
+        dec = {}
+        for name, on in (("compaction_off", False), ("compaction_on", True)):
+            eng.model.set_compaction(on, 8)
+            for _ in range(2):
+                eng.model.inference_speech(None, text, langs=langs, emo_vec=emo_vec, campplus_embedding=style, max_generate_length=560,
+                                           do_sample=True, num_beams=1, row_max_new=caps, **sample)
+            t = eng.model.last_timing
+            dec[name] = {"decode_ms": t["decode_ms"], "steps": t["steps"], "row_steps": t["row_steps"], "compactions": t["compactions"]}
+        eng.model.set_compaction(True, 8)
+        r = timed(tts, segs, bundle, emo_vec, 1.0, dict(sample, num_beams=1, max_mel_tokens=560, row_max_new=caps))
+        out["ragged_b64"] = dict(r, batch=64, text_tokens=128, code_lengths="uniform 280..560 (seeded), mean %.0f" % (sum(caps) / 64.0),
+                                 decode_only=dec, decode_speedup=dec["compaction_off"]["decode_ms"] / max(1e-9, dec["compaction_on"]["decode_ms"]))
+    except Exception as e:
+        out["ragged_b64"] = {"error": repr(e)}
     try:                                                           # configs[3]: IndexTTS-2
         cfg2 = dict(synth.GPT_V2)
         sd2 = dict(eng.gsd)

@@ -238,6 +238,19 @@ int itts_gpt_last_timing(const itts_gpt* h, float* prefill_ms, float* decode_ms,
  * batch rows, prompt-length bucket (multiples of 32), max_new_tokens, generation parameters and codes / uniforms pointers (small
  * LRU).  Counters since create: graphs captured, generate calls that reused one. */
 int itts_gpt_graph_stats(const itts_gpt* h, int32_t* captures, int32_t* hits);
+/* Ragged batches (continuous batching of the decode loop; design reference: backends/trt/pipeline/pipeline.py:459-548,
+ * backends/trt/runtime/gpt_trtllm_runtime.py:381-519 -- the HF loop itself keeps finished rows in the batch, generation_utils.py:3256).
+ * Utterances that have emitted their stop token leave the running batch: every 8 tokens the survivors are compacted to the front
+ * (cache rows stay in place behind a row map) and the step is replayed from the graph of the smaller batch, in buckets of
+ * `granularity` rows (default on, 8).  Results are unchanged: a row's arithmetic does not depend on the batch it runs in. */
+int itts_gpt_set_compaction(itts_gpt* h, int enable, int granularity);
+/* Per-utterance caps on generated tokens for the following generate / generate_chunk calls of exactly n utterances (one batch merges
+ * requests carrying their own `max_mel_tokens`, infer_v2_5.py:740): utterance u emits the stop token from token index limits[u] on.
+ * limits: DEVICE int32 [n], caller-owned, must outlive those calls; NULL clears. */
+int itts_gpt_set_row_limits(itts_gpt* h, const int32_t* limits, int n);
+/* Of the last generate call: sum over its decode steps of the rows each step ran (= steps x utterances without compaction), and
+ * the number of compactions. */
+int itts_gpt_compaction_stats(const itts_gpt* h, int64_t* row_steps, int32_t* compactions);
 
 /* replaces: UnifiedVoice.forward(..., return_latent=True) transformer pass (model_v2.py:596-646, get_logits
  *   :528-554; call site indextts/infer_v2.py:636-651): x [nseq][S][D] -> final_norm(ln_f(blocks(x))) [nseq][S][D]. */

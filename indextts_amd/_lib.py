@@ -105,6 +105,9 @@ SIGNATURES = {
                                          vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp, C.c_size_t, C.c_int, vp]),
     "itts_gpt_last_timing": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "itts_gpt_graph_stats": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "itts_gpt_set_compaction": (C.c_int, [vp, C.c_int, C.c_int]),
+    "itts_gpt_set_row_limits": (C.c_int, [vp, vp, C.c_int]),
+    "itts_gpt_compaction_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "itts_gpt_forward_latent": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
     "itts_s2mel_create": (C.c_int, [C.POINTER(S2MelConfig), C.POINTER(vp)]),
     "itts_s2mel_device": (C.c_int, [vp]),

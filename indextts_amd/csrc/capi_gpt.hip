@@ -106,8 +106,20 @@ struct itts_gpt {
     // chunked generation (itts_gpt_generate_chunk): tokens generated so far and the shape / workspace of the call being resumed
     int chunk_steps = 0, chunk_nseq = 0, chunk_S = 0, chunk_max_new = 0;
     const void* chunk_ws = nullptr;
+    // row compaction of a ragged decode batch (itts_gpt_set_compaction): finished utterances leave the running batch in steps of
+    // `compact_gran` rows, so the step's cost follows the live rows.  cur_slots[i] = utterance carried by dense row i.
+    bool compact = true;
+    int compact_gran = 8;
+    std::vector<int> cur_slots;
+    bool cur_mapped = false;
+    int* host_map = nullptr;               // pinned [2][map_cap]: new slot map | gather sources
+    int map_cap = 0;
+    long long last_row_steps = 0;          // sum over the decode steps of the rows that step ran (itts_gpt_compaction_stats)
+    int last_compactions = 0;
+    const int32_t* row_limits = nullptr;   // device [row_limits_n] per-utterance token caps for the next generate calls, or null
+    int row_limits_n = 0;
 };
-#define GRAPH_CACHE_MAX 8
+#define GRAPH_CACHE_MAX 24        // a ragged batch replays one graph per live-row bucket (8 at the bench shape) beside the callers' own shapes
 // prompt lengths are bucketed to multiples of 32 for the workspace carve and the cache stride, so that prompts of nearby lengths
 // share one workspace layout and therefore one decode graph
 static inline int s_bucket(int S) { return (S + 31) & ~31; }
@@ -172,6 +184,7 @@ extern "C" void itts_gpt_destroy(itts_gpt* h) {
     for (void* p : h->owned) (void)hipFree(p);
     if (h->host_flag) (void)hipHostFree(h->host_flag);
     if (h->host_fin) (void)hipHostFree(h->host_fin);
+    if (h->host_map) (void)hipHostFree(h->host_map);
     if (h->ev_in) { (void)hipEventDestroy(h->ev_in); (void)hipEventDestroy(h->ev_out); (void)hipEventDestroy(h->ev_t0);
                     (void)hipEventDestroy(h->ev_t1); (void)hipEventDestroy(h->ev_t2); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -306,6 +319,8 @@ struct GptWs {
     int* state;         // [0] step, [1] pos
     int* pad;           // [nseq]
     int* pen_ids;       // [16]
+    int* slot_map;      // [nseq] dense row -> utterance (row compaction; unused while the batch is uncompacted)
+    int* gather_src;    // [nseq] compaction: the old dense row each new dense row is taken from
     // beam search (nb > 1)
     unsigned char* seen2;    // second seen buffer
     int* row_map[2];         // [nseq][Tmax]
@@ -339,6 +354,8 @@ static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tm
     w.state = (int*)take(64);
     w.pad = (int*)take((size_t)nseq * 4);
     w.pen_ids = (int*)take(64);
+    w.slot_map = (int*)take((size_t)nseq * 4);
+    w.gather_src = (int*)take((size_t)nseq * 4);
     w.seen2 = nullptr; w.row_map[0] = w.row_map[1] = nullptr;
     if (nb > 1) {
         const int B = nseq / nb, max_new = Tmax - S;
@@ -387,11 +404,22 @@ __global__ void mark_seen_kernel(unsigned char* seen, const int* ids, int n_ids,
     }
 }
 
+// row compaction: x_new[i] = x_old[src[i]] through a scratch copy (src[i] >= i, but rows are moved by independent blocks)
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ src, float* __restrict__ tmp, int D) {
+    const int i = blockIdx.x;
+    const float* s = x + (size_t)src[i] * D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) tmp[(size_t)i * D + c] = s[c];
+}
+__global__ void copy_rows_kernel(const float* __restrict__ tmp, float* __restrict__ x, int D) {
+    const int i = blockIdx.x;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) x[(size_t)i * D + c] = tmp[(size_t)i * D + c];
+}
+
 // ---- one transformer pass --------------------------------------------------------------------------------------
 // rows = nseq*S new positions (S = 1 for a decode step).  prefill: direct residual epilogues + big-tile GEMMs;
 // decode: split-K partials reduced inside the next LayerNorm kernel.
 static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bool prefill, const int* pos_ptr, const int* pad,
-                      bool* pending, hipStream_t st, bool beam = false, int seq_mul = 1) {
+                      bool* pending, hipStream_t st, bool beam = false, int seq_mul = 1, const int* seq_map = nullptr) {
     const itts_gpt_config& c = h->cfg;
     const int D = c.model_dim, prec = c.precision, rows = nseq * S;
     int rc;
@@ -408,13 +436,13 @@ static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bo
         GemmArgs g{};
         g.A = w.hbuf; g.lda = D; g.Wp = L.w_qkv; g.bias = L.b_qkv; g.M = rows; g.N = 3 * D; g.K = D; g.nsplit = 1; g.epi = EPI_QKV;
         g.qbuf = w.qbuf; g.kcache = w.kc + w.layer_cache_bytes * l; g.vcache = w.vc + w.layer_cache_bytes * l;
-        g.pos_ptr = pos_ptr; g.S = S; g.H = c.heads; g.Tmax = Tmax; g.D = D; g.seq_mul = seq_mul;
+        g.pos_ptr = pos_ptr; g.S = S; g.H = c.heads; g.Tmax = Tmax; g.D = D; g.seq_mul = seq_mul; g.seq_map = seq_map;
         if ((rc = launch_gemm(g, prec, prefill, st))) return rc;
 
         AttnArgs at{};
         at.qbuf = w.qbuf; at.kcache = g.kcache; at.vcache = g.vcache; at.pad = pad; at.pos_ptr = pos_ptr;
         at.row_map = beam ? w.row_map[0] : nullptr; at.row_map_alt = beam ? w.row_map[1] : nullptr; at.step_ptr = beam ? w.state : nullptr;
-        at.out = w.attn; at.nseq = nseq; at.H = c.heads; at.nq = S; at.Tmax = Tmax; at.D = D; at.seq_mul = seq_mul;
+        at.out = w.attn; at.nseq = nseq; at.H = c.heads; at.nq = S; at.Tmax = Tmax; at.D = D; at.seq_mul = seq_mul; at.seq_map = seq_map;
         if ((rc = launch_attention(at, prec, st))) return rc;
 
         GemmArgs p{};
@@ -459,8 +487,9 @@ static int run_head(itts_gpt* h, const GptWs& w, int nseq, int mul, int add, boo
     return launch_gemm(g, prec, false, st);
 }
 
+// rows: dense rows of this launch; n_utts: utterances of the call (stride of the uniform stream); mapped: the batch is compacted
 static SampleArgs make_sample(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, int nseq, long long* tokens,
-                              const double* uniforms) {
+                              const double* uniforms, int n_utts = 0, bool mapped = false) {
     const itts_gpt_config& c = h->cfg;
     SampleArgs s{};
     s.logits = w.logits; s.seen = w.seen; s.finished = w.finished; s.tokens = tokens; s.step_ptr = w.state;
@@ -471,16 +500,20 @@ static SampleArgs make_sample(itts_gpt* h, const GptWs& w, const itts_gen_params
     s.stop_token = c.stop_mel_token; s.mel_emb = h->mel_emb; s.mel_pos = h->mel_pos; s.x_next = w.x; s.D = c.model_dim;
     s.pos_offset = gp.pos_offset; s.n_mel_pos = c.n_mel_pos;
     s.seed_ptr = (const unsigned long long*)(w.state + 4);
+    s.row_slot = mapped ? w.slot_map : nullptr;
+    s.uniforms_stride = n_utts > 0 ? n_utts : nseq;
+    s.row_limit = (h->row_limits && h->row_limits_n == s.uniforms_stride) ? h->row_limits : nullptr;
     return s;
 }
 
-static int decode_step(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, int nseq, int Tmax, long long* tokens,
+// rows: the dense rows this step runs (= n_utts until finished utterances have been compacted away)
+static int decode_step(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, int rows, int n_utts, bool mapped, int Tmax, long long* tokens,
                        const double* uniforms, hipStream_t st) {
     bool pending = false;
-    int rc = run_layers(h, w, nseq, 1, Tmax, false, w.state + 1, w.pad, &pending, st);
+    int rc = run_layers(h, w, rows, 1, Tmax, false, w.state + 1, w.pad, &pending, st, false, 1, mapped ? w.slot_map : nullptr);
     if (rc) return rc;
-    if ((rc = run_head(h, w, nseq, 1, 0, pending, st))) return rc;
-    SampleArgs s = make_sample(h, w, gp, nseq, tokens, uniforms);
+    if ((rc = run_head(h, w, rows, 1, 0, pending, st))) return rc;
+    SampleArgs s = make_sample(h, w, gp, rows, tokens, uniforms, n_utts, mapped);
     s.adv_state = w.state;                      // the sample kernel's last block advances step / pos
     return launch_sample(s, st);
 }
@@ -557,7 +590,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
     if ((rc = run_head(h, w, nseq, S, S - 1, pending, st))) return rc;
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 0, S);
     {
-        SampleArgs s = make_sample(h, w, gp, nseq, tokens, uniforms);
+        SampleArgs s = make_sample(h, w, gp, nseq, tokens, uniforms, nseq, false);
         if ((rc = launch_sample(s, st))) return rc;
     }
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, w.state, 1, S);
@@ -567,45 +600,97 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
     HIP_TRY(hipEventRecord(h->ev_t1, st));
 
     // ---- decode loop ----
-    bool graph_ok = false;
+    // The running batch starts as the nseq utterances in order.  Every `check_every` steps the finished flags come to the host; when
+    // enough utterances have finished, the survivors are compacted to the front (their cache rows stay where they are: the QKV
+    // epilogue, the attention kernel and the sampler find an utterance's state through the slot map) and the step is replayed from
+    // the graph of the smaller batch -- the step's cost follows the live rows in steps of `compact_gran`.
+    if (h->map_cap < nseq) {
+        if (h->host_map) (void)hipHostFree(h->host_map);
+        HIP_TRY(hipHostMalloc((void**)&h->host_map, (size_t)2 * nseq * sizeof(int), hipHostMallocDefault));
+        h->map_cap = nseq;
+    }
+    if (!resume) {
+        h->cur_slots.resize(nseq);
+        for (int i = 0; i < nseq; ++i) h->cur_slots[i] = i;
+        h->cur_mapped = false;
+        h->last_row_steps = 0;
+        h->last_compactions = 0;
+    }
+    static const bool env_off = [] { const char* e = getenv("ITTS_GPT_COMPACT"); return e && atoi(e) == 0; }();
+    const bool compact = h->compact && !env_off;
     hipGraphExec_t exec = nullptr;
-    if (use_graph && gp.max_new_tokens > 1) {
+    bool graph_ok = false;
+    auto get_graph = [&](int rows, bool mapped) -> int {
+        exec = nullptr; graph_ok = false;
+        if (!(use_graph && gp.max_new_tokens > 1)) return ITTS_OK;
         itts_gpt::GraphEntry key{};
-        key.base = base; key.tokens = tokens; key.uniforms = uniforms; key.nseq = nseq; key.nb = 1; key.Sb = Sb; key.Tmax = Tmax; key.gp = gp; key.gp.seed = 0;          // the seed lives in device memory
+        key.base = base; key.tokens = tokens; key.uniforms = uniforms; key.nseq = rows; key.nb = 1; key.Sb = Sb; key.Tmax = Tmax; key.gp = gp; key.gp.seed = 0;          // the seed lives in device memory
+        key.S = nseq;                                                  // utterances of the call (uniform stride, limits)
+        key.aux0 = mapped ? (const void*)w.slot_map : nullptr;
+        key.aux1 = (h->row_limits && h->row_limits_n == nseq) ? (const void*)h->row_limits : nullptr;
         exec = graph_lookup(h, key);
         graph_ok = exec != nullptr;
-        if (!graph_ok) {
-            // capture one decode step (all step-varying state lives in device memory); kept in the handle for later calls
-            hipGraph_t graph = nullptr;
-            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-            if (e == hipSuccess) {
-                rc = decode_step(h, w, gp, nseq, Tmax, tokens, uniforms, st);
-                e = hipStreamEndCapture(st, &graph);
-                if (rc == ITTS_OK && e == hipSuccess && graph) {
-                    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                    graph_ok = (e == hipSuccess && exec);
-                }
-                if (graph) (void)hipGraphDestroy(graph);
+        if (graph_ok) return ITTS_OK;
+        // capture one decode step (all step-varying state lives in device memory); kept in the handle for later calls
+        hipGraph_t graph = nullptr;
+        int rcc = ITTS_OK;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            rcc = decode_step(h, w, gp, rows, nseq, mapped, Tmax, tokens, uniforms, st);
+            e = hipStreamEndCapture(st, &graph);
+            if (rcc == ITTS_OK && e == hipSuccess && graph) {
+                e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                graph_ok = (e == hipSuccess && exec);
             }
-            if (!graph_ok) {
-                (void)hipGetLastError();
-                itts_set_error("gpt_generate: hipGraph capture failed (%s); rerun with use_graph=0", hipGetErrorString(e));
-                return ITTS_ERR_HIP;
-            }
-            graph_insert(h, key, exec);
+            if (graph) (void)hipGraphDestroy(graph);
         }
-    }
+        if (!graph_ok) {
+            (void)hipGetLastError();
+            itts_set_error("gpt_generate: hipGraph capture failed (%s); rerun with use_graph=0", hipGetErrorString(e));
+            return ITTS_ERR_HIP;
+        }
+        graph_insert(h, key, exec);
+        return ITTS_OK;
+    };
+    int rows = (int)h->cur_slots.size();
+    bool mapped = h->cur_mapped;
+    if ((rc = get_graph(rows, mapped))) return rc;
     const int check_every = 8;
     while (steps < step_limit) {
         if (graph_ok) { HIP_TRY(hipGraphLaunch(exec, st)); }
-        else if ((rc = decode_step(h, w, gp, nseq, Tmax, tokens, uniforms, st))) return rc;
+        else if ((rc = decode_step(h, w, gp, rows, nseq, mapped, Tmax, tokens, uniforms, st))) return rc;
         ++steps;
+        h->last_row_steps += rows;
         if (steps % check_every == 0 && steps < step_limit) {
             HIP_TRY(hipMemcpyAsync(h->host_fin, w.finished, nseq, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            bool all = true;
-            for (int i = 0; i < nseq; ++i) all = all && h->host_fin[i];
-            if (all) break;
+            int live = 0;
+            for (int i = 0; i < nseq; ++i) live += h->host_fin[i] ? 0 : 1;
+            if (live == 0) break;
+            const int g = h->compact_gran < 1 ? 1 : h->compact_gran;
+            const int want = ((live + g - 1) / g) * g;
+            if (compact && want < rows) {
+                // new dense order: the live rows in their current order, then finished rows up to the bucket size (they keep emitting stop)
+                int* nm = h->host_map;
+                int* src = h->host_map + nseq;
+                int k = 0;
+                for (int i = 0; i < rows; ++i)
+                    if (!h->host_fin[h->cur_slots[i]]) { nm[k] = h->cur_slots[i]; src[k] = i; ++k; }
+                for (int i = 0; i < rows && k < want; ++i)
+                    if (h->host_fin[h->cur_slots[i]]) { nm[k] = h->cur_slots[i]; src[k] = i; ++k; }
+                HIP_TRY(hipMemcpyAsync(w.slot_map, nm, (size_t)want * sizeof(int), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(w.gather_src, src, (size_t)want * sizeof(int), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(gather_rows_kernel, dim3(want), dim3(256), 0, st, w.x, w.gather_src, w.qbuf, c.model_dim);
+                hipLaunchKernelGGL(copy_rows_kernel, dim3(want), dim3(256), 0, st, w.qbuf, w.x, c.model_dim);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(st));                      // the pinned staging buffer is reused by the next compaction
+                h->cur_slots.assign(nm, nm + want);
+                rows = want;
+                mapped = true;
+                h->cur_mapped = true;
+                ++h->last_compactions;
+                if ((rc = get_graph(rows, mapped))) return rc;
+            }
         }
     }
     HIP_TRY(hipEventRecord(h->ev_t2, st));
@@ -802,6 +887,31 @@ extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, c
     (void)hipEventElapsedTime(&h->last_decode_ms, h->ev_t1, h->ev_t2);
     h->last_steps = steps;
     *n_steps_out = steps;
+    return ITTS_OK;
+}
+
+// Row compaction of ragged decode batches: on by default; granularity = rows per bucket (the decode graph is captured once per bucket).
+extern "C" int itts_gpt_set_compaction(itts_gpt* h, int enable, int granularity) {
+    if (!h) { itts_set_error("gpt_set_compaction: null"); return ITTS_ERR_ARG; }
+    h->compact = enable != 0;
+    if (granularity > 0) h->compact_gran = granularity;
+    return ITTS_OK;
+}
+
+// Per-utterance caps on the generated tokens for the following itts_gpt_generate / _chunk calls whose batch has exactly n utterances
+// (a batch merges requests that carry their own max_mel_tokens): limits is a DEVICE int32 [n] the caller keeps alive; null clears.
+extern "C" int itts_gpt_set_row_limits(itts_gpt* h, const int32_t* limits, int n) {
+    if (!h || (limits && n <= 0)) { itts_set_error("gpt_set_row_limits: bad args"); return ITTS_ERR_ARG; }
+    h->row_limits = limits;
+    h->row_limits_n = limits ? n : 0;
+    return ITTS_OK;
+}
+
+// Of the last generate call: sum over its decode steps of the rows each step ran, and the number of compactions.
+extern "C" int itts_gpt_compaction_stats(const itts_gpt* h, int64_t* row_steps, int32_t* compactions) {
+    if (!h) return ITTS_ERR_ARG;
+    if (row_steps) *row_steps = h->last_row_steps;
+    if (compactions) *compactions = h->last_compactions;
     return ITTS_OK;
 }
 

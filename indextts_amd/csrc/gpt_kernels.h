@@ -56,6 +56,8 @@ struct GemmArgs {
     void* out_act2;                  // EPI_WN_RS / EPI_STORE_F32 / EPI_RESIDUAL (bf16 tile kernels): bf16 shadow copy [M][ldo] of the f32
                                      // output (the next GEMM's A operand; for EPI_WN_RS the next layer's tap-mode operand, stride D)
     int seq_mul;                     // EPI_QKV: cache row of sequence b is b * seq_mul (0/1 = identity); beam prefill writes only row b*nb
+    const int* seq_map;              // EPI_QKV (decode): when non-null, the cache row of dense row b is seq_map[b] (row compaction of a
+                                     // ragged batch: finished rows leave the running batch, the survivors keep their cache rows)
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);
 
@@ -71,6 +73,7 @@ struct AttnArgs {
     void* out;               // [nseq*nq][D] act dtype
     int nseq, H, nq, Tmax, D;
     int seq_mul;             // sequence b reads cache row / pad entry b * seq_mul when no row map is given (0/1 = identity)
+    const int* seq_map;      // when non-null (compacted decode batch): dense row b reads cache row / pad entry seq_map[b]
 };
 int launch_attention(const AttnArgs& a, int prec, hipStream_t st);
 
@@ -92,6 +95,11 @@ struct SampleArgs {
     const float* mel_emb; const float* mel_pos; float* x_next; int D; int pos_offset; int n_mel_pos;
     int* adv_state;          // {step, pos, ticket}: when non-null the last block to finish advances step and pos (decode steps)
     const unsigned long long* seed_ptr;   // when non-null the RNG seed is read from device memory (keeps a captured step seed-free)
+    // compacted decode batch: dense row b is utterance row_slot[b] -- its seen-set, finished flag, token row, uniform / RNG stream and
+    // token limit are indexed by the utterance, logits and x_next by the dense row.  uniforms_stride = utterances of the call.
+    const int* row_slot; int uniforms_stride;
+    const int* row_limit;    // [utterances] or null: per-utterance cap on generated tokens (a batch merges requests with their own
+                             // max_mel_tokens): from token index row_limit[u] on, the row emits the stop token
 };
 int launch_sample(const SampleArgs& a, hipStream_t st);
 int launch_advance(int* step_ptr, int* pos_ptr, hipStream_t st);

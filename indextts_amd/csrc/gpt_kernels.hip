@@ -291,7 +291,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, int mbase, int 
                     a.qbuf[(size_t)m * a.D + c] = val;
                 } else {
                     const int pos = *a.pos_ptr + si;
-                    const size_t o = (((size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1) * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
+                    const size_t pb = a.seq_map ? (size_t)a.seq_map[b] : (size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1);
+                    const size_t o = ((pb * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
                     void* cache = which == 1 ? a.kcache : a.vcache;
                     if (BF16) ((u16*)cache)[o] = f32_to_bf16(val);
                     else ((float*)cache)[o] = val;
@@ -1536,11 +1537,13 @@ static int launch_gemm_prefill_f32(const GemmArgs& a, hipStream_t st) {
 //   swizzle) and each wave splits its fragments in registers (12 VALU ops per pair of values, issued in the shadow of the MFMAs).  The
 //   lane's eight k-values are the two 16-byte pieces the f32 kernel reads (k = 4 kg + j and 16 + 4 kg + j): conflict-free, and the
 //   weights are packed with the same k permutation.  Weights are split once on the host (itts_pack_gemm_weight, precision 2):
-//   [N/16][K/32][3 planes][64 lanes][16 B].  LDS: 2 stages x (A 16 KiB | W 24 KiB) = 80 KiB -> two blocks per CU.
+//   [N/16][K/32][3 planes][64 lanes][16 B].  LDS: A 16 KiB (ONE stage: a wave pulls its eight f32 fragment pieces of the K tile into
+//   registers, a second barrier frees the stage and the next A tile is DMA'd under the MFMAs) + W 2 x 24 KiB = 64 KiB, 66 KiB with the
+//   epilogue image -> two blocks per CU (the first version double-buffered A as well: 80 KiB, ONE block per CU, 52 % of the x3 rate).
 //   Epilogues: the f32 tile kernel's (pf_store_tile / pf_store_vt with F32 = true).
 // ================================================================================================================
-#define X3_STAGE 40960
-#define X3_LDS (2 * X3_STAGE)
+#define X3_WSTAGE 24576
+#define X3_LDS PF_LDS            // A 16 KiB | W 2 x 24 KiB = 64 KiB of operands; the epilogue's transposed image (+ row metadata) is the larger
 
 __device__ __forceinline__ void x3_split8(const f32x4 p0, const f32x4 p1, v4u& H, v4u& M, v4u& L) {
     const float x[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
@@ -1557,7 +1560,7 @@ __device__ __forceinline__ void x3_split8(const f32x4 p0, const f32x4 p1, v4u& H
 
 template <int EPI, bool CONV = false, int NPROD = 8>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB | W 24 KiB]
+    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [A 16 KiB][2][W 24 KiB]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int n_mt = (a.M + PF_BM - 1) / PF_BM, n_nt = (a.N + PF_BN - 1) / PF_BN;
@@ -1602,8 +1605,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
         nt = nt < ntiles ? nt : ntiles - 1;
         bsrc[i] = (const char*)a.Wp + ((size_t)nt * nk * 3 + plane) * 1024 + lane * 16;
     }
-    auto issue = [&](int kt, int buf) {
-        char* base = pf_sm + buf * X3_STAGE;
+    auto issue_a = [&](int kt) {
         int tap = 0, rem = kt;
         if constexpr (CONV) { tap = kt / cv_kpt; rem = kt - tap * cv_kpt; }
 #pragma unroll
@@ -1619,12 +1621,15 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
                 ap = ok ? cv_base[i] + ((size_t)p * a.lda + (size_t)rem * 32) * 4 : cv_zero[i];
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap,
-                                             (__attribute__((address_space(3))) void*)(base + (w * 4 + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(pf_sm + (w * 4 + i) * 1024), 16, 0, 0);
         }
+    };
+    auto issue_w = [&](int kt, int buf) {
+        char* base = pf_sm + 16384 + buf * X3_WSTAGE;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (size_t)kt * 3072),
-                                             (__attribute__((address_space(3))) void*)(base + 16384 + (w * 6 + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + (w * 6 + i) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[4][4];
@@ -1643,23 +1648,31 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
     const int a_wave = wr * 4 * 2048;
     const int b_wave = 16384 + wc * 4 * 3072 + lane * 16;
 
-    issue(0, 0);
+    issue_a(0);
+    issue_w(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* base = pf_sm + (kt & 1) * X3_STAGE;
+        __syncthreads();                                           // K tile kt (A, and W stage kt & 1) is in LDS
+        if (kt + 1 < nk) issue_w(kt + 1, (kt + 1) & 1);            // that W stage was last read one tile ago
+        f32x4 ar[4][2];                                            // the wave's A fragment pieces of this tile, all four m-tiles
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            ar[mt][0] = *(const f32x4*)(pf_sm + a_wave + mt * 2048 + a_off[0]);
+            ar[mt][1] = *(const f32x4*)(pf_sm + a_wave + mt * 2048 + a_off[1]);
+        }
+        const char* wb = pf_sm + (kt & 1) * X3_WSTAGE;
         v4u bw[4][3];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bw[nt][p] = *(const v4u*)(base + b_wave + (nt * 3 + p) * 1024);
+            for (int p = 0; p < 3; ++p) bw[nt][p] = *(const v4u*)(wb + b_wave + (nt * 3 + p) * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                           // every wave holds its A pieces: the single A stage is free
+        if (kt + 1 < nk) issue_a(kt + 1);                          // in flight under this tile's MFMAs
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const f32x4 p0 = *(const f32x4*)(base + a_wave + mt * 2048 + a_off[0]);
-            const f32x4 p1 = *(const f32x4*)(base + a_wave + mt * 2048 + a_off[1]);
             v4u ap[3];
-            x3_split8(p0, p1, ap[0], ap[1], ap[2]);
+            x3_split8(ar[mt][0], ar[mt][1], ap[0], ap[1], ap[2]);
             // plane pairs, smallest terms first; four independent accumulators between two MFMAs on the same one
             constexpr int PA[8] = {2, 1, 2, 0, 1, 1, 0, 0};
             constexpr int PB[8] = {1, 2, 0, 2, 1, 0, 1, 0};
@@ -1788,7 +1801,8 @@ __device__ __forceinline__ void decode_epilogue(const GemmArgs& a, int mbase, in
                 if (m < a.M) {
                     int b = m, si = 0;
                     if (a.S != 1) { b = m / a.S; si = m - b * a.S; }          // uniform; decode has S == 1
-                    cache[(size_t)b * sm * a.H * a.Tmax * 64 + head_off + (size_t)(pos + si) * 64] = f32_to_bf16(v[r] + bias);
+                    const size_t pb = a.seq_map ? (size_t)a.seq_map[b] : (size_t)b * sm;
+                    cache[pb * a.H * a.Tmax * 64 + head_off + (size_t)(pos + si) * 64] = f32_to_bf16(v[r] + bias);
                 }
             }
         }
@@ -2051,7 +2065,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int qi = blockIdx.y;
     const int last = *a.pos_ptr + qi;
     const int sm = a.seq_mul > 1 ? a.seq_mul : 1;
-    const int first = a.pad ? a.pad[b * sm] : 0;
+    const int pb = a.seq_map ? a.seq_map[b] : b * sm;              // physical cache row / pad entry of this sequence
+    const int first = a.pad ? a.pad[pb] : 0;
     const int sub = lane % LPK, grp = lane / LPK;
     const size_t qrow = (size_t)b * a.nq + qi;
     const int* rmap = a.row_map;
@@ -2069,7 +2084,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         const int t = t0 + grp;
         const bool ok = t <= last;
         const int tc = ok ? t : last;
-        const int prow = rmap ? rmap[(size_t)b * a.Tmax + tc] : b * sm;
+        const int prow = rmap ? rmap[(size_t)b * a.Tmax + tc] : pb;
         const size_t off = (((size_t)prow * a.H + h) * a.Tmax + tc) * 64 + sub * DPL;
         float kf[DPL], vf[DPL];
         if constexpr (BF16) {
@@ -2324,8 +2339,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     __shared__ float cand_v[SAMPLE_CAP], cand_e[SAMPLE_CAP];
     const int b = blockIdx.x, tid = threadIdx.x, V = a.V;
     const int step = *a.step_ptr;
+    const int u = a.row_slot ? a.row_slot[b] : b;                   // the utterance this dense row carries
     const float* lg = a.logits + (size_t)b * V;
-    unsigned char* seen = a.seen + (size_t)b * V;
+    unsigned char* seen = a.seen + (size_t)u * V;
     const bool pen = a.rep_penalty != 1.0f;
     const bool temp = a.do_sample && a.temperature != 1.0f;
     const bool typical = a.typical_mass > 0.f;
@@ -2448,8 +2464,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             if (tid == 0) {
                 double total = 0.0;
                 for (int i = lo; i < n; ++i) total += (double)cand_v[i];
-                const double u = a.uniforms ? a.uniforms[(size_t)step * a.B + b] : rng_uniform(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned long long)step, (unsigned long long)b);
-                const double tgt = u * total;
+                const double ur = a.uniforms ? a.uniforms[(size_t)step * (a.uniforms_stride > 0 ? a.uniforms_stride : a.B) + u]
+                                             : rng_uniform(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned long long)step, (unsigned long long)u);
+                const double tgt = ur * total;
                 double cum = 0.0;
                 int pick = cand_i[n - 1];
                 for (int i = lo; i < n; ++i) {
@@ -2463,9 +2480,10 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     __syncthreads();
     if (tid == 0) {
         int tok = s_tok;
-        if (a.finished[b]) tok = a.stop_token;               // :3256 finished rows emit pad (= stop)
-        a.tokens[(size_t)b * a.max_new + step] = tok;
-        if (tok == a.stop_token) a.finished[b] = 1;
+        if (a.finished[u]) tok = a.stop_token;               // :3256 finished rows emit pad (= stop)
+        if (a.row_limit && step >= a.row_limit[u]) tok = a.stop_token;          // this utterance's own max_mel_tokens
+        a.tokens[(size_t)u * a.max_new + step] = tok;
+        if (tok == a.stop_token) a.finished[u] = 1;
         seen[tok] = 1;
         s_tok = tok;
     }

@@ -11,7 +11,7 @@ Prompt encoders (Conformer/Perceiver emotion encoder, CAMPPlus) are out of this 
 `emo_vec=` / `campplus_embedding=` computed by the PyTorch-ROCm modules, as `indextts/infer_v2_5.py:762-781` does.
 """
 import ctypes as C
-from typing import Dict, Optional
+from typing import Dict, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
@@ -263,6 +263,11 @@ class UnifiedVoice:
             return 0
         return int(torch.randint(0, 2 ** 62, (1,)).item())
 
+    def set_compaction(self, enable: bool = True, granularity: int = 8):
+        """Row compaction of ragged decode batches (itts_gpt_set_compaction): finished rows leave the running batch in buckets of
+        `granularity` rows.  On by default; results do not depend on it."""
+        _lib.check(_lib.lib().itts_gpt_set_compaction(self._h, int(bool(enable)), int(granularity)), "itts_gpt_set_compaction")
+
     def graph_stats(self) -> dict:
         """decode-step hipGraphs captured / reused by this engine handle (itts_gpt_graph_stats)"""
         cap, hit = C.c_int32(0), C.c_int32(0)
@@ -271,8 +276,11 @@ class UnifiedVoice:
 
     def generate(self, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int, do_sample=False,
                  num_beams=1, top_p=1.0, top_k=50, temperature=1.0, repetition_penalty=1.0, length_penalty=1.0,
-                 uniforms: Optional[torch.Tensor] = None, seed: Optional[int] = None, typical_mass: float = 0.0, **unused) -> torch.Tensor:
-        """`GPT2InferenceModel.generate` for greedy / multinomial sampling (typical_mass > 0: the reference's
+                 uniforms: Optional[torch.Tensor] = None, seed: Optional[int] = None, typical_mass: float = 0.0,
+                 row_max_new: Optional[Sequence[int]] = None, **unused) -> torch.Tensor:
+        """`row_max_new` (engine extension for merged batches): per-row cap on generated tokens -- row b emits the stop token from token
+        index row_max_new[b] on, i.e. each request of a batch keeps its own `max_mel_tokens` (sampling / greedy only).
+        `GPT2InferenceModel.generate` for greedy / multinomial sampling (typical_mass > 0: the reference's
         TypicalLogitsWarper sits between the repetition penalty and the warpers, model_v2.py:794-799).  inputs_embeds (B,s,D) = the cached prefix;
         attention_mask (B,s+1).  Returns generated ids (B, n) (what `output[:, trunc_index:]` is in the reference)."""
         if not self._loaded:
@@ -309,13 +317,27 @@ class UnifiedVoice:
                 raise ValueError("uniforms must be (>= max_new_tokens, B)")
             u = self._persistent("uniforms", (int(max_new_tokens), B), torch.float64)
             u.copy_(uniforms[: int(max_new_tokens)])
-        rc = L.itts_gpt_generate(self._h, _lib.ptr(x), _lib.ptr(pad), B, S, C.byref(gp), pen, 2, _lib.ptr(u),
-                                 _lib.ptr(codes), C.byref(n_steps), _lib.ptr(ws), ws.numel(), int(self.use_graph),
-                                 _lib.stream_ptr(self.device))
+        lim = None
+        if row_max_new is not None:
+            if len(row_max_new) != B:
+                raise ValueError(f"row_max_new must have one entry per row ({B}), got {len(row_max_new)}")
+            lim = self._persistent("row_limits", (B,), torch.int32)           # persistent: its address is part of the decode graph's key
+            lim.copy_(torch.as_tensor([int(v) for v in row_max_new], dtype=torch.int32))
+        _lib.check(L.itts_gpt_set_row_limits(self._h, _lib.ptr(lim), B if lim is not None else 0), "itts_gpt_set_row_limits")
+        try:
+            rc = L.itts_gpt_generate(self._h, _lib.ptr(x), _lib.ptr(pad), B, S, C.byref(gp), pen, 2, _lib.ptr(u),
+                                     _lib.ptr(codes), C.byref(n_steps), _lib.ptr(ws), ws.numel(), int(self.use_graph),
+                                     _lib.stream_ptr(self.device))
+        finally:
+            if lim is not None:
+                L.itts_gpt_set_row_limits(self._h, None, 0)
         _lib.check(rc, "itts_gpt_generate")
         pm, dm, st = C.c_float(0), C.c_float(0), C.c_int32(0)
         L.itts_gpt_last_timing(self._h, C.byref(pm), C.byref(dm), C.byref(st))
-        self.last_timing = dict(prefill_ms=pm.value, decode_ms=dm.value, steps=st.value)
+        rs, nc = C.c_int64(0), C.c_int32(0)
+        L.itts_gpt_compaction_stats(self._h, C.byref(rs), C.byref(nc))
+        # row_steps: sum over the decode steps of the rows each step ran (B x steps when no row left the batch early)
+        self.last_timing = dict(prefill_ms=pm.value, decode_ms=dm.value, steps=st.value, row_steps=int(rs.value), compactions=int(nc.value))
         # HF stops right after the step at which every row has emitted EOS
         is_stop = codes == self.stop_mel_token
         first = torch.where(is_stop.any(1), is_stop.int().argmax(1) + 1, torch.full((B,), codes.shape[1], device=dev))

@@ -34,8 +34,9 @@ def test_x3_gemm_is_at_least_as_accurate_as_native_f32(M, N, K):
     e = _errors(M, N, K, seed=M + N + K)
     print(f"GEMM {M} x {N} x {K} vs f64: native f32 MFMA max-rel {e['f32'][0]:.3e} rms-rel {e['f32'][1]:.3e}; "
           f"f32x3 (8 products) max-rel {e['f32x3'][0]:.3e} rms-rel {e['f32x3'][1]:.3e}")
-    assert e["f32x3"][1] <= 1.5 * e["f32"][1] + 1e-9 and e["f32x3"][0] <= 2.0 * e["f32"][0] + 1e-9
-    assert e["f32x3"][1] <= 3e-7
+    # not worse than the native f32 MFMA (whose own error, 1e-7 .. 4e-7 of the output scale at these K, is f32 accumulation rounding)
+    assert e["f32x3"][1] <= 1.25 * e["f32"][1] + 1e-9 and e["f32x3"][0] <= 2.0 * e["f32"][0] + 1e-9
+    assert e["f32x3"][1] <= 1e-6
 
 
 def test_x3_six_products_error_reported():
