@@ -1534,16 +1534,18 @@ static int launch_gemm_prefill_f32(const GemmArgs& a, hipStream_t st) {
 // MFMAs of twice the issue time: 2x the native-f32 matrix rate (2.67x with 6 products) -- tests/test_gpu_gemm_x3.py holds the
 // result to an f64 GEMM and compares its error with the native f32 kernel's on the same operands.
 //   Activations stay f32 in HBM and LDS: the A tile is DMA'd exactly like the f32 tile kernel's ([128 rows][32 k] f32, same image and
-//   swizzle) and each wave splits its fragments in registers (12 VALU ops per pair of values, issued in the shadow of the MFMAs).  The
+//   swizzle) and each wave splits its fragments in registers (11 VALU ops per pair of values, software-pipelined under the MFMAs).  The
 //   lane's eight k-values are the two 16-byte pieces the f32 kernel reads (k = 4 kg + j and 16 + 4 kg + j): conflict-free, and the
 //   weights are packed with the same k permutation.  Weights are split once on the host (itts_pack_gemm_weight, precision 2):
-//   [N/16][K/32][3 planes][64 lanes][16 B].  LDS: A 16 KiB (ONE stage: a wave pulls its eight f32 fragment pieces of the K tile into
-//   registers, a second barrier frees the stage and the next A tile is DMA'd under the MFMAs) + W 2 x 24 KiB = 64 KiB, 66 KiB with the
-//   epilogue image -> two blocks per CU (the first version double-buffered A as well: 80 KiB, ONE block per CU, 52 % of the x3 rate).
-//   Epilogues: the f32 tile kernel's (pf_store_tile / pf_store_vt with F32 = true).
-// ================================================================================================================
-#define X3_WSTAGE 24576
-#define X3_LDS PF_LDS            // A 16 KiB | W 2 x 24 KiB = 64 KiB of operands; the epilogue's transposed image (+ row metadata) is the larger
+//   [N/16][K/32][3 planes][64 lanes][16 B], read by the waves straight into registers (no LDS stage).  LDS: two 16 KiB A stages; the
+//   66 KiB epilogue image is the allocation -> two blocks per CU.
+//   Measured (profiles/r03e..r03i): 155-165 TFLOP/s f32-equivalent with 8 products (native f32 MFMA kernel: 128), ~190 with 6 -- not
+//   the 2x the instruction rates promise.  Variants that changed nothing: weights through LDS (80 / 66 KiB), the split as a burst or
+//   interleaved, v_mfma_f32_32x32x16_bf16 (slower: 132).  The SQ counters show the matrix pipe 42 % busy with the waves issue-stalled,
+//   and rocm-smi shows why the ceiling is low: under this kernel the socket sits at its ~1.25 kW power limit and the engine clock falls
+//   from 2.39 GHz (the native f32 solve holds it at 1.2 kW) to ~2.03 GHz -- eight bf16 MFMAs cost more energy than the one f32 MFMA
+//   they replace, so the power cap, not the issue rate, prices this mode.
+#define X3_LDS PF_LDS            // 2 x 16 KiB of A stages; the epilogue's transposed image (+ row metadata) is the larger
 
 __device__ __forceinline__ void x3_split8(const f32x4 p0, const f32x4 p1, v4u& H, v4u& M, v4u& L) {
     const float x[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
@@ -1558,9 +1560,9 @@ __device__ __forceinline__ void x3_split8(const f32x4 p0, const f32x4 p1, v4u& H
     }
 }
 
-template <int EPI, bool CONV = false, int NPROD = 8>
+template <int EPI, bool CONV = false, int NPROD = 8, bool SCHED = true>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [A 16 KiB][2][W 24 KiB]
+    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB] operand stages; the epilogue image is the larger
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int n_mt = (a.M + PF_BM - 1) / PF_BM, n_nt = (a.N + PF_BN - 1) / PF_BN;
@@ -1576,7 +1578,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
     const int ntiles = (a.N + 15) >> 4;
 
     const char* asrc[4];
-    const char* bsrc[6];
     int cv_t[4], cv_T[4];
     const char* cv_base[4];
     const char* cv_zero[4];
@@ -1598,14 +1599,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
             cv_zero[i] = (const char*)a.zero_row + piece * 16;
         }
     }
+    // The weight fragments never touch LDS: they are stored in fragment order (one contiguous KiB per (n-tile, K tile, plane)), so the
+    // wave loads its own twelve straight into registers with plain coalesced loads, one K tile ahead (two register sets, the loop is
+    // unrolled by two).  An LDS-DMA piece costs 60-185 cycles of issue beside MFMAs (MI355X guide).
+    const v4u* wsrc[4];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int c = w * 6 + i, nblk = c / 3, plane = c - nblk * 3;       // W chunk (n-block of the tile, plane)
-        int nt = nt0 + nblk;
-        nt = nt < ntiles ? nt : ntiles - 1;
-        bsrc[i] = (const char*)a.Wp + ((size_t)nt * nk * 3 + plane) * 1024 + lane * 16;
+    for (int nt = 0; nt < 4; ++nt) {
+        int ntile = nt0 + wc * 4 + nt;
+        ntile = ntile < ntiles ? ntile : ntiles - 1;
+        wsrc[nt] = (const v4u*)((const char*)a.Wp + (size_t)ntile * nk * 3072) + lane;
     }
-    auto issue_a = [&](int kt) {
+    auto issue_a = [&](int kt, int buf) {
+        char* base = pf_sm + buf * 16384;
         int tap = 0, rem = kt;
         if constexpr (CONV) { tap = kt / cv_kpt; rem = kt - tap * cv_kpt; }
 #pragma unroll
@@ -1621,15 +1626,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
                 ap = ok ? cv_base[i] + ((size_t)p * a.lda + (size_t)rem * 32) * 4 : cv_zero[i];
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap,
-                                             (__attribute__((address_space(3))) void*)(pf_sm + (w * 4 + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + (w * 4 + i) * 1024), 16, 0, 0);
         }
     };
-    auto issue_w = [&](int kt, int buf) {
-        char* base = pf_sm + 16384 + buf * X3_WSTAGE;
+    auto load_w = [&](int kt, v4u (&bw)[4][3]) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (size_t)kt * 3072),
-                                             (__attribute__((address_space(3))) void*)(base + (w * 6 + i) * 1024), 16, 0, 0);
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bw[nt][p] = wsrc[nt][((size_t)kt * 3 + p) * 64];
     };
 
     f32x4 acc[4][4];
@@ -1646,33 +1650,31 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
         a_off[s2] = (row16 >> 3) * 1024 + ((row16 & 7) * 8 + pos) * 16;
     }
     const int a_wave = wr * 4 * 2048;
-    const int b_wave = 16384 + wc * 4 * 3072 + lane * 16;
 
-    issue_a(0);
-    issue_w(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                           // K tile kt (A, and W stage kt & 1) is in LDS
-        if (kt + 1 < nk) issue_w(kt + 1, (kt + 1) & 1);            // that W stage was last read one tile ago
-        f32x4 ar[4][2];                                            // the wave's A fragment pieces of this tile, all four m-tiles
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            ar[mt][0] = *(const f32x4*)(pf_sm + a_wave + mt * 2048 + a_off[0]);
-            ar[mt][1] = *(const f32x4*)(pf_sm + a_wave + mt * 2048 + a_off[1]);
+    // one K tile: `bw` holds its weight fragments (loaded during the previous tile), `bn_` receives the next tile's.  Software pipeline
+    // over the four m-tiles: the operand split of m-tile mt + 1 (two LDS reads, 44 VALU ops) is issued in the shadow of m-tile mt's
+    // 4 x NPROD MFMAs (SCHED: 2 MFMAs, then 3 VALU ops, ...) instead of as a burst in front of them.
+    auto ktile = [&](int kt, v4u (&bw)[4][3], v4u (&bn_)[4][3]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this tile's A DMA and weight loads have landed
+        __syncthreads();                                           // ... for every wave; the other A stage is free again
+        if (kt + 1 < nk) {
+            issue_a(kt + 1, (kt + 1) & 1);
+            load_w(kt + 1, bn_);
         }
-        const char* wb = pf_sm + (kt & 1) * X3_WSTAGE;
-        v4u bw[4][3];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bw[nt][p] = *(const v4u*)(wb + b_wave + (nt * 3 + p) * 1024);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                           // every wave holds its A pieces: the single A stage is free
-        if (kt + 1 < nk) issue_a(kt + 1);                          // in flight under this tile's MFMAs
+        const char* base = pf_sm + (kt & 1) * 16384;
+        v4u ap[3], an[3];
+        {
+            const f32x4 p0 = *(const f32x4*)(base + a_wave + a_off[0]);
+            const f32x4 p1 = *(const f32x4*)(base + a_wave + a_off[1]);
+            x3_split8(p0, p1, ap[0], ap[1], ap[2]);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            v4u ap[3];
-            x3_split8(ar[mt][0], ar[mt][1], ap[0], ap[1], ap[2]);
+            if (mt < 3) {
+                const f32x4 p0 = *(const f32x4*)(base + a_wave + (mt + 1) * 2048 + a_off[0]);
+                const f32x4 p1 = *(const f32x4*)(base + a_wave + (mt + 1) * 2048 + a_off[1]);
+                x3_split8(p0, p1, an[0], an[1], an[2]);
+            }
             // plane pairs, smallest terms first; four independent accumulators between two MFMAs on the same one
             constexpr int PA[8] = {2, 1, 2, 0, 1, 1, 0, 0};
             constexpr int PB[8] = {1, 2, 0, 2, 1, 0, 1, 0};
@@ -1682,7 +1684,23 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
                 for (int nt = 0; nt < 4; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ap[PA[q]]),
                                                                           __builtin_bit_cast(bf16x8_t, bw[nt][PB[q]]), acc[mt][nt], 0, 0, 0);
+            if (SCHED && mt < 3) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // the next m-tile's two fragment pieces
+#pragma unroll
+                for (int i = 0; i < 2 * NPROD; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMAs ...
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // ... 3 VALU ops of the next split
+                }
+            }
+            if (mt < 3) { ap[0] = an[0]; ap[1] = an[1]; ap[2] = an[2]; }
         }
+    };
+    v4u bw0[4][3], bw1[4][3];
+    issue_a(0, 0);
+    load_w(0, bw0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        ktile(kt, bw0, bw1);
+        if (kt + 1 < nk) ktile(kt + 1, bw1, bw0);
     }
     // epilogue: the f32 tile kernel's vector path
     __syncthreads();
@@ -1715,14 +1733,20 @@ static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
     const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
     const int per = ceil_div(n_mt * n_nt, 8);
     static const int nprod = [] { const char* e = getenv("ITTS_X3_PRODUCTS"); const int v = e ? atoi(e) : 8; return v == 6 ? 6 : 8; }();
+    static const bool sched = [] { const char* e = getenv("ITTS_X3_SCHED"); return !e || atoi(e) != 0; }();      // A/B switch of the MFMA / split interleave
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
         attr_set = true;
     }
-    if (nprod == 6) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6>), dim3(per * 8), dim3(256), X3_LDS, st, a);
-    else hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8>), dim3(per * 8), dim3(256), X3_LDS, st, a);
+    const dim3 grid(per * 8), blk(256);
+    if (nprod == 6 && sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true>), grid, blk, X3_LDS, st, a);
+    else if (nprod == 6) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, false>), grid, blk, X3_LDS, st, a);
+    else if (sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, true>), grid, blk, X3_LDS, st, a);
+    else hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, false>), grid, blk, X3_LDS, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
