@@ -116,10 +116,28 @@ class IndexTTS2(_IndexTTS2V25):
                           f"Consider reducing `max_text_tokens_per_segment`({max_text_tokens_per_segment}) or increasing "
                           f"`max_mel_tokens`.", category=RuntimeWarning)
         codes, code_lens = self.trim_codes(codes)
-        # teacher-forced latent pass (infer_v2.py:636-651) on the trimmed codes, one row per segment at its own lengths
-        latent = self.gpt(lat1.expand(B, -1, -1), text.to(dev), text_lens, codes, code_lens, emo_cond_emb,
-                          cond_mel_lengths=None, emo_cond_mel_lengths=None, emo_vec=emovec.expand(B, -1) if emovec.shape[0] == 1 else emovec,
-                          use_speed=torch.zeros(B, dtype=torch.long))
+        # teacher-forced latent pass (infer_v2.py:636-651) on the trimmed codes.  The reference runs it per segment at batch 1; the pass
+        # has no attention mask (get_logits, model_v2.py:534), so a row padded to a longer neighbour's text / code length would see the
+        # padding: rows are grouped by (text length, code length) and every group runs unpadded -- each row gets exactly its batch-1 result
+        emo_b = emovec.expand(B, -1) if emovec.shape[0] == 1 else emovec
+        cl = [int(v) for v in code_lens]
+        groups = {}
+        for b in range(B):
+            groups.setdefault((int(text_lens[b]), cl[b]), []).append(b)
+        latent = None
+        for (tl, ml), rows in groups.items():
+            if ml == 0:
+                continue
+            idx = torch.tensor(rows, device=codes.device)
+            n = len(rows)
+            lat_g = self.gpt(lat1.expand(n, -1, -1), text[rows][:, :tl].to(dev), torch.full((n,), tl), codes[idx][:, :ml],
+                             torch.full((n,), ml), emo_cond_emb, cond_mel_lengths=None, emo_cond_mel_lengths=None, emo_vec=emo_b[rows],
+                             use_speed=torch.zeros(n, dtype=torch.long))
+            if latent is None:
+                latent = torch.zeros(B, codes.shape[1], lat_g.shape[-1], dtype=torch.float32, device=codes.device)
+            latent[idx, :ml] = lat_g.to(latent.device, torch.float32)
+        if latent is None:                                     # every row stopped at once: nothing to render
+            latent = torch.zeros(B, codes.shape[1], 1, dtype=torch.float32, device=codes.device)
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         t2 = time.perf_counter()
         mel, mel_lens = self.codes_latent_to_mel(codes, code_lens, latent, bundle)

@@ -346,3 +346,128 @@ def test_infer_stream_yields_crossfaded_chunks():
         total = sum(len(p) for p in pieces[b])
         assert abs(total - one[b][1].shape[0]) <= 2 * 256, (b, total, one[b][1].shape)
     assert tts.last_stream.first_chunk_latency is not None
+
+
+# ---- IndexTTS-2 class: constructor from a checkpoint directory, the reference v2 call signature, latent-pass parity --------
+def _v2_checkpoint_pieces():
+    from tools.make_golden_cond import CCFG, ECFG, EPCFG, MODEL_DIM, PCFG, weights
+    gcfg = dict(layers=2, model_dim=MODEL_DIM, heads=2, max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200, number_mel_codes=8194,
+                start_mel_token=8192, stop_mel_token=8193, condition_type="conformer_perceiver", condition_num_latent=PCFG.num_latents,
+                condition_module=dict(input_size=CCFG.input_size, output_size=CCFG.output_size, linear_units=CCFG.linear_units,
+                                      attention_heads=CCFG.attention_heads, num_blocks=CCFG.num_blocks, input_layer="conv2d2",
+                                      perceiver_mult=PCFG.ff_mult),
+                emo_condition_module=dict(input_size=ECFG.input_size, output_size=ECFG.output_size, linear_units=ECFG.linear_units,
+                                          attention_heads=ECFG.attention_heads, num_blocks=ECFG.num_blocks, input_layer="conv2d2",
+                                          perceiver_mult=EPCFG.ff_mult, perceiver_dim=EPCFG.dim))
+    cfg = G.GPTConfig(layers=2, model_dim=MODEL_DIM, heads=2, max_text_tokens=40, max_mel_tokens=60, number_text_tokens=200)
+    sd = dict(G.synth_weights(cfg, seed=41))
+    sd["mel_head.bias"][cfg.stop_mel_token] += 2.0
+    for k in ("spk_emb_proj.weight", "spk_emb_proj.bias", "lang_embedding.weight"):          # an IndexTTS-2 gpt.pth has none of these
+        sd.pop(k, None)
+    sd["speed_emb.weight"] = torch.randn(2, MODEL_DIM, generator=torch.Generator().manual_seed(42)) * 0.2
+    sd.update(weights())
+    return gcfg, cfg, sd, CCFG.input_size, MODEL_DIM
+
+
+class _FrontendV2(StubFrontend):
+    """what the IndexTTS-2 pipeline reads from a speaker bundle: prompt features of the encoders' input width, fewer frames than
+    the feature-width "length" the reference hands over (T < width: every frame valid)"""
+
+    def __init__(self, model_dim, width, **kw):
+        super().__init__(model_dim, **kw)
+        g = torch.Generator().manual_seed(8)
+        self.spk_feat = torch.randn(1, 29, width, generator=g)
+        self.emo_feat = torch.randn(1, 23, width, generator=g)
+
+    def speaker_bundle(self, p):
+        return dict(super().speaker_bundle(p), spk_cond_emb=self.spk_feat.to(self.device), emo_cond_emb=self.emo_feat.to(self.device))
+
+    def emo_cond(self, p):
+        return self.emo_feat.to(self.device)
+
+
+def test_v2_constructor_from_checkpoint_directory_and_reference_signature(tmp_path):
+    """`IndexTTS2(cfg_path, model_dir)` of infer_v2.py:37-41,98,176-177 on a v2-shaped checkpoint directory: `UnifiedVoice(**cfg.gpt)` in the
+    default (conformer) conditioning mode -- the state dict has no `spk_emb_proj.*` --, the conditioning encoders built from the
+    checkpoint, BigVGAN from `aux_paths["bigvgan"]` or `<model_dir>/hf_cache/bigvgan`; `infer()` takes the reference v2 positional
+    arguments (4th = emo_audio_prompt); the engine encoders run on a prompt shorter than the feature-width "length"."""
+    import json
+    import yaml
+    from indextts_amd.infer_v2 import IndexTTS2 as IndexTTS2V2
+    gcfg, cfg, sd, width, D = _v2_checkpoint_pieces()
+    h = dict(BO.V2_HPARAMS, upsample_initial_channel=512)
+    bsd = BO.synth_weights(h, seed=43)
+    d = tmp_path / "ckpt"
+    (d / "hf_cache" / "bigvgan").mkdir(parents=True)
+    (d / "config.yaml").write_text(yaml.safe_dump({"gpt": gcfg, "gpt_checkpoint": "gpt.pth", "version": 2.0}))
+    torch.save({"model": sd}, d / "gpt.pth")
+    (d / "hf_cache" / "bigvgan" / "config.json").write_text(json.dumps(h))
+    torch.save({"generator": bsd}, d / "hf_cache" / "bigvgan" / "bigvgan_generator.pt")
+    fe = _FrontendV2(D, width, device=DEV)
+    tts = IndexTTS2V2(cfg_path=str(d / "config.yaml"), model_dir=str(d), use_fp16=False, device=DEV, frontend=fe)
+    assert tts.gpt.spk_cond_mode == "conformer" and tts.gpt.cond_encoders is not None and tts.model_version == 2.0
+    assert tts.codes_to_mel_mode == "frontend"
+    kw = dict(num_beams=1, top_k=1, max_mel_tokens=14)
+    a = tts.infer("spk.wav", "loaded from a v2 directory. second segment", None, "emo.wav", 0.6, **kw)       # reference v2 positional order
+    b = tts.infer("spk.wav", "loaded from a v2 directory. second segment", None, emo_audio_prompt="emo.wav", emo_alpha=0.6, **kw)
+    assert a[0] == b[0] == 22050 and a[1].dtype == np.int16 and a[1].shape[0] > 0 and np.array_equal(a[1], b[1])
+    assert ("emo", "emo.wav") not in fe.calls                                # _FrontendV2.emo_cond overrides the recording stub
+    # the same checkpoint with the vocoder handed over by `aux_paths` (ensure_models_available's contract)
+    other = tmp_path / "elsewhere"
+    other.mkdir()
+    for f in ("config.json", "bigvgan_generator.pt"):
+        (other / f).write_bytes((d / "hf_cache" / "bigvgan" / f).read_bytes())
+    tts2 = IndexTTS2V2(cfg_path=str(d / "config.yaml"), model_dir=str(d), device=DEV, frontend=fe, aux_paths={"bigvgan": str(other)})
+    c = tts2.infer("spk.wav", "loaded from a v2 directory. second segment", None, "emo.wav", 0.6, **kw)
+    assert np.array_equal(a[1], c[1])
+    with pytest.raises(ValueError):
+        IndexTTS2V2(cfg_path=str(d / "config.yaml"), model_dir=str(d), device=DEV, frontend=fe, codes_to_mel="nowhere")
+    with pytest.raises(RuntimeError, match="codes_to_mel='engine'"):
+        IndexTTS2V2(cfg_path=str(d / "config.yaml"), model_dir=str(d), device=DEV, frontend=fe, codes_to_mel="engine")
+
+
+def test_v2_latent_pass_matches_oracle_per_segment():
+    """The latents `_synthesize` hands to gpt_layer / s2mel for a ragged batch of segments equal, row by row, what the reference computes
+    for that segment ALONE (infer_v2.py:558-560,636-651): `[start, ids, stop]` text -- the Frontend protocol's trailing stop id is not
+    part of it -- and the row's own code length, against `oracle.gpt_oracle.forward_latent`."""
+    from indextts_amd import bigvgan, gpt
+    from indextts_amd.infer_v2 import IndexTTS2 as IndexTTS2V2
+    cfg = G.GPTConfig(layers=2, model_dim=128, heads=2, max_text_tokens=60, max_mel_tokens=60, number_text_tokens=200)
+    sd = dict(G.synth_weights(cfg, seed=71))
+    sd["mel_head.bias"][cfg.stop_mel_token] += 1.5
+    sd["speed_emb.weight"] = torch.randn(2, 128, generator=torch.Generator().manual_seed(72)) * 0.3
+    lat = torch.randn(1, 32, 128, generator=torch.Generator().manual_seed(73)) * 0.3
+    gm = gpt.UnifiedVoice(layers=2, model_dim=128, heads=2, max_text_tokens=60, max_mel_tokens=60, number_text_tokens=200,
+                          precision="fp32", device=DEV, conditioning_fn=lambda x, lengths=None: lat.to(DEV))
+    gm.load_state_dict(sd)
+    gm.post_init_gpt2_config(kv_cache=True)
+    h = dict(BO.V2_HPARAMS, upsample_initial_channel=512)
+    v = bigvgan.BigVGAN(h)
+    v.load_state_dict(BO.synth_weights(h, seed=74))
+    v.to(DEV)
+    fe = StubFrontend(128, device=DEV)
+    tts = IndexTTS2V2(cfg={"gpt": {"stop_mel_token": 8193}, "version": 2.0}, device=DEV, frontend=fe, gpt=gm, bigvgan=v)
+    seen = {}
+    inner = tts.codes_latent_to_mel
+
+    def spy(codes, code_lens, latent, bundle, *a, **k):
+        seen.update(codes=codes.cpu(), code_lens=[int(x) for x in code_lens], latent=latent.cpu())
+        return inner(codes, code_lens, latent, bundle, *a, **k)
+    tts.codes_latent_to_mel = spy
+    segs = fe.text_segments("short one. a noticeably longer second sentence. mid size third", "en", 120, True, 60)
+    assert all(int(s[-1]) == 1 for s in segs) and len({int(s.numel()) for s in segs}) == 3        # the protocol's stop id; ragged lengths
+    bundle = dict(fe.speaker_bundle("spk.wav"), emo_cond_emb=torch.zeros(1, 4, 1024, device=DEV))
+    emo = fe.emo.to(DEV)
+    tts._synthesize(segs, [0] * 3, bundle, emo, 1.0, dict(num_beams=1, top_k=1, max_mel_tokens=18), 120)
+    conds = gm.conds_latent_v2(lat, emo).cpu()
+    assert len(set(seen["code_lens"])) >= 1
+    for b, s in enumerate(segs):
+        ids = s[:-1].long()[None]                                   # the segment without the protocol's stop id
+        n = seen["code_lens"][b]
+        if n == 0:
+            continue
+        with torch.no_grad():
+            ref = G.forward_latent(sd, cfg, conds, ids, torch.tensor([ids.shape[1]]), seen["codes"][b:b + 1, :n], torch.tensor([n]))
+        err = float((seen["latent"][b, :n] - ref[0]).abs().max())
+        print(f"v2 latent pass, segment {b} ({ids.shape[1]} text tokens, {n} codes) inside a ragged batch vs the oracle alone: max|d| {err:.2e}")
+        assert err <= 5e-5

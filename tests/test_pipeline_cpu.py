@@ -132,7 +132,7 @@ def test_v2_pipeline_control_flow():
     assert tts.model_version == 2.0 and tts.use_fp16 is False
     sr, wav = tts.infer("spk.wav", "hello there. how are you. fine", None, "en", num_beams=1)
     assert sr == 22050 and wav.dtype == np.int16 and wav.shape[0] > 0
-    assert g.latent_calls == 1 and g.calls[0][0].shape[0] == 3
+    assert 1 <= g.latent_calls <= 3 and g.calls[0][0].shape[0] == 3      # one unpadded latent pass per (text length, code length) group
     assert set(tts.last_timing) == {"gpt", "gpt_forward", "s2mel", "bigvgan"}
     res = tts.infer_batch("spk.wav", ["a. b", "c"], "en", num_beams=1)
     assert len(res) == 2 and all(r[0] == 22050 for r in res)
