@@ -23,8 +23,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE]
 # No SLP vectorisation in s2mel_kernels.hip / bigvgan_kernels.hip: hipcc otherwise packs adjacent f32 adds / muls / fmas into
 # v_pk_*_f32, which cost more than the scalar pair they replace (MI355X guide: ~13 extra cycles each beside MFMAs).  Measured: the
 # anti-aliased activation kernel 2.32 -> 2.55 TB/s (profiles/r02l/voc_*.log), the flash-attention solve -4 % (profiles/r02j).
-EXTRA = {"gpt_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],      # no-SLP: the f32x3 operand split beside MFMAs
-                                                                                                     # (decode: 1.502 vs 1.507 ms/token, r02)
+# gpt_kernels.hip keeps SLP vectorisation: building it with -fno-slp-vectorize (tried for the f32x3 operand split) changes how hipcc
+# contracts / packs the f32 arithmetic of typical_filter, and a borderline token of the reference-minted `gpt_typical_greedy` fixture
+# flipped (profiles/r03j) -- the bit-exact-ids contract outranks a few percent on an optional GEMM mode.
+EXTRA = {"gpt_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
          "s2mel_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
          "bigvgan_kernels.hip": ["-fno-slp-vectorize"]}
 
