@@ -321,6 +321,15 @@ int itts_s2mel_solve(itts_s2mel* h, float* x_state, const float* const_in, const
 int itts_s2mel_set_profiling(itts_s2mel* h, int enable);
 int itts_s2mel_profile_read(itts_s2mel* h, double* ms, double* launches, double* flops);
 
+/* Dead-row elimination for the following itts_s2mel_solve calls.  The Euler step never reads the estimator's output at prompt frames
+ * (flow_matching.py:107 zeroes them) and everything after the DiT's last attention is row-wise except the WaveNet's few frames of
+ * context, so that part can run on the TAIL of every sequence only (frames >= prompt_len - receptive field).  Device tables of the
+ * tail layout: per tail row its sequence and its frame relative to the sequence's cut; per sequence the first tail row, the tail
+ * frames and the valid tail frames; tail_src [n_tail] = full-layout row of a tail row; tail_base [n_seq]: frame t of sequence s is
+ * tail row tail_base[s] + t.  Caller-owned, must outlive the solves; tok_seq = NULL clears.  Results of the solve are bit-identical. */
+int itts_s2mel_set_tail(itts_s2mel* h, const int32_t* tok_seq, const int32_t* tok_t, const int32_t* seq_start, const int32_t* seq_T,
+                        const int32_t* seq_len, const int32_t* tail_src, const int32_t* tail_base, int n_seq, int n_tail, int t_max);
+
 /* unit-level (parity tests): one layer's RoPE + split + non-causal attention.  replaces: Attention.forward between wqkv and wo
  * (gpt_fast/model.py:262-307): qkv f32 [n_tok][3 * heads * 64] -> out [n_tok][heads * 64] in the precision's activation type. */
 size_t itts_s2mel_attention_scratch_bytes(int n_tok, int n_seq, int heads, int t_max, int precision);

@@ -112,6 +112,7 @@ SIGNATURES = {
     "itts_s2mel_create": (C.c_int, [C.POINTER(S2MelConfig), C.POINTER(vp)]),
     "itts_s2mel_device": (C.c_int, [vp]),
     "itts_s2mel_load_tensor": (C.c_int, [vp, C.c_char_p, vp, c_i64p, C.c_int]),
+    "itts_s2mel_set_tail": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]),
     "itts_s2mel_finalize": (C.c_int, [vp]),
     "itts_s2mel_destroy": (None, [vp]),
     "itts_s2mel_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int]),

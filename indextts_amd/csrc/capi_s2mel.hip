@@ -58,6 +58,13 @@ struct itts_s2mel {
     struct Rec { int cls; double flops; };
     std::vector<Rec> recs;
     hipStream_t prof_stream = nullptr;
+    // Dead-row elimination in itts_s2mel_solve (itts_s2mel_set_tail): the Euler step never reads the estimator's output at prompt frames
+    // (flow_matching.py:107 zeroes them), and everything after the last attention is row-wise except the WaveNet's +-halo frames of
+    // context -- so that part runs on the TAIL of every sequence only (frames >= prompt_len - halo).  Device tables of the tail layout:
+    SeqTab tail{};                         // tok_seq / tok_t (relative to the cut) / seq_start / seq_T / seq_len of the tail rows
+    const int* tail_src = nullptr;         // [tail.n_tok] full-layout row of each tail row
+    const int* tail_base = nullptr;        // [n_seq] tail row of frame t of sequence s = tail_base[s] + t
+    bool tail_set = false;
 };
 
 enum { S2_GEMM = 0, S2_ATTN = 1, S2_OTHER = 2, S2_CLASSES = 3 };
@@ -379,8 +386,10 @@ static int s2_gemm(itts_s2mel* h, const void* A, int lda, const void* Wp, const 
 
 // x_src [src_rows][C] f32 (row m of the token matrix reads x_src row m % src_rows); d_out [n_tok][C]
 // attn_flops: 4 * hidden * sum_s T_s * len_s of one attention call (for the profile records only)
+// tail (optional): run the stages after the transformer on the tail rows only; d_out is then [tail->n_tok][C] in the tail layout
 static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_pad, const float* x_src, int src_rows, const float* const_in,
-                        const float* mods, const float* rope, float* d_out, hipStream_t st, double attn_flops = 0.0) {
+                        const float* mods, const float* rope, float* d_out, hipStream_t st, double attn_flops = 0.0,
+                        const SeqTab* tail = nullptr, const int* tail_src = nullptr) {
     S2Prof whole(h, st, S2_OTHER, 0.0);          // the call's wall span; the GEMM / attention spans inside are subtracted by the reader
     const itts_s2mel_config& c = h->cfg;
     const int H = c.hidden_dim, I = h->I, W = c.wavenet_hidden, C = c.in_channels, Kx = h->Kx, N = tab.n_tok, prec = c.precision;
@@ -439,47 +448,56 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     const float* m_norm = mods + (size_t)c.depth * 4 * H;
     const float* m_gc = m_norm + 2 * H;
     const float* m_fl = m_gc + (size_t)c.wavenet_layers * 2 * W;
+    // From here on every stage is row-wise except the WaveNet's few frames of context: with a tail layout only the rows the Euler step
+    // reads (and their halo) are computed -- gathered by the norm / cast kernels through tail_src -- with the tail's own sequence tables.
+    const SeqTab& tt = tail ? *tail : tab;
+    const void* XAt = w.XA;
+    if (tail) {
+        if ((rc = launch_cast_pad(x_src, w.QA, tail->n_tok, src_rows, C, Kx, prec, st, tail_src))) return rc;      // QA is free after the last attention
+        XAt = w.QA;
+    }
+    const int NT = tt.n_tok;
     // x_res = skip_linear([transformer.norm(x) | x^T])
-    if ((rc = launch_ada_rmsnorm(X, h->g_norm, m_norm, w.HB, N, H, c.norm_eps, prec, st))) return rc;
-    if ((rc = s2_gemm(h, w.HB, H, h->w_sl_a, h->b_sl, X2, H, N, H, H, EPI_STORE_F32, st))) return rc;
-    if ((rc = s2_gemm(h, w.XA, Kx, h->w_sl_b, nullptr, X2, H, N, H, Kx, EPI_RESIDUAL, st, fused ? w.HB : nullptr))) return rc;
-    if (!fused && (rc = launch_cast_pad(X2, w.HB, N, N, H, H, prec, st))) return rc;
-    if ((rc = s2_gemm(h, w.HB, H, h->w_c1, h->b_c1, w.WX, W, N, W, H, EPI_STORE_F32, st, fused ? w.WXA : nullptr))) return rc;
-    if ((rc = s2_gemm(h, w.HB, H, h->w_rp, h->b_rp, w.RP, W, N, W, H, EPI_STORE_F32, st))) return rc;
+    if ((rc = launch_ada_rmsnorm(X, h->g_norm, m_norm, w.HB, NT, H, c.norm_eps, prec, st, tail ? tail_src : nullptr))) return rc;
+    if ((rc = s2_gemm(h, w.HB, H, h->w_sl_a, h->b_sl, X2, H, NT, H, H, EPI_STORE_F32, st))) return rc;
+    if ((rc = s2_gemm(h, XAt, Kx, h->w_sl_b, nullptr, X2, H, NT, H, Kx, EPI_RESIDUAL, st, fused ? w.HB : nullptr))) return rc;
+    if (!fused && (rc = launch_cast_pad(X2, w.HB, NT, NT, H, H, prec, st))) return rc;
+    if ((rc = s2_gemm(h, w.HB, H, h->w_c1, h->b_c1, w.WX, W, NT, W, H, EPI_STORE_F32, st, fused ? w.WXA : nullptr))) return rc;
+    if ((rc = s2_gemm(h, w.HB, H, h->w_rp, h->b_rp, w.RP, W, NT, W, H, EPI_STORE_F32, st))) return rc;
     // WaveNet (wavenet.py:143-166)
     int dil = 1;
     // (fused: WXA, the bf16 shadow of WX that the tap-mode GEMM reads, was written by the conv1 GEMM above)
     for (int i = 0; i < c.wavenet_layers; ++i) {
         const S2Wn& Wn = h->wn[i];
         const int last = i == c.wavenet_layers - 1;
-        if (!fused && (rc = launch_im2col_reflect(w.WX, w.COL, tab, W, c.wavenet_kernel, dil, prec, st))) return rc;
+        if (!fused && (rc = launch_im2col_reflect(w.WX, w.COL, tt, W, c.wavenet_kernel, dil, prec, st))) return rc;
         const int ro = last ? W : 2 * W;
         if (fused) {                                               // gate in the in_layer epilogue, residual / skip update in the res_skip one
             GemmArgs g{};
             // dilated reflect-padded conv as a GEMM whose A operand is an implicit im2col of the bf16 shadow (no [n][k*W] buffer)
-            g.A = w.WXA; g.lda = W; g.Wp = Wn.w_in; g.bias = Wn.b_in; g.M = N; g.N = 2 * W; g.K = c.wavenet_kernel * W;
+            g.A = w.WXA; g.lda = W; g.Wp = Wn.w_in; g.bias = Wn.b_in; g.M = NT; g.N = 2 * W; g.K = c.wavenet_kernel * W;
             g.nsplit = 1; g.epi = EPI_GATE; g.out_act = w.FC; g.gvec = m_gc + (size_t)i * 2 * W; g.D = W;
-            g.conv_taps = c.wavenet_kernel; g.conv_dil = dil; g.conv_W = W; g.tok_seq = tab.tok_seq; g.tok_t = tab.tok_t;
-            g.seq_start = tab.seq_start; g.seq_T = tab.seq_T; g.zero_row = w.ZR;
+            g.conv_taps = c.wavenet_kernel; g.conv_dil = dil; g.conv_W = W; g.tok_seq = tt.tok_seq; g.tok_t = tt.tok_t;
+            g.seq_start = tt.seq_start; g.seq_T = tt.seq_T; g.zero_row = w.ZR;
             if ((rc = s2_launch_gemm(h, g, st))) return rc;
             GemmArgs r{};
-            r.A = w.FC; r.lda = W; r.Wp = Wn.w_rs; r.bias = Wn.b_rs; r.M = N; r.N = ro; r.K = W; r.nsplit = 1; r.epi = EPI_WN_RS;
+            r.A = w.FC; r.lda = W; r.Wp = Wn.w_rs; r.bias = Wn.b_rs; r.M = NT; r.N = ro; r.K = W; r.nsplit = 1; r.epi = EPI_WN_RS;
             r.out_f32 = w.WX; r.out2 = w.OUT; r.D = W; r.wn_first = i == 0; r.wn_last = last; r.out_act2 = last ? nullptr : w.WXA;
-            r.tok_seq = tab.tok_seq; r.tok_t = tab.tok_t; r.seq_len = tab.seq_len;
+            r.tok_seq = tt.tok_seq; r.tok_t = tt.tok_t; r.seq_len = tt.seq_len;
             if ((rc = s2_launch_gemm(h, r, st))) return rc;
         } else {
-            if ((rc = s2_gemm(h, w.COL, c.wavenet_kernel * W, Wn.w_in, Wn.b_in, w.BIG, 2 * W, N, 2 * W, c.wavenet_kernel * W, EPI_STORE_F32, st))) return rc;
-            if ((rc = launch_wn_gate(w.BIG, m_gc + (size_t)i * 2 * W, w.FC, N, W, prec, st))) return rc;
-            if ((rc = s2_gemm(h, w.FC, W, Wn.w_rs, Wn.b_rs, w.BIG, ro, N, ro, W, EPI_STORE_F32, st))) return rc;
-            if ((rc = launch_wn_update(w.BIG, w.WX, w.OUT, tab, W, i == 0, last, st))) return rc;
+            if ((rc = s2_gemm(h, w.COL, c.wavenet_kernel * W, Wn.w_in, Wn.b_in, w.BIG, 2 * W, NT, 2 * W, c.wavenet_kernel * W, EPI_STORE_F32, st))) return rc;
+            if ((rc = launch_wn_gate(w.BIG, m_gc + (size_t)i * 2 * W, w.FC, NT, W, prec, st))) return rc;
+            if ((rc = s2_gemm(h, w.FC, W, Wn.w_rs, Wn.b_rs, w.BIG, ro, NT, ro, W, EPI_STORE_F32, st))) return rc;
+            if ((rc = launch_wn_update(w.BIG, w.WX, w.OUT, tt, W, i == 0, last, st))) return rc;
         }
         dil *= c.wavenet_dilation_rate;
     }
     // FinalLayer + conv2
-    if ((rc = launch_final_ln_mod(w.OUT, w.RP, m_fl, w.HB, tab, W, prec, st))) return rc;
-    if ((rc = s2_gemm(h, w.HB, W, h->w_fl, h->b_fl, w.BIG, W, N, W, W, EPI_STORE_F32, st, fused ? w.FC : nullptr))) return rc;
-    if (!fused && (rc = launch_cast_pad(w.BIG, w.FC, N, N, W, W, prec, st))) return rc;
-    return s2_gemm(h, w.FC, W, h->w_c2, h->b_c2, d_out, C, N, C, W, EPI_STORE_F32, st);
+    if ((rc = launch_final_ln_mod(w.OUT, w.RP, m_fl, w.HB, tt, W, prec, st))) return rc;
+    if ((rc = s2_gemm(h, w.HB, W, h->w_fl, h->b_fl, w.BIG, W, NT, W, W, EPI_STORE_F32, st, fused ? w.FC : nullptr))) return rc;
+    if (!fused && (rc = launch_cast_pad(w.BIG, w.FC, NT, NT, W, W, prec, st))) return rc;
+    return s2_gemm(h, w.FC, W, h->w_c2, h->b_c2, d_out, C, NT, C, W, EPI_STORE_F32, st);
 }
 
 static int s2_check(const itts_s2mel* h, const void* a, const void* b, const char* who) {
@@ -553,11 +571,31 @@ extern "C" int itts_s2mel_solve(itts_s2mel* h, float* x_state, const float* cons
     h->recs.clear();
     h->prof_stream = st;
     for (int step = 0; step < n_steps; ++step) {                   // flow_matching.py:84-113
-        int rc = s2_estimator(h, w, tab, t_pad, x_state, n_tok / n_branch, const_in, mods + (size_t)step * mps, rope, w.D, st);
+        const bool use_tail = h->tail_set && h->tail.n_seq == n_seq && h->tail.n_tok > 0 && h->tail.n_tok <= n_tok && h->tail.n_tok % n_branch == 0;
+        int rc = s2_estimator(h, w, tab, t_pad, x_state, n_tok / n_branch, const_in, mods + (size_t)step * mps, rope, w.D, st, 0.0,
+                              use_tail ? &h->tail : nullptr, use_tail ? h->tail_src : nullptr);
         if (rc) return rc;
         const float dt = t_span[step + 1] - t_span[step];
-        if ((rc = launch_euler_update(x_state, w.D, tab, prompt_len, h->cfg.in_channels, n_branch, dt, cfg_rate, st))) return rc;
+        if ((rc = launch_euler_update(x_state, w.D, tab, prompt_len, h->cfg.in_channels, n_branch, dt, cfg_rate, st,
+                                      use_tail ? h->tail_base : nullptr, use_tail ? h->tail.n_tok / n_branch : 0))) return rc;
     }
+    return ITTS_OK;
+}
+
+// Dead-row elimination for the following itts_s2mel_solve calls (see itts_s2mel.tail): device tables of the tail layout -- per tail row
+// its sequence and its frame RELATIVE to the sequence's cut, per sequence the first tail row / tail frames / valid tail frames -- plus
+// tail_src [n_tail] (full-layout row of a tail row) and tail_base [n_seq] (tail row of frame t = tail_base[s] + t).  The caller keeps
+// the arrays alive; all-null clears.  The cut of a sequence must lie at least one WaveNet receptive field before its first target frame.
+extern "C" int itts_s2mel_set_tail(itts_s2mel* h, const int32_t* tok_seq, const int32_t* tok_t, const int32_t* seq_start, const int32_t* seq_T,
+                                   const int32_t* seq_len, const int32_t* tail_src, const int32_t* tail_base, int n_seq, int n_tail, int t_max) {
+    if (!h) { itts_set_error("s2mel_set_tail: null"); return ITTS_ERR_ARG; }
+    if (!tok_seq) { h->tail_set = false; return ITTS_OK; }
+    if (!tok_t || !seq_start || !seq_T || !seq_len || !tail_src || !tail_base || n_seq <= 0 || n_tail <= 0 || t_max <= 0) {
+        itts_set_error("s2mel_set_tail: bad args");
+        return ITTS_ERR_ARG;
+    }
+    h->tail = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tail, t_max);
+    h->tail_src = tail_src; h->tail_base = tail_base; h->tail_set = true;
     return ITTS_OK;
 }
 

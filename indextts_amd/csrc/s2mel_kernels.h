@@ -17,10 +17,12 @@ struct SeqTab {
 };
 
 // AdaptiveLayerNorm of gpt_fast (weight * RMSNorm(x) * g + bias) / FinalLayer norm (LayerNorm without affine, modulated)
-int launch_ada_rmsnorm(const float* x, const float* g, const float* wb, void* out, int n_tok, int H, float eps, int prec, hipStream_t st);
+// row_map (optional): output row m reads input row row_map[m] (the rows that survive dead-row elimination, capi_s2mel.hip)
+int launch_ada_rmsnorm(const float* x, const float* g, const float* wb, void* out, int n_tok, int H, float eps, int prec, hipStream_t st,
+                       const int* row_map = nullptr);
 int launch_final_ln_mod(const float* wn_out, const float* rp, const float* mod, void* out, const SeqTab& tab, int W, int prec, hipStream_t st);
 // f32 [rows][C_in] -> act dtype [rows][C_out >= C_in] (zero padded); src row of output row m is m % src_rows (CFG stacking)
-int launch_cast_pad(const float* in, void* out, int rows, int src_rows, int C_in, int C_out, int prec, hipStream_t st);
+int launch_cast_pad(const float* in, void* out, int rows, int src_rows, int C_in, int C_out, int prec, hipStream_t st, const int* row_map = nullptr);
 // RoPE + split of a fused QKV GEMM output: qkv f32 [n_tok][3H] -> Q act [n_tok][H] (rotated), K [n_seq][heads][t_pad][64]
 // (rotated), V^T [n_seq][heads][64][t_pad] (bf16 mode) or V [n_seq][heads][t_pad][64] (f32 mode)
 int launch_rope_split(const float* qkv, const float* rope, void* q, void* k, void* v, const SeqTab& tab, int heads, int t_pad, int prec, hipStream_t st);
@@ -35,4 +37,5 @@ int launch_wn_gate(const float* in, const float* g, void* out, int n_tok, int W,
 // WaveNet residual/skip update: rs f32 [n][2W] (last layer: [n][W]); x = (x + rs[:, :W]) * mask; out (=|+=) rs[:, W:] (last: rs)
 int launch_wn_update(const float* rs, float* x, float* out, const SeqTab& tab, int W, int first, int last, hipStream_t st);
 // CFG combine + Euler step on the solver state xs [n_tok / n_branch][C]: xs += dt * ((1 + r) * d_cond - r * d_null); prompt frames 0
-int launch_euler_update(float* xs, const float* d, const SeqTab& tab, const int* prompt_len, int C, int n_branch, float dt, float cfg_rate, hipStream_t st);
+int launch_euler_update(float* xs, const float* d, const SeqTab& tab, const int* prompt_len, int C, int n_branch, float dt, float cfg_rate, hipStream_t st,
+                        const int* tail_base = nullptr, int tail_half = 0);

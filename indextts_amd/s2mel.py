@@ -19,6 +19,7 @@ computed and the WaveNet's reflect padding sits at the tensor end; the pipeline 
 batch-1 reference call per utterance does).
 """
 import ctypes as C
+import os
 import math
 from typing import Dict, Optional
 
@@ -73,6 +74,8 @@ class CFM:
         self.precision = {"bf16": 1, "bfloat16": 1, "fp32": 0, "float32": 0, "f32": 0, "fp32x3": 2, "f32x3": 2}[precision]
         # the once-per-solve projections of the step-invariant inputs (K = 784 is not a multiple of the x3 kernel's 32-deep tile) run f32
         self._host_prec = 0 if self.precision == 2 else self.precision
+        # solve_euler: skip the post-attention stages on prompt rows whose output the Euler step discards (bit-identical results; A/B switch)
+        self.prune_dead_rows = os.environ.get("ITTS_S2MEL_PRUNE", "1") != "0"
         cfg = _lib.S2MelConfig()
         cfg.hidden_dim, cfg.num_heads, cfg.depth, cfg.in_channels = self.hidden_dim, self.num_heads, self.depth, self.in_channels
         cfg.wavenet_hidden, cfg.wavenet_layers = self.wavenet_hidden, self.wavenet_layers
@@ -208,6 +211,34 @@ class CFM:
         t = dict(seq_T=seq_T, seq_len=seq_len, seq_start=seq_start, tok_seq=tok_seq, tok_t=tok_t)
         return {k: v.to(dev).contiguous() for k, v in t.items()}, n_tok, int(fl.max())
 
+    def _tail_tables(self, frame_lens, x_lens, prompt_lens, n_branch):
+        """Tables of the TAIL layout for the solver's dead-row elimination (itts_s2mel_set_tail): of every sequence only the frames
+        from `prompt_len - halo` on, halo = the WaveNet stack's one-sided receptive field (sum of (k - 1) / 2 * dilation per layer).  The
+        Euler step never reads the estimator at prompt frames (flow_matching.py:107) and the stages after the last attention are
+        row-wise apart from that halo, so their outputs at the kept target frames are bit-identical.  None when nothing can be cut."""
+        halo = sum((self.wavenet_kernel - 1) // 2 * self.wavenet_dilation_rate ** i for i in range(self.wavenet_layers))
+        fl = [int(v) for v in frame_lens]
+        xl = [min(int(v), f) for v, f in zip(torch.as_tensor(x_lens).reshape(-1).tolist(), fl)]
+        cuts = [max(0, min(int(p), f) - halo) for p, f in zip(prompt_lens, fl)]
+        span = (self.wavenet_kernel - 1) * self.wavenet_dilation_rate ** (self.wavenet_layers - 1)
+        if not any(cuts) or any(f - c <= span for f, c in zip(fl, cuts)):          # nothing to cut / a tail shorter than one conv's padding
+            return None
+        fl2 = [f - c for f, c in zip(fl, cuts)]
+        xl2 = [max(0, x - c) for x, c in zip(xl, cuts)]
+        full_T = torch.tensor(fl * n_branch, dtype=torch.int64)
+        full_start = torch.cumsum(full_T, 0) - full_T
+        T2 = torch.tensor(fl2 * n_branch, dtype=torch.int64)
+        start2 = torch.cumsum(T2, 0) - T2
+        cut = torch.tensor(cuts * n_branch, dtype=torch.int64)
+        tok_seq = torch.repeat_interleave(torch.arange(T2.numel()), T2)
+        tok_t = torch.arange(int(T2.sum())) - start2[tok_seq]
+        t = dict(tok_seq=tok_seq, tok_t=tok_t, seq_start=start2, seq_T=T2, seq_len=torch.tensor(xl2 * n_branch),
+                 tail_src=full_start[tok_seq] + cut[tok_seq] + tok_t, tail_base=start2 - cut)
+        out = {k: v.to(torch.int32).to(self.device).contiguous() for k, v in t.items()}
+        out["n_tok"], out["t_max"] = int(T2.sum()), int(max(fl2))
+        self._tail_keep = out                                       # the engine reads the arrays during the solve
+        return out
+
     def _const_in(self, prompt_x_rows, mu_rows, style_rows, n_null_rows):
         """cond_x_merge_linear on the step-invariant columns [prompt | cond_projection(mu) | style] + bias for the conditional
         rows; the null branch (all three inputs zero) sees cond_projection(0) = its bias.  Engine GEMMs."""
@@ -331,6 +362,13 @@ class CFM:
             L = _lib.lib()
             ws = self._workspace(L.itts_s2mel_workspace_bytes(self._h, n_tok, B * nb, t_max))
             tsp = (C.c_float * (n_steps + 1))(*[float(v) for v in ts])
+            tail = self._tail_tables(fl, x_lens, pl, nb) if self.prune_dead_rows else None
+            if tail is not None:
+                _lib.check(L.itts_s2mel_set_tail(self._h, *[_lib.ptr(tail[k]) for k in ("tok_seq", "tok_t", "seq_start", "seq_T", "seq_len",
+                                                                                        "tail_src", "tail_base")],
+                                                 B * nb, tail["n_tok"], tail["t_max"]), "itts_s2mel_set_tail")
+            else:
+                L.itts_s2mel_set_tail(self._h, None, None, None, None, None, None, None, 0, 0, 0)
             _lib.check(L.itts_s2mel_solve(self._h, _lib.ptr(xs), _lib.ptr(cin), _lib.ptr(mods), _lib.ptr(rope), _lib.ptr(tabs["tok_seq"]),
                                           _lib.ptr(tabs["tok_t"]), _lib.ptr(tabs["seq_start"]), _lib.ptr(tabs["seq_T"]),
                                           _lib.ptr(tabs["seq_len"]), _lib.ptr(plen), B * nb, n_tok, t_max, nb, n_steps, tsp,

@@ -241,3 +241,32 @@ def test_f32_fast_path_vs_separate_kernels(tmp_path):
     print(f"f32 s2mel: fused f32-MFMA tile GEMMs + f32 flash attention vs the separate-kernel path: max|d| = {d:.3e} "
           f"(output rms {rms(out['separate_reg']):.3f})")
     assert rms(out["separate_reg"]) > 1e-3 and d <= 2e-5
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_dead_row_elimination_is_bit_identical(precision):
+    """`solve_euler` runs the stages after the DiT's last attention (skip_linear, conv1, the WaveNet, the final layer, conv2) only on the
+    tail of every sequence -- the frames from `prompt_len - receptive field` on: the Euler step never reads the estimator at prompt frames
+    (flow_matching.py:107).  Every kept row must come out BIT-identical to the full computation (rows are independent in the GEMMs,
+    the WaveNet's context is inside the halo), with ragged prompts incl. one shorter than the halo; and fewer GEMM FLOPs are issued."""
+    cfg = S.S2MelConfig(depth=3, wavenet_layers=3, wavenet_dilation_rate=2)          # halo = 2 * (1 + 2 + 4) = 14 frames
+    sd = S.synth_weights(cfg, 5)
+    m = engine(cfg, sd, precision)
+    g = torch.Generator().manual_seed(6)
+    T, Tp = [391, 97, 258], [140, 33, 9]
+    Tm = max(T)
+    x = torch.randn(3, 80, Tm, generator=g)
+    mu = torch.randn(3, Tm, cfg.content_dim, generator=g)
+    prompt = torch.randn(3, 80, max(Tp), generator=g) * 0.5 - 1.0
+    style = torch.randn(3, cfg.style_dim, generator=g)
+    t_span = torch.linspace(0, 1, 4)
+    out, flops = {}, {}
+    m.set_profiling(True)
+    for on in (False, True):
+        m.prune_dead_rows = on
+        out[on] = m.solve_euler(x.clone(), torch.tensor(T), prompt, mu, style, None, t_span, 0.7, prompt_lens=Tp, frame_lens=T).cpu()
+        flops[on] = m.profile()["gemm"]["flops"]
+    m.set_profiling(False)
+    assert rms(out[False]) > 1e-3 and torch.equal(out[False], out[True])
+    assert flops[True] < 0.97 * flops[False], flops
+    print(f"{precision}: GEMM FLOPs of the solve {flops[False]:.3e} -> {flops[True]:.3e} with the prompt rows' dead tail work removed")

@@ -2,7 +2,7 @@
 # round 3, call 10: f32 tile GEMM with the weight fragments in registers (bitwise A/B + timing), the IndexTTS-2 class tests, x3 regression.
 set -u
 cd "$(dirname "$0")/.."
-O=$PWD/gpurun_out/r03j
+O=$PWD/gpurun_out/r03l
 mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_s2mel.py tests/test_gpu_pipeline.py tests/test_gpu_gemm_x3.py tests/test_gpu_gpt.py -x -q -s > $O/pytest.log 2>&1; echo "pytest rc=$?" > $O/status.txt
 timeout 120 python tools/gemm_x3_bench.py 312704 3 > $O/gemm_bench_wreg.log 2>&1
