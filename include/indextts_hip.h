@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 5
+#define ITTS_ABI_VERSION 6
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -146,6 +146,9 @@ int itts_bigvgan_profile_records(itts_bigvgan* h, double* out, int max_records);
  * ---------------------------------------------------------------------------------------------------------- */
 #define ITTS_PREC_F32 0   /* parity mode: f32 weights / KV / MFMA (v_mfma_f32_16x16x4_f32, exact f32) */
 #define ITTS_PREC_BF16 1  /* bf16 weights / KV / GEMM inputs, f32 accumulate and residual stream */
+#define ITTS_PREC_F32X3 2 /* s2mel and itts_gemm_forward only: f32 activations; GEMMs on the bf16 matrix pipe with every f32 operand carried
+                           * exactly as three bf16 planes (x = h + m + l), 8 plane products per f32 product, f32 accumulate.  Weights are
+                           * packed for it by itts_pack_gemm_weight(..., precision = 2); attention, norms, gates run their f32 code. */
 
 typedef struct {
     int32_t layers, model_dim, heads;   /* head_dim = model_dim / heads must be 64 */
@@ -257,6 +260,8 @@ int itts_gpt_compaction_stats(const itts_gpt* h, int64_t* row_steps, int32_t* co
 int itts_gpt_forward_latent(itts_gpt* h, const float* x, int nseq, int S, float* out, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* diagnostics: resident blocks per CU the HIP runtime predicts for the 128 x 128 tile GEMM kernel of a precision (0 f32, 1 bf16, 2 f32x3) */
+int itts_gemm_tile_occupancy(int precision, int32_t* blocks_per_cu);
 /* unit-level ops for the parity tests: C[M,N] = A[M,K] * W + bias (A in the precision's activation dtype), LayerNorm */
 int itts_gemm_forward(const void* A, const void* Wp, const float* bias, float* out, int M, int N, int K, int precision,
                       int prefill_tiles, int gelu, void* stream);
@@ -270,7 +275,8 @@ typedef struct {
     int32_t hidden_dim, num_heads, depth;          /* DiT (head_dim must be 64)                                   */
     int32_t in_channels;                           /* mel bands (80)                                              */
     int32_t wavenet_hidden, wavenet_layers, wavenet_kernel, wavenet_dilation_rate;
-    int32_t precision;                             /* 0 f32 (parity), 1 bf16 GEMM operands / Q K V P, f32 accumulate */
+    int32_t precision;                             /* ITTS_PREC_F32 (what the reference computes, infer_v2_5.py:827-828), _BF16 (GEMM
+                                                    * operands / Q K V P in bf16, f32 accumulate) or _F32X3 */
     float norm_eps;
 } itts_s2mel_config;
 

@@ -43,7 +43,7 @@ class GPTConfig(C.Structure):
                 ("stop_mel_token", C.c_int32), ("ln_eps", C.c_float)]
 
 
-ABI_VERSION = 5          # include/indextts_hip.h ITTS_ABI_VERSION
+ABI_VERSION = 6          # include/indextts_hip.h ITTS_ABI_VERSION
 
 
 class GenParams(C.Structure):
@@ -109,6 +109,7 @@ SIGNATURES = {
     "itts_gpt_set_row_limits": (C.c_int, [vp, vp, C.c_int]),
     "itts_gpt_compaction_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "itts_gpt_forward_latent": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
+    "itts_gemm_tile_occupancy": (C.c_int, [C.c_int, C.POINTER(C.c_int32)]),
     "itts_s2mel_create": (C.c_int, [C.POINTER(S2MelConfig), C.POINTER(vp)]),
     "itts_s2mel_device": (C.c_int, [vp]),
     "itts_s2mel_load_tensor": (C.c_int, [vp, C.c_char_p, vp, c_i64p, C.c_int]),

@@ -962,6 +962,14 @@ extern "C" int itts_gpt_forward_latent(itts_gpt* h, const float* x, int nseq, in
     return ITTS_OK;
 }
 
+extern "C" int itts_gemm_tile_occupancy(int precision, int32_t* blocks_per_cu) {
+    if (!blocks_per_cu) { itts_set_error("gemm_tile_occupancy: null"); return ITTS_ERR_ARG; }
+    int n = 0;
+    const int rc = gemm_tile_occupancy(precision, &n);
+    *blocks_per_cu = n;
+    return rc;
+}
+
 // ---- unit-level entry points (parity tests) --------------------------------------------------------------------
 extern "C" int itts_gemm_forward(const void* A, const void* Wp, const float* bias, float* out, int M, int N, int K,
                                  int precision, int prefill_tiles, int gelu, void* stream) {

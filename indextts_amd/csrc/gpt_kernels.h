@@ -60,6 +60,7 @@ struct GemmArgs {
                                      // ragged batch: finished rows leave the running batch, the survivors keep their cache rows)
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);
+int gemm_tile_occupancy(int prec, int* blocks);      // diagnostics: predicted resident blocks per CU of the 128 x 128 tile kernel
 
 // ---- attention over the KV cache ------------------------------------------------------------------------------
 struct AttnArgs {

@@ -2060,6 +2060,25 @@ static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
     return launch_gemm_cfg<BF16, 4, 1, true>(a, st);
 }
 
+// diagnostics: resident blocks per CU the runtime predicts for the tile GEMM kernels at their launch configuration (residual epilogue)
+int gemm_tile_occupancy(int prec, int* blocks) {
+    int n = 0;
+    hipError_t e;
+    if (prec == PREC_F32) {
+        (void)hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI_RESIDUAL, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_prefill_kernel<EPI_RESIDUAL, false, true, true>, 256, PF_LDS);
+    } else if (prec == PREC_F32X3) {
+        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI_RESIDUAL, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_x3_kernel<EPI_RESIDUAL, false, 8, true>, 256, X3_LDS);
+    } else {
+        (void)hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI_RESIDUAL, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_prefill_kernel<EPI_RESIDUAL, false, true, false>, 256, PF_LDS);
+    }
+    if (e != hipSuccess) { itts_set_error("occupancy query: %s", hipGetErrorString(e)); return ITTS_ERR_HIP; }
+    *blocks = n;
+    return ITTS_OK;
+}
+
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st) {
     if (a.M <= 0 || a.N <= 0) return ITTS_OK;
     const int KB = prec == PREC_F32 ? 16 : 32;
