@@ -1890,9 +1890,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MT == 4 
             m = m < a.M ? m : a.M - 1;
             arow[rg] = (const char*)a.A + ((size_t)m * a.lda + (size_t)kb_lo * 32 + piece * 8) * 2;
         }
+        // a.dma_rot (ITTS_DECODE_ROT=1, experiment): every block starts its sweep of the slab at a different k-pair, so the CUs of
+        // an XCD do not walk the same L2 lines in lock step (same bytes, same LDS image, different issue order)
+        const int rot = a.dma_rot ? (int)(blockIdx.x % 5u) : 0;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int kp = w * 5 + j;
+            int jj = j + rot;
+            jj = jj >= 5 ? jj - 5 : jj;
+            const int kp = w * 5 + jj;
             if (kp < kps) {                                        // wave-uniform
 #pragma unroll
                 for (int rg = 0; rg < RG; ++rg)
@@ -1969,6 +1974,8 @@ static int launch_gemm_decode64_e(const GemmArgs& a, int ntiles, size_t lds, hip
     if (attr_state < 0) return -1;
     GemmArgs a2 = a;
     a2.kb_slice = (a.K / 32) / a.nsplit;                           // exact: the caller checked (K/32) % (2 * nsplit) == 0
+    static const int rot = [] { const char* e = getenv("ITTS_DECODE_ROT"); return e ? atoi(e) : 0; }();
+    a2.dma_rot = rot;
     hipLaunchKernelGGL((gemm_decode64_kernel<NT, MT, WNT, EPI>), dim3(ceil_div(ntiles, NT), ceil_div(a.M, 16 * MT), a.nsplit), dim3(256), lds, st, a2);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;

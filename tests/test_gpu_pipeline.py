@@ -471,3 +471,28 @@ def test_v2_latent_pass_matches_oracle_per_segment():
         err = float((seen["latent"][b, :n] - ref[0]).abs().max())
         print(f"v2 latent pass, segment {b} ({ids.shape[1]} text tokens, {n} codes) inside a ragged batch vs the oracle alone: max|d| {err:.2e}")
         assert err <= 5e-5
+
+
+def test_engine_refuses_a_second_generation_while_a_stream_is_open():
+    """the suspended chunk state (KV cache in the workspace, the persistent code buffer) is shared with `generate`; while a
+    chunked generation is open the engine refuses other generations instead of corrupting the stream, and works again once it is closed."""
+    tts = build()
+    g = tts.gpt
+    style, emo = tts.frontend.style.to(DEV), tts.frontend.emo.to(DEV)
+    text = torch.randint(2, 200, (2, 9), generator=torch.Generator().manual_seed(3)).to(DEV)
+    langs = torch.full((2,), 3, dtype=torch.long, device=DEV)
+    kw = dict(langs=langs, emo_vec=emo, campplus_embedding=style, max_generate_length=24, num_beams=1, repetition_penalty=10.0, do_sample=False)
+    emb, mask, max_new, hf = g.inference_speech_stream(None, text, 8, 2, **kw)
+    chunks = g.generate_chunks(emb, mask, max_new, 8, 2, **hf)
+    first = next(chunks)
+    assert first[0].shape[0] == 2
+    with pytest.raises(RuntimeError, match="chunked generation"):
+        g.inference_speech(None, text, **kw)
+    with pytest.raises(RuntimeError, match="chunked generation"):
+        next(g.generate_chunks(emb, mask, max_new, 8, 2, **hf))
+    chunks.close()
+    ids, _ = g.inference_speech(None, text, **kw)
+    assert ids.shape[0] == 2 and ids.shape[1] >= 1
+    # duration_factor reaches the streaming cross-fade: the decoder is sized by the frames the chunks actually render
+    from indextts_amd.streaming import overlap_samples
+    assert overlap_samples(20) == int(20 * 1.72) * 256 and overlap_samples(20, 2 * 1.72 * 1.5) == int(20 * 2 * 1.72 * 1.5) * 256
