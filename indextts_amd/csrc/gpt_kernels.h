@@ -43,7 +43,7 @@ struct GemmArgs {
     float* qbuf; void* kcache; void* vcache;
     const int* pos_ptr; int S, H, Tmax, D;
     int kb_slice;                    // filled by the decode-GEMM launcher: 32-wide k-blocks per K slice
-    int dma_rot;                     // experiment switch (ITTS_DECODE_ROT): per-block rotation of the slab DMA issue order
+    int dma_rot;                     // per-block rotation of the slab DMA issue order (ITTS_DECODE_ROT=0 turns it off: A/B switch)
     // s2mel epilogues (packed token rows): sequence / frame of a row, valid frames per sequence, RoPE table [t][32][2],
     // per-step conditioning vector (EPI_GATE), second f32 output (EPI_WN_RS) with its overwrite / last-layer switches
     const int* tok_seq; const int* tok_t; const int* seq_len; const float* rope; const float* gvec;

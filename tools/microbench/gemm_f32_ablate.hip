@@ -1,0 +1,65 @@
+// Ablation microbench of the f32-MFMA tile GEMM (gemm_prefill_kernel<EPI_STORE_F32, false, true, true>: the s2mel f32 mode's dominant
+// kernel).  Builds against the product source with -DPF_ABL=<mask> and times the shapes of the flow-matching solve (plain store).
+//   mask bits: 1 no in-loop LDS-DMA (both stages keep K tile 0), 2 no barrier in the K loop, 4 no LDS fragment reads (register-made
+//              operands), 8 no epilogue, 16 start stagger by dispatch order (blocks 256..511 sleep half a tile), 64 start stagger by
+//              the hardware wave slot (HW_ID.WAVE_ID bit 0 of the block's first wave)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I indextts_amd/csrc -mllvm -amdgpu-mfma-vgpr-form=1 -DPF_ABL=0 \
+//         tools/microbench/gemm_f32_ablate.hip -o /tmp/ga_0 && /tmp/ga_0 312704
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../../indextts_amd/csrc/common.h"
+void itts_set_error(const char* fmt, ...) { (void)fmt; }
+#include "../../indextts_amd/csrc/gpt_kernels.hip"
+// order-independent fingerprint of the output bits: variants that only move instructions (16, 64, 128) must print the baseline's value
+__global__ void fingerprint_kernel(const unsigned* __restrict__ p, size_t n, unsigned long long* out) {
+    unsigned long long h = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        h += (unsigned long long)p[i] * (2ull * i + 1ull);
+    atomicAdd(out, h);
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 312704;
+    const int reps = argc > 2 ? atoi(argv[2]) : 5;
+    const int shapes[][2] = {{512, 512}, {1536, 512}, {3072, 512}, {512, 1536}, {1024, 2560}};      // N, K
+    size_t a_max = 0, w_max = 0, o_max = 0;
+    for (auto& s : shapes) {
+        a_max = a_max > (size_t)M * s[1] ? a_max : (size_t)M * s[1];
+        w_max = w_max > (size_t)s[0] * s[1] ? w_max : (size_t)s[0] * s[1];
+        o_max = o_max > (size_t)M * s[0] ? o_max : (size_t)M * s[0];
+    }
+    float *A, *W, *O;
+    CK(hipMalloc(&A, a_max * 4)); CK(hipMalloc(&W, w_max * 4)); CK(hipMalloc(&O, o_max * 4));
+    {
+        std::vector<float> h(1 << 20);
+        unsigned x = 12345;
+        for (auto& v : h) { x = x * 1664525u + 1013904223u; v = ((x >> 8) & 0xffff) / 65536.0f - 0.5f; }
+        for (size_t off = 0; off < a_max; off += h.size()) CK(hipMemcpy(A + off, h.data(), (a_max - off < h.size() ? a_max - off : h.size()) * 4, hipMemcpyHostToDevice));
+        for (size_t off = 0; off < w_max; off += h.size()) CK(hipMemcpy(W + off, h.data(), (w_max - off < h.size() ? w_max - off : h.size()) * 4, hipMemcpyHostToDevice));
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (auto& s : shapes) {
+        const int N = s[0], K = s[1];
+        GemmArgs g{};
+        g.A = A; g.lda = K; g.Wp = W; g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.epi = EPI_STORE_F32; g.out_f32 = O; g.ldo = N; g.D = N;
+        for (int i = 0; i < 2; ++i)
+            if (launch_gemm(g, PREC_F32, true, 0) != ITTS_OK) { printf("launch failed\n"); return 1; }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) launch_gemm(g, PREC_F32, true, 0);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long* d_h; unsigned long long h_h = 0;
+        CK(hipMalloc(&d_h, 8)); CK(hipMemset(d_h, 0, 8));
+        hipLaunchKernelGGL(fingerprint_kernel, dim3(2048), dim3(256), 0, 0, (const unsigned*)O, (size_t)M * N, d_h);
+        CK(hipMemcpy(&h_h, d_h, 8, hipMemcpyDeviceToHost)); CK(hipFree(d_h));
+        printf("PF_ABL=%d M=%d N=%d K=%d: %.3f ms  %.1f TFLOP/s (nominal)  out-bits %016llx\n", PF_ABL, M, N, K, ms / reps, 2.0 * M * N * K / (ms / reps * 1e-3) / 1e12, h_h);
+    }
+    return 0;
+}

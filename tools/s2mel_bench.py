@@ -37,4 +37,5 @@ gemm = tok * (D * 2 * (H * 3 * H + H * H + H * 2 * I + I * H) + (D // 2) * 2 * 2
 attn = 2 * B * D * 4 * T * T * H
 print(f"B={B} T={T} steps={steps} {prec}: {dt * 1e3:.1f} ms total, {dt / steps * 1e3:.2f} ms/step; "
       f"GEMM {gemm * steps / 1e12:.1f} TFLOP + attention {attn * steps / 1e12:.1f} TFLOP -> {(gemm + attn) * steps / dt / 1e12:.0f} TFLOP/s; "
-      f"finite={bool(torch.isfinite(y).all())} rms={float(y.pow(2).mean().sqrt()):.3f}", flush=True)
+      f"finite={bool(torch.isfinite(y).all())} rms={float(y.pow(2).mean().sqrt()):.3f} "
+      f"bits={__import__('hashlib').sha1(y.float().cpu().numpy().tobytes()).hexdigest()[:12]}", flush=True)
