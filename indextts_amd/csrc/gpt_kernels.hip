@@ -1208,8 +1208,17 @@ static int launch_gemm_prefill_e(const GemmArgs& a, hipStream_t st) {
 
 template <int VM> __device__ __forceinline__ void t2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory"); }
 
-template <int EPI, bool CONV = false>
+// F32 = true: the same schedule on v_mfma_f32_16x16x4_f32 (the s2mel f32 mode): a K tile is 32 f32 = the same 128 bytes per row and 2 KiB per
+// n-tile of packed f32 weights, so the LDS images, DMA issue and fragment offsets are byte-identical; a 16-byte fragment piece feeds 4
+// MFMAs (k-step s2, element j: k = 16 s2 + 4 kg + j), issued j-outer like gemm_prefill_kernel<.., F32 = true> -> bitwise its results.  A phase
+// is then 64 MFMAs x 32 cycles against the same 12 fragment reads and 2-4 DMA pieces: half the staged bytes per MFMA of the 128 x 128 kernel
+// (whose staging costs 8-10 % whatever the schedule, profiles/r03n).  Measured (tools/microbench/gemm_f32_ablate.hip -DUSE_T256,
+// profiles/r03n/gemm_f32_tile256.log): identical output bits, 1-3 % SLOWER than the 128 x 128 kernel at M = 312 704 (129-133 vs 131-137
+// TFLOP/s), far behind it at small M (one block per CU: tail rounds) -> not instantiated in the product; the microbench builds it.
+template <int EPI, bool CONV = false, bool F32 = false>
 __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs a) {
+    constexpr int ES = F32 ? 4 : 2;                                    // operand element size
+    constexpr int BK = 128 / ES;                                       // K tile: 128 bytes per row
     extern __shared__ __attribute__((aligned(16))) char t2_sm[];      // [2][A 32 KiB | W 32 KiB]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 2, wc = w & 3;                                 // wr = wave group = M half of the tile
@@ -1222,7 +1231,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs a) {
     const int rr = t - gq * PF_GM * n_nt;
     const int bn = rr / gm, bm = first_m + (rr - bn * gm);
     const int m0 = bm * 256, nt0 = bn * 16;
-    const int nkb = a.K >> 5, nk = a.K / PF_BK;
+    const int nkb = F32 ? a.K >> 4 : a.K >> 5, nk = a.K / BK;
     const int ntiles = (a.N + 15) >> 4;
 
     // Staging sources of this lane.  Operand halves follow the quadrant order: A half h = m-tiles {8 wr' + 4 h + 0..3, wr' = 0, 1},
@@ -1233,7 +1242,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs a) {
     int cv_t[2][2], cv_T[2][2];
     const char* cv_base[2][2];
     const char* cv_zero[2][2];
-    const int cv_kpt = CONV ? a.conv_W / PF_BK : 1;            // K tiles per tap
+    const int cv_kpt = CONV ? a.conv_W / BK : 1;               // K tiles per tap
     const int cv_left = CONV ? (a.conv_taps - 1) * a.conv_dil - ((a.conv_taps - 1) * a.conv_dil) / 2 : 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -1245,13 +1254,13 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs a) {
             const int piece = (lane & 7) ^ ((row16 >> 1) & 7);
             int m = m0 + row_t;
             m = m < a.M ? m : a.M - 1;
-            asrc[h][i] = (const char*)a.A + ((size_t)m * a.lda + piece * 8) * 2;
+            asrc[h][i] = (const char*)a.A + (size_t)m * a.lda * ES + piece * 16;
             a_dst[h][i] = chunk * 1024;
             if constexpr (CONV) {
                 const int sq = a.tok_seq[m];
                 cv_t[h][i] = a.tok_t[m];
                 cv_T[h][i] = a.seq_T[sq];
-                cv_base[h][i] = (const char*)a.A + ((size_t)a.seq_start[sq] * a.lda + piece * 8) * 2;
+                cv_base[h][i] = (const char*)a.A + (size_t)a.seq_start[sq] * a.lda * ES + piece * 16;
                 cv_zero[h][i] = (const char*)a.zero_row + piece * 16;
             }
             const int ntl = (w >> 1) * 4 + h * 2 + (w & 1);     // n-tile inside the block tile; k-block of the pair = i
@@ -1265,7 +1274,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs a) {
         if constexpr (CONV) { tap = kt / cv_kpt; rem = kt - tap * cv_kpt; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const char* ap = asrc[h][i] + (size_t)kt * (PF_BK * 2);
+            const char* ap = asrc[h][i] + (size_t)kt * 128;
             if constexpr (CONV) {
                 const int maxpad = cv_left;
                 const int Tv = cv_T[h][i] <= maxpad ? maxpad + 1 : cv_T[h][i];
@@ -1273,7 +1282,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs a) {
                 p = p < 0 ? -p : p;
                 p = p >= Tv ? 2 * (Tv - 1) - p : p;
                 const bool ok = p >= 0 && p < cv_T[h][i];
-                ap = ok ? cv_base[h][i] + ((size_t)p * a.lda + (size_t)rem * PF_BK) * 2 : cv_zero[h][i];
+                ap = ok ? cv_base[h][i] + ((size_t)p * a.lda + (size_t)rem * BK) * ES : cv_zero[h][i];
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap,
                                              (__attribute__((address_space(3))) void*)(t2_sm + buf * 65536 + a_dst[h][i]), 16, 0, 0);
@@ -1310,10 +1319,17 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs a) {
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)     \
         DST_[nt][s2] = *(const v4u*)(base + b_wave + (((H_) * 2 + nt) * 2 + s2) * 1024);
 #define T2_MMA(MH_, NH_, BF_)                                                                             \
+    if constexpr (F32) {                                                                                  \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int j = 0; j < 4; ++j)    \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)  \
+                acc[(MH_) * 4 + mt][(NH_) * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(               \
+                    __uint_as_float(af[mt][s2][j]), __uint_as_float(BF_[nt][s2][j]), acc[(MH_) * 4 + mt][(NH_) * 2 + nt], 0, 0, 0);  \
+    } else {                                                                                              \
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)     \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                  \
             acc[(MH_) * 4 + mt][(NH_) * 2 + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                \
-                __builtin_bit_cast(bf16x8_t, af[mt][s2]), __builtin_bit_cast(bf16x8_t, BF_[nt][s2]), acc[(MH_) * 4 + mt][(NH_) * 2 + nt], 0, 0, 0);
+                __builtin_bit_cast(bf16x8_t, af[mt][s2]), __builtin_bit_cast(bf16x8_t, BF_[nt][s2]), acc[(MH_) * 4 + mt][(NH_) * 2 + nt], 0, 0, 0);  \
+    }
 #define T2_PRE_MMA()                                        \
     __builtin_amdgcn_s_barrier();                           \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
@@ -1400,8 +1416,8 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(GemmArgs a) {
         if (!v_region) pf_stage_meta<EPI, 64>(a, meta, rm0, ltid);
         __syncthreads();
         if (rn0 < a.N) {
-            if (v_region) pf_store_vt<64, 128>(a, ct, rm0, rn0, ltid);
-            else pf_store_tile<EPI, 64, 128>(a, ct, meta, rm0, rn0, ltid);
+            if (v_region) pf_store_vt<64, 128, F32>(a, ct, rm0, rn0, ltid);
+            else pf_store_tile<EPI, 64, 128, F32>(a, ct, meta, rm0, rn0, ltid);
         }
         if (h == 0) __syncthreads();
     }

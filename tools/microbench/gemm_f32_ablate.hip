@@ -3,6 +3,8 @@
 //   mask bits: 1 no in-loop LDS-DMA (both stages keep K tile 0), 2 no barrier in the K loop, 4 no LDS fragment reads (register-made
 //              operands), 8 no epilogue, 16 start stagger by dispatch order (blocks 256..511 sleep half a tile), 64 start stagger by
 //              the hardware wave slot (HW_ID.WAVE_ID bit 0 of the block's first wave)
+//              128 DMA pieces hand-placed inside the MFMA stream, 256 a fifth (loader) wave stages every piece, 512 register staging
+//              (global_load -> ds_write) instead of LDS-DMA;  -DUSE_T256: the 256 x 256 tile kernel on the f32 MFMA instead
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I indextts_amd/csrc -mllvm -amdgpu-mfma-vgpr-form=1 -DPF_ABL=0 \
 //         tools/microbench/gemm_f32_ablate.hip -o /tmp/ga_0 && /tmp/ga_0 312704
 #include <hip/hip_runtime.h>
@@ -46,6 +48,14 @@ int main(int argc, char** argv) {
         const int N = s[0], K = s[1];
         GemmArgs g{};
         g.A = A; g.lda = K; g.Wp = W; g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.epi = EPI_STORE_F32; g.out_f32 = O; g.ldo = N; g.D = N;
+#ifdef USE_T256      // the 256 x 256 tile kernel on the f32 MFMA (not instantiated in the product), plain store
+        auto launch_gemm = [&](const GemmArgs& ga, int, bool, hipStream_t st) {
+            const int per = ceil_div(ceil_div(ga.M, 256) * ceil_div(ga.N, 256), 8);
+            (void)hipFuncSetAttribute((const void*)gemm_tile256_kernel<EPI_STORE_F32, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS);
+            hipLaunchKernelGGL((gemm_tile256_kernel<EPI_STORE_F32, false, true>), dim3(per * 8), dim3(512), T2_LDS, st, ga);
+            return hipGetLastError() == hipSuccess ? ITTS_OK : ITTS_ERR_HIP;
+        };
+#endif
         for (int i = 0; i < 2; ++i)
             if (launch_gemm(g, PREC_F32, true, 0) != ITTS_OK) { printf("launch failed\n"); return 1; }
         CK(hipDeviceSynchronize());
