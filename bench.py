@@ -652,6 +652,7 @@ def configs_leg(args, eng, bundle0, dev):
     PRODUCT pipeline classes' own `_synthesize` (GPT batch -> stop-token trim -> codes -> mel -> ragged BigVGAN batch -> float waveforms
     on the host), with this process's engines: untimed extras beside the headline (`stages.configs`), one warm call + one timed call
     each; EOS is suppressed, so every row decodes `gen_tokens`.  s2mel runs in the headline's precision (--s2mel-precision).
+      configs[0]  IndexTTS-1.5, one utterance x 32 text tokens, greedy, 96 codes -> latent pass -> v1 vocoder (`config0_leg`)
       configs[1]  IndexTTS-2.5, 8 utterances x 64 text tokens, reference-default 3-beam beam-sample (top-p 0.8 / top-k 30 / T 0.8), 350 codes
       configs[3]  IndexTTS-2, 16 utterances x 64 text tokens at 24 x 1280: emotion path (merge_emovec: two Conformer + Perceiver passes
                   over 15 s prompts), speaker latents, 34 conditioning tokens, 700 codes (50 / s), teacher-forced latent pass,
@@ -746,6 +747,10 @@ def configs_leg(args, eng, bundle0, dev):
                                  decode_only=dec, decode_speedup=dec["compaction_off"]["decode_ms"] / max(1e-9, dec["compaction_on"]["decode_ms"]))
     except Exception as e:
         out["ragged_b64"] = {"error": repr(e)}
+    try:                                                           # configs[0]: IndexTTS-1.5, one utterance, greedy
+        out["config0_v15_single"] = config0_leg(args, dev)
+    except Exception as e:
+        out["config0_v15_single"] = {"error": repr(e)}
     try:                                                           # configs[3]: IndexTTS-2
         cfg2 = dict(synth.GPT_V2)
         sd2 = dict(eng.gsd)
@@ -780,6 +785,60 @@ def configs_leg(args, eng, bundle0, dev):
     except Exception as e:
         out["config3_v2_emotion_b16"] = {"error": repr(e)}
     return out
+
+
+def config0_leg(args, dev):
+    """BASELINE.json configs[0] at its stated size through the product's v1 pipeline class (`indextts_amd.infer.IndexTTS.infer`): IndexTTS-1.5, one
+    utterance of 32 text tokens, a 3 s reference clip (conditioning mel (1, 100, 282) at 24 kHz / 256), greedy decode (repetition penalty 10) of 96
+    speech tokens (EOS suppressed), the teacher-forced latent pass, the v1 vocoder (ECAPA-TDNN speaker embedding of the reference mel on the
+    engine, BigVGAN on the 1280-wide GPT latent, 1024 samples per latent frame) -> 98 304 samples at 24 kHz.  Seeded random weights of that
+    architecture; the conditioning Conformer / Perceiver is a once-per-speaker prompt stage and is stood in by a fixed latent, like the speaker
+    bundle of the other lines.  The reference runs this config on its CPU path; `cpu_baseline` holds the oracle's per-token / per-frame CPU costs."""
+    import warnings
+    from indextts_amd import bigvgan, gpt, infer as infer_v1, synth
+    cfg15 = dict(synth.GPT_V15)
+    g15 = gpt.UnifiedVoiceV1(**cfg15, precision=args.precision, device=str(dev))
+    g15.load_state_dict(synth.gpt_v1_weights(cfg15, suppress_eos=True))
+    g15.post_init_gpt2_config(kv_cache=True, half=args.precision == "bf16")
+    h1 = dict(synth.BIGVGAN_V1_24K)
+    v1 = bigvgan.BigVGAN(h1, cond_dim=h1["speaker_embedding_dim"], in_channels=h1["gpt_dim"], device=dev)
+    v1.load_state_dict(synth.bigvgan_v1_weights(h1))
+    v1.to(dev)
+    g = torch.Generator().manual_seed(300)
+
+    class Tok:                                                     # token strings "t<id>": the text front end is not part of the timed path
+        def tokenize(self, text): return text.split()
+        def split_segments(self, tokens, max_text_tokens_per_segment=120, **kw):
+            n = int(max_text_tokens_per_segment)
+            return [tokens[i:i + n] for i in range(0, len(tokens), n)]
+        def convert_tokens_to_ids(self, tokens): return [int(t[1:]) for t in tokens]
+
+    class Front(infer_v1.FrontendV1):
+        tokenizer = Tok()
+        mel = (torch.randn(1, 100, 282, generator=g) * 2.0 - 4.0)
+        latent = (torch.randn(1, 32, cfg15["model_dim"], generator=g) * 0.5).to(dev)
+        def cond_mel(self, audio_prompt, truncate_seconds=None): return self.mel
+        def conditioning(self, cond_mel, cond_mel_lengths): return self.latent
+
+    tts = infer_v1.IndexTTS(cfg={"gpt": {"stop_mel_token": 8193, "stop_text_token": 1, "start_text_token": 0}, "version": 1.5}, device=str(dev),
+                            use_fp16=args.precision == "bf16", frontend=Front(), gpt=g15, bigvgan=v1)
+    text = " ".join("t%d" % int(v) for v in torch.randint(2, 12000, (32,), generator=g))
+    res = None
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                       # max_mel_tokens overflow: EOS is suppressed
+            sr, wav = tts.infer("prompt.wav", text, None, do_sample=False, num_beams=1, repetition_penalty=10.0, max_mel_tokens=96)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        audio = wav.shape[0] / float(sr)
+        res = {"ms": dt * 1e3, "audio_seconds": audio, "audio_seconds_per_sec": audio / dt, "rtf_per_stream": dt / audio, "samples": int(wav.shape[0]),
+               "sampling_rate": int(sr), "stage_seconds": {k: round(float(v), 4) for k, v in tts.last_timing.items()},
+               "batch": 1, "text_tokens": 32, "gen_tokens": 96, "cond_mel_frames": 282, "decode": "greedy, repetition_penalty 10"}
+    del tts, g15, v1
+    torch.cuda.empty_cache()
+    return res
 
 
 def alt_precision_leg(args, eng, precision, text, langs, mel, bundle, n_gen, audio_per_step, stages):

@@ -8,11 +8,14 @@ Reference mirrored: `indextts/infer_v2_5.py::IndexTTS2` (`__init__` :77-279, `in
   * all text segments of one call are decoded as ONE left-padded GPT batch and vocoded as ONE ragged BigVGAN batch
     (the reference loops segment by segment, `:749`); per-segment results are unchanged (padding invariance is a tested
     property), and `infer_batch()` extends the same to many utterances;
-  * everything that is NOT on the hot path -- audio loading, w2v-bert features, CAMPPlus, the emotion Conformer/Perceiver,
-    text normalisation + tokenizer, semantic codec, s2mel length regulator + CFM -- stays on the reference's PyTorch
-    modules, reached through a `frontend` object.  `ReferenceFrontend` builds them from the reference package + checkpoint
-    directory (needs the reference's `indextts` package, torchaudio, librosa, ... -- none exist in the build/bench
-    images, so that class is exercised only where they do); tests inject a stub with the same methods.
+  * codes -> mel (semantic-codec decode, length regulator, 25-step CFG flow matching) runs on the HIP engine too when its stages are
+    given or buildable from the frontend's state dicts (`codes_to_mel=` "auto" / "engine" / "frontend", recorded in
+    `self.codes_to_mel_mode`); "frontend" keeps that stage on the frontend's PyTorch modules;
+  * what is NOT on the engine -- audio file decoding, text normalisation + tokenizer + segment splitting, the QwenEmotion LLM -- is
+    reached through a `frontend` object.  `ReferenceFrontend` builds the reference's own modules from the reference package +
+    checkpoint directory (needs the reference's `indextts` package, torchaudio, librosa, ... -- none exist in the build/bench images,
+    so that class is exercised only where they do) and moves the prompt encoders / DSP onto the engine where their configuration
+    is the shipped one; `indextts_amd.frontend.EngineFrontend*` need no reference package; tests inject a stub with the same methods.
 There is no silent fallback: a missing frontend dependency raises at construction.
 """
 import os

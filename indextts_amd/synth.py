@@ -105,6 +105,85 @@ def bigvgan_weights(h: dict = BIGVGAN_V2_22K, seed: int = 1234, post_gain: float
     return sd
 
 
+# ---- IndexTTS-1.5 (BASELINE.json configs[0]): the same 24 x 1280 GPT-2 stack behind 32 Conformer / Perceiver latents (no language
+# embedding, no style projection; 800 mel positions), and the v1 vocoder: BigVGAN on the GPT latent (gpt_dim 1280) with 1024 samples per
+# latent frame at 24 kHz, a 512-d ECAPA-TDNN speaker embedding (100-band reference mel) added after conv_pre and every upsampler
+# (indextts/BigVGAN/models.py:139-250; checkpoints/config.yaml is not in the repository: rates as SURVEY.md section 8 config 1) ----------
+GPT_V15 = dict(layers=24, model_dim=1280, heads=20, max_text_tokens=600, max_mel_tokens=800, number_text_tokens=12000,
+               number_mel_codes=8194, start_mel_token=8192, stop_mel_token=8193, start_text_token=0, stop_text_token=1,
+               max_conditioning_inputs=1, types=1)
+BIGVGAN_V1_24K = dict(num_mels=100, upsample_rates=[4, 4, 4, 4, 2, 2], upsample_kernel_sizes=[8, 8, 4, 4, 4, 4],
+                      upsample_initial_channel=1536, resblock_kernel_sizes=[3, 7, 11],
+                      resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]], activation="snakebeta",
+                      snake_logscale=True, use_tanh_at_final=True, use_bias_at_final=True, resblock="1",
+                      sampling_rate=24000, hop_size=256, gpt_dim=1280, speaker_embedding_dim=512)
+
+
+def gpt_v1_weights(cfg: dict = GPT_V15, seed: int = 1234, suppress_eos: bool = False) -> Dict[str, torch.Tensor]:
+    """`UnifiedVoiceV1` tensors: the GPT-2 stack, heads and embeddings of `gpt_weights` without the v2.5-only host tensors."""
+    sd = gpt_weights(cfg, seed=seed, suppress_eos=suppress_eos)
+    for k in ("lang_embedding.weight", "spk_emb_proj.weight", "spk_emb_proj.bias"):
+        sd.pop(k, None)
+    return sd
+
+
+def ecapa_weights(input_size: int = 100, lin_neurons: int = 512, C: int = 512, attention_channels: int = 128, se_channels: int = 128,
+                  scale: int = 8, seed: int = 41, prefix: str = "") -> Dict[str, torch.Tensor]:
+    """ECAPA-TDNN (indextts/BigVGAN/ECAPA_TDNN.py) under the reference class's parameter names, eval-mode BatchNorm statistics included."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    kernels = (5, 3, 3, 3, 1)
+
+    def conv(p, cout, cin, k):
+        sd[prefix + p + "conv.weight"] = torch.randn(cout, cin, k, generator=g) * math.sqrt(2.0 / (cin * k))
+        sd[prefix + p + "conv.bias"] = 0.1 * torch.randn(cout, generator=g)
+
+    def bn(p, ch):
+        sd[prefix + p + "weight"] = 1 + 0.2 * torch.randn(ch, generator=g)
+        sd[prefix + p + "bias"] = 0.1 * torch.randn(ch, generator=g)
+        sd[prefix + p + "running_mean"] = 0.2 * torch.randn(ch, generator=g)
+        sd[prefix + p + "running_var"] = 0.5 + torch.rand(ch, generator=g)
+
+    def tdnn(p, cin, cout, k):
+        conv(p + "conv.", cout, cin, k)
+        bn(p + "norm.norm.", cout)
+
+    tdnn("blocks.0.", input_size, C, kernels[0])
+    for i in (1, 2, 3):
+        p = f"blocks.{i}."
+        tdnn(p + "tdnn1.", C, C, 1)
+        for j in range(scale - 1):
+            tdnn(p + f"res2net_block.blocks.{j}.", C // scale, C // scale, kernels[i])
+        tdnn(p + "tdnn2.", C, C, 1)
+        conv(p + "se_block.conv1.", se_channels, C, 1)
+        conv(p + "se_block.conv2.", C, se_channels, 1)
+    tdnn("mfa.", 3 * C, 3 * C, 1)
+    tdnn("asp.tdnn.", 9 * C, attention_channels, 1)
+    conv("asp.conv.", 3 * C, attention_channels, 1)
+    bn("asp_bn.norm.", 6 * C)
+    sd[prefix + "fc.conv.weight"] = torch.randn(lin_neurons, 6 * C, 1, generator=g) * math.sqrt(2.0 / (6 * C))
+    sd[prefix + "fc.conv.bias"] = 0.1 * torch.randn(lin_neurons, generator=g)
+    return sd
+
+
+def bigvgan_v1_weights(h: dict = BIGVGAN_V1_24K, seed: int = 1234, post_gain: float = 0.2) -> Dict[str, torch.Tensor]:
+    """v1 / v1.5 vocoder: `bigvgan_weights` on the GPT latent instead of a mel + the speaker-conditioning 1x1 convs + `speaker_encoder.*`."""
+    cond, gpt_dim = h["speaker_embedding_dim"], h["gpt_dim"]
+    sd = bigvgan_weights(dict(h, num_mels=gpt_dim), seed=seed, post_gain=post_gain)
+    g = torch.Generator().manual_seed(seed + 1)
+    c0 = h["upsample_initial_channel"]
+
+    def conv1(name, cout):
+        sd[name + ".weight"] = torch.randn(cout, cond, 1, generator=g) * (0.3 / math.sqrt(cond))
+        sd[name + ".bias"] = torch.randn(cout, generator=g) * 0.02
+
+    conv1("cond_layer", c0)
+    for i in range(len(h["upsample_rates"])):
+        conv1(f"conds.{i}", c0 // 2 ** (i + 1))
+    sd.update(ecapa_weights(input_size=h["num_mels"], lin_neurons=cond, seed=seed + 2, prefix="speaker_encoder."))
+    return sd
+
+
 # ---- s2mel flow-matching decoder (DiT + WaveNet head) at the shipped IndexTTS-2 / 2.5 widths (Seed-VC style configuration;
 # checkpoints/config.yaml is not in the repository, the widths follow backends/trt/export/export_dit_onnx.py:88-96 and the
 # module defaults: hidden 512, 13 layers, 8 heads, content 512, style 192, WaveNet 512 x 8, k = 5, dilation rate 1) ----------
