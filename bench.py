@@ -216,7 +216,7 @@ class HipEngine:
 
     def new_stage_acc(self):
         return {"codec_regulator_ms": 0.0, "cfm_ms": 0.0, "gemm_ms": 0.0, "gemm_flops": 0.0, "attention_ms": 0.0,
-                "attention_flops": 0.0, "estimator_ms": 0.0, "launches": 0}
+                "attention_flops": 0.0, "estimator_ms": 0.0, "launches": 0, "attention_launches": 0}
 
     def step(self, text, langs, mel, bundle, n_gen, record):
         """-> int16 waveforms (b, T*256) of this rank's utterances"""
@@ -269,7 +269,8 @@ class HipEngine:
                 t["attention_ms"] += pr["attention"]["ms"]
                 t["attention_flops"] += 4.0 * cfm.hidden_dim * (2 * B) * float(total[0]) ** 2 * pr["attention"]["launches"]
                 t["estimator_ms"] += pr["estimator_calls"]["ms"]
-                t["launches"] += pr["gemm"]["launches"] + pr["attention"]["launches"]
+                t["launches"] += pr["gemm"]["launches"]            # GEMM launches only: `roofline.avg_launch_ms` is per launch of THAT kernel
+                t["attention_launches"] += pr["attention"]["launches"]
         chunk = self.args.bigvgan_chunk or B
         outs = []
         for b0 in range(0, B, chunk):
@@ -874,6 +875,7 @@ def s2_stage(t, n_prof, prompt_frames, precision):
             "cfm_estimator_ms_per_step": t["estimator_ms"] / n, "cfm_gemm_ms_per_step": t["gemm_ms"] / n,
             "cfm_gemm_tflops": gemm_tf, "cfm_gemm_mfma_frac": gemm_tf / peak, "cfm_gemm_launches_per_step": t["launches"] // n,
             "cfm_attention_ms_per_step": t["attention_ms"] / n, "cfm_attention_tflops": attn_tf,
+            "cfm_attention_launches_per_step": t.get("attention_launches", 0) // n,
             "cfm_attention_mfma_frac": attn_tf / (PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
             "cfm_elementwise_ms_per_step": (t["estimator_ms"] - t["gemm_ms"] - t["attention_ms"]) / n,
             "mfma_peak_tflops": peak, "prompt_frames": prompt_frames, "euler_steps": EULER_STEPS, "cfg_rate": 0.7}
