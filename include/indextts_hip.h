@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 6
+#define ITTS_ABI_VERSION 7
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -267,6 +267,13 @@ int itts_gemm_forward(const void* A, const void* Wp, const float* bias, float* o
                       int prefill_tiles, int gelu, void* stream);
 int itts_layernorm_forward(const float* x, const float* gamma, const float* beta, const float* gamma2,
                            const float* beta2, float* out, int rows, int D, float eps, void* stream);
+/* unit-level form of the LayerNorm-fused decode GEMM (what a decode step of 1-4 rows runs instead of a LayerNorm launch + a GEMM launch;
+ * replaces GPT2Block's ln_1 -> c_attn and ln_2 -> c_fc pairs, indextts/gpt/transformers_gpt2.py:616-618,652-654, for a single new position):
+ *   x' = x + (p0 + p1) + (p2 + p3) + bias_prev  when `partial` ([4][M][K] f32 split-K partials of the previous GEMM) is given, else x' = x;
+ *   out [M][N] f32 = bf16(LayerNorm(x'; ln_gamma, ln_beta, eps)) * W (bf16-packed, precision 1) + bias;  x_out [M][K] = x' (required with
+ *   `partial`, and a different buffer than x).  M <= 4, K in {256, 512, 1280}.  Bitwise itts_layernorm_forward -> bf16 -> itts_gemm_forward. */
+int itts_gemm_ln_forward(const float* x, const float* partial, const float* bias_prev, const float* ln_gamma, const float* ln_beta, float eps,
+                         const void* Wp, const float* bias, float* out, float* x_out, int M, int N, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * s2mel flow-matching decoder (DiT estimator + classifier-free-guidance Euler solver)

@@ -43,7 +43,7 @@ class GPTConfig(C.Structure):
                 ("stop_mel_token", C.c_int32), ("ln_eps", C.c_float)]
 
 
-ABI_VERSION = 6          # include/indextts_hip.h ITTS_ABI_VERSION
+ABI_VERSION = 7          # include/indextts_hip.h ITTS_ABI_VERSION
 
 
 class GenParams(C.Structure):
@@ -146,6 +146,7 @@ SIGNATURES = {
     "itts_tok_groupnorm_mish_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "itts_gemm_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "itts_layernorm_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    "itts_gemm_ln_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "itts_fbank_frames": (C.c_int, [C.POINTER(FbankConfig), C.c_int]),
     "itts_fbank_forward": (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(FbankConfig), vp, vp, vp, vp, C.c_int, C.c_int64, vp]),
     "itts_resample_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, vp]),

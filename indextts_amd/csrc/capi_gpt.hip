@@ -307,6 +307,7 @@ static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct GptWs {
     char *kc, *vc;      // [L][nseq][H][Tmax][64] cache dtype
     float* x;           // [rows][D]
+    float* x2;          // [4][D] second residual buffer of the LayerNorm-fused decode GEMMs (1-4 rows; run_layers alternates x / x2)
     char* hbuf;         // [rows][D] act
     float* qbuf;        // [rows][D]
     char* attn;         // [rows][D] act
@@ -342,6 +343,7 @@ static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tm
     w.kc = take(w.layer_cache_bytes * c.layers);
     w.vc = take(w.layer_cache_bytes * c.layers);
     w.x = (float*)take(rows * D * 4);
+    w.x2 = (float*)take((size_t)4 * D * 4);
     w.hbuf = take(rows * D * esz);
     w.qbuf = (float*)take(rows * D * 4);
     w.attn = take(rows * D * esz);
@@ -418,26 +420,38 @@ __global__ void copy_rows_kernel(const float* __restrict__ tmp, float* __restric
 // ---- one transformer pass --------------------------------------------------------------------------------------
 // rows = nseq*S new positions (S = 1 for a decode step).  prefill: direct residual epilogues + big-tile GEMMs;
 // decode: split-K partials reduced inside the next LayerNorm kernel.
+// x_cur (optional out): the buffer that holds the residual stream after the pass (w.x, or w.x2 when the LayerNorm-fused decode GEMMs ran)
 static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bool prefill, const int* pos_ptr, const int* pad,
-                      bool* pending, hipStream_t st, bool beam = false, int seq_mul = 1, const int* seq_map = nullptr) {
+                      bool* pending, hipStream_t st, bool beam = false, int seq_mul = 1, const int* seq_map = nullptr, float** x_cur = nullptr) {
     const itts_gpt_config& c = h->cfg;
     const int D = c.model_dim, prec = c.precision, rows = nseq * S;
     int rc;
     const float* pend_bias = nullptr;   // bias of a GEMM whose partials are pending reduction
+    // Decode steps of 1-4 rows (one utterance, its beams): the two LayerNorm launches of a layer are fused into the GEMMs that consume them
+    // (gemm_decode_ln_kernel: same arithmetic, bitwise the same results; ITTS_DECODE_FUSE_LN=0 is the A/B switch).  The fused kernel's block 0
+    // writes the updated residual to the OTHER buffer (its sibling blocks still read the current one): cur / alt alternate.
+    static const bool fuse_env = [] { const char* e = getenv("ITTS_DECODE_FUSE_LN"); return !(e && atoi(e) == 0); }();
+    const bool fuse_ln = fuse_env && !prefill && S == 1 && prec == PREC_BF16 && gemm_decode_ln_ok(rows, D, EPI_QKV) && w.x2 != nullptr;
+    float *cur = w.x, *alt = w.x2;
     for (int l = 0; l < c.layers; ++l) {
         const GLayer& L = h->layers[l];
         LnArgs ln{};
-        ln.x = w.x; ln.partial = pend_bias ? w.partial : nullptr; ln.nsplit = 4; ln.bias_prev = pend_bias;
+        ln.x = cur; ln.partial = pend_bias ? w.partial : nullptr; ln.nsplit = 4; ln.bias_prev = pend_bias;
         ln.g1 = L.ln1_g; ln.b1 = L.ln1_b; ln.g2 = nullptr; ln.b2 = nullptr; ln.out = w.hbuf; ln.out_f32 = 0;
         ln.rows = rows; ln.D = D; ln.in_row_mul = 1; ln.in_row_add = 0; ln.eps = c.ln_eps;
-        if ((rc = launch_ln(ln, prec, st))) return rc;
-        pend_bias = nullptr;
+        if (!fuse_ln && (rc = launch_ln(ln, prec, st))) return rc;
 
         GemmArgs g{};
         g.A = w.hbuf; g.lda = D; g.Wp = L.w_qkv; g.bias = L.b_qkv; g.M = rows; g.N = 3 * D; g.K = D; g.nsplit = 1; g.epi = EPI_QKV;
         g.qbuf = w.qbuf; g.kcache = w.kc + w.layer_cache_bytes * l; g.vcache = w.vc + w.layer_cache_bytes * l;
         g.pos_ptr = pos_ptr; g.S = S; g.H = c.heads; g.Tmax = Tmax; g.D = D; g.seq_mul = seq_mul; g.seq_map = seq_map;
-        if ((rc = launch_gemm(g, prec, prefill, st))) return rc;
+        if (fuse_ln) {
+            g.ln_x = cur; g.ln_partial = ln.partial; g.ln_bias_prev = pend_bias; g.ln_g = L.ln1_g; g.ln_b = L.ln1_b; g.ln_eps = c.ln_eps;
+            g.ln_x_out = pend_bias ? alt : nullptr;
+            if ((rc = launch_gemm_decode_ln(g, st))) return rc;
+            if (pend_bias) { float* t = cur; cur = alt; alt = t; }
+        } else if ((rc = launch_gemm(g, prec, prefill, st))) return rc;
+        pend_bias = nullptr;
 
         AttnArgs at{};
         at.qbuf = w.qbuf; at.kcache = g.kcache; at.vcache = g.vcache; at.pad = pad; at.pos_ptr = pos_ptr;
@@ -452,14 +466,20 @@ static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bo
         if ((rc = launch_gemm(p, prec, prefill, st))) return rc;
 
         LnArgs ln2 = ln;
+        ln2.x = cur;
         ln2.partial = prefill ? nullptr : w.partial; ln2.bias_prev = prefill ? nullptr : L.b_proj;
         ln2.g1 = L.ln2_g; ln2.b1 = L.ln2_b;
-        if ((rc = launch_ln(ln2, prec, st))) return rc;
+        if (!fuse_ln && (rc = launch_ln(ln2, prec, st))) return rc;
 
         GemmArgs f{};
         f.A = w.hbuf; f.lda = D; f.Wp = L.w_fc; f.bias = L.b_fc; f.M = rows; f.N = 4 * D; f.K = D; f.nsplit = 1; f.epi = EPI_GELU_ACT;
         f.out_act = w.fc; f.ldo = 4 * D; f.D = D;
-        if ((rc = launch_gemm(f, prec, prefill, st))) return rc;
+        if (fuse_ln) {                                             // (decode: the proj GEMM left partials, so the residual moves to `alt`)
+            f.ln_x = cur; f.ln_partial = w.partial; f.ln_bias_prev = L.b_proj; f.ln_g = L.ln2_g; f.ln_b = L.ln2_b; f.ln_eps = c.ln_eps;
+            f.ln_x_out = alt;
+            if ((rc = launch_gemm_decode_ln(f, st))) return rc;
+            float* t = cur; cur = alt; alt = t;
+        } else if ((rc = launch_gemm(f, prec, prefill, st))) return rc;
 
         GemmArgs f2{};
         f2.A = w.fc; f2.lda = 4 * D; f2.Wp = L.w_fc2; f2.bias = L.b_fc2; f2.M = rows; f2.N = D; f2.K = 4 * D; f2.D = D;
@@ -468,16 +488,19 @@ static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bo
         if ((rc = launch_gemm(f2, prec, prefill, st))) return rc;
     }
     *pending = pend_bias != nullptr;   // decode: the last FC2's partials are reduced by the caller's final LayerNorm
+    if (x_cur) *x_cur = cur;
+    else if (cur != w.x) { itts_set_error("run_layers: the fused-LayerNorm path needs the caller to take x_cur"); return ITTS_ERR_STATE; }
     return ITTS_OK;
 }
 
 // final norm(s) + head: rows_out rows, input row r*mul+add
-static int run_head(itts_gpt* h, const GptWs& w, int nseq, int mul, int add, bool pending, hipStream_t st) {
+static int run_head(itts_gpt* h, const GptWs& w, int nseq, int mul, int add, bool pending, hipStream_t st, float* x = nullptr) {
     const itts_gpt_config& c = h->cfg;
     const int D = c.model_dim, prec = c.precision;
     int rc;
     LnArgs ln{};
-    ln.x = w.x; ln.partial = pending ? w.partial : nullptr; ln.nsplit = 4; ln.bias_prev = pending ? h->layers.back().b_fc2 : nullptr;
+    ln.x = x ? x : w.x;                  // (the residual stream: w.x2 after a decode pass on the LayerNorm-fused GEMMs)
+    ln.partial = pending ? w.partial : nullptr; ln.nsplit = 4; ln.bias_prev = pending ? h->layers.back().b_fc2 : nullptr;
     ln.g1 = h->lnf_g; ln.b1 = h->lnf_b; ln.g2 = h->fn_g; ln.b2 = h->fn_b; ln.out = w.hlast; ln.out_f32 = 0;
     ln.rows = nseq; ln.D = D; ln.in_row_mul = mul; ln.in_row_add = add; ln.eps = c.ln_eps;
     if ((rc = launch_ln(ln, prec, st))) return rc;
@@ -510,9 +533,10 @@ static SampleArgs make_sample(itts_gpt* h, const GptWs& w, const itts_gen_params
 static int decode_step(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, int rows, int n_utts, bool mapped, int Tmax, long long* tokens,
                        const double* uniforms, hipStream_t st) {
     bool pending = false;
-    int rc = run_layers(h, w, rows, 1, Tmax, false, w.state + 1, w.pad, &pending, st, false, 1, mapped ? w.slot_map : nullptr);
+    float* xc = w.x;
+    int rc = run_layers(h, w, rows, 1, Tmax, false, w.state + 1, w.pad, &pending, st, false, 1, mapped ? w.slot_map : nullptr, &xc);
     if (rc) return rc;
-    if ((rc = run_head(h, w, rows, 1, 0, pending, st))) return rc;
+    if ((rc = run_head(h, w, rows, 1, 0, pending, st, xc))) return rc;
     SampleArgs s = make_sample(h, w, gp, rows, tokens, uniforms, n_utts, mapped);
     s.adv_state = w.state;                      // the sample kernel's last block advances step / pos
     return launch_sample(s, st);
@@ -754,9 +778,10 @@ static BeamArgs make_beam(itts_gpt* h, const GptWs& w, const itts_gen_params& gp
 
 static int decode_step_beam(itts_gpt* h, const GptWs& w, const BeamArgs& ba, int nseq, int Tmax, hipStream_t st) {
     bool pending = false;
-    int rc = run_layers(h, w, nseq, 1, Tmax, false, w.state + 1, w.pad, &pending, st, true);
+    float* xc = w.x;
+    int rc = run_layers(h, w, nseq, 1, Tmax, false, w.state + 1, w.pad, &pending, st, true, 1, nullptr, &xc);
     if (rc) return rc;
-    if ((rc = run_head(h, w, nseq, 1, 0, pending, st))) return rc;
+    if ((rc = run_head(h, w, nseq, 1, 0, pending, st, xc))) return rc;
     if ((rc = launch_beam_step(ba, st))) return rc;
     BeamArgs bb = ba;
     bb.adv_state = w.state;                     // the apply kernel's last block advances step / pos
@@ -979,6 +1004,17 @@ extern "C" int itts_gemm_forward(const void* A, const void* Wp, const float* bia
     g.epi = EPI_STORE_F32; g.out_f32 = out; g.ldo = N;
     (void)gelu;
     return launch_gemm(g, precision, prefill_tiles != 0, (hipStream_t)stream);
+}
+
+extern "C" int itts_gemm_ln_forward(const float* x, const float* partial, const float* bias_prev, const float* ln_gamma, const float* ln_beta,
+                                    float eps, const void* Wp, const float* bias, float* out, float* x_out, int M, int N, int K, void* stream) {
+    if (!x || !ln_gamma || !ln_beta || !Wp || !out) { itts_set_error("gemm_ln_forward: null pointer"); return ITTS_ERR_ARG; }
+    if (!gemm_decode_ln_ok(M, K, EPI_STORE_F32)) { itts_set_error("gemm_ln_forward: M = %d (1..4), K = %d (256, 512, 1280) unsupported", M, K); return ITTS_ERR_ARG; }
+    GemmArgs g{};
+    g.Wp = Wp; g.bias = bias; g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.D = N;
+    g.epi = EPI_STORE_F32; g.out_f32 = out; g.ldo = N;
+    g.ln_x = x; g.ln_partial = partial; g.ln_bias_prev = bias_prev; g.ln_g = ln_gamma; g.ln_b = ln_beta; g.ln_eps = eps; g.ln_x_out = x_out;
+    return launch_gemm_decode_ln(g, (hipStream_t)stream);
 }
 
 extern "C" int itts_layernorm_forward(const float* x, const float* gamma, const float* beta, const float* gamma2,

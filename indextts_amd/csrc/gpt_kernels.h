@@ -44,6 +44,11 @@ struct GemmArgs {
     const int* pos_ptr; int S, H, Tmax, D;
     int kb_slice;                    // filled by the decode-GEMM launcher: 32-wide k-blocks per K slice
     int dma_rot;                     // per-block rotation of the slab DMA issue order (ITTS_DECODE_ROT=0 turns it off: A/B switch)
+    // LayerNorm fused into a decode GEMM's operand staging (gemm_decode_ln_kernel: at most 4 rows, K == model_dim, bf16): when ln_x is set the
+    // A operand is LayerNorm(ln_x [+ the 4 split-K partials ln_partial + ln_bias_prev]) computed by every block (one wave per row, ln_kernel's
+    // arithmetic) straight into the LDS slab; block 0 also stores the updated residual rows to ln_x_out (a DIFFERENT buffer: the other
+    // blocks still read ln_x).  A / lda are unused then.
+    const float* ln_x; float* ln_x_out; const float* ln_partial; const float* ln_bias_prev; const float* ln_g; const float* ln_b; float ln_eps;
     // s2mel epilogues (packed token rows): sequence / frame of a row, valid frames per sequence, RoPE table [t][32][2],
     // per-step conditioning vector (EPI_GATE), second f32 output (EPI_WN_RS) with its overwrite / last-layer switches
     const int* tok_seq; const int* tok_t; const int* seq_len; const float* rope; const float* gvec;
@@ -61,6 +66,8 @@ struct GemmArgs {
                                      // ragged batch: finished rows leave the running batch, the survivors keep their cache rows)
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);
+bool gemm_decode_ln_ok(int M, int K, int epi);                 // shapes of the LayerNorm-fused decode GEMM (bf16, 1-4 rows)
+int launch_gemm_decode_ln(const GemmArgs& a, hipStream_t st);  // A = LayerNorm(ln_x [+ ln_partial + ln_bias_prev]) built inside the kernel
 int gemm_tile_occupancy(int prec, int* blocks);      // diagnostics: predicted resident blocks per CU of the 128 x 128 tile kernel
 
 // ---- attention over the KV cache ------------------------------------------------------------------------------

@@ -31,17 +31,18 @@ typedef unsigned int v4u __attribute__((ext_vector_type(4)));   // native vector
 //   lane holds elements 4*lane + 256*i + {0..3}, i < NV = D/256.
 enum { LN_PARTIAL = 1, LN_BIAS = 2, LN_SECOND = 4 };
 
-template <int NV, bool OUT_BF16, int FLAGS>
-__global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = blockIdx.x * (int)(blockDim.x >> 6) + w;
-    if (r >= a.rows) return;
-    const int D = a.D;
-    const size_t in_r = (size_t)r * a.in_row_mul + a.in_row_add;
-    float* xr = a.x + in_r * D;
-    f32x4 v[NV], p0[NV], p1[NV], p2[NV], p3[NV], bp[NV], g1[NV], b1[NV], g2[NV], b2[NV];
-    const size_t ps = (size_t)a.rows * D;
-    const float* pp = a.partial + (size_t)r * D;
+// One row by one wave: loads, split-K reduce / bias, (optional) residual write-back to `xw`, one or two normalisations; leaves the result in v.
+// Shared by ln_kernel and the LayerNorm-fused decode GEMM (gemm_decode_ln_kernel) so both produce the same bits.
+template <int NV, int FLAGS>
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, float* __restrict__ xw, const float* __restrict__ pp, size_t ps,
+                                       const float* __restrict__ bias_prev, const float* __restrict__ ga1, const float* __restrict__ be1,
+                                       const float* __restrict__ ga2, const float* __restrict__ be2, int D, float eps, int lane, f32x4 (&v)[NV]) {
+    // Contraction is spelled out (hipcc's default, fp-contract=fast, lets the backend fuse a * b + c or not depending on the surrounding
+    // code: the same source gave 23 FMAs inside ln_kernel and 72 inside the fused GEMM, i.e. last-bit differences between the two).  The
+    // forms below are the ones ln_kernel compiled to before they were pinned: squares as products then sequential adds, fma for
+    // sum * (1 / D) + eps and for t * gamma + beta.
+#pragma clang fp contract(off)
+    f32x4 p0[NV], p1[NV], p2[NV], p3[NV], bp[NV], g1[NV], b1[NV], g2[NV], b2[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int e = 4 * lane + 256 * i;
@@ -50,10 +51,10 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
             p0[i] = *(const f32x4*)(pp + e); p1[i] = *(const f32x4*)(pp + ps + e);
             p2[i] = *(const f32x4*)(pp + 2 * ps + e); p3[i] = *(const f32x4*)(pp + 3 * ps + e);
         }
-        if constexpr (FLAGS & LN_BIAS) bp[i] = *(const f32x4*)(a.bias_prev + e);
-        g1[i] = *(const f32x4*)(a.g1 + e);
-        b1[i] = *(const f32x4*)(a.b1 + e);
-        if constexpr (FLAGS & LN_SECOND) { g2[i] = *(const f32x4*)(a.g2 + e); b2[i] = *(const f32x4*)(a.b2 + e); }
+        if constexpr (FLAGS & LN_BIAS) bp[i] = *(const f32x4*)(bias_prev + e);
+        g1[i] = *(const f32x4*)(ga1 + e);
+        b1[i] = *(const f32x4*)(be1 + e);
+        if constexpr (FLAGS & LN_SECOND) { g2[i] = *(const f32x4*)(ga2 + e); b2[i] = *(const f32x4*)(be2 + e); }
     }
     __builtin_amdgcn_sched_barrier(0);          // keep hipcc from sinking the affine loads below the reductions
     if constexpr (FLAGS & LN_PARTIAL) {
@@ -69,8 +70,10 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
             for (int j = 0; j < 4; ++j) v[i][j] += bp[i][j];
     }
     if constexpr (FLAGS & (LN_PARTIAL | LN_BIAS)) {
+        if (xw) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) *(f32x4*)(xr + 4 * lane + 256 * i) = v[i];
+            for (int i = 0; i < NV; ++i) *(f32x4*)(xw + 4 * lane + 256 * i) = v[i];
+        }
     }
     const float invD = 1.0f / (float)D;
     auto normalise = [&](const f32x4 (&g)[NV], const f32x4 (&bb)[NV]) {
@@ -83,14 +86,26 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
         for (int i = 0; i < NV; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) * invD + a.eps);
+        const float rstd = 1.0f / sqrtf(__builtin_fmaf(wave_sum(q), invD, eps));
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mean) * rstd * g[i][j] + bb[i][j];
+            for (int j = 0; j < 4; ++j) v[i][j] = __builtin_fmaf((v[i][j] - mean) * rstd, g[i][j], bb[i][j]);
     };
     normalise(g1, b1);
     if constexpr (FLAGS & LN_SECOND) normalise(g2, b2);
+}
+
+template <int NV, bool OUT_BF16, int FLAGS>
+__global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = blockIdx.x * (int)(blockDim.x >> 6) + w;
+    if (r >= a.rows) return;
+    const int D = a.D;
+    const size_t in_r = (size_t)r * a.in_row_mul + a.in_row_add;
+    float* xr = a.x + in_r * D;
+    f32x4 v[NV];
+    ln_row<NV, FLAGS>(xr, xr, a.partial + (size_t)r * D, (size_t)a.rows * D, a.bias_prev, a.g1, a.b1, a.g2, a.b2, D, a.eps, lane, v);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const size_t o = (size_t)r * D + 4 * lane + 256 * i;
@@ -2196,6 +2211,130 @@ static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
         case 2: return launch_gemm_decode64_nt<2, 4>(a, ntiles, lds, st);
         default: return launch_gemm_decode64_nt<4, 4>(a, ntiles, lds, st);
     }
+}
+
+// ================================================================================================================
+// Decode GEMM with the LayerNorm in front of it fused into the operand staging, for at most 4 rows (one utterance, its beams, a batch of
+// 4): at that size a token step is a chain of 172 launches of 4-6 us each and the two LayerNorm launches of a layer are a quarter of it.
+//   Same decomposition as gemm_decode64_kernel<1, 1> (one 16-column n-tile per block, K <= 1280 split over the 4 waves by k-block, LDS
+//   reduce, decode_epilogue), but the activation slab is not DMA'd from a LayerNorm kernel's output: wave w < M computes row w itself with
+//   ln_row (ln_kernel's arithmetic: split-K reduce of the previous GEMM's 4 partials + its bias + residual, then the normalisation) and
+//   writes the bf16 row into the slab image (row r of k-pair kp: chunk 2 kp, 128-byte row r & 7, 16-byte pieces XOR-permuted by (r >> 1) & 7
+//   -- what the DMA of gemm_decode64_kernel produces), while its weight fragments are in flight.  Every block repeats the 1-4 rows of
+//   LayerNorm (<= 30 KB of L2 reads per row); block 0 stores the updated residual to ln_x_out, a different buffer than ln_x (the other blocks
+//   are still reading ln_x), and the host alternates the two.  Rows M..15 of the MFMA tile hold whatever the LDS held: MFMA rows are
+//   independent and their outputs are never stored.  Same bf16 operands, same MFMAs in the same order -> bitwise the unfused path.
+// ================================================================================================================
+template <int NV, int EPI, int FLAGS>
+__global__ __launch_bounds__(256) void gemm_decode_ln_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];     // [kp][2 row groups][1 KiB]; reused for the reduction
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int NKL = NV * 8;                                    // 32-wide k-blocks of the row (K = 256 NV)
+    const int ntiles = (a.N + 15) >> 4;
+    const int nt0 = blockIdx.x;
+    float bias_epi = 0.f;
+    int pos_epi = 0;
+    if (a.bias) {
+        int nb = nt0 * 16 + (lane & 15);
+        nb = nb < a.N ? nb : a.N - 1;
+        bias_epi = a.bias[nb];
+    }
+    if constexpr (EPI == EPI_QKV) pos_epi = *a.pos_ptr;
+    // weight fragments of this wave's k-blocks (w, w + 4, ...): straight to registers, all issued now
+    constexpr int NI = (NKL + 3) / 4;
+    v4u bq[NI];
+    {
+        const int t = nt0 < ntiles ? nt0 : ntiles - 1;
+        const v4u* wp = (const v4u*)a.Wp + (size_t)t * NKL * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int kl = w + 4 * i;
+            const bool ok = kl < NKL;
+            v4u v = *(wp + (size_t)(ok ? kl : 0) * 64);
+            if (!ok) v = v4u{0u, 0u, 0u, 0u};
+            bq[i] = v;
+        }
+    }
+    if (w < a.M) {                                                 // wave-uniform: this wave's row
+        const int D = a.K;
+        f32x4 v[NV];
+        ln_row<NV, FLAGS>(a.ln_x + (size_t)w * D, (blockIdx.x == 0) ? a.ln_x_out + (size_t)w * D : (float*)nullptr,
+                          a.ln_partial + (size_t)w * D, (size_t)a.M * D, a.ln_bias_prev, a.ln_g, a.ln_b, nullptr, nullptr, D, a.ln_eps, lane, v);
+        char* row = dsm + (w & 7) * 128 + ((((lane & 15) >> 1) ^ ((w >> 1) & 7)) << 4) + (lane & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {                             // elements 4 lane + 256 i ..+3 = k-pair (lane >> 4) + 4 i, piece (lane & 15) >> 1
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v[i][0]) | ((uint32_t)f32_to_bf16(v[i][1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v[i][2]) | ((uint32_t)f32_to_bf16(v[i][3]) << 16);
+            *(uint2*)(row + ((lane >> 4) + 4 * i) * 2048) = pk;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int row16 = lane & 15, kg = lane >> 4;
+    const int a_lane = (row16 >> 3) * 1024 + (row16 & 7) * 128;
+    const int sw = (row16 >> 1) & 7;
+    auto lds_frag = [&](int i) -> v4u {
+        int kl = w + 4 * i;
+        kl = kl < NKL ? kl : NKL - 1;
+        const int kp = kl >> 1, pos = (((kl & 1) << 2) + kg) ^ sw;
+        return *(const v4u*)(dsm + kp * 2048 + a_lane + pos * 16);
+    };
+    v4u af_cur = lds_frag(0), af_nxt = af_cur;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (i + 1 < NI) af_nxt = lds_frag(i + 1);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af_cur), __builtin_bit_cast(bf16x8_t, bq[i]), acc, 0, 0, 0);
+        af_cur = af_nxt;
+    }
+    __syncthreads();                                               // every wave is done with the slab: reuse it
+    f32x4* r4 = (f32x4*)dsm;
+    r4[(size_t)w * 64 + lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+        f32x4 sacc = r4[lane];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            const f32x4 o = r4[(size_t)ww * 64 + lane];
+            sacc[0] += o[0]; sacc[1] += o[1]; sacc[2] += o[2]; sacc[3] += o[3];
+        }
+        if (nt0 < ntiles) decode_epilogue<EPI>(a, 0, nt0 * 16, lane, 0, sacc, bias_epi, pos_epi);
+    }
+}
+
+template <int NV, int EPI>
+static int launch_gemm_decode_ln_e(const GemmArgs& a, hipStream_t st) {
+    const int ntiles = (a.N + 15) / 16;
+    size_t lds = (size_t)NV * 4 * 2048;                            // NV * 8 k-blocks = NV * 4 k-pairs of 2 KiB (two 8-row groups)
+    if (lds < 4096) lds = 4096;                                    // reduction scratch: 4 waves x 1 KiB
+    if (a.ln_partial || a.ln_bias_prev) {
+        if (!a.ln_partial || !a.ln_bias_prev || !a.ln_x_out || a.ln_x_out == a.ln_x) { itts_set_error("gemm_decode_ln: partials need a bias and a separate ln_x_out"); return ITTS_ERR_ARG; }
+        hipLaunchKernelGGL((gemm_decode_ln_kernel<NV, EPI, LN_PARTIAL | LN_BIAS>), dim3(ntiles), dim3(256), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((gemm_decode_ln_kernel<NV, EPI, 0>), dim3(ntiles), dim3(256), lds, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// shapes the fused kernel takes: bf16, 1-4 rows, K = model_dim in {256, 512, 1280}, one K slice, QKV / GELU epilogue (plain store: the unit op)
+bool gemm_decode_ln_ok(int M, int K, int epi) {
+    return M >= 1 && M <= 4 && (K == 256 || K == 512 || K == 1280) && (epi == EPI_QKV || epi == EPI_GELU_ACT || epi == EPI_STORE_F32);
+}
+
+int launch_gemm_decode_ln(const GemmArgs& a, hipStream_t st) {
+    if (!gemm_decode_ln_ok(a.M, a.K, a.epi) || a.nsplit != 1 || !a.ln_x || !a.ln_g || !a.ln_b) {
+        itts_set_error("gemm_decode_ln: unsupported call (M=%d K=%d epi=%d nsplit=%d)", a.M, a.K, a.epi, a.nsplit);
+        return ITTS_ERR_ARG;
+    }
+#define LN_GEMM_CASE(NV_)                                                                                        \
+    case NV_: return a.epi == EPI_QKV ? launch_gemm_decode_ln_e<NV_, EPI_QKV>(a, st) : a.epi == EPI_GELU_ACT ? launch_gemm_decode_ln_e<NV_, EPI_GELU_ACT>(a, st) \
+                                                                                                               : launch_gemm_decode_ln_e<NV_, EPI_STORE_F32>(a, st);
+    switch (a.K / 256) { LN_GEMM_CASE(1) LN_GEMM_CASE(2) LN_GEMM_CASE(5) default: break; }
+#undef LN_GEMM_CASE
+    return ITTS_ERR_ARG;
 }
 
 template <bool BF16, int MT, int NT, bool KSPLIT>

@@ -725,6 +725,18 @@ def gemm(a: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], 
         return out
 
 
+def gemm_ln(x, g, b, w_packed, bias, N: int, partial=None, bias_prev=None, eps=1e-5):
+    """The LayerNorm-fused decode GEMM as a unit op (`itts_gemm_ln_forward`): 1-4 rows, bf16-packed weights.  Returns (out (M, N) f32, x' (M, K))."""
+    M, K = x.shape
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    x_out = torch.empty_like(x) if partial is not None else None
+    with _lib.on_device(x.device):
+        _lib.check(_lib.lib().itts_gemm_ln_forward(_lib.ptr(x.contiguous()), _lib.ptr(partial), _lib.ptr(bias_prev), _lib.ptr(g), _lib.ptr(b),
+                                                   float(eps), _lib.ptr(w_packed), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(x_out), M, N, K,
+                                                   _lib.stream_ptr(x.device)), "itts_gemm_ln_forward")
+    return out, x_out
+
+
 def layernorm(x, g, b, g2=None, b2=None, eps=1e-5):
     rows, D = x.shape
     out = torch.empty_like(x)

@@ -71,6 +71,49 @@ def test_layernorm_vs_torch():
         assert (y2 - ref2).abs().max() < 5e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(1, 1280, 3840), (3, 1280, 5120), (4, 1280, 8194), (2, 256, 96), (4, 512, 1536)])
+@pytest.mark.parametrize("pending", [False, True])
+def test_layernorm_fused_decode_gemm_is_bitwise_the_two_launches(M, K, N, pending):
+    """gemm_decode_ln_kernel (decode steps of 1-4 rows: LayerNorm computed inside the consuming GEMM's operand staging, with the split-K reduce of
+    the previous GEMM's partials + bias + residual) against the two launches it replaces -- itts_layernorm_forward -> bf16 -> itts_gemm_forward
+    (the 16-row slab kernel): output BITWISE equal, and so is the updated residual row it writes back."""
+    from indextts_amd import gpt
+    g = torch.Generator().manual_seed(7 * M + K + N + int(pending))
+    x = (torch.randn(M, K, generator=g) * 2 + 0.3).to(DEV)
+    g1, b1 = (1 + 0.1 * torch.randn(K, generator=g)).to(DEV), (0.1 * torch.randn(K, generator=g)).to(DEV)
+    w = torch.randn(K, N, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g).to(DEV)
+    wp = gpt.pack_gemm_weight(w, 1).to(DEV)
+    partial = bias_prev = None
+    xr = x
+    if pending:
+        partial = (torch.randn(4, M, K, generator=g) * 0.5).to(DEV)
+        bias_prev = (0.1 * torch.randn(K, generator=g)).to(DEV)
+        xr = (x + ((partial[0] + partial[1]) + (partial[2] + partial[3]))) + bias_prev          # ln_row's order of additions (exact IEEE adds)
+    ref = gpt.gemm(gpt.layernorm(xr, g1, b1).bfloat16(), wp, bias, N, 1)
+    out, x_out = gpt.gemm_ln(x, g1, b1, wp, bias, N, partial=partial, bias_prev=bias_prev)
+    assert torch.equal(out, ref), float((out - ref).abs().max())
+    if pending:
+        assert torch.equal(x_out, xr)
+    assert float(out.abs().mean()) > 1e-2
+
+
+def test_fused_layernorm_decode_steps_equal_unfused(tmp_path):
+    """Whole decode loops of 1, 3 and 4 rows (greedy, sampled, 3-beam beam-sample of one utterance) with the LayerNorm-fused GEMMs (default) and
+    without (ITTS_DECODE_FUSE_LN=0): identical ids -- at the production width (K = 1280: NV = 5) and at 256."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuse_ln_probe.py")
+    for big in ("1", "0"):
+        outs = []
+        for v in ("0", "1"):
+            env = dict(os.environ, ITTS_DECODE_FUSE_LN=v, PROBE_BIG=big)
+            r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+        assert outs[0] == outs[1], outs
+
+
 def run_case(m, z, cfg, sd):
     g = z["gen"]
     kw = dict(do_sample=bool(g[0]), num_beams=int(g[1]), top_p=float(g[2]), top_k=int(g[3]), temperature=float(g[4]),
