@@ -107,6 +107,7 @@ struct SampleArgs {
     // compacted decode batch: dense row b is utterance row_slot[b] -- its seen-set, finished flag, token row, uniform / RNG stream and
     // token limit are indexed by the utterance, logits and x_next by the dense row.  uniforms_stride = utterances of the call.
     const int* row_slot; int uniforms_stride;
+    int radix_select;        // filled by the launcher (ITTS_SAMPLE_RADIX=1): the 4-pass radix-select top-k instead of the ballot bisection (A/B switch)
     const int* row_limit;    // [utterances] or null: per-utterance cap on generated tokens (a batch merges requests with their own
                              // max_mel_tokens): from token index row_limit[u] on, the row emits the stop token
 };
@@ -140,6 +141,7 @@ struct BeamArgs {
     const float* mel_emb; const float* mel_pos; float* x_next; int D; int pos_offset; int n_mel_pos;
     int* adv_state;               // as SampleArgs::adv_state, honoured by the apply kernel (the step's last launch)
     const unsigned long long* seed_ptr;   // as SampleArgs::seed_ptr
+    int radix_select;             // as SampleArgs::radix_select (filled by the launcher)
 };
 int launch_beam_step(const BeamArgs& a, hipStream_t st);
 int launch_beam_apply(const BeamArgs& a, hipStream_t st);

@@ -2584,6 +2584,60 @@ __device__ __forceinline__ int pick_bucket_wave(const unsigned* hist, unsigned k
     return b;
 }
 
+// k-th largest order-preserving key of a score row in LDS (k <= 64, V <= 256 * TOPK_KPT), by a block of 256 threads, without atomics or a
+// serial bucket scan.  Measured against the 4-pass radix select (profiles/r03x/sample_topk.log, identical ids): par in sample_kernel (0.934 vs
+// 0.934 ms per token at 1 row, 1.51 vs 1.50 at 64 rows: the selection is not what that kernel's 48 us are made of), -2 % per token in the beam
+// kernel (1.113 -> 1.088 at 1 x 3 rows, 2.40 -> 2.355 at 64 x 3), whose radix passes each ended in one thread scanning 256 buckets -> default there.
+//   level 1: every wave bisects the 32 key bits over the keys its own lanes hold in registers -- count(key >= candidate) is one ballot + popcount
+//            per register key, no cross-wave traffic -- to the k-th largest of ITS keys, T_w.  The global top-k lies inside the union of the waves'
+//            local top-k sets: the wave emits its keys > T_w (fewer than k) and pads with copies of T_w to exactly k entries.
+//   level 2: wave 0 bisects the <= 4 k emitted keys the same way -> the global k-th largest key.  Two barriers in all.
+// A lane past the row end holds key 0 (below every real key; candidates are >= 1).
+#define TOPK_KPT 33
+__device__ __forceinline__ uint32_t topk_kth_key(const float* sl, int V, int k, int tid, uint32_t* cand /* LDS [4][64] */, uint32_t* result /* LDS [1] */) {
+    const int lane = tid & 63, w = tid >> 6;
+    uint32_t key[TOPK_KPT];
+#pragma unroll
+    for (int j = 0; j < TOPK_KPT; ++j) {
+        const int i = tid + 256 * j;
+        key[j] = i < V ? f2key(sl[i]) : 0u;
+    }
+    uint32_t T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t c = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < TOPK_KPT; ++j) cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[j] >= c));
+        if (cnt >= k) T = c;                                          // wave-uniform
+    }
+    {   // emit: keys > T (fewer than k of them), then copies of T up to k entries
+        int base = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int j = 0; j < TOPK_KPT; ++j) {
+            const bool p = key[j] > T;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+            if (p) { const int o = base + __builtin_popcountll(m & lt); if (o < 64) cand[w * 64 + o] = key[j]; }
+            base += __builtin_popcountll(m);
+        }
+        if (lane >= base && lane < 64) cand[w * 64 + lane] = lane < k ? T : 0u;      // pad to k with T, the rest of the 64 slots with 0
+    }
+    __syncthreads();
+    if (w == 0) {
+        const uint32_t c0 = cand[lane], c1 = cand[64 + lane], c2 = cand[128 + lane], c3 = cand[192 + lane];
+        uint32_t G = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t c = G | (1u << bit);
+            const int cnt = __builtin_popcountll(__builtin_amdgcn_ballot_w64(c0 >= c)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c1 >= c)) +
+                            __builtin_popcountll(__builtin_amdgcn_ballot_w64(c2 >= c)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c3 >= c));
+            if (cnt >= k) G = c;
+        }
+        if (lane == 0) *result = G;
+    }
+    __syncthreads();
+    return *result;
+}
+
 // ---- TypicalLogitsWarper (indextts/utils/typical_sampling.py:9-30; appended after the repetition penalty by
 // UnifiedVoice.inference_speech, model_v2.py:794-799) on one LDS score row `sl[V]`; `q[V]` is scratch.
 //   s_i = | -log_softmax(x)_i - H |,  tokens ordered by ascending s, kept while the softmax mass of the tokens before
@@ -2748,6 +2802,11 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         // ---- top-k threshold by 4-pass radix select on order-preserving keys ----
         const int k = max(a.top_k, a.min_keep) < V ? max(a.top_k, a.min_keep) : V;
         if (tid == 0) { s_prefix = 0; s_mask = 0; s_kk = (unsigned)k; s_count = 0; }
+        uint32_t kth;
+        if (V <= 256 * TOPK_KPT && k <= 64 && !a.radix_select) {     // ballot bisection (topk_kth_key); the radix select stays as the A/B path
+            __syncthreads();                                           // s_count = 0 visible before the survivors are counted below
+            kth = topk_kth_key(sl, V, k, tid, hist, &s_prefix);
+        } else {
         for (int pass = 3; pass >= 0; --pass) {
             hist[tid] = 0;
             __syncthreads();
@@ -2769,7 +2828,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             }
             __syncthreads();
         }
-        const uint32_t kth = s_prefix;
+        kth = s_prefix;
+        }
         for (int i = tid; i < V; i += 256) {
             if (f2key(sl[i]) >= kth && sl[i] > -INFINITY) {   // masked (-inf) entries carry no probability
                 const unsigned slot = atomicAdd(&s_count, 1u);
@@ -2892,7 +2952,12 @@ int launch_sample(const SampleArgs& a, hipStream_t st) {
     const size_t lds = (size_t)a.V * sizeof(float) * (a.typical_mass > 0.f ? 2 : 1);
     static size_t granted = 0;
     if (int rc = ensure_dyn_lds(sample_kernel, lds, &granted, "sampling")) return rc;
-    hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), lds, st, a);
+    // top-k threshold: the radix select here (par with the ballot bisection at 1 row, 1 % ahead at 64 rows), the bisection in the beam
+    // kernel (-2 %: its radix pass ended in a serial 256-bucket scan); ITTS_SAMPLE_RADIX=0 / 1 forces one of them in both (profiles/r03x)
+    static const int radix = [] { const char* e = getenv("ITTS_SAMPLE_RADIX"); return e ? atoi(e) : 1; }();
+    SampleArgs a2 = a;
+    a2.radix_select = radix;
+    hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), lds, st, a2);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
@@ -2974,7 +3039,11 @@ __global__ __launch_bounds__(256) void beam_rows_kernel(BeamArgs a) {
                 __syncthreads();
             }
         }
-        // top-ksel threshold (radix select)
+        // top-ksel threshold: ballot bisection (topk_kth_key), or the radix select (A/B path, and for rows it does not cover)
+        uint32_t kth;
+        if (V <= 256 * TOPK_KPT && ksel <= 64 && !a.radix_select) {
+            kth = topk_kth_key(sl, V, ksel, tid, hist, &s_prefix);
+        } else {
         for (int pass = 3; pass >= 0; --pass) {
             hist[tid] = 0;
             __syncthreads();
@@ -2998,7 +3067,8 @@ __global__ __launch_bounds__(256) void beam_rows_kernel(BeamArgs a) {
             }
             __syncthreads();
         }
-        const uint32_t kth = s_prefix;
+        kth = s_prefix;
+        }
         for (int i = tid; i < V; i += 256) {
             if (f2key(sl[i]) >= kth && sl[i] > -INFINITY) {
                 const unsigned slot = atomicAdd(&s_count, 1u);
@@ -3223,7 +3293,10 @@ int launch_beam_step(const BeamArgs& a, hipStream_t st) {
     const size_t lds = (size_t)a.V * sizeof(float) * (a.typical_mass > 0.f ? 2 : 1);
     static size_t granted = 0;
     if (int rc = ensure_dyn_lds(beam_rows_kernel, lds, &granted, "beam search")) return rc;
-    hipLaunchKernelGGL(beam_rows_kernel, dim3(a.B * a.nb), dim3(256), lds, st, a);
+    static const int radix = [] { const char* e = getenv("ITTS_SAMPLE_RADIX"); return e ? atoi(e) : 0; }();
+    BeamArgs a2 = a;
+    a2.radix_select = radix;
+    hipLaunchKernelGGL(beam_rows_kernel, dim3(a.B * a.nb), dim3(256), lds, st, a2);
     hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;

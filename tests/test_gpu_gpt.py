@@ -114,6 +114,22 @@ def test_fused_layernorm_decode_steps_equal_unfused(tmp_path):
         assert outs[0] == outs[1], outs
 
 
+def test_topk_bisection_equals_radix_select():
+    """The top-k threshold of the sampling / beam kernels by ballot bisection (default) and by the 4-pass radix select (ITTS_SAMPLE_RADIX=1): the
+    same k-th key, hence identical ids over sampled and 3-beam beam-sample decode loops (both paths are also gated against the oracle's and the
+    reference's ids by the golden tests, which run the default)."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuse_ln_probe.py")
+    outs = []
+    for v in ("0", "1"):
+        env = dict(os.environ, ITTS_SAMPLE_RADIX=v, PROBE_BIG="0")
+        r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert outs[0] == outs[1], outs
+
+
 def run_case(m, z, cfg, sd):
     g = z["gen"]
     kw = dict(do_sample=bool(g[0]), num_beams=int(g[1]), top_p=float(g[2]), top_k=int(g[3]), temperature=float(g[4]),
