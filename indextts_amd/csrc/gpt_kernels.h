@@ -108,6 +108,7 @@ struct SampleArgs {
     // token limit are indexed by the utterance, logits and x_next by the dense row.  uniforms_stride = utterances of the call.
     const int* row_slot; int uniforms_stride;
     int radix_select;        // filled by the launcher (ITTS_SAMPLE_RADIX=1): the 4-pass radix-select top-k instead of the ballot bisection (A/B switch)
+    unsigned long long* stamps;   // microbench builds only (-DITTS_SAMPLE_STAMPS): [B][8] phase time stamps, else null
     const int* row_limit;    // [utterances] or null: per-utterance cap on generated tokens (a batch merges requests with their own
                              // max_mel_tokens): from token index row_limit[u] on, the row emits the stop token
 };

@@ -2746,6 +2746,13 @@ __device__ __forceinline__ void advance_when_last(int* state, int nblocks) {
     }
 }
 
+// tools/microbench/sample_stamps.hip builds this kernel with -DITTS_SAMPLE_STAMPS: thread 0 of every block stores the constant-rate clock
+// (s_memrealtime, 100 MHz) at eight phase boundaries into a.stamps[block][8]; nothing is compiled in the product.
+#ifdef ITTS_SAMPLE_STAMPS
+#define SAMPLE_STAMP(K_) do { if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (K_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SAMPLE_STAMP(K_) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     extern __shared__ float sl[];                    // [V] processed scores
     __shared__ unsigned hist[256];
@@ -2757,6 +2764,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     __shared__ float cand_v[SAMPLE_CAP], cand_e[SAMPLE_CAP];
     const int b = blockIdx.x, tid = threadIdx.x, V = a.V;
     const int step = *a.step_ptr;
+    SAMPLE_STAMP(0);
     const int u = a.row_slot ? a.row_slot[b] : b;                   // the utterance this dense row carries
     const float* lg = a.logits + (size_t)b * V;
     unsigned char* seen = a.seen + (size_t)u * V;
@@ -2770,6 +2778,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         sl[i] = x;
     }
     __syncthreads();
+    SAMPLE_STAMP(1);
     if (typical) {
         typical_filter(sl, sl + V, V, a.typical_mass, a.min_keep, tid);
         if (temp) {
@@ -2830,6 +2839,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         }
         kth = s_prefix;
         }
+        SAMPLE_STAMP(2);
         for (int i = tid; i < V; i += 256) {
             if (f2key(sl[i]) >= kth && sl[i] > -INFINITY) {   // masked (-inf) entries carry no probability
                 const unsigned slot = atomicAdd(&s_count, 1u);
@@ -2851,6 +2861,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             if (tid < n) { cand_v[rank] = myv; cand_i[rank] = myi; }
             __syncthreads();
         }
+        SAMPLE_STAMP(3);
         {   // exponentials in parallel; the float / double sums below keep the sequential ascending order
             const int n = (int)(s_count < SAMPLE_CAP ? s_count : SAMPLE_CAP);
             if (tid < n) cand_e[tid] = expf(cand_v[tid] - cand_v[n - 1]);
@@ -2902,6 +2913,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         }
     }
     __syncthreads();
+    SAMPLE_STAMP(4);
     if (tid == 0) {
         int tok = s_tok;
         if (a.finished[u]) tok = a.stop_token;               // :3256 finished rows emit pad (= stop)
@@ -2912,6 +2924,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         s_tok = tok;
     }
     __syncthreads();
+    SAMPLE_STAMP(5);
     if (a.x_next) {
         const int tok = s_tok;
         int p = step + a.pos_offset;
@@ -2919,7 +2932,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         for (int d = tid; d < a.D; d += 256)
             a.x_next[(size_t)b * a.D + d] = a.mel_emb[(size_t)tok * a.D + d] + a.mel_pos[(size_t)p * a.D + d];
     }
+    SAMPLE_STAMP(6);
     advance_when_last(a.adv_state, (int)gridDim.x);
+    SAMPLE_STAMP(7);
 }
 
 // The selection kernels keep the whole score row in LDS ([V] f32, twice that with typical sampling: 65.5 KB at the production
