@@ -2603,6 +2603,48 @@ __device__ __forceinline__ uint32_t topk_kth_key(const float* sl, int V, int k, 
         key[j] = i < V ? f2key(sl[i]) : 0u;
     }
     uint32_t T = 0;
+#ifdef ITTS_TOPK_V2
+    // Variant for tools/microbench/sample_stamps.hip (-DITTS_TOPK_V2; NOT in the product until measured and GPU-tested): the stamps put the plain
+    // bisection below at 17.9 us -- 32 rounds x 33 (v_cmp -> s_bcnt1 -> s_add) at ~41 cycles each.  Bound the wave's k-th largest key from below
+    // first: L = the k-th largest of the 64 per-lane maxima (the lane maxima themselves are k keys >= L, so T_w >= L): 33 VALU max + a bisection
+    // with ONE ballot per round.  The keys >= L (about k..2k of the wave's 2112) are compacted through LDS to at most two per lane, and the full
+    // bisection runs on those: a candidate c <= L is feasible without counting, a candidate c > L is counted over the live keys only.
+    // More than 128 live keys (heavy ties): the plain bisection.
+    bool v2_done = false;
+    uint32_t c0 = 0, c1 = 0;
+    {
+        __shared__ uint32_t topk_live[4 * 128];
+        uint32_t mx = 0;
+#pragma unroll
+        for (int j = 0; j < TOPK_KPT; ++j) mx = key[j] > mx ? key[j] : mx;
+        uint32_t L = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t c = L | (1u << bit);
+            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(mx >= c)) >= k) L = c;
+        }
+        int n_live = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int j = 0; j < TOPK_KPT; ++j) {
+            const bool keep = key[j] >= L && L != 0u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) { const int o = n_live + __builtin_popcountll(m & lt); if (o < 128) topk_live[w * 128 + o] = key[j]; }
+            n_live += __builtin_popcountll(m);
+        }
+        if (L != 0u && n_live <= 128) {                              // wave-uniform
+            __builtin_amdgcn_wave_barrier();
+            c0 = lane < n_live ? topk_live[w * 128 + lane] : 0u;
+            c1 = 64 + lane < n_live ? topk_live[w * 128 + 64 + lane] : 0u;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t c = T | (1u << bit);
+                const bool feas = c <= L || __builtin_popcountll(__builtin_amdgcn_ballot_w64(c0 >= c)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c1 >= c)) >= k;
+                if (feas) T = c;
+            }
+            v2_done = true;
+        }
+    }
+    if (!v2_done)
+#endif
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t c = T | (1u << bit);
         int cnt = 0;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# NEXT ROUND, first GPU call (about one minute): the sampler's phase stamps for the three top-k selections -- radix select (product default in
+# sample_kernel), ballot bisection (product default in the beam kernel), and the lower-bound + compaction variant (-DITTS_TOPK_V2, microbench
+# build only) -- with the token fingerprint that must agree across them.  Build first (see the header of tools/microbench/sample_stamps.hip):
+#   hipcc ... -DITTS_SAMPLE_STAMPS                  tools/microbench/sample_stamps.hip -o tools/microbench/bin/sample_stamps
+#   hipcc ... -DITTS_SAMPLE_STAMPS -DITTS_TOPK_V2   tools/microbench/sample_stamps.hip -o tools/microbench/bin/sample_stamps_v2
+set -u
+cd "$(dirname "$0")/.."
+O=$PWD/gpurun_out/r04a
+mkdir -p $O
+for B in 1 64; do
+  ITTS_SAMPLE_RADIX=1 timeout 30 tools/microbench/bin/sample_stamps $B 2>&1 | sed "s/^/[radix] /" >> $O/sample_stamps.log
+  ITTS_SAMPLE_RADIX=0 timeout 30 tools/microbench/bin/sample_stamps $B 2>&1 | sed "s/^/[bisection] /" >> $O/sample_stamps.log
+  ITTS_SAMPLE_RADIX=0 timeout 30 tools/microbench/bin/sample_stamps_v2 $B 2>&1 | sed "s/^/[bisection v2] /" >> $O/sample_stamps.log
+done
+grep -E "sample_kernel|top-k|fingerprint" $O/sample_stamps.log

@@ -61,5 +61,11 @@ int main(int argc, char** argv) {
     double sum = 0;
     for (int k = 1; k < 8; ++k) { printf("  %-44s %7.2f\n", names[k], acc[k] / reps / B); sum += acc[k] / reps / B; }
     printf("  %-44s %7.2f\n", "sum (entry -> exit of a block)", sum);
+    // the chosen tokens (step 0 of every row): every selection variant must print the same fingerprint
+    std::vector<long long> ht((size_t)B * max_new);
+    CK(hipMemcpy(ht.data(), tokens, ht.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long fp = 0;
+    for (int b = 0; b < B; ++b) fp = fp * 1000003ull + (unsigned long long)ht[(size_t)b * max_new];
+    printf("  tokens fingerprint %016llx (row 0 -> %lld)\n", fp, ht[0]);
     return 0;
 }
