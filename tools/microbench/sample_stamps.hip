@@ -1,4 +1,5 @@
-// Where sample_kernel's ~48 us per token go (not the top-k selection, not the row loads): builds the product kernel with
+// Where sample_kernel's ~40 us per launch go (first result, profiles/r03x/sample_stamps.log: top-k threshold 17 us with either
+// selection, row staging 6.5, thread-0 tail 5.5, rank sort 4.2): builds the product kernel with
 // -DITTS_SAMPLE_STAMPS (thread 0 of every block stores s_memrealtime, 100 MHz, at eight phase boundaries) and prints the mean phase lengths.
 //   phases: 0 entry -> 1 row staged in LDS (penalty, temperature) -> 2 top-k threshold -> 3 survivors collected + rank-sorted -> 4 token chosen
 //           (top-p, renormalise, multinomial on thread 0) -> 5 token / seen / finished written -> 6 next-step embedding written -> 7 advanced
