@@ -2523,11 +2523,149 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     }
 }
 
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+// attn_kernel with the K / V loads of U consecutive key groups of a wave issued before the first of them is used (experiment switch
+// ITTS_ATTN_UNROLL=4; default off until measured on the GPU).  At 1-4 rows the kernel is 20-80 blocks walking their keys in a chain of
+// dependent memory round trips -- one per 32 keys of the block: 9.3 us per layer at a 40-token context, the largest launch of a 1-row token step
+// (profiles/r03x/decode_step_timeline_b1.txt) -- and U = 4 puts four of them in flight.  The key groups are consumed in the original order, so
+// every running maximum / sum / accumulator sees the same sequence of updates: bitwise attn_kernel.
+template <bool BF16, int U, bool RMAP>      // RMAP: the beam search's row map is in use (a template flag: a run-time `rmap ? load : pb` costs a
+                                            // branch and a vmcnt(0) in front of every group's loads, which serialises them again)
+__global__ __launch_bounds__(256) void attn_kernel_u(AttnArgs a) {
+    constexpr int LPK = BF16 ? 8 : 16;      // lanes per key
+    constexpr int DPL = 64 / LPK;           // dims per lane
+    constexpr int KPW = 64 / LPK;           // keys per wave-load
+    __shared__ float sm_m[4], sm_l[4], sm_acc[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int qi = blockIdx.y;
+    const int last = *a.pos_ptr + qi;
+    const int sm = a.seq_mul > 1 ? a.seq_mul : 1;
+    const int pb = a.seq_map ? a.seq_map[b] : b * sm;              // physical cache row / pad entry of this sequence
+    const int first = a.pad ? a.pad[pb] : 0;
+    const int sub = lane % LPK, grp = lane / LPK;
+    const size_t qrow = (size_t)b * a.nq + qi;
+    const int* rmap = a.row_map;
+    if (rmap && a.row_map_alt && a.step_ptr && (*a.step_ptr & 1)) rmap = a.row_map_alt;
+
+    float q[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) q[d] = a.qbuf[qrow * a.D + h * 64 + sub * DPL + d];
+
+    float m_run = -INFINITY, l_run = 0.f, acc[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) acc[d] = 0.f;
+
+    for (int t0 = first + w * KPW; t0 <= last; t0 += 4 * KPW * U) {
+        bool okv[U];
+        int tcv[U], prowv[U];
+        v4u_t kraw[U], vraw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u * 4 * KPW + grp;
+            okv[u] = t <= last;
+            tcv[u] = okv[u] ? t : last;
+            if constexpr (RMAP) prowv[u] = rmap[(size_t)b * a.Tmax + tcv[u]];
+            else prowv[u] = pb;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                                 // every K / V load of the U groups before the first use
+            const int tc = tcv[u];
+            const size_t off = (((size_t)prowv[u] * a.H + h) * a.Tmax + tc) * 64 + sub * DPL;
+            if constexpr (BF16) {
+                kraw[u] = *(const v4u_t*)((const u16*)a.kcache + off);
+                vraw[u] = *(const v4u_t*)((const u16*)a.vcache + off);
+            } else {
+                kraw[u] = *(const v4u_t*)((const float*)a.kcache + off);
+                vraw[u] = *(const v4u_t*)((const float*)a.vcache + off);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                            // keep hipcc from sinking the later groups' loads below the first group's use
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                                 // then the groups in their original order
+            const bool ok = okv[u];
+            float kf[DPL], vf[DPL];
+            if constexpr (BF16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    kf[2 * i] = __uint_as_float(kraw[u][i] << 16);
+                    kf[2 * i + 1] = __uint_as_float(kraw[u][i] & 0xffff0000u);
+                    vf[2 * i] = __uint_as_float(vraw[u][i] << 16);
+                    vf[2 * i + 1] = __uint_as_float(vraw[u][i] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { kf[i] = __uint_as_float(kraw[u][i]); vf[i] = __uint_as_float(vraw[u][i]); }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < DPL; ++d) s = fmaf(q[d], kf[d], s);
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+            s *= 0.125f;    // / sqrt(64)
+            if (ok) {
+                const float nm = fmaxf(m_run, s);
+                const float sc = exp_sel<BF16>(m_run - nm);      // m_run = -inf -> 0
+                const float p = exp_sel<BF16>(s - nm);
+                l_run = l_run * sc + p;
+#pragma unroll
+                for (int d = 0; d < DPL; ++d) acc[d] = acc[d] * sc + p * vf[d];
+                m_run = nm;
+            }
+        }
+    }
+    // merge the KPW key groups of the wave
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        const float om = __shfl_xor(m_run, o, 64), ol = __shfl_xor(l_run, o, 64);
+        const float nm = fmaxf(m_run, om);
+        const float sa = (m_run == -INFINITY) ? 0.f : exp_sel<BF16>(m_run - nm);
+        const float sb = (om == -INFINITY) ? 0.f : exp_sel<BF16>(om - nm);
+        l_run = l_run * sa + ol * sb;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) {
+            const float oa = __shfl_xor(acc[d], o, 64);
+            acc[d] = acc[d] * sa + oa * sb;
+        }
+        m_run = nm;
+    }
+    if (lane < LPK) {
+        sm_m[w] = m_run;
+        sm_l[w] = l_run;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) sm_acc[w][sub * DPL + d] = acc[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int d = threadIdx.x;
+        float nm = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float l = 0.f, o = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float sc = (sm_m[ww] == -INFINITY) ? 0.f : exp_sel<BF16>(sm_m[ww] - nm);
+            l += sm_l[ww] * sc;
+            o += sm_acc[ww][d] * sc;
+        }
+        const float r = l > 0.f ? o / l : 0.f;
+        const size_t oo = qrow * a.D + h * 64 + d;
+        if (BF16) ((u16*)a.out)[oo] = f32_to_bf16(r);
+        else ((float*)a.out)[oo] = r;
+    }
+}
+
 int launch_attention(const AttnArgs& a, int prec, hipStream_t st) {
     if (a.nseq <= 0 || a.nq <= 0) return ITTS_OK;
     if (a.D != a.H * 64) { itts_set_error("attention: head_dim must be 64 (D=%d H=%d)", a.D, a.H); return ITTS_ERR_ARG; }
     if (a.nq > 65535) { itts_set_error("attention: more than 65535 queries per sequence"); return ITTS_ERR_ARG; }
     dim3 grid(a.nseq * a.H, a.nq);
+    static const int unroll = [] { const char* e = getenv("ITTS_ATTN_UNROLL"); return e ? atoi(e) : 1; }();      // 4: attn_kernel_u (experiment, bitwise the same)
+    if (unroll == 4) {
+        const bool rm = a.row_map != nullptr;
+        if (prec == PREC_BF16) { if (rm) hipLaunchKernelGGL((attn_kernel_u<true, 4, true>), grid, dim3(256), 0, st, a);
+                                 else hipLaunchKernelGGL((attn_kernel_u<true, 4, false>), grid, dim3(256), 0, st, a); }
+        else { if (rm) hipLaunchKernelGGL((attn_kernel_u<false, 4, true>), grid, dim3(256), 0, st, a);
+               else hipLaunchKernelGGL((attn_kernel_u<false, 4, false>), grid, dim3(256), 0, st, a); }
+    } else
     if (prec == PREC_BF16) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());

@@ -14,3 +14,9 @@ for B in 1 64; do
   ITTS_SAMPLE_RADIX=0 timeout 30 tools/microbench/bin/sample_stamps_v2 $B 2>&1 | sed "s/^/[bisection v2] /" >> $O/sample_stamps.log
 done
 grep -E "sample_kernel|top-k|fingerprint" $O/sample_stamps.log
+# decode attention with four key groups in flight per wave (ITTS_ATTN_UNROLL=4; bitwise test first, then ms/token at 1 and 64 rows)
+ITTS_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_gpu_gpt.py -q -k unrolled_decode_attention > $O/pytest_attn_unroll.log 2>&1; tail -2 $O/pytest_attn_unroll.log
+for B in 1 64; do for u in 1 4 1 4; do
+  ITTS_ATTN_UNROLL=$u ITTS_BEAM_BENCH_MODES=1 timeout 200 python tools/beam_bench.py $B 400 2>&1 | grep "^B=" | cut -c1-110 | sed "s/^/unroll=$u /" >> $O/attn_unroll.log
+done; done
+cat $O/attn_unroll.log
