@@ -36,7 +36,12 @@ class Mode:
         return not any(s in name for s in self.keep_f32)
 
     def r(self, x):
-        return x if self.dtype is None else x.to(self.dtype).float()
+        if self.dtype is None:
+            return x
+        if self.dtype == "bf16x2":                                 # two bf16 planes: 16 significand bits (the first two planes of the x3 split)
+            h = x.bfloat16().float()
+            return h + (x - h).bfloat16().float()
+        return x.to(self.dtype).float()
 
 
 MODE = Mode("f32")
@@ -121,7 +126,10 @@ def main():
              Mode("only the attention operands (Q, K, V, P) in fp16, every GEMM f32", torch.float16, only=("attention_operands",)),
              Mode("attention operands + the big GEMMs (wqkv, wo, w1/w3, w2, WaveNet) in fp16; merge / skip / head / final GEMMs f32", torch.float16,
                   only=("attention_operands", "wqkv", "attention.wo", "feed_forward", "in_layers", "res_skip_layers")),
-             Mode("attention operands + w1/w3 + w2 in fp16, the rest f32", torch.float16, only=("attention_operands", "feed_forward"))]
+             Mode("attention operands + w1/w3 + w2 in fp16, the rest f32", torch.float16, only=("attention_operands", "feed_forward")),
+             # index 11, 12: GEMM operands as TWO bf16 planes (16 bits; 3 plane products hh, hm, mh on the bf16 pipe)
+             Mode("every GEMM operand as two bf16 planes (16 bits), attention operands f32", "bf16x2", keep_f32=("attention_operands",)),
+             Mode("every GEMM operand as two bf16 planes (16 bits) AND attention operands as two planes", "bf16x2")]
     if os.environ.get("STUDY_SWEEP"):                # one GEMM group at a time in the low precision, everything else f32
         dt_ = torch.float16 if os.environ["STUDY_SWEEP"] == "fp16" else torch.bfloat16
         groups = [("wqkv", ("wqkv",)), ("attention operands (Q, K, V, P)", ("attention_operands",)), ("wo", ("attention.wo",)),
