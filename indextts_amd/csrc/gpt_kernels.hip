@@ -2953,6 +2953,30 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     const bool pen = a.rep_penalty != 1.0f;
     const bool temp = a.do_sample && a.temperature != 1.0f;
     const bool typical = a.typical_mass > 0.f;
+#ifdef ITTS_SAMPLE_ROWS_V2
+    // microbench variant (tools/microbench/sample_stamps.hip, -DITTS_SAMPLE_ROWS_V2; not in the product until measured by the stamps and
+    // GPU-tested): every load of the row (score + seen flag) issued before the first use.  Written as one loop, `if (pen && seen[i])`
+    // compiles to a load, a wait and a branch per element -- 33 dependent round trips: the stamps put this phase at 6.5 us.
+    if (V <= 256 * TOPK_KPT) {
+        float xv[TOPK_KPT];
+        unsigned char sv[TOPK_KPT];
+#pragma unroll
+        for (int j = 0; j < TOPK_KPT; ++j) {
+            const int i = tid + 256 * j, ic = i < V ? i : V - 1;
+            xv[j] = lg[ic];
+            sv[j] = seen[ic];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TOPK_KPT; ++j) {
+            const int i = tid + 256 * j;
+            float x = xv[j];
+            if (pen && sv[j]) x = x < 0.f ? x * a.rep_penalty : x / a.rep_penalty;
+            if (temp && !typical) x = x / a.temperature;
+            if (i < V) sl[i] = x;
+        }
+    } else
+#endif
     for (int i = tid; i < V; i += 256) {
         float x = lg[i];
         if (pen && seen[i]) x = x < 0.f ? x * a.rep_penalty : x / a.rep_penalty;

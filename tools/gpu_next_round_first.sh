@@ -3,7 +3,8 @@
 # sample_kernel), ballot bisection (product default in the beam kernel), and the lower-bound + compaction variant (-DITTS_TOPK_V2, microbench
 # build only) -- with the token fingerprint that must agree across them.  Build first (see the header of tools/microbench/sample_stamps.hip):
 #   hipcc ... -DITTS_SAMPLE_STAMPS                  tools/microbench/sample_stamps.hip -o tools/microbench/bin/sample_stamps
-#   hipcc ... -DITTS_SAMPLE_STAMPS -DITTS_TOPK_V2   tools/microbench/sample_stamps.hip -o tools/microbench/bin/sample_stamps_v2
+#   hipcc ... -DITTS_SAMPLE_STAMPS -DITTS_TOPK_V2 -DITTS_SAMPLE_ROWS_V2   tools/microbench/sample_stamps.hip -o tools/microbench/bin/sample_stamps_v2
+#   (v2 = lower-bound top-k + row staging with every load in flight)
 set -u
 cd "$(dirname "$0")/.."
 O=$PWD/gpurun_out/r04a
