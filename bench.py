@@ -79,9 +79,27 @@ def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel, threads, s2
     utterance of `n_gen` tokens / `t_mel` frames (decode cost per token grows with context; the sample covers the first
     120 of `n_gen` positions, which favours the CPU).  The reference itself cannot run on the GPU box (/root/reference
     does not travel), hence kind = "port": the oracle is the restatement pinned to it by the committed fixtures.
+    The two stages whose checked form is slower on CPU than the reference's own modules (index-arithmetic resamplers, written-out attention) run
+    in the oracles' TIMING_MODE (strided depthwise convolutions, fused CPU attention: the forms the reference calls), so that the port is not a
+    slower baseline than the reference: measured beside the reference's classes in the build container, profiles/r03z_cpu/reference_cpu_timing.log.
     """
     from oracle import bigvgan_oracle as BO
     from oracle import gpt_oracle as GO
+    from oracle import s2mel_oracle as SO
+    BO.TIMING_MODE = SO.TIMING_MODE = True
+    try:
+        return _cpu_baseline_timed(BO, GO, SO, gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel, threads, s2mel_frames)
+    finally:
+        BO.TIMING_MODE = SO.TIMING_MODE = False
+
+
+def _timed(f):
+    t0 = time.perf_counter()
+    f()
+    return time.perf_counter() - t0
+
+
+def _cpu_baseline_timed(BO, GO, SO, gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel, threads, s2mel_frames):
     cores = max(1, int(threads))
     torch.set_num_threads(cores)
     log(f"[bench] cpu_baseline on {cores} threads (os.cpu_count()={os.cpu_count()}, usable={usable_cores()})")
@@ -110,26 +128,22 @@ def cpu_baseline(gpt_sd, gpt_cfg, bv_sd, bv_h, n_text, n_gen, t_mel, threads, s2
         frames = 480
         mel = torch.randn(1, bv_h["num_mels"], frames, generator=g) * 2 - 4
         BO.bigvgan_forward(bv_sd, mel[:, :, :8], bv_h)      # warm
-        t0 = time.perf_counter()
-        BO.bigvgan_forward(bv_sd, mel, bv_h)
-        t_frame = (time.perf_counter() - t0) / frames
+        t_frame = min(_timed(lambda: BO.bigvgan_forward(bv_sd, mel, bv_h)) for _ in range(2)) / frames        # first call creates the oneDNN primitives
         # s2mel: ONE Euler step (one CFG-stacked estimator call of the DiT 13 x 512 + WaveNet 8 x 512) at the bench's frame count,
         # x euler_steps; skipped (and left out of `value`) when the GPU line runs without the s2mel stage
         t_euler = None
         if s2mel_frames:
-            from oracle import s2mel_oracle as SO
             scfg = SO.S2MelConfig()
             ssd = SO.synth_weights(scfg, 3)
             T, Tp = s2mel_frames
             z = torch.randn(1, scfg.in_channels, T, generator=g)
-            t0 = time.perf_counter()
-            SO.cfm_solve_euler(ssd, scfg, z, torch.tensor([T]), torch.randn(1, scfg.in_channels, Tp, generator=g),
-                               torch.randn(1, T, scfg.content_dim, generator=g), torch.randn(1, scfg.style_dim, generator=g), 1, 0.7)
-            t_euler = time.perf_counter() - t0
+            pr, mu, st = (torch.randn(1, scfg.in_channels, Tp, generator=g), torch.randn(1, T, scfg.content_dim, generator=g),
+                          torch.randn(1, scfg.style_dim, generator=g))
+            t_euler = min(_timed(lambda: SO.cfm_solve_euler(ssd, scfg, z, torch.tensor([T]), pr, mu, st, 1, 0.7)) for _ in range(2))
     audio_s = t_mel * HOP / SR
     cpu_time = t_prefill + n_gen * t_tok + t_mel * t_frame + (EULER_STEPS * t_euler if t_euler is not None else 0.0)
     res = {"value": audio_s / cpu_time, "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-           "sample": f"oracle (torch fp32 CPU restatement of the reference path): GPT 1 utt x {n_text} text tokens, prefill + "
+           "sample": f"oracle (torch fp32 CPU restatement of the reference path; resamplers and attention in the forms the reference calls on CPU): GPT 1 utt x {n_text} text tokens, prefill + "
                      f"{steps} greedy decode steps; BigVGAN 1 utt x {frames} mel frames"
                      + (f"; s2mel 1 utt x {s2mel_frames[0]} frames, 1 of {EULER_STEPS} CFG Euler steps" if t_euler is not None else "")
                      + f"; extrapolated to {n_gen} tokens / {t_mel} frames / {EULER_STEPS} steps (codec decode + length regulator, "

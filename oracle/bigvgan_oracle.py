@@ -113,11 +113,26 @@ def downsample2x(v: torch.Tensor, fd: torch.Tensor) -> torch.Tensor:
     return y
 
 
+# bench.py's cpu_baseline leg times the restatement as the reference's CPU path: with TIMING_MODE on, the two resamplers run as strided depthwise
+# convolutions (the form the reference's torch modules use, resample.py:29-38,55-58) instead of the index arithmetic above, which is 2.7 x slower on
+# CPU (profiles/r03z_cpu/reference_cpu_timing.log).  Same taps, same padding; summation order differs (tests/test_oracle_timing_mode.py bounds the
+# difference).  The CHECKER (tests, smoke) always runs the index form.
+TIMING_MODE = False
+
+
+def _resample_conv(x: torch.Tensor, fu: torch.Tensor, fd: torch.Tensor, act) -> torch.Tensor:
+    C = x.shape[1]
+    u = 2.0 * F.conv_transpose1d(F.pad(x, (5, 5), mode="replicate"), fu.view(1, 1, 12).expand(C, 1, 12), stride=2, groups=C)[..., 15:-15]
+    return F.conv1d(F.pad(act(u), (5, 6), mode="replicate"), fd.view(1, 1, 12).expand(C, 1, 12), stride=2, groups=C)
+
+
 def activation1d(x: torch.Tensor, alpha_log: torch.Tensor, beta_log: torch.Tensor,
                  fu: Optional[torch.Tensor] = None, fd: Optional[torch.Tensor] = None,
                  logscale: bool = True) -> torch.Tensor:
     fu = default_filter() if fu is None else fu.reshape(-1).float()
     fd = default_filter() if fd is None else fd.reshape(-1).float()
+    if TIMING_MODE:
+        return _resample_conv(x, fu, fd, lambda u: snake_beta(u, alpha_log, beta_log, logscale))
     return downsample2x(snake_beta(upsample2x(x, fu), alpha_log, beta_log, logscale), fd)
 
 

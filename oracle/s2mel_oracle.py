@@ -188,6 +188,10 @@ def apply_rope(x: torch.Tensor, tab: torch.Tensor) -> torch.Tensor:
     return out.flatten(3)
 
 
+# see oracle/bigvgan_oracle.py::TIMING_MODE: set by bench.py's cpu_baseline leg only; the checker keeps the written-out attention below
+TIMING_MODE = False
+
+
 def attention(sd, prefix: str, c: S2MelConfig, x: torch.Tensor, tab: torch.Tensor, key_mask: torch.Tensor) -> torch.Tensor:
     """Attention.forward (gpt_fast/model.py:262-307), n_local_heads == n_head, no KV cache; key_mask (B, T) True = attend."""
     B, T, _ = x.shape
@@ -196,6 +200,9 @@ def attention(sd, prefix: str, c: S2MelConfig, x: torch.Tensor, tab: torch.Tenso
     q = apply_rope(q.view(B, T, H, hd), tab).transpose(1, 2)
     k = apply_rope(k.view(B, T, H, hd), tab).transpose(1, 2)
     v = v.view(B, T, H, hd).transpose(1, 2)
+    if TIMING_MODE:        # bench.py's cpu_baseline only: the fused CPU attention the reference calls (gpt_fast/model.py:303), not the checked form
+        y = F.scaled_dot_product_attention(q, k, v, attn_mask=key_mask[:, None, None, :].expand(B, 1, T, T))
+        return F.linear(y.transpose(1, 2).reshape(B, T, H * hd), sd[prefix + "wo.weight"])
     s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
     s = s.masked_fill(~key_mask[:, None, None, :], float("-inf"))
     y = torch.softmax(s, dim=-1) @ v
