@@ -58,3 +58,29 @@ def test_padded_keys_do_not_reach_valid_frames(golden_dir):
         b = S.dit_forward(sd, cfg, x2, px, torch.tensor([n]), t, style, mu)
     reach = sum((cfg.wavenet_kernel - 1) // 2 * cfg.wavenet_dilation_rate ** i for i in range(cfg.wavenet_layers)) + 1
     assert float((a - b)[..., : n - reach].abs().max()) < 1e-4
+
+
+def load_prod(golden_dir):
+    """Third fixture (tools/make_golden_s2mel.py::main_prod): the PRODUCTION widths (DiT 13 x 512 x 8 heads, WaveNet 8 x 512) and solve depth (25
+    CFG Euler steps) run through the reference's classes; `mu` is regenerated from the seed (its sum is the fixture's drift check)."""
+    z = np.load(os.path.join(golden_dir, "s2mel_cfm_prod.npz"))
+    cfg = S.S2MelConfig()
+    seed, T = int(z["seed"]), int(z["T"])
+    mu = torch.randn(1, T, cfg.content_dim, generator=torch.Generator().manual_seed(seed + 2))
+    assert abs(float(mu.double().sum()) - float(z["mu_sum"])) < 1e-6, "torch's CPU generator no longer reproduces the fixture's mu"
+    return z, cfg, S.synth_weights(cfg, seed), mu
+
+
+def test_production_widths_estimator_and_25_step_solve_match_reference(golden_dir):
+    z, cfg, sd, mu = load_prod(golden_dir)
+    x, prompt, style, x_lens = (torch.from_numpy(z[k]) for k in ("z", "prompt", "style", "x_lens"))
+    Tp = prompt.shape[-1]
+    px = torch.zeros_like(x)
+    px[..., :Tp] = prompt
+    with torch.no_grad():
+        d = S.dit_forward(sd, cfg, torch.cat([x, x]), torch.cat([px, torch.zeros_like(px)]), x_lens, torch.full((2,), float(z["t"])),
+                          torch.cat([style, torch.zeros_like(style)]), torch.cat([mu, torch.zeros_like(mu)]))
+        y = S.cfm_solve_euler(sd, cfg, x, x_lens, prompt, mu, style, int(z["n_steps"]), float(z["cfg_rate"]))
+    np.testing.assert_allclose(d.numpy(), z["estimator_out"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(y.numpy(), z["euler_out"], rtol=0, atol=3e-5)
+    assert float(y[..., :Tp].abs().max()) == 0.0

@@ -118,6 +118,49 @@ def main_hd64():
                                       cfg.wavenet_hidden, cfg.wavenet_layers, cfg.wavenet_kernel, cfg.wavenet_dilation_rate]), **out)
 
 
+def prod_inputs(cfg, seed, T, Tp):
+    """Inputs of the production-width fixture; `mu` (T x 512: the bulk) is regenerated from the seed by the tests instead of being stored --
+    the fixture carries its sum as a drift check of the generator."""
+    g = torch.Generator().manual_seed(seed + 1)
+    z = torch.randn(1, cfg.in_channels, T, generator=g)
+    prompt = torch.randn(1, cfg.in_channels, Tp, generator=g) * 0.5 - 1.0
+    style = torch.randn(1, cfg.style_dim, generator=g)
+    mu = torch.randn(1, T, cfg.content_dim, generator=torch.Generator().manual_seed(seed + 2))
+    return z, prompt, mu, style
+
+
+def main_prod():
+    """Third fixture: the PRODUCTION widths (S2MelConfig defaults = the v2 / v2.5 checkpoint config: DiT 13 x 512 x 8 heads, WaveNet 8 x 512,
+    content 512, style 192) and the production solve depth (25 CFG Euler steps), one utterance of 211 frames behind a 73-frame prompt with 9
+    padded frames, run through the reference's own classes.  Pins the oracle (and, on the GPU, the engine's f32 mode) at the benchmarked
+    architecture rather than at a miniature."""
+    cfg = S.S2MelConfig()
+    seed, T, Tp, pad, n_steps, cfg_rate = 71, 211, 73, 9, 25, 0.7
+    sd = S.synth_weights(cfg, seed)
+    m = reference(cfg, sd)
+    z, prompt, mu, style = prod_inputs(cfg, seed, T, Tp)
+    x_lens = torch.tensor([T - pad])
+    with torch.no_grad():
+        t = torch.tensor([0.35, 0.35])
+        px = torch.zeros(1, cfg.in_channels, T)
+        px[..., :Tp] = prompt
+        d_ref = m.estimator(torch.cat([z, z]), torch.cat([px, torch.zeros_like(px)]), x_lens, t,
+                            torch.cat([style, torch.zeros_like(style)]), torch.cat([mu, torch.zeros_like(mu)]))
+        d_o = S.dit_forward(sd, cfg, torch.cat([z, z]), torch.cat([px, torch.zeros_like(px)]), x_lens, t,
+                            torch.cat([style, torch.zeros_like(style)]), torch.cat([mu, torch.zeros_like(mu)]))
+        y_ref = m.solve_euler(z.clone(), x_lens, prompt, mu.clone(), style, None, torch.linspace(0, 1, n_steps + 1), inference_cfg_rate=cfg_rate)
+        y_o = S.cfm_solve_euler(sd, cfg, z, x_lens, prompt, mu, style, n_steps, cfg_rate)
+    print(f"production widths (T={T}, prompt {Tp}, x_lens {T - pad}, {n_steps} steps): estimator rms {d_ref.pow(2).mean().sqrt():.3f} oracle max|d| "
+          f"{(d_ref - d_o).abs().max():.3e}; solve_euler rms {y_ref.pow(2).mean().sqrt():.3f} oracle max|d| {(y_ref - y_o).abs().max():.3e}")
+    np.savez_compressed(os.path.join(GOLD, "s2mel_cfm_prod.npz"), z=z.numpy(), prompt=prompt.numpy(), style=style.numpy(), x_lens=x_lens.numpy(),
+                        mu_sum=np.float64(mu.double().sum()), t=np.float32(0.35), estimator_out=d_ref.numpy(), euler_out=y_ref.numpy(),
+                        n_steps=np.int64(n_steps), cfg_rate=np.float64(cfg_rate), seed=np.int64(seed), T=np.int64(T), Tp=np.int64(Tp))
+
+
 if __name__ == "__main__":
-    main()
-    main_hd64()
+    if len(sys.argv) > 1 and sys.argv[1] == "prod":
+        main_prod()
+    else:
+        main()
+        main_hd64()
+        main_prod()
