@@ -20,12 +20,51 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 7
+#define ITTS_ABI_VERSION 8
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
 /* number of HIP devices visible, or <0 with the HIP error recorded (the library itself loads without a GPU) */
 int itts_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Run-time options.  The library reads NO environment variable; every switch between kernels that tests hold to the same
+ * results (most of them bitwise) is a named integer option, process-wide, read by the launchers at launch time.  The defaults
+ * are the measured-best paths.  Changing a value retires the decode hipGraphs cached in GPT handles (they bake kernel choices
+ * in); options marked "at create" are sampled when a model handle is created.  The reference has no counterpart (its kernels are
+ * picked by PyTorch's dispatcher); the table exists for A/B tests and measurement tools.
+ *   name              default  range    meaning
+ *   decode_fuse_ln       1     0..1    GPT decode steps of 1-16 rows: LayerNorm inside the consuming GEMM (0: ln_kernel launches)
+ *   decode_gemm          1     0..1    bf16 decode GEMMs on the LDS-DMA slab kernel (0: register-path kernel)
+ *   decode_rot           1     0..1    per-block rotation of the slab DMA issue order
+ *   decode_wnt           0     0..1    non-temporal policy on the decode weight stream
+ *   decode_nt            0     0..4    force the n-tiles per block of the 64-row decode GEMM
+ *   prefill_gemm         1     0..1    bf16 prefill GEMMs on the LDS-DMA tile kernels (0: register-path kernel)
+ *   tile256             -1    -1..2    bf16 tile GEMM: -1 by shape, 0 128x128, 1 256x256, 2 256x128
+ *   f32_tile             1     0..1    f32 GEMMs with plain epilogues on the f32-MFMA tile kernel
+ *   x3_products          8     6..8    plane products per f32 product of the fp32x3 GEMM (8 or 6)
+ *   x3_sched             1     0..1    fp32x3 GEMM: operand split interleaved with the MFMAs
+ *   x3_planes            1     0..1    fp32x3 s2mel: producers emit the bf16 planes of the next GEMM's A operand (at create)
+ *   sample_radix        -1    -1..1    top-k threshold: -1 per-kernel default, 0 ballot bisection, 1 radix select
+ *   gpt_compact          1     0..1    row compaction of ragged decode batches
+ *   attn_waves           0     0..16   waves per block of the KV-cache attention kernel (0: by shape; 4 / 8 / 16)
+ *   s2mel_fused          1     0..1    bf16 / f32 s2mel: fused GEMM epilogues (at create)
+ *   fa_qs                0     0..4    bf16 flash attention: query sub-tiles per wave (0: by shape)
+ *   f32_attn_scalar      0     0..1    f32 s2mel attention on the one-wave-per-query reference kernel
+ *   fa32_qs              2     1..2    f32 flash attention: query sub-tiles per wave
+ *   aa_act               2     0..2    anti-aliased activation kernel variant
+ *   conv_bm              0     0..128  force the co-tile height of the vocoder conv kernel
+ *   h3_kernel            1     0..1    f16x3 vocoder conv: window kernel / two-stage kernel
+ *   s2mel_fuse_norm      1     0..1    f32 / fp32x3 s2mel: adaptive RMSNorm inside the residual GEMM that feeds it
+ * itts_option_count / _name / _doc / _default enumerate the table (index 0 .. count-1).
+ * ---------------------------------------------------------------------------------------------------------- */
+int itts_set_option(const char* name, int value);      /* ITTS_ERR_ARG: unknown name or value out of range */
+int itts_get_option(const char* name, int* value);
+int itts_reset_options(void);                          /* every option back to its default */
+int itts_option_count(void);
+const char* itts_option_name(int index);
+const char* itts_option_doc(int index);
+int itts_option_default(int index);
 
 /* ------------------------------------------------------------------------------------------------------------
  * BigVGAN vocoder

@@ -43,7 +43,7 @@ class GPTConfig(C.Structure):
                 ("stop_mel_token", C.c_int32), ("ln_eps", C.c_float)]
 
 
-ABI_VERSION = 7          # include/indextts_hip.h ITTS_ABI_VERSION
+ABI_VERSION = 8          # include/indextts_hip.h ITTS_ABI_VERSION
 
 
 class GenParams(C.Structure):
@@ -59,6 +59,13 @@ SIGNATURES = {
     "itts_abi_version": (C.c_int, []),
     "itts_last_error": (C.c_char_p, []),
     "itts_device_count": (C.c_int, []),
+    "itts_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "itts_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "itts_reset_options": (C.c_int, []),
+    "itts_option_count": (C.c_int, []),
+    "itts_option_name": (C.c_char_p, [C.c_int]),
+    "itts_option_doc": (C.c_char_p, [C.c_int]),
+    "itts_option_default": (C.c_int, [C.c_int]),
     "itts_aa_act_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "itts_packed_conv_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "itts_pack_conv1d_weight": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
@@ -188,6 +195,50 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().itts_last_error().decode(errors="replace")
         raise HipEngineError(f"{what} failed (code {rc}): {msg}")
+
+
+def set_option(name: str, value: int):
+    """Process-wide engine option (include/indextts_hip.h: the table above itts_set_option)."""
+    check(lib().itts_set_option(name.encode(), int(value)), f"set_option({name})")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(lib().itts_get_option(name.encode(), C.byref(v)), f"get_option({name})")
+    return int(v.value)
+
+
+def reset_options():
+    check(lib().itts_reset_options(), "reset_options")
+
+
+def options() -> dict:
+    """name -> (current value, default, doc) of every engine option."""
+    L = lib()
+    out = {}
+    for i in range(L.itts_option_count()):
+        name = L.itts_option_name(i).decode()
+        out[name] = (get_option(name), int(L.itts_option_default(i)), L.itts_option_doc(i).decode())
+    return out
+
+
+class option_scope:
+    """with option_scope(decode_fuse_ln=0): ...  -- sets options for the block and restores the previous values."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+        self.prev = {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.prev[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(k, v)
+        return False
 
 
 def ptr(t):

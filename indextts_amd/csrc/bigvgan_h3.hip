@@ -482,9 +482,9 @@ int launch_conv_h3(const ConvH3Args& a0, hipStream_t st) {
     if (a0.B <= 0 || a0.T <= 0) return ITTS_OK;
     if (a0.Cin % H3_BK || !(a0.k & 1) || a0.Cout < 1) { itts_set_error("conv_h3: need C_in %% 32 == 0 and odd k"); return ITTS_ERR_ARG; }
     if ((long long)a0.Cout * a0.T >= (1ll << 31) || (long long)a0.Cin * a0.T >= (1ll << 31)) { itts_set_error("conv_h3: row plane too large"); return ITTS_ERR_ARG; }
-    // ITTS_H3_KERNEL: 0 = the 128-frame two-stage kernel everywhere, 1 (default) = the window kernel where the taps fit, with the
-    // co tile (128 / 192 / 96 wide) that wastes the fewest columns; 2 = the window kernel with the 128-wide tile only
-    static const int which = [] { const char* e = getenv("ITTS_H3_KERNEL"); return e ? atoi(e) : 1; }();
+    // option h3_kernel: 0 = the 128-frame two-stage kernel everywhere, 1 (default) = the window kernel where the taps fit, with the
+    // co tile (128 / 192 / 96 wide) that wastes the fewest columns
+    const int which = itts_opt(OPT_H3_KERNEL);
     const bool win = which != 0 && a0.k >= 3 && (a0.k - 1) * a0.dil <= 48;     // the counted waits need the window requested >= 3 K tiles ahead
     if (win) {
         auto padded = [&](int bn) { return (long long)ceil_div(a0.Cout, bn) * bn; };

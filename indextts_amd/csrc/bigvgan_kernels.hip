@@ -501,10 +501,10 @@ __global__ __launch_bounds__(256) void cond_bias_kernel(const float* __restrict_
 int launch_aa_act(const float* x, float* y, const float* alpha, const float* beta, const float* fu, const float* fd,
                   int B, int C, int T, const int* lens, int len_mult, int logscale, hipStream_t st) {
     if (B <= 0 || C <= 0 || T <= 0) return ITTS_OK;
-    // ITTS_AA_ACT: 0 = v1 (LDS per tap, libm sinf), 1 = register-tiled + sinf, 2 = register-tiled + reduced v_sin (4/thread),
+    // option aa_act: 0 = v1 (LDS per tap, libm sinf), 1 = register-tiled + sinf, 2 = register-tiled + reduced v_sin (4/thread),
     //              3 = same with 8 outputs per thread.  Measured (B=16, T=1926): 4.17 / 5.4 / 3.66 / 4.98 ms per 6 launches
     //              -> default 2.
-    static const int mode = [] { const char* e = getenv("ITTS_AA_ACT"); return e ? atoi(e) : 2; }();
+    const int mode = itts_opt(OPT_AA_ACT);
     if (mode == 0) hipLaunchKernelGGL(aa_act_kernel, dim3(ceil_div(T, AA_TILE), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
     else if (mode == 1) hipLaunchKernelGGL((aa_act_kernel_v2<4, false>), dim3(ceil_div(T, 1024), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
     else if (mode == 2) hipLaunchKernelGGL((aa_act_kernel_v2<4, true>), dim3(ceil_div(T, 1024), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
@@ -540,8 +540,8 @@ int launch_conv(const ConvArgs& a, int B, hipStream_t st) {
     const int n_cosub = (a.Cout + 31) / 32;
     // co-tile choice (measured, profiles/r01_conv_tiles.txt): the 32-row tile <1,4,1,2> fits 118 registers without spilling,
     // i.e. 4 waves/SIMD with its 40 KiB x tile (4 blocks = the CU's 160 KiB of LDS), and beats or ties the taller tiles
-    // (occupancy 2 or 1) at every channel count of the generator.  ITTS_CONV_BM (32/64/96/128) forces a height for experiments.
-    static const int force_bm = [] { const char* e = getenv("ITTS_CONV_BM"); return e ? atoi(e) : 0; }();
+    // (occupancy 2 or 1) at every channel count of the generator.  Option conv_bm (32/64/96/128) forces a height for experiments.
+    const int force_bm = itts_opt(OPT_CONV_BM);
     const int bm_sub = force_bm ? force_bm / 32 : 1;               // co sub-tiles (32 rows each) per block
     (void)n_cosub;
     switch (bm_sub) {

@@ -96,6 +96,7 @@ struct itts_gpt {
     struct GraphEntry {
         const void* base; const void* tokens; const void* uniforms; const void* aux0; const void* aux1; const void* aux2;
         int nseq, nb, Sb, Tmax, S;           // S: only where the step bakes the exact prompt length in (beam kernels), else 0
+        unsigned opt_epoch;                  // itts_opt_epoch() at capture: a graph bakes the kernel choices of the options in
         itts_gen_params gp;
         hipGraphExec_t exec;
         unsigned long long stamp;
@@ -127,7 +128,7 @@ static inline int s_bucket(int S) { return (S + 31) & ~31; }
 static hipGraphExec_t graph_lookup(itts_gpt* h, const itts_gpt::GraphEntry& k) {
     for (auto& e : h->graphs)
         if (e.base == k.base && e.tokens == k.tokens && e.uniforms == k.uniforms && e.aux0 == k.aux0 && e.aux1 == k.aux1 && e.aux2 == k.aux2 &&
-            e.nseq == k.nseq && e.nb == k.nb && e.Sb == k.Sb && e.Tmax == k.Tmax && e.S == k.S && memcmp(&e.gp, &k.gp, sizeof(k.gp)) == 0) {
+            e.nseq == k.nseq && e.nb == k.nb && e.Sb == k.Sb && e.Tmax == k.Tmax && e.S == k.S && e.opt_epoch == k.opt_epoch && memcmp(&e.gp, &k.gp, sizeof(k.gp)) == 0) {
             e.stamp = ++h->graph_clock;
             ++h->graph_hits;
             return e.exec;
@@ -307,7 +308,7 @@ static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct GptWs {
     char *kc, *vc;      // [L][nseq][H][Tmax][64] cache dtype
     float* x;           // [rows][D]
-    float* x2;          // [4][D] second residual buffer of the LayerNorm-fused decode GEMMs (1-4 rows; run_layers alternates x / x2)
+    float* x2;          // [16][D] second residual buffer of the LayerNorm-fused decode GEMMs (1-16 rows; run_layers alternates x / x2)
     char* hbuf;         // [rows][D] act
     float* qbuf;        // [rows][D]
     char* attn;         // [rows][D] act
@@ -343,7 +344,7 @@ static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tm
     w.kc = take(w.layer_cache_bytes * c.layers);
     w.vc = take(w.layer_cache_bytes * c.layers);
     w.x = (float*)take(rows * D * 4);
-    w.x2 = (float*)take((size_t)4 * D * 4);
+    w.x2 = (float*)take((size_t)16 * D * 4);
     w.hbuf = take(rows * D * esz);
     w.qbuf = (float*)take(rows * D * 4);
     w.attn = take(rows * D * esz);
@@ -427,10 +428,10 @@ static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bo
     const int D = c.model_dim, prec = c.precision, rows = nseq * S;
     int rc;
     const float* pend_bias = nullptr;   // bias of a GEMM whose partials are pending reduction
-    // Decode steps of 1-4 rows (one utterance, its beams): the two LayerNorm launches of a layer are fused into the GEMMs that consume them
-    // (gemm_decode_ln_kernel: same arithmetic, bitwise the same results; ITTS_DECODE_FUSE_LN=0 is the A/B switch).  The fused kernel's block 0
+    // Decode steps of 1-16 rows (one utterance, its beams, an 8-utterance shard): the two LayerNorm launches of a layer are fused into the GEMMs
+    // that consume them (gemm_decode_ln_kernel: same arithmetic, bitwise the same results; option decode_fuse_ln = 0 is the A/B switch).  The fused kernel's block 0
     // writes the updated residual to the OTHER buffer (its sibling blocks still read the current one): cur / alt alternate.
-    static const bool fuse_env = [] { const char* e = getenv("ITTS_DECODE_FUSE_LN"); return !(e && atoi(e) == 0); }();
+    const bool fuse_env = itts_opt(OPT_DECODE_FUSE_LN) != 0;
     const bool fuse_ln = fuse_env && !prefill && S == 1 && prec == PREC_BF16 && gemm_decode_ln_ok(rows, D, EPI_QKV) && w.x2 != nullptr;
     float *cur = w.x, *alt = w.x2;
     for (int l = 0; l < c.layers; ++l) {
@@ -640,7 +641,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
         h->last_row_steps = 0;
         h->last_compactions = 0;
     }
-    static const bool env_off = [] { const char* e = getenv("ITTS_GPT_COMPACT"); return e && atoi(e) == 0; }();
+    const bool env_off = itts_opt(OPT_GPT_COMPACT) == 0;
     const bool compact = h->compact && !env_off;
     hipGraphExec_t exec = nullptr;
     bool graph_ok = false;
@@ -649,6 +650,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
         if (!(use_graph && gp.max_new_tokens > 1)) return ITTS_OK;
         itts_gpt::GraphEntry key{};
         key.base = base; key.tokens = tokens; key.uniforms = uniforms; key.nseq = rows; key.nb = 1; key.Sb = Sb; key.Tmax = Tmax; key.gp = gp; key.gp.seed = 0;          // the seed lives in device memory
+        key.opt_epoch = itts_opt_epoch();
         key.S = nseq;                                                  // utterances of the call (uniform stride, limits)
         key.aux0 = mapped ? (const void*)w.slot_map : nullptr;
         key.aux1 = (h->row_limits && h->row_limits_n == nseq) ? (const void*)h->row_limits : nullptr;
@@ -857,6 +859,7 @@ extern "C" int itts_gpt_generate_beam(itts_gpt* h, const float* prefix_embeds, c
     if (use_graph && gp.max_new_tokens > 1) {
         itts_gpt::GraphEntry key{};
         key.base = base; key.uniforms = uniforms; key.nseq = nseq; key.nb = nb; key.Sb = Sb; key.Tmax = Tmax; key.S = S; key.gp = gp; key.gp.seed = 0;
+        key.opt_epoch = itts_opt_epoch();
         exec = graph_lookup(h, key);
         graph_ok = exec != nullptr;
         if (!graph_ok) {

@@ -22,12 +22,11 @@
 // Element-wise stages live in the GEMM epilogues (no f32 round trip of the wide intermediates) and the paired weights are packed
 // tile-interleaved for them -- in both precisions: the f32 mode (what the reference computes: autocast is off around the s2mel
 // stage, infer_v2_5.py:827-828) runs the same fused structure on the f32-MFMA instantiations of the tile kernel.
-// ITTS_S2MEL_FUSED=0 (read once, before the weights are packed) forces the separate element-wise kernels -- the A/B switch of
-// tests/test_gpu_s2mel.py.
-static bool s2_fused(int precision) {
-    static const bool env = [] { const char* e = getenv("ITTS_S2MEL_FUSED"); return !e || atoi(e) != 0; }();
+// Option s2mel_fused = 0 (read when the handle is created: the weight packing depends on it) forces the separate element-wise
+// kernels -- the A/B switch of tests/test_gpu_s2mel.py.
+static bool s2_fused(int precision, bool opt_fused) {
     if (precision == PREC_F32X3) return true;                   // the f32x3 GEMM kernel exists with the fused epilogues only
-    return (precision == PREC_BF16 || precision == PREC_F32) && env;
+    return (precision == PREC_BF16 || precision == PREC_F32) && opt_fused;
 }
 
 struct S2Layer {
@@ -50,6 +49,7 @@ struct itts_s2mel {
     float *b_sl = 0, *b_c1 = 0, *b_rp = 0, *b_fl = 0, *b_c2 = 0;
     std::vector<void*> owned;
     bool finalized = false;
+    bool opt_fused = true;                      // option s2mel_fused as it stood at itts_s2mel_create
     int device = -1;
     // optional HIP-event timing per kernel class (itts_s2mel_set_profiling): events are recorded on the launch stream around
     // every launch of the last solve / estimator call
@@ -114,6 +114,7 @@ extern "C" int itts_s2mel_create(const itts_s2mel_config* cfg, itts_s2mel** out)
     }
     itts_s2mel* h = new itts_s2mel();
     h->cfg = c;
+    h->opt_fused = itts_opt(OPT_S2MEL_FUSED) != 0;
     h->I = s2_intermediate(c.hidden_dim);
     h->Kx = (c.in_channels + 63) / 64 * 64;
     h->layers.resize(c.depth);
@@ -201,7 +202,7 @@ struct Fin {
     // [K][N] with N = two halves -> n-tiles interleaved (tile 2j: first half's columns 16j.., tile 2j+1: second half's 16j..): the
     // layout the tile kernel's pair epilogues (EPI_SWIGLU / EPI_GATE) expect; identity with the separate element-wise kernels
     std::vector<float> pair_tiles(const std::vector<float>& kn, int K, int N) const {
-        if (!s2_fused(h->cfg.precision)) return kn;
+        if (!s2_fused(h->cfg.precision, h->opt_fused)) return kn;
         const int half = N / 2;
         std::vector<float> o((size_t)K * N);
         for (int k = 0; k < K; ++k)
@@ -394,7 +395,7 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     const itts_s2mel_config& c = h->cfg;
     const int H = c.hidden_dim, I = h->I, W = c.wavenet_hidden, C = c.in_channels, Kx = h->Kx, N = tab.n_tok, prec = c.precision;
     const int nh = c.num_heads;
-    const bool fused = s2_fused(prec);
+    const bool fused = s2_fused(prec, h->opt_fused);
     int rc;
     float *X = w.X, *X2 = w.X2;
     // x_in = cond_x_merge_linear([x^T | prompt | cond | style]): the x columns here, the rest (+ bias) is const_in

@@ -1625,7 +1625,7 @@ static int launch_gemm_tile_4w_e(const GemmArgs& a, hipStream_t st) {
 // Which tile kernel: 0 = 128 x 128 (four waves, two blocks per CU), 1 = 256 x 256 (eight waves, one block per CU), 2 = 256 x 128
 // (four waves, two blocks per CU).  ITTS_TILE256 = 0 | 1 | 2 forces one (A/B; the three are bitwise interchangeable).
 static int pick_tile_kernel(const GemmArgs& a) {
-    static const int mode = [] { const char* e = getenv("ITTS_TILE256"); return e ? atoi(e) : -1; }();
+    const int mode = itts_opt(OPT_TILE256);
     if (mode == 0) return 0;
     if (!pf_vec_ok(a) || a.N % 128) return 0;
     if (mode == 1 || mode == 2) return mode;
@@ -1923,8 +1923,8 @@ template <int EPI, bool CONV = false>
 static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
     const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
     const int per = ceil_div(n_mt * n_nt, 8);
-    static const int nprod = [] { const char* e = getenv("ITTS_X3_PRODUCTS"); const int v = e ? atoi(e) : 8; return v == 6 ? 6 : 8; }();
-    static const bool sched = [] { const char* e = getenv("ITTS_X3_SCHED"); return !e || atoi(e) != 0; }();      // A/B switch of the MFMA / split interleave
+    const int nprod = itts_opt(OPT_X3_PRODUCTS) == 6 ? 6 : 8;
+    const bool sched = itts_opt(OPT_X3_SCHED) != 0;                 // A/B switch of the MFMA / split interleave
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
@@ -2164,7 +2164,7 @@ static int launch_gemm_decode64_e(const GemmArgs& a, int ntiles, size_t lds, hip
     if (attr_state < 0) return -1;
     GemmArgs a2 = a;
     a2.kb_slice = (a.K / 32) / a.nsplit;                           // exact: the caller checked (K/32) % (2 * nsplit) == 0
-    static const int rot = [] { const char* e = getenv("ITTS_DECODE_ROT"); return e ? atoi(e) : 1; }();
+    const int rot = itts_opt(OPT_DECODE_ROT);
     a2.dma_rot = rot;
     hipLaunchKernelGGL((gemm_decode64_kernel<NT, MT, WNT, EPI>), dim3(ceil_div(ntiles, NT), ceil_div(a.M, 16 * MT), a.nsplit), dim3(256), lds, st, a2);
     HIP_TRY(hipGetLastError());
@@ -2186,7 +2186,7 @@ template <int NT, int MT>
 static int launch_gemm_decode64_nt(const GemmArgs& a, int ntiles, size_t lds, hipStream_t st) {
     // ITTS_DECODE_WNT=1: non-temporal policy on the weight stream (A/B switch; outputs are identical either way).  Measured
     // (profiles/r02a): no change at 64 rows (1.532 vs 1.536 ms/token), 6 % SLOWER at 8 rows (1.124 vs 1.056) -> default off.
-    static const bool wnt = [] { const char* e = getenv("ITTS_DECODE_WNT"); return e && atoi(e) != 0; }();
+    const bool wnt = itts_opt(OPT_DECODE_WNT) != 0;
     return wnt ? launch_gemm_decode64_w<NT, MT, true>(a, ntiles, lds, st) : launch_gemm_decode64_w<NT, MT, false>(a, ntiles, lds, st);
 }
 
@@ -2203,7 +2203,7 @@ static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
     }
     size_t lds = (size_t)((slice_kb + 1) / 2) * 8192;
     const int other = ceil_div(a.M, 64) * a.nsplit;
-    static const int force_nt = [] { const char* e = getenv("ITTS_DECODE_NT"); return e ? atoi(e) : 0; }();
+    const int force_nt = itts_opt(OPT_DECODE_NT);
     int nt = 1;
     if (force_nt) nt = force_nt;
     else if (ntiles * other > 256) nt = (ceil_div(ntiles, 2) * other > 256) ? 4 : 2;
@@ -2216,8 +2216,11 @@ static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
 }
 
 // ================================================================================================================
-// Decode GEMM with the LayerNorm in front of it fused into the operand staging, for at most 4 rows (one utterance, its beams, a batch of
-// 4): at that size a token step is a chain of 172 launches of 4-6 us each and the two LayerNorm launches of a layer are a quarter of it.
+// Decode GEMM with the LayerNorm in front of it fused into the operand staging, for at most 16 rows (one utterance, its beams, the
+// 8-utterance shard a rank of the 8-GPU run decodes): at that size a token step is a chain of 172 launches of 4-6 us each and the two
+// LayerNorm launches of a layer are a quarter of it.  (Round 3: 1-4 rows on 4 waves; round 4: up to 16 rows on 8 waves, one or two rows per
+// wave -- at 16 rows every block reads 16 x 25 KB of L2-resident operands, still cheaper than a 5 us launch; above that the redundant
+// LayerNorm work outgrows the launch it removes.)
 //   Same decomposition as gemm_decode64_kernel<1, 1> (one 16-column n-tile per block, K <= 1280 split over the 4 waves by k-block, LDS
 //   reduce, decode_epilogue), but the activation slab is not DMA'd from a LayerNorm kernel's output: wave w < M computes row w itself with
 //   ln_row (ln_kernel's arithmetic: split-K reduce of the previous GEMM's 4 partials + its bias + residual, then the normalisation) and
@@ -2227,8 +2230,9 @@ static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
 //   are still reading ln_x), and the host alternates the two.  Rows M..15 of the MFMA tile hold whatever the LDS held: MFMA rows are
 //   independent and their outputs are never stored.  Same bf16 operands, same MFMAs in the same order -> bitwise the unfused path.
 // ================================================================================================================
-template <int NV, int EPI, int FLAGS>
-__global__ __launch_bounds__(256) void gemm_decode_ln_kernel(GemmArgs a) {
+template <int NV, int EPI, int FLAGS, int NWV>       // NWV waves per block (4 for <= 4 rows, else 8): wave w normalises rows w, w + NWV;
+                                                    // the MFMA phase and its 4-way K split stay on waves 0-3 at every size
+__global__ __launch_bounds__(NWV * 64) void gemm_decode_ln_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];     // [kp][2 row groups][1 KiB]; reused for the reduction
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     constexpr int NKL = NV * 8;                                    // 32-wide k-blocks of the row (K = 256 NV)
@@ -2245,7 +2249,7 @@ __global__ __launch_bounds__(256) void gemm_decode_ln_kernel(GemmArgs a) {
     // weight fragments of this wave's k-blocks (w, w + 4, ...): straight to registers, all issued now
     constexpr int NI = (NKL + 3) / 4;
     v4u bq[NI];
-    {
+    if (NWV == 4 || w < 4) {
         const int t = nt0 < ntiles ? nt0 : ntiles - 1;
         const v4u* wp = (const v4u*)a.Wp + (size_t)t * NKL * 64 + lane;
 #pragma unroll
@@ -2257,12 +2261,12 @@ __global__ __launch_bounds__(256) void gemm_decode_ln_kernel(GemmArgs a) {
             bq[i] = v;
         }
     }
-    if (w < a.M) {                                                 // wave-uniform: this wave's row
+    for (int r = w; r < a.M; r += NWV) {                           // wave-uniform: this wave's row(s) -- one for <= NWV rows, two for 9-16 rows on 8 waves
         const int D = a.K;
         f32x4 v[NV];
-        ln_row<NV, FLAGS>(a.ln_x + (size_t)w * D, (blockIdx.x == 0) ? a.ln_x_out + (size_t)w * D : (float*)nullptr,
-                          a.ln_partial + (size_t)w * D, (size_t)a.M * D, a.ln_bias_prev, a.ln_g, a.ln_b, nullptr, nullptr, D, a.ln_eps, lane, v);
-        char* row = dsm + (w & 7) * 128 + ((((lane & 15) >> 1) ^ ((w >> 1) & 7)) << 4) + (lane & 1) * 8;
+        ln_row<NV, FLAGS>(a.ln_x + (size_t)r * D, (blockIdx.x == 0) ? a.ln_x_out + (size_t)r * D : (float*)nullptr,
+                          a.ln_partial + (size_t)r * D, (size_t)a.M * D, a.ln_bias_prev, a.ln_g, a.ln_b, nullptr, nullptr, D, a.ln_eps, lane, v);
+        char* row = dsm + (r >> 3) * 1024 + (r & 7) * 128 + ((((lane & 15) >> 1) ^ ((r >> 1) & 7)) << 4) + (lane & 1) * 8;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {                             // elements 4 lane + 256 i ..+3 = k-pair (lane >> 4) + 4 i, piece (lane & 15) >> 1
             uint2 pk;
@@ -2275,25 +2279,27 @@ __global__ __launch_bounds__(256) void gemm_decode_ln_kernel(GemmArgs a) {
     __syncthreads();
 
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int row16 = lane & 15, kg = lane >> 4;
-    const int a_lane = (row16 >> 3) * 1024 + (row16 & 7) * 128;
-    const int sw = (row16 >> 1) & 7;
-    auto lds_frag = [&](int i) -> v4u {
-        int kl = w + 4 * i;
-        kl = kl < NKL ? kl : NKL - 1;
-        const int kp = kl >> 1, pos = (((kl & 1) << 2) + kg) ^ sw;
-        return *(const v4u*)(dsm + kp * 2048 + a_lane + pos * 16);
-    };
-    v4u af_cur = lds_frag(0), af_nxt = af_cur;
+    if (NWV == 4 || w < 4) {                                       // wave-uniform
+        const int row16 = lane & 15, kg = lane >> 4;
+        const int a_lane = (row16 >> 3) * 1024 + (row16 & 7) * 128;
+        const int sw = (row16 >> 1) & 7;
+        auto lds_frag = [&](int i) -> v4u {
+            int kl = w + 4 * i;
+            kl = kl < NKL ? kl : NKL - 1;
+            const int kp = kl >> 1, pos = (((kl & 1) << 2) + kg) ^ sw;
+            return *(const v4u*)(dsm + kp * 2048 + a_lane + pos * 16);
+        };
+        v4u af_cur = lds_frag(0), af_nxt = af_cur;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        if (i + 1 < NI) af_nxt = lds_frag(i + 1);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af_cur), __builtin_bit_cast(bf16x8_t, bq[i]), acc, 0, 0, 0);
-        af_cur = af_nxt;
+        for (int i = 0; i < NI; ++i) {
+            if (i + 1 < NI) af_nxt = lds_frag(i + 1);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af_cur), __builtin_bit_cast(bf16x8_t, bq[i]), acc, 0, 0, 0);
+            af_cur = af_nxt;
+        }
     }
     __syncthreads();                                               // every wave is done with the slab: reuse it
     f32x4* r4 = (f32x4*)dsm;
-    r4[(size_t)w * 64 + lane] = acc;
+    if (NWV == 4 || w < 4) r4[(size_t)w * 64 + lane] = acc;
     __syncthreads();
     if (w == 0) {
         f32x4 sacc = r4[lane];
@@ -2311,19 +2317,22 @@ static int launch_gemm_decode_ln_e(const GemmArgs& a, hipStream_t st) {
     const int ntiles = (a.N + 15) / 16;
     size_t lds = (size_t)NV * 4 * 2048;                            // NV * 8 k-blocks = NV * 4 k-pairs of 2 KiB (two 8-row groups)
     if (lds < 4096) lds = 4096;                                    // reduction scratch: 4 waves x 1 KiB
-    if (a.ln_partial || a.ln_bias_prev) {
-        if (!a.ln_partial || !a.ln_bias_prev || !a.ln_x_out || a.ln_x_out == a.ln_x) { itts_set_error("gemm_decode_ln: partials need a bias and a separate ln_x_out"); return ITTS_ERR_ARG; }
-        hipLaunchKernelGGL((gemm_decode_ln_kernel<NV, EPI, LN_PARTIAL | LN_BIAS>), dim3(ntiles), dim3(256), lds, st, a);
-    } else {
-        hipLaunchKernelGGL((gemm_decode_ln_kernel<NV, EPI, 0>), dim3(ntiles), dim3(256), lds, st, a);
-    }
+    const bool part = a.ln_partial || a.ln_bias_prev;
+    if (part && (!a.ln_partial || !a.ln_bias_prev || !a.ln_x_out || a.ln_x_out == a.ln_x)) { itts_set_error("gemm_decode_ln: partials need a bias and a separate ln_x_out"); return ITTS_ERR_ARG; }
+#define LN_GEMM_LAUNCH(NWV_)                                                                                                             \
+    do {                                                                                                                                 \
+        if (part) hipLaunchKernelGGL((gemm_decode_ln_kernel<NV, EPI, LN_PARTIAL | LN_BIAS, NWV_>), dim3(ntiles), dim3(NWV_ * 64), lds, st, a); \
+        else hipLaunchKernelGGL((gemm_decode_ln_kernel<NV, EPI, 0, NWV_>), dim3(ntiles), dim3(NWV_ * 64), lds, st, a);                     \
+    } while (0)
+    if (a.M <= 4) LN_GEMM_LAUNCH(4); else LN_GEMM_LAUNCH(8);       // (16 waves would cap the kernel at 128 registers: ln_row's one-phase loads need 200)
+#undef LN_GEMM_LAUNCH
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
 
-// shapes the fused kernel takes: bf16, 1-4 rows, K = model_dim in {256, 512, 1280}, one K slice, QKV / GELU epilogue (plain store: the unit op)
+// shapes the fused kernel takes: bf16, 1-16 rows, K = model_dim in {256, 512, 1280}, one K slice, QKV / GELU epilogue (plain store: the unit op)
 bool gemm_decode_ln_ok(int M, int K, int epi) {
-    return M >= 1 && M <= 4 && (K == 256 || K == 512 || K == 1280) && (epi == EPI_QKV || epi == EPI_GELU_ACT || epi == EPI_STORE_F32);
+    return M >= 1 && M <= 16 && (K == 256 || K == 512 || K == 1280) && (epi == EPI_QKV || epi == EPI_GELU_ACT || epi == EPI_STORE_F32);
 }
 
 int launch_gemm_decode_ln(const GemmArgs& a, hipStream_t st) {
@@ -2354,12 +2363,12 @@ template <bool BF16>
 static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
     if (prefill) {
         // bf16, K a multiple of the 64-deep K tile, 16-byte aligned rows: the LDS-DMA tile kernel; else the direct-load one
-        static const bool old_path = [] { const char* e = getenv("ITTS_PREFILL_GEMM"); return e && atoi(e) == 0; }();
+        const bool old_path = itts_opt(OPT_PREFILL_GEMM) == 0;
         if (BF16 && !old_path && a.K % PF_BK == 0 && a.lda % 8 == 0 && a.nsplit == 1 && a.epi != EPI_PARTIAL) return launch_gemm_prefill(a, st);
         if constexpr (!BF16) {
             // f32: the LDS-DMA tile kernel on the f32 MFMA (bitwise the register-path kernel's results; ITTS_F32_TILE=0 forces the
             // latter for the plain epilogues -- the A/B switch of tests/test_gpu_gpt.py / test_gpu_s2mel.py)
-            static const bool f32_reg = [] { const char* e = getenv("ITTS_F32_TILE"); return e && atoi(e) == 0; }();
+            const bool f32_reg = itts_opt(OPT_F32_TILE) == 0;
             const bool fused = a.epi > EPI_QKV || a.out_act2 != nullptr;
             if (pf_f32_ok(a) && (fused || !f32_reg)) return launch_gemm_prefill_f32(a, st);
         }
@@ -2368,7 +2377,7 @@ static int launch_gemm_t(const GemmArgs& a, bool prefill, hipStream_t st) {
     }
     if constexpr (BF16) {
         // bf16 decode: the LDS-DMA slab kernel whenever the K slice fits its image (ITTS_DECODE_GEMM=0: the register-path kernels)
-        static const bool old_path = [] { const char* e = getenv("ITTS_DECODE_GEMM"); return e && atoi(e) == 0; }();
+        const bool old_path = itts_opt(OPT_DECODE_GEMM) == 0;
         // every K slice must hold an EVEN number of 32-wide k-blocks: the slab is DMA'd in 128-byte k-pairs and a slice with
         // an odd count would pair its last k-block with bytes of the neighbouring one (D = 128, 384, 640, ... with 4 slices)
         if (!old_path && ceil_div(a.K / 32, a.nsplit) <= 40 && a.lda % 8 == 0 && (a.K / 32) % (2 * a.nsplit) == 0) {
@@ -2415,17 +2424,35 @@ int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st) {
 // ================================================================================================================
 // Attention of one query against the KV cache (decode: nq = 1; prefill / latent pass: one block per query).
 //   keys pad[b] .. pos0+qi, softmax in f32, exact skip of left-pad keys (additive finfo.min mask == weight 0).
-// block = 4 waves; LPK lanes share one key row (16 B each): bf16 8 lanes x 8 dims, f32 16 lanes x 4 dims.
+// LPK lanes share one key row (16 B each): bf16 8 lanes x 8 dims, f32 16 lanes x 4 dims; a wave-load covers 64 / LPK keys.
+//
+// The arithmetic is defined over 16 CANONICAL KEY STREAMS, independent of the launch geometry: the keys of a query are cut into
+// chunks of 64 (chunk c = keys first + 64 c ...), stream r owns chunks r, r + 16, r + 32, ...; inside a stream every lane group
+// runs an online softmax over its keys in ascending order, the lane groups of the stream are merged by a fixed butterfly, and the 16
+// stream results are merged flat, r = 0 .. 15, by the block's first wave.  A block of NW waves (4, 8 or 16) hosts streams w, w + NW,
+// ... on wave w -- every geometry performs the same operations on the same operands in the same order, so the output bits do not
+// depend on NW, on the batch size that picked it, or on where a row sits in the batch (tests/test_gpu_gpt.py: row alone == row in
+// the 64-row batch).
+//   Why: the first version (one online softmax per lane group over ALL keys, 4 waves) is a chain of one dependent memory round trip
+// per 32 keys of the block; at 1-16 rows the launch has < 1 block per CU, nothing hides that chain, and the kernel cost 9-25 us per
+// layer (the largest launch of a small-batch token step, profiles/r03x/decode_step_timeline_b1.txt).  Here a wave issues the K and
+// V loads of 8 wave-loads (a whole bf16 chunk) before it touches the first, and at small batches 16 waves put up to 1024 keys of a
+// (row, head) in flight at once: one round trip for any context the model allows.
 // ================================================================================================================
 template <bool BF16>
 __device__ __forceinline__ float exp_sel(float x) { return BF16 ? __expf(x) : expf(x); }
 
-template <bool BF16>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+#define ATTN_STREAMS 16
+template <bool BF16, int NW, bool RMAP>      // RMAP: the beam search's row map is in use (a template flag: a run-time `rmap ? load : pb` costs a
+                                            // branch and a vmcnt(0) in front of every group's loads, which serialises them again)
+__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs a) {
     constexpr int LPK = BF16 ? 8 : 16;      // lanes per key
     constexpr int DPL = 64 / LPK;           // dims per lane
     constexpr int KPW = 64 / LPK;           // keys per wave-load
-    __shared__ float sm_m[4], sm_l[4], sm_acc[4][64];
+    constexpr int CH = 64;                  // keys per chunk
+    constexpr int LPC = CH / KPW;           // wave-loads per chunk (8 / 16)
+    constexpr int UB = 8;                   // wave-loads in flight per batch
+    __shared__ float sm_m[ATTN_STREAMS], sm_l[ATTN_STREAMS], sm_acc[ATTN_STREAMS][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
     const int qi = blockIdx.y;
@@ -2436,223 +2463,125 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     const int sub = lane % LPK, grp = lane / LPK;
     const size_t qrow = (size_t)b * a.nq + qi;
     const int* rmap = a.row_map;
-    if (rmap && a.row_map_alt && a.step_ptr && (*a.step_ptr & 1)) rmap = a.row_map_alt;
+    if constexpr (RMAP) {
+        if (a.row_map_alt && a.step_ptr && (*a.step_ptr & 1)) rmap = a.row_map_alt;
+    }
 
     float q[DPL];
 #pragma unroll
     for (int d = 0; d < DPL; ++d) q[d] = a.qbuf[qrow * a.D + h * 64 + sub * DPL + d];
 
-    float m_run = -INFINITY, l_run = 0.f, acc[DPL];
+    for (int r = w; r < ATTN_STREAMS; r += NW) {                   // the streams this wave hosts
+        float m_run = -INFINITY, l_run = 0.f, acc[DPL];
 #pragma unroll
-    for (int d = 0; d < DPL; ++d) acc[d] = 0.f;
-
-    for (int t0 = first + w * KPW; t0 <= last; t0 += 4 * KPW) {
-        const int t = t0 + grp;
-        const bool ok = t <= last;
-        const int tc = ok ? t : last;
-        const int prow = rmap ? rmap[(size_t)b * a.Tmax + tc] : pb;
-        const size_t off = (((size_t)prow * a.H + h) * a.Tmax + tc) * 64 + sub * DPL;
-        float kf[DPL], vf[DPL];
-        if constexpr (BF16) {
-            const uint4 kr = *(const uint4*)((const u16*)a.kcache + off);
-            const uint4 vr = *(const uint4*)((const u16*)a.vcache + off);
-            const uint32_t kw[4] = {kr.x, kr.y, kr.z, kr.w}, vw[4] = {vr.x, vr.y, vr.z, vr.w};
+        for (int d = 0; d < DPL; ++d) acc[d] = 0.f;
+        for (int c = r; first + c * CH <= last; c += ATTN_STREAMS) {
+            const int tb = first + c * CH;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                kf[2 * i] = __uint_as_float(kw[i] << 16);
-                kf[2 * i + 1] = __uint_as_float(kw[i] & 0xffff0000u);
-                vf[2 * i] = __uint_as_float(vw[i] << 16);
-                vf[2 * i + 1] = __uint_as_float(vw[i] & 0xffff0000u);
+            for (int h0 = 0; h0 < LPC; h0 += UB) {
+                if (tb + h0 * KPW > last) break;                   // wave-uniform: the rest of the chunk is past the query
+                bool okv[UB];
+                int tcv[UB], prowv[UB];
+                v4u kraw[UB], vraw[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int t = tb + (h0 + u) * KPW + grp;
+                    okv[u] = t <= last;
+                    tcv[u] = okv[u] ? t : last;
+                    if constexpr (RMAP) prowv[u] = rmap[(size_t)b * a.Tmax + tcv[u]];
+                    else prowv[u] = pb;
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {                     // every K / V load of the batch before the first use
+                    const size_t off = (((size_t)prowv[u] * a.H + h) * a.Tmax + tcv[u]) * 64 + sub * DPL;
+                    if constexpr (BF16) {
+                        kraw[u] = *(const v4u*)((const u16*)a.kcache + off);
+                        vraw[u] = *(const v4u*)((const u16*)a.vcache + off);
+                    } else {
+                        kraw[u] = *(const v4u*)((const float*)a.kcache + off);
+                        vraw[u] = *(const v4u*)((const float*)a.vcache + off);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);                 // keep hipcc from sinking the later loads below the first use
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {                     // then the keys in ascending order
+                    float kf[DPL], vf[DPL];
+                    if constexpr (BF16) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            kf[2 * i] = __uint_as_float(kraw[u][i] << 16);
+                            kf[2 * i + 1] = __uint_as_float(kraw[u][i] & 0xffff0000u);
+                            vf[2 * i] = __uint_as_float(vraw[u][i] << 16);
+                            vf[2 * i + 1] = __uint_as_float(vraw[u][i] & 0xffff0000u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { kf[i] = __uint_as_float(kraw[u][i]); vf[i] = __uint_as_float(vraw[u][i]); }
+                    }
+                    float s = 0.f;
+#pragma unroll
+                    for (int d = 0; d < DPL; ++d) s = fmaf(q[d], kf[d], s);
+#pragma unroll
+                    for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
+                    s *= 0.125f;    // / sqrt(64)
+                    if (okv[u]) {
+                        const float nm = fmaxf(m_run, s);
+                        const float sc = exp_sel<BF16>(m_run - nm);      // m_run = -inf -> 0
+                        const float p = exp_sel<BF16>(s - nm);
+                        l_run = l_run * sc + p;
+#pragma unroll
+                        for (int d = 0; d < DPL; ++d) acc[d] = acc[d] * sc + p * vf[d];
+                        m_run = nm;
+                    }
+                }
             }
-        } else {
-            const float4 kr = *(const float4*)((const float*)a.kcache + off);
-            const float4 vr = *(const float4*)((const float*)a.vcache + off);
-            kf[0] = kr.x; kf[1] = kr.y; kf[2] = kr.z; kf[3] = kr.w;
-            vf[0] = vr.x; vf[1] = vr.y; vf[2] = vr.z; vf[3] = vr.w;
         }
-        float s = 0.f;
+        // merge the KPW lane groups of the stream
 #pragma unroll
-        for (int d = 0; d < DPL; ++d) s = fmaf(q[d], kf[d], s);
+        for (int o = LPK; o < 64; o <<= 1) {
+            const float om = __shfl_xor(m_run, o, 64), ol = __shfl_xor(l_run, o, 64);
+            const float nm = fmaxf(m_run, om);
+            const float sa = (m_run == -INFINITY) ? 0.f : exp_sel<BF16>(m_run - nm);
+            const float sb = (om == -INFINITY) ? 0.f : exp_sel<BF16>(om - nm);
+            l_run = l_run * sa + ol * sb;
 #pragma unroll
-        for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
-        s *= 0.125f;    // / sqrt(64)
-        if (ok) {
-            const float nm = fmaxf(m_run, s);
-            const float sc = exp_sel<BF16>(m_run - nm);      // m_run = -inf -> 0
-            const float p = exp_sel<BF16>(s - nm);
-            l_run = l_run * sc + p;
-#pragma unroll
-            for (int d = 0; d < DPL; ++d) acc[d] = acc[d] * sc + p * vf[d];
+            for (int d = 0; d < DPL; ++d) {
+                const float oa = __shfl_xor(acc[d], o, 64);
+                acc[d] = acc[d] * sa + oa * sb;
+            }
             m_run = nm;
         }
-    }
-    // merge the KPW key groups of the wave
+        if (lane < LPK) {
+            sm_m[r] = m_run;
+            sm_l[r] = l_run;
 #pragma unroll
-    for (int o = LPK; o < 64; o <<= 1) {
-        const float om = __shfl_xor(m_run, o, 64), ol = __shfl_xor(l_run, o, 64);
-        const float nm = fmaxf(m_run, om);
-        const float sa = (m_run == -INFINITY) ? 0.f : exp_sel<BF16>(m_run - nm);
-        const float sb = (om == -INFINITY) ? 0.f : exp_sel<BF16>(om - nm);
-        l_run = l_run * sa + ol * sb;
-#pragma unroll
-        for (int d = 0; d < DPL; ++d) {
-            const float oa = __shfl_xor(acc[d], o, 64);
-            acc[d] = acc[d] * sa + oa * sb;
+            for (int d = 0; d < DPL; ++d) sm_acc[r][sub * DPL + d] = acc[d];
         }
-        m_run = nm;
-    }
-    if (lane < LPK) {
-        sm_m[w] = m_run;
-        sm_l[w] = l_run;
-#pragma unroll
-        for (int d = 0; d < DPL; ++d) sm_acc[w][sub * DPL + d] = acc[d];
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 64) {                                        // flat merge of the 16 streams, r ascending
         const int d = threadIdx.x;
-        float nm = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float nm = sm_m[0];
+#pragma unroll
+        for (int r = 1; r < ATTN_STREAMS; ++r) nm = fmaxf(nm, sm_m[r]);
         float l = 0.f, o = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-            const float sc = (sm_m[ww] == -INFINITY) ? 0.f : exp_sel<BF16>(sm_m[ww] - nm);
-            l += sm_l[ww] * sc;
-            o += sm_acc[ww][d] * sc;
+        for (int r = 0; r < ATTN_STREAMS; ++r) {
+            const float sc = (sm_m[r] == -INFINITY) ? 0.f : exp_sel<BF16>(sm_m[r] - nm);
+            l += sm_l[r] * sc;
+            o += sm_acc[r][d] * sc;
         }
-        const float r = l > 0.f ? o / l : 0.f;
+        const float res = l > 0.f ? o / l : 0.f;
         const size_t oo = qrow * a.D + h * 64 + d;
-        if (BF16) ((u16*)a.out)[oo] = f32_to_bf16(r);
-        else ((float*)a.out)[oo] = r;
+        if (BF16) ((u16*)a.out)[oo] = f32_to_bf16(res);
+        else ((float*)a.out)[oo] = res;
     }
 }
 
-typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
-// attn_kernel with the K / V loads of U consecutive key groups of a wave issued before the first of them is used (experiment switch
-// ITTS_ATTN_UNROLL=4; default off until measured on the GPU).  At 1-4 rows the kernel is 20-80 blocks walking their keys in a chain of
-// dependent memory round trips -- one per 32 keys of the block: 9.3 us per layer at a 40-token context, the largest launch of a 1-row token step
-// (profiles/r03x/decode_step_timeline_b1.txt) -- and U = 4 puts four of them in flight.  The key groups are consumed in the original order, so
-// every running maximum / sum / accumulator sees the same sequence of updates: bitwise attn_kernel.
-template <bool BF16, int U, bool RMAP>      // RMAP: the beam search's row map is in use (a template flag: a run-time `rmap ? load : pb` costs a
-                                            // branch and a vmcnt(0) in front of every group's loads, which serialises them again)
-__global__ __launch_bounds__(256) void attn_kernel_u(AttnArgs a) {
-    constexpr int LPK = BF16 ? 8 : 16;      // lanes per key
-    constexpr int DPL = 64 / LPK;           // dims per lane
-    constexpr int KPW = 64 / LPK;           // keys per wave-load
-    __shared__ float sm_m[4], sm_l[4], sm_acc[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
-    const int qi = blockIdx.y;
-    const int last = *a.pos_ptr + qi;
-    const int sm = a.seq_mul > 1 ? a.seq_mul : 1;
-    const int pb = a.seq_map ? a.seq_map[b] : b * sm;              // physical cache row / pad entry of this sequence
-    const int first = a.pad ? a.pad[pb] : 0;
-    const int sub = lane % LPK, grp = lane / LPK;
-    const size_t qrow = (size_t)b * a.nq + qi;
-    const int* rmap = a.row_map;
-    if (rmap && a.row_map_alt && a.step_ptr && (*a.step_ptr & 1)) rmap = a.row_map_alt;
-
-    float q[DPL];
-#pragma unroll
-    for (int d = 0; d < DPL; ++d) q[d] = a.qbuf[qrow * a.D + h * 64 + sub * DPL + d];
-
-    float m_run = -INFINITY, l_run = 0.f, acc[DPL];
-#pragma unroll
-    for (int d = 0; d < DPL; ++d) acc[d] = 0.f;
-
-    for (int t0 = first + w * KPW; t0 <= last; t0 += 4 * KPW * U) {
-        bool okv[U];
-        int tcv[U], prowv[U];
-        v4u_t kraw[U], vraw[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t = t0 + u * 4 * KPW + grp;
-            okv[u] = t <= last;
-            tcv[u] = okv[u] ? t : last;
-            if constexpr (RMAP) prowv[u] = rmap[(size_t)b * a.Tmax + tcv[u]];
-            else prowv[u] = pb;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                                 // every K / V load of the U groups before the first use
-            const int tc = tcv[u];
-            const size_t off = (((size_t)prowv[u] * a.H + h) * a.Tmax + tc) * 64 + sub * DPL;
-            if constexpr (BF16) {
-                kraw[u] = *(const v4u_t*)((const u16*)a.kcache + off);
-                vraw[u] = *(const v4u_t*)((const u16*)a.vcache + off);
-            } else {
-                kraw[u] = *(const v4u_t*)((const float*)a.kcache + off);
-                vraw[u] = *(const v4u_t*)((const float*)a.vcache + off);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);                            // keep hipcc from sinking the later groups' loads below the first group's use
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                                 // then the groups in their original order
-            const bool ok = okv[u];
-            float kf[DPL], vf[DPL];
-            if constexpr (BF16) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    kf[2 * i] = __uint_as_float(kraw[u][i] << 16);
-                    kf[2 * i + 1] = __uint_as_float(kraw[u][i] & 0xffff0000u);
-                    vf[2 * i] = __uint_as_float(vraw[u][i] << 16);
-                    vf[2 * i + 1] = __uint_as_float(vraw[u][i] & 0xffff0000u);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { kf[i] = __uint_as_float(kraw[u][i]); vf[i] = __uint_as_float(vraw[u][i]); }
-            }
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < DPL; ++d) s = fmaf(q[d], kf[d], s);
-#pragma unroll
-            for (int o = 1; o < LPK; o <<= 1) s += __shfl_xor(s, o, 64);
-            s *= 0.125f;    // / sqrt(64)
-            if (ok) {
-                const float nm = fmaxf(m_run, s);
-                const float sc = exp_sel<BF16>(m_run - nm);      // m_run = -inf -> 0
-                const float p = exp_sel<BF16>(s - nm);
-                l_run = l_run * sc + p;
-#pragma unroll
-                for (int d = 0; d < DPL; ++d) acc[d] = acc[d] * sc + p * vf[d];
-                m_run = nm;
-            }
-        }
-    }
-    // merge the KPW key groups of the wave
-#pragma unroll
-    for (int o = LPK; o < 64; o <<= 1) {
-        const float om = __shfl_xor(m_run, o, 64), ol = __shfl_xor(l_run, o, 64);
-        const float nm = fmaxf(m_run, om);
-        const float sa = (m_run == -INFINITY) ? 0.f : exp_sel<BF16>(m_run - nm);
-        const float sb = (om == -INFINITY) ? 0.f : exp_sel<BF16>(om - nm);
-        l_run = l_run * sa + ol * sb;
-#pragma unroll
-        for (int d = 0; d < DPL; ++d) {
-            const float oa = __shfl_xor(acc[d], o, 64);
-            acc[d] = acc[d] * sa + oa * sb;
-        }
-        m_run = nm;
-    }
-    if (lane < LPK) {
-        sm_m[w] = m_run;
-        sm_l[w] = l_run;
-#pragma unroll
-        for (int d = 0; d < DPL; ++d) sm_acc[w][sub * DPL + d] = acc[d];
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int d = threadIdx.x;
-        float nm = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
-        float l = 0.f, o = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-            const float sc = (sm_m[ww] == -INFINITY) ? 0.f : exp_sel<BF16>(sm_m[ww] - nm);
-            l += sm_l[ww] * sc;
-            o += sm_acc[ww][d] * sc;
-        }
-        const float r = l > 0.f ? o / l : 0.f;
-        const size_t oo = qrow * a.D + h * 64 + d;
-        if (BF16) ((u16*)a.out)[oo] = f32_to_bf16(r);
-        else ((float*)a.out)[oo] = r;
-    }
+template <bool BF16, int NW>
+static void launch_attention_nw(const AttnArgs& a, dim3 grid, hipStream_t st) {
+    if (a.row_map) hipLaunchKernelGGL((attn_kernel<BF16, NW, true>), grid, dim3(NW * 64), 0, st, a);
+    else hipLaunchKernelGGL((attn_kernel<BF16, NW, false>), grid, dim3(NW * 64), 0, st, a);
 }
 
 int launch_attention(const AttnArgs& a, int prec, hipStream_t st) {
@@ -2660,16 +2589,13 @@ int launch_attention(const AttnArgs& a, int prec, hipStream_t st) {
     if (a.D != a.H * 64) { itts_set_error("attention: head_dim must be 64 (D=%d H=%d)", a.D, a.H); return ITTS_ERR_ARG; }
     if (a.nq > 65535) { itts_set_error("attention: more than 65535 queries per sequence"); return ITTS_ERR_ARG; }
     dim3 grid(a.nseq * a.H, a.nq);
-    static const int unroll = [] { const char* e = getenv("ITTS_ATTN_UNROLL"); return e ? atoi(e) : 1; }();      // 4: attn_kernel_u (experiment, bitwise the same)
-    if (unroll == 4) {
-        const bool rm = a.row_map != nullptr;
-        if (prec == PREC_BF16) { if (rm) hipLaunchKernelGGL((attn_kernel_u<true, 4, true>), grid, dim3(256), 0, st, a);
-                                 else hipLaunchKernelGGL((attn_kernel_u<true, 4, false>), grid, dim3(256), 0, st, a); }
-        else { if (rm) hipLaunchKernelGGL((attn_kernel_u<false, 4, true>), grid, dim3(256), 0, st, a);
-               else hipLaunchKernelGGL((attn_kernel_u<false, 4, false>), grid, dim3(256), 0, st, a); }
-    } else
-    if (prec == PREC_BF16) hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, st, a);
+    // waves per block (option attn_waves forces 4 / 8 / 16; every choice gives the same bits): 16 while the launch has at most two
+    // blocks per CU (one round trip for the whole context), 8 up to four, else 4 (occupancy hides the chain of chunk loads)
+    const long long blocks = (long long)grid.x * grid.y;
+    int nw = itts_opt(OPT_ATTN_WAVES);
+    if (nw != 4 && nw != 8 && nw != 16) nw = blocks <= 512 ? 16 : blocks <= 1024 ? 8 : 4;
+    if (prec == PREC_BF16) { if (nw == 16) launch_attention_nw<true, 16>(a, grid, st); else if (nw == 8) launch_attention_nw<true, 8>(a, grid, st); else launch_attention_nw<true, 4>(a, grid, st); }
+    else { if (nw == 16) launch_attention_nw<false, 16>(a, grid, st); else if (nw == 8) launch_attention_nw<false, 8>(a, grid, st); else launch_attention_nw<false, 4>(a, grid, st); }
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
@@ -3175,7 +3101,7 @@ int launch_sample(const SampleArgs& a, hipStream_t st) {
     if (int rc = ensure_dyn_lds(sample_kernel, lds, &granted, "sampling")) return rc;
     // top-k threshold: the radix select here (par with the ballot bisection at 1 row, 1 % ahead at 64 rows), the bisection in the beam
     // kernel (-2 %: its radix pass ended in a serial 256-bucket scan); ITTS_SAMPLE_RADIX=0 / 1 forces one of them in both (profiles/r03x)
-    static const int radix = [] { const char* e = getenv("ITTS_SAMPLE_RADIX"); return e ? atoi(e) : 1; }();
+    const int radix = itts_opt(OPT_SAMPLE_RADIX) < 0 ? 1 : itts_opt(OPT_SAMPLE_RADIX);
     SampleArgs a2 = a;
     a2.radix_select = radix;
     hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), lds, st, a2);
@@ -3514,7 +3440,7 @@ int launch_beam_step(const BeamArgs& a, hipStream_t st) {
     const size_t lds = (size_t)a.V * sizeof(float) * (a.typical_mass > 0.f ? 2 : 1);
     static size_t granted = 0;
     if (int rc = ensure_dyn_lds(beam_rows_kernel, lds, &granted, "beam search")) return rc;
-    static const int radix = [] { const char* e = getenv("ITTS_SAMPLE_RADIX"); return e ? atoi(e) : 0; }();
+    const int radix = itts_opt(OPT_SAMPLE_RADIX) < 0 ? 0 : itts_opt(OPT_SAMPLE_RADIX);
     BeamArgs a2 = a;
     a2.radix_select = radix;
     hipLaunchKernelGGL(beam_rows_kernel, dim3(a.B * a.nb), dim3(256), lds, st, a2);

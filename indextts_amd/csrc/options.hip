@@ -1,0 +1,98 @@
+// Run-time options of the engine: ONE documented table behind itts_set_option / itts_get_option (include/indextts_hip.h).
+// The library reads no environment variable.  Every option selects between kernels (or kernel geometries) that are held to
+// the same results by tests -- most of them bitwise -- and exists so that those tests, and the measurement tools, can switch
+// paths inside one process; the defaults are the measured-best paths and are what the shipped host code runs.
+#include <atomic>
+#include <string.h>
+
+#include "../../include/indextts_hip.h"
+#include "common.h"
+
+namespace {
+struct OptDef {
+    const char* name;
+    int def, lo, hi;
+    const char* doc;
+};
+// order == the OPT_* enum of common.h
+const OptDef kDefs[OPT_COUNT] = {
+    {"decode_fuse_ln", 1, 0, 1, "GPT decode steps of 1-16 rows: LayerNorm (+ split-K reduce, bias, residual) inside the consuming GEMM (0: separate ln_kernel launches; bitwise equal)"},
+    {"decode_gemm", 1, 0, 1, "bf16 decode GEMMs on the LDS-DMA slab kernel (0: register-path gemm_kernel; bitwise equal)"},
+    {"decode_rot", 1, 0, 1, "per-block rotation of the slab DMA issue order in the decode GEMM (same bytes, same LDS image)"},
+    {"decode_wnt", 0, 0, 1, "non-temporal policy on the decode GEMM's weight stream"},
+    {"decode_nt", 0, 0, 4, "force the n-tiles per block of the 64-row decode GEMM (0: smallest that fits one round of blocks)"},
+    {"prefill_gemm", 1, 0, 1, "bf16 prefill GEMMs on the LDS-DMA tile kernels (0: register-path gemm_kernel; bitwise equal)"},
+    {"tile256", -1, -1, 2, "bf16 tile GEMM: -1 pick by shape, 0 always 128x128, 1 always 256x256, 2 always 256x128 (bitwise equal)"},
+    {"f32_tile", 1, 0, 1, "f32 GEMMs with plain epilogues on the f32-MFMA tile kernel (0: register-path kernel; bitwise equal)"},
+    {"x3_products", 8, 6, 8, "plane products per f32 product of the fp32x3 GEMM: 8 (every term down to 2^-24 |ab|) or 6 (drops m*l and l*m)"},
+    {"x3_sched", 1, 0, 1, "fp32x3 GEMM: interleave the operand split with the MFMAs (0: split as a burst; bitwise equal)"},
+    {"x3_planes", 1, 0, 1, "fp32x3 s2mel: producers emit the three bf16 planes of the next GEMM's A operand (0: each GEMM block splits its own f32 A tile; bitwise equal)"},
+    {"sample_radix", -1, -1, 1, "top-k threshold: -1 per-kernel default (radix select in sample_kernel, ballot bisection in the beam kernels), 0 bisection, 1 radix select (identical ids)"},
+    {"gpt_compact", 1, 0, 1, "row compaction of ragged decode batches (0 disables it for every handle; identical ids)"},
+    {"attn_waves", 0, 0, 16, "waves per block of the KV-cache attention kernel: 0 pick by shape, else 4 / 8 / 16 (the 16 canonical key streams are mapped onto them; bitwise equal)"},
+    {"s2mel_fused", 1, 0, 1, "bf16 s2mel: fused GEMM epilogues (0: separate element-wise kernels)"},
+    {"fa_qs", 0, 0, 4, "bf16 flash attention: query sub-tiles per wave (0: pick by shape)"},
+    {"f32_attn_scalar", 0, 0, 1, "f32 s2mel attention on the one-wave-per-query reference kernel (the A/B path of the f32 flash kernel)"},
+    {"fa32_qs", 2, 1, 2, "f32 flash attention: query sub-tiles per wave"},
+    {"aa_act", 2, 0, 2, "anti-aliased activation kernel variant (2: swizzled LDS tiles)"},
+    {"conv_bm", 0, 0, 128, "force the co-tile height of conv_mfma_kernel (0: pick by channel count)"},
+    {"h3_kernel", 1, 0, 1, "f16x3 vocoder conv: 1 window kernel, 0 two-stage kernel"},
+    {"s2mel_fuse_norm", 1, 0, 1, "f32 / fp32x3 s2mel: adaptive RMSNorm fused into the residual GEMM that produces its input (0: separate ada_rmsnorm launches; bitwise equal)"},
+};
+std::atomic<int> g_val[OPT_COUNT];
+std::atomic<unsigned> g_epoch{1};
+std::atomic<bool> g_init{false};
+
+void ensure_init() {
+    if (g_init.load(std::memory_order_acquire)) return;
+    static std::atomic_flag once = ATOMIC_FLAG_INIT;
+    if (!once.test_and_set()) {
+        for (int i = 0; i < OPT_COUNT; ++i) g_val[i].store(kDefs[i].def, std::memory_order_relaxed);
+        g_init.store(true, std::memory_order_release);
+    } else {
+        while (!g_init.load(std::memory_order_acquire)) {}
+    }
+}
+int find(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (strcmp(kDefs[i].name, name) == 0) return i;
+    return -1;
+}
+}  // namespace
+
+int itts_opt(int id) {
+    ensure_init();
+    return g_val[id].load(std::memory_order_relaxed);
+}
+unsigned itts_opt_epoch() { return g_epoch.load(std::memory_order_relaxed); }
+
+extern "C" int itts_set_option(const char* name, int value) {
+    ensure_init();
+    const int i = find(name);
+    if (i < 0) { itts_set_error("set_option: unknown option '%s'", name ? name : "(null)"); return ITTS_ERR_ARG; }
+    if (value < kDefs[i].lo || value > kDefs[i].hi) {
+        itts_set_error("set_option: %s = %d outside [%d, %d]", name, value, kDefs[i].lo, kDefs[i].hi);
+        return ITTS_ERR_ARG;
+    }
+    if (g_val[i].exchange(value) != value) g_epoch.fetch_add(1);      // cached decode graphs bake kernel choices in: a new epoch retires them
+    return ITTS_OK;
+}
+extern "C" int itts_get_option(const char* name, int* value) {
+    ensure_init();
+    const int i = find(name);
+    if (i < 0 || !value) { itts_set_error("get_option: unknown option '%s'", name ? name : "(null)"); return ITTS_ERR_ARG; }
+    *value = g_val[i].load();
+    return ITTS_OK;
+}
+extern "C" int itts_reset_options(void) {
+    ensure_init();
+    bool changed = false;
+    for (int i = 0; i < OPT_COUNT; ++i) changed |= g_val[i].exchange(kDefs[i].def) != kDefs[i].def;
+    if (changed) g_epoch.fetch_add(1);
+    return ITTS_OK;
+}
+extern "C" int itts_option_count(void) { return OPT_COUNT; }
+extern "C" const char* itts_option_name(int index) { return (index >= 0 && index < OPT_COUNT) ? kDefs[index].name : nullptr; }
+extern "C" const char* itts_option_doc(int index) { return (index >= 0 && index < OPT_COUNT) ? kDefs[index].doc : nullptr; }
+extern "C" int itts_option_default(int index) { return (index >= 0 && index < OPT_COUNT) ? kDefs[index].def : 0; }

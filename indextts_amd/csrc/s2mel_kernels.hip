@@ -677,21 +677,21 @@ int launch_s2mel_attention(const void* q, const void* k, const void* v, void* ou
     if (tab.n_tok <= 0) return ITTS_OK;
     if (prec == PREC_BF16) {
         const float scale_log2e = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64) * log2(e)
-        // query sub-tiles per wave (ITTS_FA_QS forces a variant).  One sub-tile is LDS-bound (every K / V^T fragment read feeds one
+        // query sub-tiles per wave (option fa_qs forces a variant).  One sub-tile is LDS-bound (every K / V^T fragment read feeds one
         // MFMA: SQ_LDS_IDX_ACTIVE at 70-90 % of the kernel's cycles, profiles/r02l), two halve the fragment traffic per MFMA and
         // still fit three waves per SIMD; four need 256 registers (one wave per SIMD) and lose to latency.
-        static const int force_qs = [] { const char* e = getenv("ITTS_FA_QS"); return e ? atoi(e) : 0; }();
+        const int force_qs = itts_opt(OPT_FA_QS);
         const int qs = force_qs ? force_qs : 2;
 #define FA_LAUNCH(QS_) hipLaunchKernelGGL(flash_attn_bf16_kernel<QS_>, dim3(ceil_div(tab.t_max, 64 * QS_), heads, tab.n_seq), dim3(256), 0, st, \
                                           (const u16*)q, (const u16*)k, (const u16*)v, (u16*)out, tab, heads, t_pad, scale_log2e)
         if (qs >= 4) FA_LAUNCH(4); else if (qs == 2) FA_LAUNCH(2); else FA_LAUNCH(1);
 #undef FA_LAUNCH
     } else {
-        static const bool scalar = [] { const char* e = getenv("ITTS_F32_ATTN"); return e && e[0] == 's'; }();      // "scalar": the A/B reference
+        const bool scalar = itts_opt(OPT_F32_ATTN_SCALAR) != 0;      // the one-wave-per-query A/B reference
         if (scalar) {
             hipLaunchKernelGGL(attn_f32_kernel, dim3(tab.n_tok, heads), dim3(64), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, tab, heads, t_pad);
         } else {
-            static const int qs = [] { const char* e = getenv("ITTS_FA32_QS"); const int v = e ? atoi(e) : 2; return v == 1 ? 1 : 2; }();
+            const int qs = itts_opt(OPT_FA32_QS) == 1 ? 1 : 2;
             static bool attr_set = false;
             if (!attr_set) {
                 HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FA32_LDS));

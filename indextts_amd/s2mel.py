@@ -75,7 +75,7 @@ class CFM:
         # the once-per-solve projections of the step-invariant inputs (K = 784 is not a multiple of the x3 kernel's 32-deep tile) run f32
         self._host_prec = 0 if self.precision == 2 else self.precision
         # solve_euler: skip the post-attention stages on prompt rows whose output the Euler step discards (bit-identical results; A/B switch)
-        self.prune_dead_rows = os.environ.get("ITTS_S2MEL_PRUNE", "1") != "0"
+        self.prune_dead_rows = True
         cfg = _lib.S2MelConfig()
         cfg.hidden_dim, cfg.num_heads, cfg.depth, cfg.in_channels = self.hidden_dim, self.num_heads, self.depth, self.in_channels
         cfg.wavenet_hidden, cfg.wavenet_layers = self.wavenet_hidden, self.wavenet_layers

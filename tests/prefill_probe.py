@@ -1,6 +1,6 @@
 """Helper for test_gpu_gpt.py::test_prefill_gemm_kernels_agree: runs the bf16 engine's prefill-shaped paths (teacher-forced
-latent pass + a short greedy decode) and prints a digest of the raw outputs.  The env var ITTS_PREFILL_GEMM selects the
-prefill GEMM kernel (read once per process), hence a separate process per setting."""
+latent pass + a short greedy decode) and prints a digest of the raw outputs.  PROBE_OPTS ("name=value,...": engine options applied through
+itts_set_option) selects the GEMM kernels under test, one process per setting."""
 import hashlib
 import os
 import sys
@@ -10,6 +10,9 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from indextts_amd import gpt  # noqa: E402
 from oracle import gpt_oracle as G  # noqa: E402  (seeded synthetic weights only)
+from indextts_amd import _lib  # noqa: E402
+for _kv in filter(None, os.environ.get("PROBE_OPTS", "").split(",")):      # engine options of this run (itts_set_option), e.g. "decode_fuse_ln=0"
+    _lib.set_option(_kv.split("=")[0], int(_kv.split("=")[1]))
 
 BIG = os.environ.get("PROBE_BIG") == "1"       # full-width stack (K = 1280 / 5120 slices) and 40 rows: the 33..64-row decode GEMM
 cfg = (G.GPTConfig(layers=2, model_dim=1280, heads=20, max_text_tokens=60, max_mel_tokens=80, number_text_tokens=200) if BIG

@@ -1,6 +1,7 @@
 """Helper for test_gpu_s2mel.py::test_tile_gemm_kernels_agree / test_f32_fast_path_vs_separate_kernels: runs the s2mel solve (PROBE_PREC,
-default bf16) at the shipped widths on three ragged utterances and prints a digest of the raw output (PROBE_SAVE: also saves it).  ITTS_TILE256 (read once per process) selects the tile GEMM kernel: 0 = the
-128 x 128 kernel, 1 = the 256 x 256 eight-wave kernel, 2 = the 256 x 128 four-wave kernel, for every shape -- hence one process per setting."""
+default bf16) at the shipped widths on three ragged utterances and prints a digest of the raw output (PROBE_SAVE: also saves it).  PROBE_OPTS
+("name=value,...": engine options applied through itts_set_option before the model is built, e.g. tile256 = 0 / 1 / 2: the 128 x 128, 256 x 256
+eight-wave, 256 x 128 four-wave tile GEMM for every shape) selects the kernels under test, one process per setting."""
 import hashlib
 import os
 import sys
@@ -11,6 +12,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from oracle import s2mel_oracle as S  # noqa: E402  (seeded synthetic weights only)
 from test_gpu_s2mel import engine  # noqa: E402
+from indextts_amd import _lib  # noqa: E402
+for _kv in filter(None, os.environ.get("PROBE_OPTS", "").split(",")):      # engine options of this run (itts_set_option), e.g. "decode_fuse_ln=0"
+    _lib.set_option(_kv.split("=")[0], int(_kv.split("=")[1]))
 
 cfg = S.S2MelConfig(depth=3, wavenet_layers=2, wavenet_dilation_rate=int(os.environ.get("PROBE_DIL", "1")))
 sd = S.synth_weights(cfg, 5)

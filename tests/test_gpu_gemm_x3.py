@@ -40,10 +40,10 @@ def test_x3_gemm_is_at_least_as_accurate_as_native_f32(M, N, K):
 
 
 def test_x3_six_products_error_reported():
-    """ITTS_X3_PRODUCTS=6 drops the two 2^-24-relative cross terms (ml, lm): reported beside the 8-product default."""
-    code = ("import sys; sys.path.insert(0, %r); from tests import test_gpu_gemm_x3 as T; "
+    """Option x3_products = 6 drops the two 2^-24-relative cross terms (ml, lm): reported beside the 8-product default."""
+    code = ("import sys; sys.path.insert(0, %r); from tests import test_gpu_gemm_x3 as T; from indextts_amd import _lib; _lib.set_option('x3_products', 6); "
             "e = T._errors(300, 512, 512, 9); print('X3SIX', e['f32'][1], e['f32x3'][1])") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ITTS_X3_PRODUCTS="6"), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     f32, six = [float(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("X3SIX")][-1].split()[1:]]
     print(f"6-product variant: rms-rel error {six:.3e} vs native f32 {f32:.3e}")

@@ -71,10 +71,11 @@ def test_layernorm_vs_torch():
         assert (y2 - ref2).abs().max() < 5e-5
 
 
-@pytest.mark.parametrize("M,K,N", [(1, 1280, 3840), (3, 1280, 5120), (4, 1280, 8194), (2, 256, 96), (4, 512, 1536)])
+@pytest.mark.parametrize("M,K,N", [(1, 1280, 3840), (3, 1280, 5120), (4, 1280, 8194), (2, 256, 96), (4, 512, 1536),
+                                   (5, 1280, 3840), (8, 1280, 5120), (11, 1280, 3840), (16, 1280, 5120), (13, 256, 96), (16, 512, 1536)])
 @pytest.mark.parametrize("pending", [False, True])
 def test_layernorm_fused_decode_gemm_is_bitwise_the_two_launches(M, K, N, pending):
-    """gemm_decode_ln_kernel (decode steps of 1-4 rows: LayerNorm computed inside the consuming GEMM's operand staging, with the split-K reduce of
+    """gemm_decode_ln_kernel (decode steps of 1-16 rows -- 4 waves up to 4 rows, 8 waves above, two rows per wave from 9: LayerNorm computed inside the consuming GEMM's operand staging, with the split-K reduce of
     the previous GEMM's partials + bias + residual) against the two launches it replaces -- itts_layernorm_forward -> bf16 -> itts_gemm_forward
     (the 16-row slab kernel): output BITWISE equal, and so is the updated residual row it writes back."""
     from indextts_amd import gpt
@@ -99,15 +100,16 @@ def test_layernorm_fused_decode_gemm_is_bitwise_the_two_launches(M, K, N, pendin
 
 
 def test_fused_layernorm_decode_steps_equal_unfused(tmp_path):
-    """Whole decode loops of 1, 3 and 4 rows (greedy, sampled, 3-beam beam-sample of one utterance) with the LayerNorm-fused GEMMs (default) and
-    without (ITTS_DECODE_FUSE_LN=0): identical ids -- at the production width (K = 1280: NV = 5) and at 256."""
+    """Whole decode loops of 1 .. 17 rows (greedy, sampled, 3-beam beam-sample of one utterance) with the LayerNorm-fused GEMMs (default: 1-16 rows
+    on 4 / 8 waves, one or two rows per wave) and without (option decode_fuse_ln = 0): identical ids -- at the production width (K = 1280: NV = 5)
+    and at 256."""
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuse_ln_probe.py")
     for big in ("1", "0"):
         outs = []
         for v in ("0", "1"):
-            env = dict(os.environ, ITTS_DECODE_FUSE_LN=v, PROBE_BIG=big)
+            env = dict(os.environ, PROBE_OPTS=f"decode_fuse_ln={v}", PROBE_BIG=big)
             r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
@@ -115,7 +117,7 @@ def test_fused_layernorm_decode_steps_equal_unfused(tmp_path):
 
 
 def test_topk_bisection_equals_radix_select():
-    """The top-k threshold of the sampling / beam kernels by ballot bisection (default) and by the 4-pass radix select (ITTS_SAMPLE_RADIX=1): the
+    """The top-k threshold of the sampling / beam kernels by ballot bisection (option sample_radix = 0) and by the 4-pass radix select (= 1): the
     same k-th key, hence identical ids over sampled and 3-beam beam-sample decode loops (both paths are also gated against the oracle's and the
     reference's ids by the golden tests, which run the default)."""
     import subprocess
@@ -123,29 +125,57 @@ def test_topk_bisection_equals_radix_select():
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuse_ln_probe.py")
     outs = []
     for v in ("0", "1"):
-        env = dict(os.environ, ITTS_SAMPLE_RADIX=v, PROBE_BIG="0")
+        env = dict(os.environ, PROBE_OPTS=f"sample_radix={v}", PROBE_BIG="0")
         r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
     assert outs[0] == outs[1], outs
 
 
-@pytest.mark.skipif(os.environ.get("ITTS_TEST_EXPERIMENTAL") != "1", reason="experiment switch not yet measured / validated on the GPU "
-                    "(ITTS_ATTN_UNROLL=4: attn_kernel_u, written at the end of round 3 with no GPU time left); run with ITTS_TEST_EXPERIMENTAL=1")
-def test_unrolled_decode_attention_equals_default():
-    """attn_kernel_u<.., 4, ..> (four key groups' K / V loads in flight per wave) consumes the key groups in attn_kernel's order: identical ids over
-    greedy / sampled / beam loops of 1-5 rows, bf16, at both probe widths."""
+def test_attention_geometries_agree():
+    """The KV-cache attention kernel maps its 16 canonical key streams onto 4, 8 or 16 waves per block (picked by the launch's block count; option
+    attn_waves forces one): every geometry performs the same operations in the same order -> identical ids over greedy / sampled / beam loops of
+    1-17 rows, bf16, at both probe widths (the f32 engine's geometries are compared in test_attention_geometries_agree_f32)."""
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuse_ln_probe.py")
     for big in ("1", "0"):
         outs = []
-        for v in ("1", "4"):
-            env = dict(os.environ, ITTS_ATTN_UNROLL=v, PROBE_BIG=big)
+        for v in ("4", "8", "16"):
+            env = dict(os.environ, PROBE_OPTS=f"attn_waves={v}", PROBE_BIG=big)
             r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
-        assert outs[0] == outs[1], outs
+        assert outs[0] == outs[1] == outs[2], outs
+
+
+def test_attention_geometries_agree_f32(golden_dir):
+    """f32 engine, one process: the teacher-forced latents (prefill attention, one block per query) and 30 greedy steps of a ragged batch come out
+    BITWISE equal with 4, 8 and 16 waves per attention block (option attn_waves; changing it also retires the cached decode graph)."""
+    from indextts_amd import _lib
+    z = np.load(os.path.join(golden_dir, "gpt_latent.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]),
+                      max_mel_tokens=int(c[4]), number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))
+    sd["mel_head.bias"][cfg.stop_mel_token] -= 1e4
+    m = engine(cfg, sd, "fp32")
+    B = z["text"].shape[0]
+    style, emo = torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"])
+    conds, _ = m.conds_latent(style, emo)
+    text = torch.from_numpy(z["text"])
+    outs = []
+    for nw in (4, 8, 16, 0):
+        with _lib.option_scope(attn_waves=nw):
+            lat = m.forward_latent(conds.repeat(B, 1, 1), text, torch.from_numpy(z["text_lens"]),
+                                   torch.from_numpy(z["mel_codes"]), torch.from_numpy(z["mel_lens"])).cpu()
+            ids, _ = m.inference_speech(None, text, langs=torch.full((B,), 1), emo_vec=emo, campplus_embedding=style, max_generate_length=30,
+                                        do_sample=False, num_beams=1, repetition_penalty=10.0)
+        outs.append((lat, ids.cpu()))
+    assert _lib.get_option("attn_waves") == 0
+    for lat, ids in outs[1:]:
+        assert torch.equal(lat, outs[0][0]) and torch.equal(ids, outs[0][1])
+    assert float(outs[0][0].abs().mean()) > 1e-3
 
 
 def run_case(m, z, cfg, sd):
@@ -276,7 +306,7 @@ def test_prefill_gemm_kernels_agree():
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prefill_probe.py")
     outs = []
     for v in ("0", "1"):
-        env = dict(os.environ, ITTS_PREFILL_GEMM=v)
+        env = dict(os.environ, PROBE_OPTS=f"prefill_gemm={v}")
         r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1]
@@ -287,13 +317,13 @@ def test_prefill_gemm_kernels_agree():
 
 def test_prefill_tile_kernels_agree():
     """GPT prefill / latent pass (EPI_QKV cache append, GELU, residual, plain store) through the 256 x 256 and 256 x 128 tile
-    kernels (ITTS_TILE256 = 1 / 2 force them for every shape) vs the 128 x 128 kernel: bitwise equal latents and ids."""
+    kernels (option tile256 = 1 / 2 forces them for every shape) vs the 128 x 128 kernel: bitwise equal latents and ids."""
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prefill_probe.py")
     outs = []
     for v in ("0", "1", "2"):
-        env = dict(os.environ, ITTS_TILE256=v, PROBE_BIG="1")
+        env = dict(os.environ, PROBE_OPTS=f"tile256={v}", PROBE_BIG="1")
         r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
@@ -309,7 +339,7 @@ def test_decode_gemm_kernels_agree():
     for big in ("1", "0"):                 # 40 rows of the full-width stack (64-row slab), 5 rows of a small one (16-row slab)
         outs = []
         for v in ("0", "1"):
-            env = dict(os.environ, ITTS_DECODE_GEMM=v, PROBE_BIG=big)
+            env = dict(os.environ, PROBE_OPTS=f"decode_gemm={v}", PROBE_BIG=big)
             r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
@@ -326,7 +356,7 @@ def test_decode_gemm_odd_kblock_slices(dim, rows):
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prefill_probe.py")
     outs = []
     for v in ("0", "1"):
-        env = dict(os.environ, ITTS_DECODE_GEMM=v, PROBE_DIM=str(dim), PROBE_B=str(rows))
+        env = dict(os.environ, PROBE_OPTS=f"decode_gemm={v}", PROBE_DIM=str(dim), PROBE_B=str(rows))
         r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
@@ -633,12 +663,19 @@ def test_full_size_bf16_gated_vs_oracle(full_size):
     full = _decode(m, fs)
     firsts = _gated_agreement(full[rows], fs["oracle_ids"], fs["margins"], BF16_LOGIT_BOUND_FULL, "full-size bf16 engine")
     print("full-size bf16: first divergence vs the oracle's fp32 ids (4 rows):", firsts)
-    # (c) row invariance in bf16 (a 1-row batch takes the 16-row slab kernel, the 64-row batch the 64-row one: same sums)
+    # (c) row invariance in bf16: a row decoded alone (LayerNorm-fused 1-row GEMMs, 16-wave attention blocks), in a group of 8 (fused GEMMs on 8
+    # waves) and in the 64-row batch (ln_kernel + 64-row slab GEMMs, 4-wave attention blocks) goes through the same sums in the same order --
+    # every kernel family keeps one K order and the attention's 16 key streams do not depend on the geometry -- so the ids are EQUAL, not
+    # merely close (parity per utterance vs the B = 1 run; the reference's tests/padding_test.py:77-99 property)
     for r in (0, 17, 40):
         alone = _decode(m, fs, [r])
         k = int(np.cumprod(alone[0] == full[r]).sum())
         print(f"bf16 row {r}: alone vs in-batch agreement prefix {k}/{n}")
-        assert k >= 1
+        assert np.array_equal(alone[0], full[r]), f"bf16 row {r} alone != row {r} in the 64-row batch (first difference at step {k})"
+    for grp in ([3, 8, 17, 29, 40, 55, 62, 63], list(range(20, 36))):
+        part = _decode(m, fs, grp)
+        for j, r in enumerate(grp):
+            assert np.array_equal(part[j], full[r]), f"bf16 row {r} in a group of {len(grp)} != row {r} in the 64-row batch"
     m32 = engine(cfg, sd, "fp32")
     ids32 = _decode(m32, fs)
     pref = [int(np.cumprod(full[r] == ids32[r]).sum()) for r in range(64)]

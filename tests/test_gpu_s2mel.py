@@ -231,7 +231,7 @@ def test_tile_gemm_kernels_agree(dil):
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "s2mel_probe.py")
     outs = []
     for v in ("0", "1", "2"):
-        env = dict(os.environ, ITTS_TILE256=v, PROBE_DIL=str(dil))
+        env = dict(os.environ, PROBE_OPTS=f"tile256={v}", PROBE_DIL=str(dil))
         r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
@@ -243,14 +243,14 @@ def test_f32_fast_path_vs_separate_kernels(tmp_path):
     """The f32 mode's fast path -- f32-MFMA tile GEMMs with the fused epilogues (RoPE + Q / K / V^T scatter, SwiGLU, tap-mode conv +
     gate, res/skip, shadows) and the f32-MFMA flash attention -- against the round-2 f32 path it replaces (register-path GEMM,
     separate element-wise kernels, one-wave-per-query scalar attention; the path the reference goldens pinned), same process setup:
-      (a) switching ONLY the GEMM kernel (ITTS_F32_TILE) leaves the whole solve bitwise unchanged (same MFMAs, same k order);
+      (a) switching ONLY the GEMM kernel (option f32_tile) leaves the whole solve bitwise unchanged (same MFMAs, same k order);
       (b) the full fast path agrees with the separate-kernel path to 2e-5 (libm gate functions in both; the flash softmax works in
           the exp2 domain and sums keys in a different order)."""
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "s2mel_probe.py")
-    runs = {"fast": {}, "separate_tile": dict(ITTS_S2MEL_FUSED="0", ITTS_F32_ATTN="scalar"),
-            "separate_reg": dict(ITTS_S2MEL_FUSED="0", ITTS_F32_ATTN="scalar", ITTS_F32_TILE="0")}
+    runs = {"fast": {}, "separate_tile": dict(PROBE_OPTS="s2mel_fused=0,f32_attn_scalar=1"),
+            "separate_reg": dict(PROBE_OPTS="s2mel_fused=0,f32_attn_scalar=1,f32_tile=0")}
     digest, out = {}, {}
     for name, extra in runs.items():
         path = str(tmp_path / f"{name}.pt")
