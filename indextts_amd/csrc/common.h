@@ -64,6 +64,17 @@ static inline int itts_ptr_device(const void* p) {
     return at.type == hipMemoryTypeDevice ? at.device : -1;
 }
 
+// hipFuncSetAttribute (dynamic-LDS limits) is per DEVICE: a "done once" flag kept per device ordinal, so a process driving several GPUs
+// raises the limit on each of them (a process-wide static left the second GPU's kernels at the 64 KiB default).
+template <class T>
+struct ItPerDevice {
+    T v[32] = {};
+    T& cur() {
+        const int d = itts_current_device();
+        return v[(d >= 0 && d < 32) ? d : 0];
+    }
+};
+
 #ifdef __HIPCC__
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1182,7 +1182,8 @@ template <int EPI, bool CONV = false>
 static int launch_gemm_prefill_e(const GemmArgs& a, hipStream_t st) {
     const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
     const int per = ceil_div(n_mt * n_nt, 8);
-    static bool attr_set = false;
+    static ItPerDevice<bool> attr_set_pd;
+    bool& attr_set = attr_set_pd.cur();
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS));
         if constexpr (EPI <= EPI_QKV) HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS));
@@ -1442,7 +1443,8 @@ template <int EPI, bool CONV = false>
 static int launch_gemm_tile256_e(const GemmArgs& a, hipStream_t st) {
     const int n_mt = ceil_div(a.M, 256), n_nt = ceil_div(a.N, 256);
     const int per = ceil_div(n_mt * n_nt, 8);
-    static bool attr_set = false;
+    static ItPerDevice<bool> attr_set_pd;
+    bool& attr_set = attr_set_pd.cur();
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_tile256_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS));
         attr_set = true;
@@ -1610,7 +1612,8 @@ template <int EPI, bool CONV = false>
 static int launch_gemm_tile_4w_e(const GemmArgs& a, hipStream_t st) {
     const int n_mt = ceil_div(a.M, 256), n_nt = ceil_div(a.N, 128);
     const int per = ceil_div(n_mt * n_nt, 8);
-    static bool attr_set = false;
+    static ItPerDevice<bool> attr_set_pd;
+    bool& attr_set = attr_set_pd.cur();
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_tile_4w_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, T3_LDS));
         attr_set = true;
@@ -1681,7 +1684,8 @@ template <int EPI, bool CONV = false>
 static int launch_gemm_prefill_f32_e(const GemmArgs& a, hipStream_t st) {
     const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
     const int per = ceil_div(n_mt * n_nt, 8);
-    static bool attr_set = false;
+    static ItPerDevice<bool> attr_set_pd;
+    bool& attr_set = attr_set_pd.cur();
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS));
         attr_set = true;
@@ -1925,7 +1929,8 @@ static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
     const int per = ceil_div(n_mt * n_nt, 8);
     const int nprod = itts_opt(OPT_X3_PRODUCTS) == 6 ? 6 : 8;
     const bool sched = itts_opt(OPT_X3_SCHED) != 0;                 // A/B switch of the MFMA / split interleave
-    static bool attr_set = false;
+    static ItPerDevice<bool> attr_set_pd;
+    bool& attr_set = attr_set_pd.cur();
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
@@ -2155,7 +2160,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MT == 4 
 
 template <int NT, int MT, bool WNT, int EPI>
 static int launch_gemm_decode64_e(const GemmArgs& a, int ntiles, size_t lds, hipStream_t st) {
-    static int attr_state = 0;                                     // 0 unknown, 1 ok, -1 the device refuses the LDS size
+    static ItPerDevice<int> attr_state_pd;                         // per device: 0 unknown, 1 ok, -1 the device refuses the LDS size
+    int& attr_state = attr_state_pd.cur();
     if (attr_state == 0) {
         const hipError_t e = hipFuncSetAttribute((const void*)gemm_decode64_kernel<NT, MT, WNT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 40960 * MT);
         attr_state = (e == hipSuccess) ? 1 : -1;
@@ -3097,7 +3103,8 @@ int launch_sample(const SampleArgs& a, hipStream_t st) {
         return ITTS_ERR_ARG;
     }
     const size_t lds = (size_t)a.V * sizeof(float) * (a.typical_mass > 0.f ? 2 : 1);
-    static size_t granted = 0;
+    static ItPerDevice<size_t> granted_pd;
+    size_t& granted = granted_pd.cur();
     if (int rc = ensure_dyn_lds(sample_kernel, lds, &granted, "sampling")) return rc;
     // top-k threshold: the radix select here (par with the ballot bisection at 1 row, 1 % ahead at 64 rows), the bisection in the beam
     // kernel (-2 %: its radix pass ended in a serial 256-bucket scan); ITTS_SAMPLE_RADIX=0 / 1 forces one of them in both (profiles/r03x)
@@ -3438,7 +3445,8 @@ int launch_beam_step(const BeamArgs& a, hipStream_t st) {
         return ITTS_ERR_ARG;
     }
     const size_t lds = (size_t)a.V * sizeof(float) * (a.typical_mass > 0.f ? 2 : 1);
-    static size_t granted = 0;
+    static ItPerDevice<size_t> granted_pd;
+    size_t& granted = granted_pd.cur();
     if (int rc = ensure_dyn_lds(beam_rows_kernel, lds, &granted, "beam search")) return rc;
     const int radix = itts_opt(OPT_SAMPLE_RADIX) < 0 ? 0 : itts_opt(OPT_SAMPLE_RADIX);
     BeamArgs a2 = a;

@@ -692,7 +692,8 @@ int launch_s2mel_attention(const void* q, const void* k, const void* v, void* ou
             hipLaunchKernelGGL(attn_f32_kernel, dim3(tab.n_tok, heads), dim3(64), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)out, tab, heads, t_pad);
         } else {
             const int qs = itts_opt(OPT_FA32_QS) == 1 ? 1 : 2;
-            static bool attr_set = false;
+            static ItPerDevice<bool> attr_set_pd;
+    bool& attr_set = attr_set_pd.cur();
             if (!attr_set) {
                 HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FA32_LDS));
                 HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_f32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FA32_LDS));

@@ -19,6 +19,24 @@ import torch.nn.functional as F
 from . import _lib
 
 
+# HF `generate` options that change the generated ids and that the device loop does not implement (the reference forwards every
+# hf_generate_kwarg to `GenerationMixin.generate`, model_v2.py:815-820): passing one raises instead of being ignored.
+_UNSUPPORTED_GENERATE_KWARGS = frozenset((
+    "no_repeat_ngram_size", "encoder_no_repeat_ngram_size", "bad_words_ids", "min_length", "min_new_tokens", "num_beam_groups",
+    "diversity_penalty", "penalty_alpha", "early_stopping", "stopping_criteria", "prefix_allowed_tokens_fn", "constraints",
+    "force_words_ids", "suppress_tokens", "begin_suppress_tokens", "forced_bos_token_id", "forced_eos_token_id",
+    "encoder_repetition_penalty", "epsilon_cutoff", "eta_cutoff", "exponential_decay_length_penalty", "renormalize_logits",
+    "guidance_scale", "sequence_bias", "min_p", "typical_p", "assistant_model", "negative_prompt_ids"))
+
+
+def _reject_logits_processor(hf_generate_kwargs: dict):
+    """The reference builds its own `logits_processor` list and passes it beside **hf_generate_kwargs (model_v2.py:793-799,815-820;
+    model.py:655-660), so a caller-supplied one is a TypeError there (duplicate keyword); the same error here, not a silent drop."""
+    if "logits_processor" in hf_generate_kwargs:
+        raise TypeError("inference_speech() got multiple values for keyword argument 'logits_processor' (the reference passes its own "
+                        "LogitsProcessorList to generate; use typical_sampling / typical_mass)")
+
+
 class UnifiedVoice:
     """`spk_cond_mode="campplus"` (IndexTTS-2.5, infer_v2_5.py:139): 3 conditioning tokens from the CAMPPlus style vector.
     Any other mode (IndexTTS-2, infer_v2.py:98; the reference default is "conformer"): 34 conditioning tokens -- 32 latents of
@@ -285,8 +303,16 @@ class UnifiedVoice:
         attention_mask (B,s+1).  Returns generated ids (B, n) (what `output[:, trunc_index:]` is in the reference)."""
         if not self._loaded:
             raise RuntimeError("UnifiedVoice: load_state_dict() first")
+        altering = sorted(k for k in unused if k in _UNSUPPORTED_GENERATE_KWARGS and unused[k] is not None)
+        if altering:             # the reference forwards these to HF `generate`, where they change the ids: never drop them silently
+            raise NotImplementedError(f"generate: {altering} would change the generated ids and the device loop does not implement them "
+                                      "(supported: do_sample, num_beams, top_p, top_k, temperature, repetition_penalty, length_penalty, "
+                                      "typical sampling)")
         self._check_idle("generate")
         if num_beams != 1:
+            if row_max_new is not None:
+                raise NotImplementedError("generate: row_max_new (per-row token caps of a merged batch) is implemented for num_beams=1 only; "
+                                          "the beam kernels take one max_new_tokens per call")
             return self._generate_beam(inputs_embeds, attention_mask, max_new_tokens, do_sample, num_beams, top_p, top_k,
                                        temperature, repetition_penalty, length_penalty, uniforms, seed, typical_mass)
         dev = self.device
@@ -551,7 +577,7 @@ class UnifiedVoice:
         input_ids, inputs_embeds, attention_mask = self.prepare_gpt_inputs(conds_latent, text_inputs, langs)
         max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
         hf = dict(hf_generate_kwargs)
-        hf.pop("logits_processor", None)
+        _reject_logits_processor(hf)
         hf["typical_mass"] = float(typical_mass) if typical_sampling else 0.0
         return inputs_embeds, attention_mask, max_new, hf, spk_lat
 
@@ -682,7 +708,7 @@ class UnifiedVoiceV1(UnifiedVoice):
         input_ids, inputs_embeds, attention_mask = self.prepare_gpt_inputs(conds_latent, text_inputs)
         max_new = (self.max_mel_tokens - 1) if max_generate_length is None else int(max_generate_length)
         hf = dict(hf_generate_kwargs)
-        hf.pop("logits_processor", None)
+        _reject_logits_processor(hf)
         return self.generate(inputs_embeds, attention_mask, max_new, uniforms=uniforms,
                              typical_mass=float(typical_mass) if typical_sampling else 0.0, **hf)
 

@@ -94,8 +94,10 @@ class IndexTTS2(_IndexTTS2V25):
             flat = t.reshape(-1).to(torch.int32)
             text[i, : flat.numel()] = flat
             n = int(flat.numel())
-            while n > 0 and int(flat[n - 1]) == 1:
+            if n > 0 and int(flat[n - 1]) == 1:          # exactly the ONE stop id the Frontend protocol appends (ids inside a segment are >= 2)
                 n -= 1
+            if n <= 0:
+                raise ValueError(f"segment {i} holds no text tokens (the reference never synthesises an empty segment, infer_v2.py:566-567)")
             text_lens.append(n)
         text_lens = torch.tensor(text_lens)
         spk_cond_emb, emo_cond_emb = bundle["spk_cond_emb"], bundle.get("emo_cond_emb", bundle["spk_cond_emb"])

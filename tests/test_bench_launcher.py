@@ -38,6 +38,31 @@ def test_two_ranks_weak_scaling_and_single_rank():
     assert j1["n_gpus"] == 1 and j1["config"]["global_batch"] == 5 and j1["config"]["per_gpu_batch"] == 5 and j1["stub_rows_ok"] is True
 
 
+def test_eight_ranks_uneven_shares():
+    """The real rank count of the metric's last point: 8 gloo ranks, 13 utterances -> shares of 2 and 1 (uneven gather), and the BASELINE split
+    64 -> 8 per rank; every utterance reaches rank 0 in utterance order."""
+    j = _run(["--gpus", "8", "--utts", "13"])
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and j["config"]["global_batch"] == 13
+    assert j["config"]["per_gpu_batch"] == 2 and j["stub_rows_ok"] is True and j["config"]["parallelism"] == "utterance-dp8"
+    j = _run(["--gpus", "8", "--utts", "64"])
+    assert j["config"]["per_gpu_batch"] == 8 and j["stub_rows_ok"] is True
+
+
+def test_lpt_sharding_at_eight_ranks():
+    """`shard_utterances` with ragged lengths at world size 8: a partition of all utterances, deterministic, and balanced to within the longest
+    utterance (the LPT bound) -- what keeps the ranks of a ragged batch finishing together."""
+    import random
+    from indextts_amd import dist as D
+    rnd = random.Random(5)
+    lengths = [rnd.randint(20, 128) for _ in range(64)]
+    shares = [D.shard_utterances(64, r, 8, lengths=lengths) for r in range(8)]
+    assert sorted(i for sh in shares for i in sh) == list(range(64))
+    loads = [sum(lengths[i] for i in sh) for sh in shares]
+    assert max(loads) - min(loads) <= max(lengths)
+    assert shares == [D.shard_utterances(64, r, 8, lengths=lengths) for r in range(8)]
+    assert [len(D.shard_utterances(64, r, 8, lengths=[128] * 64)) for r in range(8)] == [8] * 8
+
+
 def test_world_size_mismatch_is_an_error():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--engine", "stub", "--gpus", "4"], capture_output=True,

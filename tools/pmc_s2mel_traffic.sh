@@ -1,23 +1,26 @@
 #!/bin/bash
-# GPU box: HBM traffic of the s2mel f32 GEMM launches (gemm_prefill_kernel<..., F32 = true>, the dominant kernel of the fp32-CFM step) over
+# usage: tools/pmc_s2mel_traffic.sh [B=64] [precision=fp32x3|fp32]
+# GPU box: HBM traffic of the s2mel GEMM launches (gemm_x3_kernel in the fp32x3 mode / gemm_prefill_kernel<..., F32 = true> in fp32: the dominant kernel of the step) over
 # ONE Euler step (one CFG-stacked estimator call) at the bench shape, from PMC counters in two separate rocprofv3 passes (FETCH_SIZE,
 # WRITE_SIZE; MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced 16 B / lane reads --
 # LDS-DMA included -- so it is doubled; WRITE_SIZE measured 1.000 on a known byte count in round 2, profiles/conv_traffic.json).
 set -u
 B=${1:-64}
+PREC=${2:-fp32x3}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/pmc_s2mel
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OUT/raw_$ctr" -o p -- python $ROOT/tools/s2mel_bench.py $B 517 1926 1 fp32 > "$OUT/run_$ctr.log" 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OUT/raw_$ctr" -o p -- python $ROOT/tools/s2mel_bench.py $B 517 1926 1 $PREC > "$OUT/run_$ctr.log" 2>&1
+  grep -q "finite=True" "$OUT/run_$ctr.log" || { echo "pmc_s2mel_traffic: workload of pass $ctr failed: $(tail -3 "$OUT/run_$ctr.log")" >&2; exit 1; }
   f=$(find "$OUT/raw_$ctr" -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && grep -E "Counter_Name|gemm_prefill_kernel|flash_attn_f32" "$f" > "$OUT/cc_$ctr.csv"
+  [ -n "$f" ] && grep -E "Counter_Name|gemm_prefill_kernel|gemm_x3_kernel|flash_attn_f32" "$f" > "$OUT/cc_$ctr.csv"
   rm -rf "$OUT/raw_$ctr"
 done
-python3 - "$OUT" "$B" <<'PY'
+python3 - "$OUT" "$B" "$PREC" <<'PY'
 import csv, json, sys, collections
-out, B = sys.argv[1], int(sys.argv[2])
+out, B, PREC = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 T, Tp = 1926, 517
 M = 2 * B * (T + Tp)                       # packed rows: CFG branches x utterances x frames
 H, I, W, C, Kx, L, D = 512, 1536, 512, 80, 128, 8, 13
@@ -44,13 +47,15 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f"{out}/cc_{ctr}.csv")):
         if r.get("Counter_Name") == ctr:
-            k = "gemm" if "gemm_prefill_kernel" in r["Kernel_Name"] else "attn"
+            k = "gemm" if ("gemm_prefill_kernel" in r["Kernel_Name"] or "gemm_x3_kernel" in r["Kernel_Name"]) else "attn"
             agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     res[ctr] = {k: {"kb_sum": v[0], "dispatches": v[1]} for k, v in agg.items()}
-n = res["FETCH_SIZE"]["gemm"]["dispatches"]
+n = res["FETCH_SIZE"].get("gemm", {}).get("dispatches", 0)
+if n == 0:
+    print("pmc_s2mel_traffic: no GEMM dispatches in the counter file", file=sys.stderr); sys.exit(1)
 fetch = res["FETCH_SIZE"]["gemm"]["kb_sum"] * 1024.0 * 2.0      # gfx950: half of the coalesced 16 B / lane bytes are reported
 write = res["WRITE_SIZE"]["gemm"]["kb_sum"] * 1024.0
-summary = {"B": B, "mel_frames": T, "prompt_frames": Tp, "precision": "fp32", "rows": M, "gemm_dispatches": n, "expected_gemm_launches": len(alg),
+summary = {"B": B, "mel_frames": T, "prompt_frames": Tp, "precision": PREC, "rows": M, "gemm_dispatches": n, "expected_gemm_launches": len(alg),
            "fetch_kb_sum_raw": res["FETCH_SIZE"]["gemm"]["kb_sum"], "write_kb_sum_raw": res["WRITE_SIZE"]["gemm"]["kb_sum"],
            "fetch_correction": 2.0, "write_correction": 1.0,
            "hbm_bytes_per_gemm_launch": (fetch + write) / max(1, n), "algorithmic_bytes_per_gemm_launch": sum(alg) / len(alg),

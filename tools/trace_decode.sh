@@ -1,7 +1,9 @@
 #!/bin/bash
 # GPU box: kernel-trace one short GPT generate and print the per-kernel timeline of one decode step (durations + gaps).
+# usage: tools/trace_decode.sh [B=8] [tokens=40]  (the step shown is the second-to-last: context = 134 + tokens - 2)
 set -u
 B=${1:-8}
+N=${2:-40}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/trace_decode
 mkdir -p "$OUT"
@@ -12,10 +14,11 @@ from indextts_amd import gpt, synth
 gcfg = dict(synth.GPT_V25)
 m = gpt.UnifiedVoice(spk_cond_mode="campplus", **gcfg, precision="bf16", device="cuda:0")
 m.load_state_dict(synth.gpt_weights(gcfg, suppress_eos=True))
+m.post_init_gpt2_config(kv_cache=True, half=True)
 B = $B
 text = torch.randint(2, 12000, (B, 128)).cuda(); langs = torch.full((B,), 3, dtype=torch.long).cuda()
 style = torch.randn(1, 192).cuda(); emo = (torch.randn(1, 1280) * 0.1).cuda()
-for n in (8, 40):
+for n in (8, $N):
     codes, _ = m.inference_speech(None, text, langs=langs, emo_vec=emo, campplus_embedding=style, max_generate_length=n,
                                   do_sample=True, top_p=0.8, top_k=30, temperature=0.8, num_beams=1, repetition_penalty=10.0)
 torch.cuda.synchronize()
