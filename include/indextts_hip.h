@@ -34,7 +34,7 @@ int itts_device_count(void);
  * in); options marked "at create" are sampled when a model handle is created.  The reference has no counterpart (its kernels are
  * picked by PyTorch's dispatcher); the table exists for A/B tests and measurement tools.
  *   name              default  range    meaning
- *   decode_fuse_ln       1     0..1    GPT decode steps of 1-16 rows: LayerNorm inside the consuming GEMM (0: ln_kernel launches)
+ *   decode_fuse_ln       1     0..2    GPT decode: LayerNorm inside the consuming GEMM, 1: at 1-4 rows, 2: up to 16 rows, 0: ln_kernel launches
  *   decode_gemm          1     0..1    bf16 decode GEMMs on the LDS-DMA slab kernel (0: register-path kernel)
  *   decode_rot           1     0..1    per-block rotation of the slab DMA issue order
  *   decode_wnt           0     0..1    non-temporal policy on the decode weight stream

@@ -2595,11 +2595,13 @@ int launch_attention(const AttnArgs& a, int prec, hipStream_t st) {
     if (a.D != a.H * 64) { itts_set_error("attention: head_dim must be 64 (D=%d H=%d)", a.D, a.H); return ITTS_ERR_ARG; }
     if (a.nq > 65535) { itts_set_error("attention: more than 65535 queries per sequence"); return ITTS_ERR_ARG; }
     dim3 grid(a.nseq * a.H, a.nq);
-    // waves per block (option attn_waves forces 4 / 8 / 16; every choice gives the same bits): 16 while the launch has at most two
-    // blocks per CU (one round trip for the whole context), 8 up to four, else 4 (occupancy hides the chain of chunk loads)
+    // waves per block (option attn_waves forces 4 / 8 / 16; every choice gives the same bits).  Measured (profiles/r04a/decode_bench.log,
+    // ms per token at 560 tokens, 16 / 8 / 4 waves): 1 row 0.776 / 0.789 / 0.846, 8 rows 1.056 / 1.065 / 1.117, 16 rows 1.376 / 1.331 / 1.356,
+    // 32 rows 1.389 / 1.291 / 1.328, 64 rows 1.782 / 1.612 / 1.639; prefill (one block per query) 66 / 45 / 36 ms at 64 rows -> decode
+    // launches of at most one block per CU take 16 waves (one round trip for the whole context), larger decode launches 8, prefill 4.
     const long long blocks = (long long)grid.x * grid.y;
     int nw = itts_opt(OPT_ATTN_WAVES);
-    if (nw != 4 && nw != 8 && nw != 16) nw = blocks <= 512 ? 16 : blocks <= 1024 ? 8 : 4;
+    if (nw != 4 && nw != 8 && nw != 16) nw = a.nq > 1 ? 4 : blocks <= 256 ? 16 : 8;
     if (prec == PREC_BF16) { if (nw == 16) launch_attention_nw<true, 16>(a, grid, st); else if (nw == 8) launch_attention_nw<true, 8>(a, grid, st); else launch_attention_nw<true, 4>(a, grid, st); }
     else { if (nw == 16) launch_attention_nw<false, 16>(a, grid, st); else if (nw == 8) launch_attention_nw<false, 8>(a, grid, st); else launch_attention_nw<false, 4>(a, grid, st); }
     HIP_TRY(hipGetLastError());

@@ -16,7 +16,7 @@ struct OptDef {
 };
 // order == the OPT_* enum of common.h
 const OptDef kDefs[OPT_COUNT] = {
-    {"decode_fuse_ln", 1, 0, 1, "GPT decode steps of 1-16 rows: LayerNorm (+ split-K reduce, bias, residual) inside the consuming GEMM (0: separate ln_kernel launches; bitwise equal)"},
+    {"decode_fuse_ln", 1, 0, 2, "GPT decode: LayerNorm (+ split-K reduce, bias, residual) inside the consuming GEMM -- 1: steps of 1-4 rows (measured faster), 2: up to 16 rows (measured slower, kept for the A/B record), 0: separate ln_kernel launches; bitwise equal"},
     {"decode_gemm", 1, 0, 1, "bf16 decode GEMMs on the LDS-DMA slab kernel (0: register-path gemm_kernel; bitwise equal)"},
     {"decode_rot", 1, 0, 1, "per-block rotation of the slab DMA issue order in the decode GEMM (same bytes, same LDS image)"},
     {"decode_wnt", 0, 0, 1, "non-temporal policy on the decode GEMM's weight stream"},

@@ -100,20 +100,20 @@ def test_layernorm_fused_decode_gemm_is_bitwise_the_two_launches(M, K, N, pendin
 
 
 def test_fused_layernorm_decode_steps_equal_unfused(tmp_path):
-    """Whole decode loops of 1 .. 17 rows (greedy, sampled, 3-beam beam-sample of one utterance) with the LayerNorm-fused GEMMs (default: 1-16 rows
-    on 4 / 8 waves, one or two rows per wave) and without (option decode_fuse_ln = 0): identical ids -- at the production width (K = 1280: NV = 5)
-    and at 256."""
+    """Whole decode loops of 1 .. 17 rows (greedy, sampled, 3-beam beam-sample of one utterance) with the LayerNorm-fused GEMMs (default 1: steps of
+    1-4 rows on 4 waves; 2: up to 16 rows on 8 waves, one or two rows per wave) and without (option decode_fuse_ln = 0): identical ids -- at the
+    production width (K = 1280: NV = 5) and at 256."""
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuse_ln_probe.py")
     for big in ("1", "0"):
         outs = []
-        for v in ("0", "1"):
+        for v in ("0", "1", "2"):
             env = dict(os.environ, PROBE_OPTS=f"decode_fuse_ln={v}", PROBE_BIG=big)
             r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
-        assert outs[0] == outs[1], outs
+        assert outs[0] == outs[1] == outs[2], outs
 
 
 def test_topk_bisection_equals_radix_select():
