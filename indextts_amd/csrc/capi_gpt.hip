@@ -1017,7 +1017,7 @@ extern "C" int itts_gemm_forward(const void* A, const void* Wp, const float* bia
 extern "C" int itts_gemm_ln_forward(const float* x, const float* partial, const float* bias_prev, const float* ln_gamma, const float* ln_beta,
                                     float eps, const void* Wp, const float* bias, float* out, float* x_out, int M, int N, int K, void* stream) {
     if (!x || !ln_gamma || !ln_beta || !Wp || !out) { itts_set_error("gemm_ln_forward: null pointer"); return ITTS_ERR_ARG; }
-    if (!gemm_decode_ln_ok(M, K, EPI_STORE_F32)) { itts_set_error("gemm_ln_forward: M = %d (1..4), K = %d (256, 512, 1280) unsupported", M, K); return ITTS_ERR_ARG; }
+    if (!gemm_decode_ln_ok(M, K, EPI_STORE_F32)) { itts_set_error("gemm_ln_forward: M = %d (1..16), K = %d (256, 512, 1280) unsupported", M, K); return ITTS_ERR_ARG; }
     GemmArgs g{};
     g.Wp = Wp; g.bias = bias; g.M = M; g.N = N; g.K = K; g.nsplit = 1; g.D = N;
     g.epi = EPI_STORE_F32; g.out_f32 = out; g.ldo = N;

@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _errors(M, N, K, seed, scale=1.0):
-    from indextts_amd import gpt
+def _errors(M, N, K, seed, scale=1.0, products=8):
+    from indextts_amd import _lib, gpt
+    _lib.set_option("x3_products", products)
     g = torch.Generator().manual_seed(seed)
     # wide dynamic range per row / column: exercises all three planes of both operands
     a = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g)) * scale
@@ -26,7 +27,27 @@ def _errors(M, N, K, seed, scale=1.0):
         wp = gpt.pack_gemm_weight(w, prec).to(DEV)
         y = gpt.gemm(a.to(DEV), wp, b.to(DEV), N, prec, prefill_tiles=True).cpu().double()
         out[name] = float((y - ref).abs().max() / ref.abs().max()), float(((y - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
+    _lib.set_option("x3_products", 8)
     return out
+
+
+# every (N, K) the flow-matching estimator launches at the production widths (hidden 512, SwiGLU 1536, WaveNet 512 x kernel 5, 80 mel channels
+# padded to K = 128): wqkv, wo / skip / projections, w1|w3, w2, tap-mode conv, res-skip, the mel-channel input GEMMs, conv2
+S2MEL_SHAPES = [(1536, 512), (512, 512), (3072, 512), (512, 1536), (1024, 2560), (1024, 512), (512, 128), (80, 512)]
+
+
+@pytest.mark.parametrize("N,K", S2MEL_SHAPES)
+def test_x3_six_products_not_worse_than_native_f32_on_every_s2mel_shape(N, K):
+    """VERDICT r3's condition for the 6-product form (drops m*l and l*m, at most 2^-24 |ab| each): on every GEMM shape of the benchmarked solve
+    its error against an f64 GEMM is not above the native f32-MFMA kernel's on the same operands (RMS-relative, wide-dynamic-range rows and
+    columns, 2048 rows; and at most 2 x on the maximum, where a single element decides).  The 8-product form is printed beside it."""
+    M = 2048
+    e6 = _errors(M, N, K, seed=N + K, products=6)
+    e8 = _errors(M, N, K, seed=N + K, products=8)
+    print(f"GEMM {M} x {N} x {K} vs f64, rms-rel (max-rel): native f32 {e6['f32'][1]:.3e} ({e6['f32'][0]:.3e}); x3 with 8 products "
+          f"{e8['f32x3'][1]:.3e} ({e8['f32x3'][0]:.3e}); with 6 products {e6['f32x3'][1]:.3e} ({e6['f32x3'][0]:.3e})")
+    assert e6["f32x3"][1] <= e6["f32"][1] and e6["f32x3"][0] <= 2.0 * e6["f32"][0] + 1e-9
+    assert e8["f32x3"][1] <= e8["f32"][1]
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 512, 512), (129, 3072, 512), (257, 512, 1536), (200, 80, 512), (64, 1024, 2560)])
@@ -41,11 +62,8 @@ def test_x3_gemm_is_at_least_as_accurate_as_native_f32(M, N, K):
 
 def test_x3_six_products_error_reported():
     """Option x3_products = 6 drops the two 2^-24-relative cross terms (ml, lm): reported beside the 8-product default."""
-    code = ("import sys; sys.path.insert(0, %r); from tests import test_gpu_gemm_x3 as T; from indextts_amd import _lib; _lib.set_option('x3_products', 6); "
-            "e = T._errors(300, 512, 512, 9); print('X3SIX', e['f32'][1], e['f32x3'][1])") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    f32, six = [float(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("X3SIX")][-1].split()[1:]]
+    e = _errors(300, 512, 512, 9, products=6)
+    f32, six = e["f32"][1], e["f32x3"][1]
     print(f"6-product variant: rms-rel error {six:.3e} vs native f32 {f32:.3e}")
     assert six <= 1e-6
 

@@ -151,14 +151,22 @@ def test_solve_euler_f32_vs_reference_single_and_batched(golden_dir):
         assert float((y[u:u + 1, :, :T] - torch.from_numpy(z[f"euler_out{u}"])).abs().max()) <= F32_TOL
 
 
-def test_production_widths_25_steps_f32_vs_reference(golden_dir):
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3", "fp32x3-6"])
+def test_production_widths_25_steps_f32_vs_reference(golden_dir, mode):
     """The benchmarked architecture (DiT 13 x 512 x 8 heads, WaveNet 8 x 512) and solve depth (25 CFG Euler steps) against outputs of the
     REFERENCE's own classes (tests/golden/s2mel_cfm_prod.npz, tools/make_golden_s2mel.py::main_prod): one estimator call and the whole solve,
-    211 frames behind a 73-frame prompt, 9 padded frames.  Bound: 2e-4 absolute on mel values of RMS 1.4 (first GPU run of this case: the
-    3-step full-length case of tests/test_gpu_fullsize.py measures 1.4e-5)."""
+    211 frames behind a 73-frame prompt, 9 padded frames -- in the native f32 mode, in the fp32x3 mode that carries the benchmark's headline (every
+    GEMM operand as three bf16 planes, 8 plane products: VERDICT r3's condition for the ruling) and in its 6-product form.  Bound: 1e-4 absolute
+    on mel values of RMS 1.4 (north_star's bar; measured 2e-5 in the f32 mode by the round-3 driver run)."""
+    from indextts_amd import _lib
     from tests.test_oracle_s2mel import load_prod
     z, cfg, sd, mu = load_prod(golden_dir)
-    m = engine(cfg, sd, "fp32")
+    with _lib.option_scope(x3_products=6 if mode.endswith("-6") else 8):
+        _production_case(z, cfg, sd, mu, mode.split("-")[0], mode)
+
+
+def _production_case(z, cfg, sd, mu, precision, mode):
+    m = engine(cfg, sd, precision)
     x, prompt, style, x_lens = (torch.from_numpy(z[k]) for k in ("z", "prompt", "style", "x_lens"))
     Tp = prompt.shape[-1]
     px = torch.zeros_like(x)
@@ -168,9 +176,9 @@ def test_production_widths_25_steps_f32_vs_reference(golden_dir):
     e1 = float((d - torch.from_numpy(z["estimator_out"])).abs().max())
     y = m.solve_euler(x.clone(), x_lens, prompt, mu, style, None, torch.linspace(0, 1, int(z["n_steps"]) + 1), float(z["cfg_rate"])).cpu()
     e2 = float((y - torch.from_numpy(z["euler_out"])).abs().max())
-    print(f"production widths vs the reference's classes: estimator max|d| {e1:.3e}, 25-step solve max|d| {e2:.3e} "
+    print(f"production widths vs the reference's classes [{mode}]: estimator max|d| {e1:.3e}, 25-step solve max|d| {e2:.3e} "
           f"(rms {rms(y - torch.from_numpy(z['euler_out'])):.3e}, output rms {rms(z['euler_out']):.3f})")
-    assert e1 <= 2e-4 and e2 <= 2e-4
+    assert e1 <= 1e-4 and e2 <= 1e-4
     assert float(y[..., :Tp].abs().max()) == 0.0
 
 
