@@ -42,9 +42,9 @@ int itts_device_count(void);
  *   prefill_gemm         1     0..1    bf16 prefill GEMMs on the LDS-DMA tile kernels (0: register-path kernel)
  *   tile256             -1    -1..2    bf16 tile GEMM: -1 by shape, 0 128x128, 1 256x256, 2 256x128
  *   f32_tile             1     0..1    f32 GEMMs with plain epilogues on the f32-MFMA tile kernel
- *   x3_products          8     6..8    plane products per f32 product of the fp32x3 GEMM (8 or 6)
+ *   x3_products          6     6..8    plane products per f32 product of the fp32x3 GEMMs / attention (6 or 8)
  *   x3_sched             1     0..1    fp32x3 GEMM: operand split interleaved with the MFMAs
- *   x3_planes            1     0..1    fp32x3 s2mel: producers emit the bf16 planes of the next GEMM's A operand (at create)
+ *   x3_attn              1     0..1    fp32x3 s2mel: attention products on bf16 planes as well (0: the f32-MFMA flash kernel)
  *   sample_radix        -1    -1..1    top-k threshold: -1 per-kernel default, 0 ballot bisection, 1 radix select
  *   gpt_compact          1     0..1    row compaction of ragged decode batches
  *   attn_waves           0     0..16   waves per block of the KV-cache attention kernel (0: by shape; 4 / 8 / 16)
@@ -55,7 +55,6 @@ int itts_device_count(void);
  *   aa_act               2     0..2    anti-aliased activation kernel variant
  *   conv_bm              0     0..128  force the co-tile height of the vocoder conv kernel
  *   h3_kernel            1     0..1    f16x3 vocoder conv: window kernel / two-stage kernel
- *   s2mel_fuse_norm      1     0..1    f32 / fp32x3 s2mel: adaptive RMSNorm inside the residual GEMM that feeds it
  * itts_option_count / _name / _doc / _default enumerate the table (index 0 .. count-1).
  * ---------------------------------------------------------------------------------------------------------- */
 int itts_set_option(const char* name, int value);      /* ITTS_ERR_ARG: unknown name or value out of range */

@@ -356,7 +356,9 @@ static S2Ws s2_carve(const itts_s2mel* h, char* base, int n_tok, int n_seq, int 
     w.sk_stride = s_a256(N * H * esz);
     w.SK = take(w.sk_stride * (size_t)(c.depth / 2));
     w.WXA = take(N * W * esz);                                     // act-dtype shadow of WX: the tap-mode GEMM's A operand
-    const size_t kv = (size_t)n_seq * c.num_heads * t_pad * 64 * esz;
+    // K / V^T images: act dtype, or -- fp32x3 -- room for the three bf16 planes of every element (6 bytes; the f32 image of option
+    // x3_attn = 0 fits in the same buffer)
+    const size_t kv = (size_t)n_seq * c.num_heads * t_pad * 64 * (c.precision == PREC_F32X3 ? 6 : esz);
     w.ZR = take(256);                                              // a zero row (adjacent to K / V: cleared by the same memset)
     w.KC = take(kv);
     w.VC = take(kv);
@@ -396,6 +398,8 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     const int H = c.hidden_dim, I = h->I, W = c.wavenet_hidden, C = c.in_channels, Kx = h->Kx, N = tab.n_tok, prec = c.precision;
     const int nh = c.num_heads;
     const bool fused = s2_fused(prec, h->opt_fused);
+    const bool x3_attn = prec == PREC_F32X3 && itts_opt(OPT_X3_ATTN) != 0;      // attention products on bf16 planes (flash_attn_x3_kernel)
+    const size_t kv_plane = (size_t)tab.n_seq * nh * t_pad * 64;
     int rc;
     float *X = w.X, *X2 = w.X2;
     // x_in = cond_x_merge_linear([x^T | prompt | cond | style]): the x columns here, the rest (+ bias) is const_in
@@ -418,13 +422,16 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
             g.A = w.HB; g.lda = H; g.Wp = L.w_qkv; g.M = N; g.N = 3 * H; g.K = H; g.nsplit = 1; g.epi = EPI_QKV_ROPE;
             g.out_act = w.QA; g.kcache = w.KC; g.vcache = w.VC; g.D = H; g.H = nh; g.Tmax = t_pad;
             g.tok_seq = tab.tok_seq; g.tok_t = tab.tok_t; g.rope = rope;
+            g.kv_planes = x3_attn ? kv_plane : 0;
             if ((rc = s2_launch_gemm(h, g, st))) return rc;
         } else {
             if ((rc = s2_gemm(h, w.HB, H, L.w_qkv, nullptr, w.BIG, 3 * H, N, 3 * H, H, EPI_STORE_F32, st))) return rc;
             if ((rc = launch_rope_split(w.BIG, rope, w.QA, w.KC, w.VC, tab, nh, t_pad, prec, st))) return rc;
         }
         { S2Prof ps(h, st, S2_ATTN, attn_flops);
-          if ((rc = launch_s2mel_attention(w.QA, w.KC, w.VC, w.AO, tab, nh, t_pad, prec, st))) return rc; }
+          if (x3_attn) rc = launch_s2mel_attention_x3(w.QA, w.KC, w.VC, w.AO, tab, nh, t_pad, st);
+          else rc = launch_s2mel_attention(w.QA, w.KC, w.VC, w.AO, tab, nh, t_pad, prec, st);
+          if (rc) return rc; }
         if ((rc = s2_gemm(h, w.AO, H, L.w_o, nullptr, X, H, N, H, H, EPI_RESIDUAL, st))) return rc;
         if ((rc = launch_ada_rmsnorm(X, L.g_ffn, mods + (size_t)i * 4 * H + 2 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
         if (fused) {                                               // [w1 ; w3] GEMM with the SwiGLU combine in the epilogue
@@ -603,17 +610,20 @@ extern "C" int itts_s2mel_set_tail(itts_s2mel* h, const int32_t* tok_seq, const 
 // ---- unit-level entry point (parity tests): RoPE + split + non-causal attention of one layer ------------------------------
 // qkv f32 [n_tok][3H] (the fused wqkv output) -> out act dtype [n_tok][H] = softmax(rope(q) rope(k)^T / 8, keys < seq_len) v.
 // scratch: q act [n_tok][H] + K + V act [n_seq * heads * t_pad * 64] each, t_pad = t_max rounded up to 64.
+// precision ITTS_PREC_F32X3: q / K / V^T are produced in f32, K and V^T are then split into three bf16 planes each (+ 2 x 6 bytes per
+// element of scratch) and the products run on flash_attn_x3_kernel with option x3_products plane products; out is f32.
 extern "C" size_t itts_s2mel_attention_scratch_bytes(int n_tok, int n_seq, int heads, int t_max, int precision) {
     const size_t esz = precision == PREC_BF16 ? 2 : 4;
     const size_t t_pad = (size_t)(t_max + 63) / 64 * 64;
-    return s_a256((size_t)n_tok * heads * 64 * esz) + 2 * s_a256((size_t)n_seq * heads * t_pad * 64 * esz) + 256;
+    const size_t planes = precision == PREC_F32X3 ? 2 * s_a256((size_t)n_seq * heads * t_pad * 64 * 6) : 0;
+    return s_a256((size_t)n_tok * heads * 64 * esz) + 2 * s_a256((size_t)n_seq * heads * t_pad * 64 * esz) + planes + 256;
 }
 
 extern "C" int itts_s2mel_attention_forward(const float* qkv, const float* rope, const int32_t* tok_seq, const int32_t* tok_t,
                                             const int32_t* seq_start, const int32_t* seq_T, const int32_t* seq_len, int n_seq, int n_tok,
                                             int t_max, int heads, int precision, void* out, void* scratch, size_t scratch_bytes, void* stream) {
     if (!qkv || !rope || !tok_seq || !tok_t || !seq_start || !seq_T || !seq_len || !out || !scratch) { itts_set_error("s2mel_attention: null pointer"); return ITTS_ERR_ARG; }
-    if (n_seq <= 0 || n_tok <= 0 || t_max <= 0 || heads <= 0 || (precision != PREC_F32 && precision != PREC_BF16)) { itts_set_error("s2mel_attention: bad sizes"); return ITTS_ERR_ARG; }
+    if (n_seq <= 0 || n_tok <= 0 || t_max <= 0 || heads <= 0 || (precision != PREC_F32 && precision != PREC_BF16 && precision != PREC_F32X3)) { itts_set_error("s2mel_attention: bad sizes"); return ITTS_ERR_ARG; }
     if (scratch_bytes < itts_s2mel_attention_scratch_bytes(n_tok, n_seq, heads, t_max, precision)) { itts_set_error("s2mel_attention: scratch too small"); return ITTS_ERR_ARG; }
     const size_t esz = precision == PREC_BF16 ? 2 : 4;
     const int t_pad = (t_max + 63) / 64 * 64;
@@ -625,7 +635,15 @@ extern "C" int itts_s2mel_attention_forward(const float* qkv, const float* rope,
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(k, 0, 2 * kv, st));
     const SeqTab tab = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tok, t_max);
-    int rc = launch_rope_split(qkv, rope, q, k, v, tab, heads, t_pad, precision, st);
+    int rc = launch_rope_split(qkv, rope, q, k, v, tab, heads, t_pad, precision == PREC_F32X3 ? PREC_F32 : precision, st);
     if (rc) return rc;
+    if (precision == PREC_F32X3) {
+        const size_t n = (size_t)n_seq * heads * t_pad * 64;
+        char* kp = v + kv;
+        char* vp = kp + s_a256(n * 6);
+        if ((rc = launch_split_planes((const float*)k, kp, n, st))) return rc;
+        if ((rc = launch_split_planes((const float*)v, vp, n, st))) return rc;
+        return launch_s2mel_attention_x3(q, kp, vp, out, tab, heads, t_pad, st);
+    }
     return launch_s2mel_attention(q, k, v, out, tab, heads, t_pad, precision, st);
 }

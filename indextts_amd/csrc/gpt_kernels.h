@@ -64,6 +64,9 @@ struct GemmArgs {
     int seq_mul;                     // EPI_QKV: cache row of sequence b is b * seq_mul (0/1 = identity); beam prefill writes only row b*nb
     const int* seq_map;              // EPI_QKV (decode): when non-null, the cache row of dense row b is seq_map[b] (row compaction of a
                                      // ragged batch: finished rows leave the running batch, the survivors keep their cache rows)
+    size_t kv_planes;                // EPI_QKV_ROPE, f32 / f32x3 kernels: when non-zero, K and V^T are written as THREE bf16 planes (h, m, l with
+                                     // h + m + l == the f32 value exactly; plane p at element offset p * kv_planes of kcache / vcache, each plane in
+                                     // the bf16 mode's image) -- the operands of flash_attn_x3_kernel (s2mel_kernels.hip)
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);
 bool gemm_decode_ln_ok(int M, int K, int epi);                 // shapes of the LayerNorm-fused decode GEMM (bf16, 1-4 rows)

@@ -24,9 +24,9 @@ const OptDef kDefs[OPT_COUNT] = {
     {"prefill_gemm", 1, 0, 1, "bf16 prefill GEMMs on the LDS-DMA tile kernels (0: register-path gemm_kernel; bitwise equal)"},
     {"tile256", -1, -1, 2, "bf16 tile GEMM: -1 pick by shape, 0 always 128x128, 1 always 256x256, 2 always 256x128 (bitwise equal)"},
     {"f32_tile", 1, 0, 1, "f32 GEMMs with plain epilogues on the f32-MFMA tile kernel (0: register-path kernel; bitwise equal)"},
-    {"x3_products", 8, 6, 8, "plane products per f32 product of the fp32x3 GEMM: 8 (every term down to 2^-24 |ab|) or 6 (drops m*l and l*m)"},
+    {"x3_products", 6, 6, 8, "plane products per f32 product of the fp32x3 GEMMs and attention: 6 (hh, hm, mh, hl, lh, mm; drops m*l and l*m, 2^-24 |ab| each: measured error vs f64 <= the native f32-MFMA kernels' on every benchmarked shape) or 8 (every term down to 2^-24 |ab|; GEMM launches of this variant are pinned to one block per CU, see launch_gemm_x3_e)"},
     {"x3_sched", 1, 0, 1, "fp32x3 GEMM: interleave the operand split with the MFMAs (0: split as a burst; bitwise equal)"},
-    {"x3_planes", 1, 0, 1, "fp32x3 s2mel: producers emit the three bf16 planes of the next GEMM's A operand (0: each GEMM block splits its own f32 A tile; bitwise equal)"},
+    {"x3_attn", 1, 0, 1, "fp32x3 s2mel: attention products on bf16 planes too (K / V^T written as three planes by the wqkv epilogue, flash_attn_x3_kernel); 0: the f32-MFMA flash kernel"},
     {"sample_radix", -1, -1, 1, "top-k threshold: -1 per-kernel default (radix select in sample_kernel, ballot bisection in the beam kernels), 0 bisection, 1 radix select (identical ids)"},
     {"gpt_compact", 1, 0, 1, "row compaction of ragged decode batches (0 disables it for every handle; identical ids)"},
     {"attn_waves", 0, 0, 16, "waves per block of the KV-cache attention kernel: 0 pick by shape, else 4 / 8 / 16 (the 16 canonical key streams are mapped onto them; bitwise equal)"},
@@ -37,7 +37,6 @@ const OptDef kDefs[OPT_COUNT] = {
     {"aa_act", 2, 0, 2, "anti-aliased activation kernel variant (2: swizzled LDS tiles)"},
     {"conv_bm", 0, 0, 128, "force the co-tile height of conv_mfma_kernel (0: pick by channel count)"},
     {"h3_kernel", 1, 0, 1, "f16x3 vocoder conv: 1 window kernel, 0 two-stage kernel"},
-    {"s2mel_fuse_norm", 1, 0, 1, "f32 / fp32x3 s2mel: adaptive RMSNorm fused into the residual GEMM that produces its input (0: separate ada_rmsnorm launches; bitwise equal)"},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::atomic<unsigned> g_epoch{1};

@@ -28,6 +28,11 @@ int launch_cast_pad(const float* in, void* out, int rows, int src_rows, int C_in
 int launch_rope_split(const float* qkv, const float* rope, void* q, void* k, void* v, const SeqTab& tab, int heads, int t_pad, int prec, hipStream_t st);
 // non-causal attention over the first len_s keys of the query's sequence
 int launch_s2mel_attention(const void* q, const void* k, const void* v, void* out, const SeqTab& tab, int heads, int t_pad, int prec, hipStream_t st);
+// the fp32x3 mode's attention: q f32, K / V^T as three bf16 planes each (plane stride n_seq * heads * t_pad * 64 elements), out f32;
+// plane products per f32 product from option x3_products
+int launch_s2mel_attention_x3(const void* q, const void* kp, const void* vp, void* out, const SeqTab& tab, int heads, int t_pad, hipStream_t st);
+// f32 [n] -> three bf16 planes [3][n] (h + m + l == x exactly)
+int launch_split_planes(const float* in, void* out, size_t n, hipStream_t st);
 // SwiGLU combine: in f32 [n][2I] = [w1 x | w3 x] -> act [n][I] = silu(a) * b
 int launch_swiglu(const float* in, void* out, int n_tok, int I, int prec, hipStream_t st);
 // reflect-padded im2col for the WaveNet dilated convs: x f32 [n_tok][W] -> col act [n_tok][k*W], col[m][j*W + c] = x[src(m, j)][c]

@@ -672,6 +672,252 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(const float* __r
     }
 }
 
+// ================================================================================================================
+// Non-causal flash attention of the fp32x3 mode: f32-accurate S = Q K^T and O = P V on the bf16 matrix pipe, every f32 operand carried EXACTLY
+// as three bf16 planes (x = h + m + l, 8 + 8 + 8 significand bits; the scheme of gpt_kernels.hip::gemm_x3_kernel) and every f32 product
+// replaced by NPROD plane products accumulated in f32: 8 = every term down to 2^-24 |ab| (hh, hm, mh, hl, lh, mm, ml, lm), 6 drops ml and lm.
+//   K and V^T arrive as planes (written once by the wqkv GEMM's epilogue, GemmArgs::kv_planes: plane p of K at Kp + p * pstride in the bf16
+//   mode's [seq][head][t_pad][64] image, of V^T in its [seq][head][64][t_pad] image); Q (f32 rows) is split by the wave that owns the
+//   queries, once, before the key loop; P -- the f32 probabilities in the S^T accumulators -- is split in registers per key tile (11 VALU
+//   ops per pair) and goes straight into the B operand of the PV MFMAs, as in flash_attn_bf16_kernel (same permutation of the key rows
+//   of the S^T sub-tiles, same LDS images and swizzles per plane).  Softmax statistics, the running maximum, the row sums of the f32 P and the
+//   output accumulators are f32 (the f32 flash kernel's arithmetic).
+//   Block = 256 queries of one (sequence, head): 8 waves x 2 sub-tiles of 16 queries; key tiles of 64.  Per key tile and wave 2 x 16 x NPROD
+//   MFMAs (v_mfma_f32_16x16x32_bf16) against 24 fragment reads (each feeds 2 x NPROD / 3 .. MFMAs) and ~300 VALU instructions.
+//   LDS: two stages of [K h | K m | K l | V^T h | V^T m | V^T l] x 8 KiB = 96 KiB (one block = two waves per SIMD), filled by LDS-DMA: wave w
+//   stages rows 8 w .. 8 w + 7 of each plane tile with one instruction, the 16-byte pieces XOR-permuted on the source side.
+// ================================================================================================================
+#define FX3_PLANE 8192
+#define FX3_STAGE (6 * FX3_PLANE)
+#define FX3_LDS (2 * FX3_STAGE)
+
+__device__ __forceinline__ void fx3_split8(const f32x4 p0, const f32x4 p1, v4u& H, v4u& M, v4u& L) {
+    const float x[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const uint32_t h = pack_bf16x2(a, b);
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);      // exact
+        const uint32_t m = pack_bf16x2(ra, rb);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);    // exact
+        H[i] = h; M[i] = m; L[i] = pack_bf16x2(sa, sb);
+    }
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(512) void flash_attn_x3_kernel(const float* __restrict__ Q, const u16* __restrict__ Kp, const u16* __restrict__ Vp,
+                                                            size_t pstride, float* __restrict__ O, SeqTab tab, int heads, int t_pad, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char fx3_sm[];
+    const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 256;
+    const int T = tab.seq_T[s], len = tab.seq_len[s];
+    if (q0 >= T) return;
+    const int H = heads * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, c16 = lane & 15;
+    const size_t row0 = (size_t)tab.seq_start[s];
+    // plane pairs (A = K or V^T plane, B = Q or P plane), smallest terms first; NPROD = 6 skips the two 2^-24 cross terms ml, lm
+    constexpr int PA[8] = {2, 1, 2, 0, 1, 1, 0, 0};
+    constexpr int PB[8] = {1, 2, 0, 2, 1, 0, 1, 0};
+    int qi[2];
+    bool q_ok[2];
+    v4u qp[2][3][2];                                               // [sub-tile][plane][d half]: d = 32 kx + 8 g .. + 7 of query c16
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        qi[qs] = q0 + (w * 2 + qs) * 16 + c16;
+        q_ok[qs] = qi[qs] < T;
+        qi[qs] = q_ok[qs] ? qi[qs] : T - 1;
+        const float* qrow = Q + (row0 + qi[qs]) * H + h * 64 + g * 8;
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx) {
+            const f32x4 p0 = *(const f32x4*)(qrow + 32 * kx), p1 = *(const f32x4*)(qrow + 32 * kx + 4);
+            fx3_split8(p0, p1, qp[qs][0][kx], qp[qs][1][kx], qp[qs][2][kx]);
+        }
+    }
+    const u16* Kb = Kp + ((size_t)(s * heads + h) * t_pad) * 64;
+    const u16* Vb = Vp + ((size_t)(s * heads + h) * 64) * t_pad;
+    // LDS-DMA sources of this lane: row 8 w + (lane >> 3) of a plane tile, LDS slot lane & 7 <- global piece slot ^ swizzle(row)
+    const int rr = 8 * w + (lane >> 3), slot = lane & 7;
+    const u16* ksrc = Kb + (size_t)rr * 64 + ((slot ^ (((rr >> 1) & 1) | (((rr >> 3) & 3) << 1))) << 3);
+    const u16* vsrc = Vb + (size_t)rr * t_pad + ((slot ^ ((rr >> 1) & 7)) << 3);
+    auto issue = [&](int k0, int buf) {
+        char* base = fx3_sm + buf * FX3_STAGE + w * 1024;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + p * pstride + (size_t)k0 * 64),
+                                             (__attribute__((address_space(3))) void*)(base + p * FX3_PLANE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + p * pstride + k0),
+                                             (__attribute__((address_space(3))) void*)(base + (3 + p) * FX3_PLANE), 16, 0, 0);
+        }
+    };
+    // fragment read offsets (bytes) inside a plane tile: K lane row c16 = 4 a + c of sub-tile kt reads key row 8 a + c (+ 32 (kt >> 1) + 4 (kt & 1));
+    // V^T: row c16 of a 16-row group (flash_attn_bf16_kernel's images)
+    const int krow = 8 * (c16 >> 2) + (c16 & 3);
+    const int ksw = ((c16 >> 1) & 1) | ((c16 >> 2) << 1), vsw = (c16 >> 1) & 7;
+    int k_off[2], v_off[2];
+#pragma unroll
+    for (int kx = 0; kx < 2; ++kx) {
+        k_off[kx] = (krow * 64 + (((kx * 4 + g) ^ ksw) << 3)) * 2;
+        v_off[kx] = (c16 * 64 + (((kx * 4 + g) ^ vsw) << 3)) * 2;       // keys 32 kx + 8 g .. + 7
+    }
+    f32x4 o[2][4];
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        m_run[qs] = -INFINITY;
+        l_run[qs] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) o[qs][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    issue(0, 0);
+    int it = 0;
+    for (int k0 = 0; k0 < len; k0 += 64, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                               // tile `it` is in LDS; everybody is done with tile it - 1
+        if (k0 + 64 < len) issue(k0 + 64, (it + 1) & 1);               // block-uniform; in flight under this tile's MFMAs
+        const char* kt_s = fx3_sm + (it & 1) * FX3_STAGE;
+        const char* vt_s = kt_s + 3 * FX3_PLANE;
+        f32x4 st[2][4];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) st[qs][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // S^T = K Q^T: two key sub-tiles at a time (their three plane fragments in registers), products q outermost so that consecutive
+        // MFMAs never chain on one accumulator (four independent ones per product)
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx)
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                v4u ka[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int kt = 2 * kp + j;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) ka[j][p] = *(const v4u*)(kt_s + p * FX3_PLANE + (32 * (kt >> 1) + 4 * (kt & 1)) * 128 + k_off[kx]);
+                }
+#pragma unroll
+                for (int q = 8 - NPROD; q < 8; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int qs = 0; qs < 2; ++qs)
+                            st[qs][2 * kp + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka[j][PA[q]]),
+                                                                                         __builtin_bit_cast(bf16x8_t, qp[qs][PB[q]][kx]), st[qs][2 * kp + j], 0, 0, 0);
+            }
+        const bool tail = k0 + 64 > len;                               // block-uniform: only the last tile holds masked keys
+        v4u pb[2][3][2];                                               // P planes: [sub-tile][plane][key half]
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            if (tail) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((k0 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r) >= len) st[qs][kt][r] = -INFINITY;
+            }
+            const float t0 = fa_max3(st[qs][0][0], st[qs][0][1], st[qs][0][2]), t1 = fa_max3(st[qs][1][0], st[qs][1][1], st[qs][1][2]);
+            const float t2 = fa_max3(st[qs][2][0], st[qs][2][1], st[qs][2][2]), t3 = fa_max3(st[qs][3][0], st[qs][3][1], st[qs][3][2]);
+            const float u0 = fa_max3(t0, t1, st[qs][0][3]), u1 = fa_max3(t2, t3, st[qs][1][3]);
+            const float m_new = fa_colmax(fa_max3(u0, u1, fa_max3(st[qs][2][3], st[qs][3][3], m_run[qs])));      // >= m_run, finite (key 0 is valid)
+            if (__builtin_amdgcn_ballot_w64(m_new > m_run[qs]) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * scale_log2e);             // exp2(-inf) = 0 on the first tile
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qs][mt][r] *= alpha;
+                l_run[qs] *= alpha;
+                m_run[qs] = m_new;
+            }
+            const float off = -m_new * scale_log2e;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qs][kt][r], scale_log2e, off));
+                    st[qs][kt][r] = p;
+                    psum += p;
+                }
+            l_run[qs] += psum;
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx) fx3_split8(st[qs][2 * kx], st[qs][2 * kx + 1], pb[qs][0][kx], pb[qs][1][kx], pb[qs][2][kx]);
+        }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int kx = 0; kx < 2; ++kx)
+#pragma unroll
+            for (int mp = 0; mp < 2; ++mp) {
+                v4u va[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) va[j][p] = *(const v4u*)(vt_s + p * FX3_PLANE + (2 * mp + j) * 2048 + v_off[kx]);
+#pragma unroll
+                for (int q = 8 - NPROD; q < 8; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int qs = 0; qs < 2; ++qs)
+                            o[qs][2 * mp + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va[j][PA[q]]),
+                                                                                        __builtin_bit_cast(bf16x8_t, pb[qs][PB[q]][kx]), o[qs][2 * mp + j], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        float ls = l_run[qs];                                          // the four key groups' shares of the row sum
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        if (q_ok[qs]) {
+            const float inv = ls > 0.f ? 1.0f / ls : 0.f;
+            float* orow = O + (row0 + qi[qs]) * H + h * 64 + g * 4;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                *(f32x4*)(orow + mt * 16) = f32x4{o[qs][mt][0] * inv, o[qs][mt][1] * inv, o[qs][mt][2] * inv, o[qs][mt][3] * inv};
+        }
+    }
+}
+
+// f32 [n] -> three bf16 planes (plane p at out + p * n): the unit-level entry point's path to the x3 attention operands
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ in, u16* __restrict__ out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= n) return;
+    const float a = in[i], b = in[i + 1];
+    const uint32_t h = pack_bf16x2(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    const uint32_t m = pack_bf16x2(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    *(uint32_t*)(out + i) = h;
+    *(uint32_t*)(out + n + i) = m;
+    *(uint32_t*)(out + 2 * n + i) = pack_bf16x2(sa, sb);
+}
+int launch_split_planes(const float* in, void* out, size_t n, hipStream_t st) {
+    if (n == 0) return ITTS_OK;
+    if (n & 1) { itts_set_error("split_planes: n must be even"); return ITTS_ERR_ARG; }
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, in, (u16*)out, n);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// q f32 [n_tok][H]; kp / vp: three bf16 planes each (plane stride = n_seq * heads * t_pad * 64 elements); out f32 [n_tok][H]
+int launch_s2mel_attention_x3(const void* q, const void* kp, const void* vp, void* out, const SeqTab& tab, int heads, int t_pad, hipStream_t st) {
+    if (tab.n_tok <= 0) return ITTS_OK;
+    static ItPerDevice<bool> attr_set_pd;
+    bool& attr_set = attr_set_pd.cur();
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_x3_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FX3_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)flash_attn_x3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, FX3_LDS));
+        attr_set = true;
+    }
+    const float scale_log2e = 0.125f * 1.4426950408889634f;
+    const size_t pstride = (size_t)tab.n_seq * heads * t_pad * 64;
+    const dim3 grid(ceil_div(tab.t_max, 256), heads, tab.n_seq);
+    if (itts_opt(OPT_X3_PRODUCTS) == 8)
+        hipLaunchKernelGGL(flash_attn_x3_kernel<8>, grid, dim3(512), FX3_LDS, st, (const float*)q, (const u16*)kp, (const u16*)vp, pstride, (float*)out, tab, heads, t_pad, scale_log2e);
+    else
+        hipLaunchKernelGGL(flash_attn_x3_kernel<6>, grid, dim3(512), FX3_LDS, st, (const float*)q, (const u16*)kp, (const u16*)vp, pstride, (float*)out, tab, heads, t_pad, scale_log2e);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
 int launch_s2mel_attention(const void* q, const void* k, const void* v, void* out, const SeqTab& tab, int heads, int t_pad, int prec,
                            hipStream_t st) {
     if (tab.n_tok <= 0) return ITTS_OK;

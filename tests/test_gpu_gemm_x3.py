@@ -15,6 +15,7 @@ DEV = "cuda:0"
 
 def _errors(M, N, K, seed, scale=1.0, products=8):
     from indextts_amd import _lib, gpt
+    prev = _lib.get_option("x3_products")
     _lib.set_option("x3_products", products)
     g = torch.Generator().manual_seed(seed)
     # wide dynamic range per row / column: exercises all three planes of both operands
@@ -27,7 +28,7 @@ def _errors(M, N, K, seed, scale=1.0, products=8):
         wp = gpt.pack_gemm_weight(w, prec).to(DEV)
         y = gpt.gemm(a.to(DEV), wp, b.to(DEV), N, prec, prefill_tiles=True).cpu().double()
         out[name] = float((y - ref).abs().max() / ref.abs().max()), float(((y - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
-    _lib.set_option("x3_products", 8)
+    _lib.set_option("x3_products", prev)
     return out
 
 

@@ -301,3 +301,39 @@ def test_dead_row_elimination_is_bit_identical(precision):
     assert rms(out[False]) > 1e-3 and torch.equal(out[False], out[True])
     assert flops[True] < 0.97 * flops[False], flops
     print(f"{precision}: GEMM FLOPs of the solve {flops[False]:.3e} -> {flops[True]:.3e} with the prompt rows' dead tail work removed")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3"])
+def test_estimator_is_bit_stable_run_to_run_at_solve_size(mode):
+    """The production architecture on two utterances of 517 + 1926 frames (9772 packed rows with the CFG branch: every tile GEMM launch runs
+    several blocks per CU): three estimator calls and three one-step solves on the same inputs return the same BITS, with the cached workspace
+    filled with NaN patterns in between (nothing may be read before it is written).  Round 4 found run-to-run differences in the x3 GEMM variants
+    that are not the shipped one when two of their blocks share a CU (profiles/r04d; they are pinned to one block per CU since) -- this test
+    holds the two modes that may carry `bench.py`'s headline to determinism at a size where that showed."""
+    import hashlib
+    from indextts_amd import s2mel, synth
+    args = synth.S2MEL_V2
+    m = s2mel.CFM(args, precision=mode, device=DEV)
+    m.load_state_dict(synth.s2mel_weights(args, seed=1234))
+    g = torch.Generator().manual_seed(0)
+    B, Tp, T = 2, 517, 517 + 1926
+    x = torch.randn(B, 80, T, generator=g).to(DEV)
+    mu = torch.randn(B, T, args["DiT"]["content_dim"], generator=g).to(DEV)
+    prompt = (torch.randn(1, 80, Tp, generator=g) * 0.5 - 1.0).to(DEV)
+    style = torch.randn(1, args["style_encoder"]["dim"], generator=g).to(DEV)
+    lens = torch.full((B,), T)
+    px = torch.zeros_like(x)
+    px[..., :Tp] = prompt
+    hsh = lambda y: hashlib.sha1(y.float().cpu().numpy().tobytes()).hexdigest()[:12]
+    est, sol = [], []
+    for _ in range(3):
+        if m._ws is not None:
+            m._ws.fill_(0xFF)
+        est.append(hsh(m.estimator(torch.cat([x, x]), torch.cat([px, torch.zeros_like(px)]), lens, torch.full((2 * B,), 0.3),
+                               torch.cat([style.expand(B, -1), torch.zeros(B, style.shape[1], device=DEV)]), torch.cat([mu, torch.zeros_like(mu)]))))
+        m._ws.fill_(0xFF)
+        y = m.solve_euler(x.clone(), lens, prompt, mu, style, None, torch.linspace(0, 1, 2), 0.7, frame_lens=[T] * B)
+        assert bool(torch.isfinite(y).all())
+        sol.append(hsh(y))
+    print(f"{mode}: estimator bits {est}, one-step solve bits {sol}")
+    assert len(set(est)) == 1 and len(set(sol)) == 1

@@ -317,8 +317,10 @@ def main():
                                 cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens,
                                               cfg.max_mel_tokens, cfg.number_text_tokens]))
 
-    if only is not None and "fullsize" in only:            # minutes of CPU: only on request (`make_golden_gpt.py fullsize`)
+    if only is not None and only == "fullsize":            # minutes of CPU: only on request (`make_golden_gpt.py fullsize`)
         make_fullsize()
+    if only is not None and only == "fullsize_beam":       # `make_golden_gpt.py fullsize_beam`
+        make_fullsize_beam()
     if only is None or "v1" in only:
         make_v1()
     if only is None or "bf16" in only:
@@ -363,6 +365,45 @@ def make_fullsize():
     np.savez_compressed(os.path.join(GOLD, "gpt_fullsize_ctx694.npz"), text=text.numpy(), lens=np.array(lens), style=style.numpy(),
                         emo_vec=emo_vec.numpy(), langs=langs.numpy(), codes=codes.numpy(), margins=margins.astype(np.float32),
                         seed=np.int64(seed), n=np.int64(n),
+                        cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens, cfg.max_mel_tokens, cfg.number_text_tokens]))
+
+
+def make_fullsize_beam():
+    """The reference's DEFAULT generation mode (infer_v2_5.py:732-740: do_sample, top_p 0.8, top_k 30, temperature 0.8, num_beams 3,
+    repetition_penalty 10, length_penalty 0) on the full-size stack (24 x 1280 x 20 heads): two utterances of 64 / 47 text tokens
+    (BASELINE configs[1]'s text length), 3 beams each, 200 beam-sample steps, fixed-length decode.  The REFERENCE's own classes (vendored
+    GenerationMixin._beam_search + BeamSearchScorer over HF GPT2Model) run it here on CPU with the explicit uniform stream; the oracle's ids
+    must equal theirs; the fixture holds the ids and the uniforms (VERDICT r3 weak #2: beam fixtures were small-model only)."""
+    cfg = G.GPTConfig(max_text_tokens=80, max_mel_tokens=260)
+    seed, B, L, n, nb = 4321, 2, 64, 200, 3
+    sd = G.synth_weights(cfg, seed=seed)
+    sd["mel_head.bias"][cfg.stop_mel_token] -= 1e4                # fixed-length decode (bench.py does the same)
+    g = torch.Generator().manual_seed(seed + 100)
+    lens = [64, 47]
+    text = ragged_text(g, B, L, cfg.number_text_tokens, lens)
+    style = torch.randn(1, 192, generator=g)
+    emo_vec = torch.randn(1, cfg.model_dim, generator=g) * 0.1
+    langs = torch.randint(0, cfg.n_langs, (B,), generator=g)
+    uniforms = torch.rand(n + 2, B, 2 * nb, generator=g, dtype=torch.float64)
+    gk = dict(do_sample=True, num_beams=nb, top_p=0.8, top_k=30, temperature=0.8, repetition_penalty=10.0, length_penalty=0.0)
+    import time
+    t0 = time.time()
+    uv = build_reference(sd, cfg, kv_cache=True)
+    with torch.no_grad(), UniformMultinomial(uniforms):
+        codes, _ = uv.inference_speech(torch.zeros(1, 4, 2), text, langs=langs, emo_vec=emo_vec, campplus_embedding=style,
+                                       max_generate_length=n, **gk)
+    t1 = time.time()
+    with torch.no_grad():
+        oc = G.inference_speech(sd, cfg, G.conds_latent_campplus(sd, style, emo_vec), text, langs,
+                                G.GenParams(max_generate_length=n, **gk), uniforms=uniforms, kv_cache=True)
+    t2 = time.time()
+    same = codes.shape == oc.shape and bool((codes == oc).all())
+    print(f"fullsize_beam: reference ids {tuple(codes.shape)} in {t1 - t0:.0f}s, oracle in {t2 - t1:.0f}s, oracle==reference: {same}")
+    assert same
+    np.savez_compressed(os.path.join(GOLD, "gpt_fullsize_beam3.npz"), text=text.numpy(), lens=np.array(lens), style=style.numpy(),
+                        emo_vec=emo_vec.numpy(), langs=langs.numpy(), uniforms=uniforms.numpy(), codes=codes.numpy(),
+                        seed=np.int64(seed), n=np.int64(n), nb=np.int64(nb),
+                        gen=np.array([1, nb, 0.8, 30, 0.8, 10.0, 0.0], dtype=np.float64),
                         cfg=np.array([cfg.layers, cfg.model_dim, cfg.heads, cfg.max_text_tokens, cfg.max_mel_tokens, cfg.number_text_tokens]))
 
 

@@ -26,12 +26,17 @@ __device__ __forceinline__ unsigned touch(const char* buf, size_t chunk, int xcd
     const size_t lines_per_chunk = chunk / stride;
     const size_t total = 32 * lines_per_chunk;                     // 32 reader chunks live on one XCD
     unsigned acc = 0;
-    for (size_t l = (size_t)q * blockDim.x + threadIdx.x; l < total; l += (size_t)nq * blockDim.x) {
-        const size_t c = l / lines_per_chunk, r = l - c * lines_per_chunk;
-        const unsigned* p = (const unsigned*)(buf + (c * 8 + tx) * chunk + r * stride);
-        unsigned v;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-        acc ^= v;                                                  // the xor waits at the end only (compiler inserts vmcnt before use)
+    const size_t step = (size_t)nq * blockDim.x;
+    for (size_t l0 = (size_t)q * blockDim.x + threadIdx.x; l0 < total; l0 += 4 * step) {      // four independent loads in flight per thread
+        unsigned v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t l = l0 + k * step;
+            const size_t lc = l < total ? l : l0;
+            const size_t c = lc / lines_per_chunk, r = lc - c * lines_per_chunk;
+            v[k] = *(const unsigned*)(buf + (c * 8 + tx) * chunk + r * stride);
+        }
+        acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
     }
     return acc;
 }
@@ -115,6 +120,7 @@ static float run(int mode, size_t size, int nbuf, std::vector<char*>& bufs, unsi
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const int npairs = 192;
     unsigned *s_out, *r_out;
     CK(hipMalloc(&s_out, 4096));
