@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
+X3_PRODUCTS = [6]                 # plane products per f32 product of the fp32x3 mode in this run (--x3-products -> engine option x3_products)
 PEAK_HBM_GBPS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
 SR, HOP = 22050, 256
@@ -392,11 +393,16 @@ def main():
     ap.add_argument("--s2mel-precision", default="fp32x3", choices=["fp32", "fp32x3", "bf16"],
                     help="precision of the flow-matching stage in the timed steps.  The reference computes the stage in fp32 (autocast off "
                          "around s2mel, infer_v2_5.py:827-828).  fp32x3 (default, carries `value`; ruled admissible in VERDICT r3): f32 "
-                         "activations and weights, every GEMM operand carried EXACTLY as three bf16 planes (24 significand bits), 8 plane "
-                         "products per f32 product on the bf16 matrix pipe, f32 accumulation -- error against an f64 GEMM not above the native "
-                         "f32-MFMA kernel's (tests/test_gpu_gemm_x3.py); attention, norms, every element-wise stage: the f32 code.  fp32: the "
+                         "activations and weights, every GEMM AND attention operand carried EXACTLY as three bf16 planes (24 significand bits), "
+                         "--x3-products plane products per f32 product on the bf16 matrix pipe, f32 accumulation -- error against an f64 result not "
+                         "above the native f32-MFMA kernels' (tests/test_gpu_gemm_x3.py, tests/test_gpu_attn_x3.py); softmax, norms, every "
+                         "element-wise stage: the f32 code.  fp32: the "
                          "native f32-MFMA kernels; bf16: 16-bit operands (not admissible as the headline).  The other modes are timed after the "
                          "headline on the same inputs and printed beside it (`value_by_s2mel_precision`)")
+    ap.add_argument("--x3-products", type=int, default=6, choices=[6, 8],
+                    help="plane products per f32 product of the fp32x3 mode (engine option x3_products): 6 = hh, hm, mh, hl, lh, mm (the two dropped "
+                         "terms are 2^-24 |ab| each; VERDICT r3's condition -- GPU error vs f64 <= the native f32 kernel's on every s2mel GEMM shape, "
+                         "solve-level tests unchanged -- is met: tests/test_gpu_gemm_x3.py, profiles/r04b), 8 = every term down to 2^-24 |ab|")
     ap.add_argument("--profile-steps", type=int, default=1, help="timed steps that carry per-launch HIP-event profiling (stage split, "
                     "roofline); the remaining timed steps run without the instrumentation")
     ap.add_argument("--alt-steps", type=int, default=2, help="timed steps of each other s2mel precision (after the headline)")
@@ -449,6 +455,10 @@ def main():
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     from indextts_amd import dist as D
 
+    X3_PRODUCTS[0] = args.x3_products
+    if not stub:
+        from indextts_amd import _lib
+        _lib.set_option("x3_products", args.x3_products)
     eng = (StubEngine if stub else HipEngine)(args, dev, rank)
     n_text, n_gen = args.text_tokens, args.gen_tokens
     t_mel = int(2 * n_gen * 1.72)
@@ -589,9 +599,9 @@ def main():
                        if args.precision == "bf16" else "f32 (GPT) + ")
                       + ("f32 (codec decode, length regulator, flow matching, BigVGAN: the reference runs these with autocast off)"
                          if args.s2mel_precision == "fp32" or args.no_s2mel else
-                         "fp32x3 (flow matching: f32 activations / weights / accumulation, GEMMs on the bf16 matrix pipe with every f32 operand "
-                         "carried exactly as three bf16 planes = 24 significand bits, 8 plane products per f32 product; attention, norms, "
-                         "element-wise stages f32) + f32 (codec decode, length regulator, BigVGAN)"
+                         f"fp32x3 (flow matching: f32 activations / weights / accumulation, GEMM and attention products on the bf16 matrix pipe with "
+                         f"every f32 operand carried exactly as three bf16 planes = 24 significand bits, {args.x3_products} plane products per f32 "
+                         f"product; softmax, norms, element-wise stages f32) + f32 (codec decode, length regulator, BigVGAN)"
                          if args.s2mel_precision == "fp32x3" else
                          "bf16 (s2mel GEMM operands / K,V / attention probabilities; f32 accumulate, residual streams, norms) + "
                          "f32 (codec decode, length regulator, BigVGAN)")),
@@ -610,6 +620,7 @@ def main():
                        "global_batch": n_total, "per_gpu_batch": B, "text_tokens": n_text, "gen_tokens": n_gen,
                        "mel_frames": t_mel, "audio_seconds_per_utt": t_mel * HOP / SR, "parallelism": f"utterance-dp{world}",
                        "gpt_precision": args.precision, "s2mel_precision": None if args.no_s2mel else args.s2mel_precision,
+                       "x3_products": args.x3_products if (not args.no_s2mel and args.s2mel_precision == "fp32x3") else None,
                        "use_hipgraph": not args.no_graph,
                        "step_overlap": bool(args.overlap and args.steps > 1)},
         }
@@ -968,8 +979,9 @@ def alt_precision_leg(args, eng, precision, text, langs, mel, bundle, n_gen, aud
 def s2_stage(t, n_prof, prompt_frames, precision):
     """stage split of the flow-matching stage from the HIP-event records of `n_prof` profiled steps"""
     n = max(1, n_prof)
-    # fp32x3: GEMMs on the bf16 pipe at 8 MFMAs per f32-equivalent one -> peak = bf16 peak / 8 (attention stays on the f32 MFMA)
-    peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else (PEAK_BF16_MFMA_TFLOPS / 8.0 if precision == "fp32x3" else PEAK_F32_MFMA_TFLOPS)
+    # fp32x3: GEMMs and attention on the bf16 pipe at `x3_products` MFMAs per f32-equivalent one -> peak = bf16 peak / products
+    x3p = float(X3_PRODUCTS[0])
+    peak = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else (PEAK_BF16_MFMA_TFLOPS / x3p if precision == "fp32x3" else PEAK_F32_MFMA_TFLOPS)
     gemm_tf = t["gemm_flops"] / max(1e-9, t["gemm_ms"] * 1e-3) / 1e12
     attn_tf = t["attention_flops"] / max(1e-9, t["attention_ms"] * 1e-3) / 1e12
     return {"precision": precision, "codec_regulator_ms_per_step": t["codec_regulator_ms"] / n,
@@ -978,9 +990,9 @@ def s2_stage(t, n_prof, prompt_frames, precision):
             "cfm_gemm_tflops": gemm_tf, "cfm_gemm_mfma_frac": gemm_tf / peak, "cfm_gemm_launches_per_step": t["launches"] // n,
             "cfm_attention_ms_per_step": t["attention_ms"] / n, "cfm_attention_tflops": attn_tf,
             "cfm_attention_launches_per_step": t.get("attention_launches", 0) // n,
-            "cfm_attention_mfma_frac": attn_tf / (PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_F32_MFMA_TFLOPS),
+            "cfm_attention_mfma_frac": attn_tf / peak,
             "cfm_elementwise_ms_per_step": (t["estimator_ms"] - t["gemm_ms"] - t["attention_ms"]) / n,
-            "mfma_peak_tflops": peak, "prompt_frames": prompt_frames, "euler_steps": EULER_STEPS, "cfg_rate": 0.7}
+            "mfma_peak_tflops": peak, "x3_products": int(x3p) if precision == "fp32x3" else None, "prompt_frames": prompt_frames, "euler_steps": EULER_STEPS, "cfg_rate": 0.7}
 
 
 def gpu_report(args, eng, B, n_text, n_gen, t_mel):
@@ -1045,8 +1057,9 @@ def gpu_report(args, eng, B, n_text, n_gen, t_mel):
         gemm_roof = {"bound": "mfma",
                      "kernel": ("gemm_prefill_kernel<EPI, CONV, VEC, F32 = true> (s2mel DiT / WaveNet GEMMs, v_mfma_f32_16x16x4_f32, every "
                                 "epilogue instantiation)" if f32 else
-                                "gemm_x3_kernel<EPI, CONV, 8> (s2mel DiT / WaveNet GEMMs with f32 operands as three bf16 planes, 8 x "
-                                "v_mfma_f32_16x16x32_bf16 per f32-equivalent MFMA; achieved / peak in f32-equivalent TFLOP/s, peak = bf16 peak / 8)"
+                                f"gemm_x3_kernel<EPI, CONV, {X3_PRODUCTS[0]}> (s2mel DiT / WaveNet GEMMs with f32 operands as three bf16 planes, "
+                                f"{X3_PRODUCTS[0]} x v_mfma_f32_16x16x32_bf16 per f32-equivalent MFMA; achieved / peak in f32-equivalent TFLOP/s, "
+                                f"peak = bf16 peak / {X3_PRODUCTS[0]})"
                                 if args.s2mel_precision == "fp32x3" else
                                 "gemm_tile256_kernel / gemm_prefill_kernel (s2mel DiT / WaveNet GEMMs, v_mfma_f32_16x16x32_bf16, every "
                                 "epilogue instantiation)"),
