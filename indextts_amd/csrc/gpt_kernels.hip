@@ -1803,9 +1803,9 @@ __device__ __forceinline__ void x3_split8(const f32x4 p0, const f32x4 p1, v4u& H
     }
 }
 
-template <int EPI, bool CONV = false, int NPROD = 8, bool SCHED = true>
+template <int EPI, bool CONV = false, int NPROD = 8, bool SCHED = true, int NST = 2>      // NST: A stages of the ring (2 or 3)
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB] operand stages; the epilogue image is the larger
+    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [NST][A 16 KiB] operand stages; the epilogue image is the larger
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int n_mt = (a.M + PF_BM - 1) / PF_BM, n_nt = (a.N + PF_BN - 1) / PF_BN;
@@ -1879,6 +1879,17 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
             for (int p = 0; p < 3; ++p) bw[nt][p] = wsrc[nt][((size_t)kt * 3 + p) * 64];
     };
 
+    auto load_w_asm = [&](int kt, v4u (&bw)[4][3]) {                  // the same twelve loads, outside the compiler's wait-count bookkeeping (NST == 3)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const v4u* wp = wsrc[nt] + (size_t)kt * 192;
+            asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:1024\n\tglobal_load_dwordx4 %2, %3, off offset:2048"
+                         : "=&v"(bw[nt][0]), "=&v"(bw[nt][1]), "=&v"(bw[nt][2])
+                         : "v"(wp)
+                         : "memory");
+        }
+    };
+
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1897,14 +1908,40 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
     // one K tile: `bw` holds its weight fragments (loaded during the previous tile), `bn_` receives the next tile's.  Software pipeline
     // over the four m-tiles: the operand split of m-tile mt + 1 (two LDS reads, 44 VALU ops) is issued in the shadow of m-tile mt's
     // 4 x NPROD MFMAs (SCHED: 2 MFMAs, then 3 VALU ops, ...) instead of as a burst in front of them.
+    // NST == 3: the A tile is requested TWO K tiles ahead.  A K tile is 96 MFMAs per wave (~0.7 us with two resident blocks); one tile of
+    // lookahead is less than a loaded DMA round trip, so with two stages every barrier waits on memory.  Issue order inside a tile: the next
+    // tile's weights, THEN the A tile after next -- vmcnt retires in order, so "this tile's A and weights have landed" is vmcnt(4): only the
+    // four DMA instructions of the youngest A tile may still be in flight.  Every load is issued unconditionally (past the end the last
+    // tile is requested again, into a stage nobody reads any more): with a branch around a load hipcc's wait-count pass loses the number of
+    // loads in flight across the loop edge and puts vmcnt(0) in front of the first MFMA that reads a weight register (K / 32 is even here:
+    // the launcher falls back to two stages otherwise).
+    int buf_cur = 0;
     auto ktile = [&](int kt, v4u (&bw)[4][3], v4u (&bn_)[4][3]) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this tile's A DMA and weight loads have landed
-        __syncthreads();                                           // ... for every wave; the other A stage is free again
-        if (kt + 1 < nk) {
-            issue_a(kt + 1, (kt + 1) & 1);
-            load_w(kt + 1, bn_);
+        if constexpr (NST == 3) {
+            // this tile's A DMA and weight loads have landed.  The weight registers pass through the wait so that no MFMA reading them can be
+            // scheduled above it (the loads are inline asm: hipcc's own wait-count pass, which knows nothing of the order kept here, answers a
+            // register load in flight across the loop edge with vmcnt(0) in front of the first MFMA -- that would drain the A tile just requested)
+            asm volatile("s_waitcnt vmcnt(4)"
+                         : "+v"(bw[0][0]), "+v"(bw[0][1]), "+v"(bw[0][2]), "+v"(bw[1][0]), "+v"(bw[1][1]), "+v"(bw[1][2]),
+                           "+v"(bw[2][0]), "+v"(bw[2][1]), "+v"(bw[2][2]), "+v"(bw[3][0]), "+v"(bw[3][1]), "+v"(bw[3][2])
+                         :
+                         : "memory");
+            // ... for every wave; the stage read during the previous tile is free again.  The bare barrier: __syncthreads() carries a release
+            // fence that hipcc lowers to vmcnt(0), which would drain the A tile requested for the tile after next at every K tile.  LDS is the
+            // only memory the waves exchange here; its reads are consumed (lgkmcnt) before a wave gets this far.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            load_w_asm(kt + 1 < nk ? kt + 1 : nk - 1, bn_);
+            issue_a(kt + 2 < nk ? kt + 2 : nk - 1, buf_cur >= 1 ? buf_cur - 1 : 2);      // stage (buf_cur + 2) mod 3
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's A DMA and weight loads have landed
+            __syncthreads();                                       // ... for every wave; the other A stage is free again
+            if (kt + 1 < nk) {
+                issue_a(kt + 1, (kt + 1) & 1);
+                load_w(kt + 1, bn_);
+            }
         }
-        const char* base = pf_sm + (kt & 1) * 16384;
+        const char* base = pf_sm + (NST == 3 ? buf_cur : (kt & 1)) * 16384;
+        if constexpr (NST == 3) buf_cur = buf_cur == 2 ? 0 : buf_cur + 1;
         v4u ap[3], an[3];
         {
             const f32x4 p0 = *(const f32x4*)(base + a_wave + a_off[0]);
@@ -1937,13 +1974,23 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
             }
             if (mt < 3) { ap[0] = an[0]; ap[1] = an[1]; ap[2] = an[2]; }
         }
+        if constexpr (NST == 3) __builtin_amdgcn_sched_barrier(0);     // (keeps this tile's MFMAs above the next tile's barrier and loads)
     };
     v4u bw0[4][3], bw1[4][3];
     issue_a(0, 0);
-    load_w(0, bw0);
-    for (int kt = 0; kt < nk; kt += 2) {
-        ktile(kt, bw0, bw1);
-        if (kt + 1 < nk) ktile(kt + 1, bw1, bw0);
+    if constexpr (NST == 3) load_w_asm(0, bw0); else load_w(0, bw0);
+    if constexpr (NST == 3) {
+        issue_a(nk > 1 ? 1 : 0, 1);
+        for (int kt = 0; kt < nk; kt += 2) {                       // nk is even (launcher)
+            ktile(kt, bw0, bw1);
+            ktile(kt + 1, bw1, bw0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the re-requested tail tiles: landed before the epilogue reuses the LDS
+    } else {
+        for (int kt = 0; kt < nk; kt += 2) {
+            ktile(kt, bw0, bw1);
+            if (kt + 1 < nk) ktile(kt + 1, bw1, bw0);
+        }
     }
     // epilogue: the f32 tile kernel's vector path
     __syncthreads();
@@ -1984,6 +2031,7 @@ static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
         attr_set = true;
     }
     const dim3 grid(per * 8), blk(256);
@@ -1993,7 +2041,9 @@ static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
     // same kernels soaked clean; one block per CU: bit-stable, cause not found) -- they are A/B and accuracy-study paths, so they are pinned to
     // one block per CU by an LDS request above half a CU's 160 KiB.
     const size_t lds = (nprod == 6 && sched) ? X3_LDS : X3_LDS_ONE;
-    if (nprod == 6 && sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true>), grid, blk, lds, st, a);
+    const bool ring3 = itts_opt(OPT_X3_STAGES) == 3 && (a.K / 32) % 2 == 0;                // A tile requested two K tiles ahead (three 16 KiB stages: still under the epilogue image)
+    if (nprod == 6 && sched && ring3) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true, 3>), grid, blk, lds, st, a);
+    else if (nprod == 6 && sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true>), grid, blk, lds, st, a);
     else if (nprod == 6) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, false>), grid, blk, lds, st, a);
     else if (sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, true>), grid, blk, lds, st, a);
     else hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, false>), grid, blk, lds, st, a);

@@ -37,6 +37,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"aa_act", 2, 0, 2, "anti-aliased activation kernel variant (2: swizzled LDS tiles)"},
     {"conv_bm", 0, 0, 128, "force the co-tile height of conv_mfma_kernel (0: pick by channel count)"},
     {"h3_kernel", 1, 0, 1, "f16x3 vocoder conv: 1 window kernel, 0 two-stage kernel"},
+    {"x3_stages", 2, 2, 3, "fp32x3 GEMM (6 products): A stages of the LDS ring -- 3 requests the A tile two K tiles ahead (bitwise equal)"},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::atomic<unsigned> g_epoch{1};
