@@ -55,7 +55,7 @@ int itts_device_count(void);
  *   aa_act               2     0..2    anti-aliased activation kernel variant
  *   conv_bm              0     0..128  force the co-tile height of the vocoder conv kernel
  *   h3_kernel            1     0..1    f16x3 vocoder conv: window kernel / two-stage kernel
- *   x3_stages            2     2..3    fp32x3 GEMM (6 products): A stages of the LDS ring (3: the A tile is requested two K tiles ahead)
+ *   decode_ln_nt         4     0..4    LayerNorm-fused decode GEMM at 5-16 rows: n-tiles per block of the wide kernel (2 / 4; 0: one-tile kernel)
  * itts_option_count / _name / _doc / _default enumerate the table (index 0 .. count-1).
  * ---------------------------------------------------------------------------------------------------------- */
 int itts_set_option(const char* name, int value);      /* ITTS_ERR_ARG: unknown name or value out of range */

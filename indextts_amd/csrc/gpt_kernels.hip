@@ -1803,9 +1803,9 @@ __device__ __forceinline__ void x3_split8(const f32x4 p0, const f32x4 p1, v4u& H
     }
 }
 
-template <int EPI, bool CONV = false, int NPROD = 8, bool SCHED = true, int NST = 2>      // NST: A stages of the ring (2 or 3)
+template <int EPI, bool CONV = false, int NPROD = 8, bool SCHED = true>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [NST][A 16 KiB] operand stages; the epilogue image is the larger
+    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB] operand stages; the epilogue image is the larger
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int n_mt = (a.M + PF_BM - 1) / PF_BM, n_nt = (a.N + PF_BN - 1) / PF_BN;
@@ -1879,17 +1879,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
             for (int p = 0; p < 3; ++p) bw[nt][p] = wsrc[nt][((size_t)kt * 3 + p) * 64];
     };
 
-    auto load_w_asm = [&](int kt, v4u (&bw)[4][3]) {                  // the same twelve loads, outside the compiler's wait-count bookkeeping (NST == 3)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const v4u* wp = wsrc[nt] + (size_t)kt * 192;
-            asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %3, off offset:1024\n\tglobal_load_dwordx4 %2, %3, off offset:2048"
-                         : "=&v"(bw[nt][0]), "=&v"(bw[nt][1]), "=&v"(bw[nt][2])
-                         : "v"(wp)
-                         : "memory");
-        }
-    };
-
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1908,40 +1897,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
     // one K tile: `bw` holds its weight fragments (loaded during the previous tile), `bn_` receives the next tile's.  Software pipeline
     // over the four m-tiles: the operand split of m-tile mt + 1 (two LDS reads, 44 VALU ops) is issued in the shadow of m-tile mt's
     // 4 x NPROD MFMAs (SCHED: 2 MFMAs, then 3 VALU ops, ...) instead of as a burst in front of them.
-    // NST == 3: the A tile is requested TWO K tiles ahead.  A K tile is 96 MFMAs per wave (~0.7 us with two resident blocks); one tile of
-    // lookahead is less than a loaded DMA round trip, so with two stages every barrier waits on memory.  Issue order inside a tile: the next
-    // tile's weights, THEN the A tile after next -- vmcnt retires in order, so "this tile's A and weights have landed" is vmcnt(4): only the
-    // four DMA instructions of the youngest A tile may still be in flight.  Every load is issued unconditionally (past the end the last
-    // tile is requested again, into a stage nobody reads any more): with a branch around a load hipcc's wait-count pass loses the number of
-    // loads in flight across the loop edge and puts vmcnt(0) in front of the first MFMA that reads a weight register (K / 32 is even here:
-    // the launcher falls back to two stages otherwise).
-    int buf_cur = 0;
     auto ktile = [&](int kt, v4u (&bw)[4][3], v4u (&bn_)[4][3]) {
-        if constexpr (NST == 3) {
-            // this tile's A DMA and weight loads have landed.  The weight registers pass through the wait so that no MFMA reading them can be
-            // scheduled above it (the loads are inline asm: hipcc's own wait-count pass, which knows nothing of the order kept here, answers a
-            // register load in flight across the loop edge with vmcnt(0) in front of the first MFMA -- that would drain the A tile just requested)
-            asm volatile("s_waitcnt vmcnt(4)"
-                         : "+v"(bw[0][0]), "+v"(bw[0][1]), "+v"(bw[0][2]), "+v"(bw[1][0]), "+v"(bw[1][1]), "+v"(bw[1][2]),
-                           "+v"(bw[2][0]), "+v"(bw[2][1]), "+v"(bw[2][2]), "+v"(bw[3][0]), "+v"(bw[3][1]), "+v"(bw[3][2])
-                         :
-                         : "memory");
-            // ... for every wave; the stage read during the previous tile is free again.  The bare barrier: __syncthreads() carries a release
-            // fence that hipcc lowers to vmcnt(0), which would drain the A tile requested for the tile after next at every K tile.  LDS is the
-            // only memory the waves exchange here; its reads are consumed (lgkmcnt) before a wave gets this far.
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            load_w_asm(kt + 1 < nk ? kt + 1 : nk - 1, bn_);
-            issue_a(kt + 2 < nk ? kt + 2 : nk - 1, buf_cur >= 1 ? buf_cur - 1 : 2);      // stage (buf_cur + 2) mod 3
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's A DMA and weight loads have landed
-            __syncthreads();                                       // ... for every wave; the other A stage is free again
-            if (kt + 1 < nk) {
-                issue_a(kt + 1, (kt + 1) & 1);
-                load_w(kt + 1, bn_);
-            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this tile's A DMA and weight loads have landed
+        __syncthreads();                                           // ... for every wave; the other A stage is free again
+        if (kt + 1 < nk) {
+            issue_a(kt + 1, (kt + 1) & 1);
+            load_w(kt + 1, bn_);
         }
-        const char* base = pf_sm + (NST == 3 ? buf_cur : (kt & 1)) * 16384;
-        if constexpr (NST == 3) buf_cur = buf_cur == 2 ? 0 : buf_cur + 1;
+        const char* base = pf_sm + (kt & 1) * 16384;
         v4u ap[3], an[3];
         {
             const f32x4 p0 = *(const f32x4*)(base + a_wave + a_off[0]);
@@ -1974,23 +1937,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
             }
             if (mt < 3) { ap[0] = an[0]; ap[1] = an[1]; ap[2] = an[2]; }
         }
-        if constexpr (NST == 3) __builtin_amdgcn_sched_barrier(0);     // (keeps this tile's MFMAs above the next tile's barrier and loads)
     };
     v4u bw0[4][3], bw1[4][3];
     issue_a(0, 0);
-    if constexpr (NST == 3) load_w_asm(0, bw0); else load_w(0, bw0);
-    if constexpr (NST == 3) {
-        issue_a(nk > 1 ? 1 : 0, 1);
-        for (int kt = 0; kt < nk; kt += 2) {                       // nk is even (launcher)
-            ktile(kt, bw0, bw1);
-            ktile(kt + 1, bw1, bw0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the re-requested tail tiles: landed before the epilogue reuses the LDS
-    } else {
-        for (int kt = 0; kt < nk; kt += 2) {
-            ktile(kt, bw0, bw1);
-            if (kt + 1 < nk) ktile(kt + 1, bw1, bw0);
-        }
+    load_w(0, bw0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        ktile(kt, bw0, bw1);
+        if (kt + 1 < nk) ktile(kt + 1, bw1, bw0);
     }
     // epilogue: the f32 tile kernel's vector path
     __syncthreads();
@@ -2031,7 +1984,6 @@ static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
         attr_set = true;
     }
     const dim3 grid(per * 8), blk(256);
@@ -2041,9 +1993,7 @@ static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
     // same kernels soaked clean; one block per CU: bit-stable, cause not found) -- they are A/B and accuracy-study paths, so they are pinned to
     // one block per CU by an LDS request above half a CU's 160 KiB.
     const size_t lds = (nprod == 6 && sched) ? X3_LDS : X3_LDS_ONE;
-    const bool ring3 = itts_opt(OPT_X3_STAGES) == 3 && (a.K / 32) % 2 == 0;                // A tile requested two K tiles ahead (three 16 KiB stages: still under the epilogue image)
-    if (nprod == 6 && sched && ring3) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true, 3>), grid, blk, lds, st, a);
-    else if (nprod == 6 && sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true>), grid, blk, lds, st, a);
+    if (nprod == 6 && sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true>), grid, blk, lds, st, a);
     else if (nprod == 6) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, false>), grid, blk, lds, st, a);
     else if (sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, true>), grid, blk, lds, st, a);
     else hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, false>), grid, blk, lds, st, a);
@@ -2422,6 +2372,103 @@ __global__ __launch_bounds__(NWV * 64) void gemm_decode_ln_kernel(GemmArgs a) {
     }
 }
 
+// The same fusion for 5-16 rows.  At that size the one-tile-per-block kernel above loses (profiles/r04a: every one of its 240-320 blocks repeats
+// the LayerNorm of every row -- 25 KB of L2 reads per row with the split-K partials -- and ln_row's registers leave one 8-wave block per CU, so the
+// launch runs in two rounds).  Here a block owns NT n-tiles (2 or 4: 60-160 blocks, one round, the redundant LayerNorm reads cut by NT) and the
+// two jobs sit on different waves: waves 0-3 request their weight fragments (NT x 10 x 16 B per lane, all in flight at once) and later run the
+// MFMAs with the usual 4-way K split, waves 4-7 normalise the rows (row w - 4, w, w + 4, ...: ln_row, the same bits as ln_kernel) into the slab
+// image meanwhile.  Wave j < NT reduces and finishes tile j.  Same operands, same MFMA order per output -> bitwise the unfused path.
+template <int NV, int EPI, int FLAGS, int NT>
+__global__ __launch_bounds__(512) void gemm_decode_lnw_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];     // [kp][2 row groups][1 KiB]; reused for the reduction
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int NKL = NV * 8;                                    // 32-wide k-blocks of the row (K = 256 NV)
+    constexpr int NI = (NKL + 3) / 4;
+    const int ntiles = (a.N + 15) >> 4;
+    const int nt0 = blockIdx.x * NT;
+    float bias_epi = 0.f;
+    int pos_epi = 0;
+    v4u bq[NI][NT];
+    if (w < 4) {                                                   // wave-uniform
+        if (w < NT && a.bias) {
+            int nb = (nt0 + w) * 16 + (lane & 15);
+            nb = nb < a.N ? nb : a.N - 1;
+            bias_epi = a.bias[nb];
+        }
+        if constexpr (EPI == EPI_QKV) pos_epi = *a.pos_ptr;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int t = (nt0 + j) < ntiles ? nt0 + j : ntiles - 1;
+            const v4u* wp = (const v4u*)a.Wp + (size_t)t * NKL * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int kl = w + 4 * i;
+                const bool ok = kl < NKL;
+                v4u v = *(wp + (size_t)(ok ? kl : 0) * 64);
+                if (!ok) v = v4u{0u, 0u, 0u, 0u};
+                bq[i][j] = v;
+            }
+        }
+    } else {
+        for (int r = w - 4; r < a.M; r += 4) {
+            const int D = a.K;
+            f32x4 v[NV];
+            ln_row<NV, FLAGS>(a.ln_x + (size_t)r * D, (blockIdx.x == 0) ? a.ln_x_out + (size_t)r * D : (float*)nullptr,
+                              a.ln_partial + (size_t)r * D, (size_t)a.M * D, a.ln_bias_prev, a.ln_g, a.ln_b, nullptr, nullptr, D, a.ln_eps, lane, v);
+            char* row = dsm + (r >> 3) * 1024 + (r & 7) * 128 + ((((lane & 15) >> 1) ^ ((r >> 1) & 7)) << 4) + (lane & 1) * 8;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {                         // elements 4 lane + 256 i ..+3 = k-pair (lane >> 4) + 4 i, piece (lane & 15) >> 1
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v[i][0]) | ((uint32_t)f32_to_bf16(v[i][1]) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v[i][2]) | ((uint32_t)f32_to_bf16(v[i][3]) << 16);
+                *(uint2*)(row + ((lane >> 4) + 4 * i) * 2048) = pk;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (w < 4) {                                                   // wave-uniform
+        const int row16 = lane & 15, kg = lane >> 4;
+        const int a_lane = (row16 >> 3) * 1024 + (row16 & 7) * 128;
+        const int sw = (row16 >> 1) & 7;
+        auto lds_frag = [&](int i) -> v4u {
+            int kl = w + 4 * i;
+            kl = kl < NKL ? kl : NKL - 1;
+            const int kp = kl >> 1, pos = (((kl & 1) << 2) + kg) ^ sw;
+            return *(const v4u*)(dsm + kp * 2048 + a_lane + pos * 16);
+        };
+        v4u af_cur = lds_frag(0), af_nxt = af_cur;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (i + 1 < NI) af_nxt = lds_frag(i + 1);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af_cur), __builtin_bit_cast(bf16x8_t, bq[i][j]), acc[j], 0, 0, 0);
+            af_cur = af_nxt;
+        }
+    }
+    __syncthreads();                                               // every wave is done with the slab: reuse it
+    f32x4* r4 = (f32x4*)dsm;
+    if (w < 4) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) r4[((size_t)w * NT + j) * 64 + lane] = acc[j];
+    }
+    __syncthreads();
+    if (w < NT) {
+        f32x4 sacc = r4[(size_t)w * 64 + lane];
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            const f32x4 o = r4[((size_t)ww * NT + w) * 64 + lane];
+            sacc[0] += o[0]; sacc[1] += o[1]; sacc[2] += o[2]; sacc[3] += o[3];
+        }
+        if (nt0 + w < ntiles) decode_epilogue<EPI>(a, 0, (nt0 + w) * 16, lane, 0, sacc, bias_epi, pos_epi);
+    }
+}
+
 template <int NV, int EPI>
 static int launch_gemm_decode_ln_e(const GemmArgs& a, hipStream_t st) {
     const int ntiles = (a.N + 15) / 16;
@@ -2434,7 +2481,20 @@ static int launch_gemm_decode_ln_e(const GemmArgs& a, hipStream_t st) {
         if (part) hipLaunchKernelGGL((gemm_decode_ln_kernel<NV, EPI, LN_PARTIAL | LN_BIAS, NWV_>), dim3(ntiles), dim3(NWV_ * 64), lds, st, a); \
         else hipLaunchKernelGGL((gemm_decode_ln_kernel<NV, EPI, 0, NWV_>), dim3(ntiles), dim3(NWV_ * 64), lds, st, a);                     \
     } while (0)
-    if (a.M <= 4) LN_GEMM_LAUNCH(4); else LN_GEMM_LAUNCH(8);       // (16 waves would cap the kernel at 128 registers: ln_row's one-phase loads need 200)
+    // 5-16 rows: option decode_ln_nt = n-tiles per block of the wide kernel (2 / 4; 0: the one-tile kernel on 8 waves, the A/B record)
+    const int wide_nt = a.M > 4 ? itts_opt(OPT_DECODE_LN_NT) : 0;
+#define LNW_GEMM_LAUNCH(NT_)                                                                                                             \
+    do {                                                                                                                                 \
+        const dim3 grid(ceil_div(ntiles, NT_));                                                                                          \
+        if (part) hipLaunchKernelGGL((gemm_decode_lnw_kernel<NV, EPI, LN_PARTIAL | LN_BIAS, NT_>), grid, dim3(512), lds, st, a);          \
+        else hipLaunchKernelGGL((gemm_decode_lnw_kernel<NV, EPI, 0, NT_>), grid, dim3(512), lds, st, a);                                  \
+    } while (0)
+    if (lds < 16384) lds = 16384;                                   // wide kernel's reduction scratch: 4 waves x 4 tiles x 1 KiB
+    if (a.M <= 4) LN_GEMM_LAUNCH(4);                               // (16 waves would cap the kernel at 128 registers: ln_row's one-phase loads need 200)
+    else if (wide_nt == 2) LNW_GEMM_LAUNCH(2);
+    else if (wide_nt == 4) LNW_GEMM_LAUNCH(4);
+    else LN_GEMM_LAUNCH(8);
+#undef LNW_GEMM_LAUNCH
 #undef LN_GEMM_LAUNCH
     HIP_TRY(hipGetLastError());
     return ITTS_OK;

@@ -37,7 +37,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"aa_act", 2, 0, 2, "anti-aliased activation kernel variant (2: swizzled LDS tiles)"},
     {"conv_bm", 0, 0, 128, "force the co-tile height of conv_mfma_kernel (0: pick by channel count)"},
     {"h3_kernel", 1, 0, 1, "f16x3 vocoder conv: 1 window kernel, 0 two-stage kernel"},
-    {"x3_stages", 2, 2, 3, "fp32x3 GEMM (6 products): A stages of the LDS ring -- 3 requests the A tile two K tiles ahead (bitwise equal)"},
+    {"decode_ln_nt", 4, 0, 4, "LayerNorm-fused decode GEMM at 5-16 rows: n-tiles per block of the wide kernel (2 / 4: weights on waves 0-3, LayerNorm on waves 4-7; 0: the one-tile kernel on 8 waves; bitwise equal)"},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::atomic<unsigned> g_epoch{1};

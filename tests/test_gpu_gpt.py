@@ -91,11 +91,15 @@ def test_layernorm_fused_decode_gemm_is_bitwise_the_two_launches(M, K, N, pendin
         partial = (torch.randn(4, M, K, generator=g) * 0.5).to(DEV)
         bias_prev = (0.1 * torch.randn(K, generator=g)).to(DEV)
         xr = (x + ((partial[0] + partial[1]) + (partial[2] + partial[3]))) + bias_prev          # ln_row's order of additions (exact IEEE adds)
+    from indextts_amd import _lib
     ref = gpt.gemm(gpt.layernorm(xr, g1, b1).bfloat16(), wp, bias, N, 1)
-    out, x_out = gpt.gemm_ln(x, g1, b1, wp, bias, N, partial=partial, bias_prev=bias_prev)
-    assert torch.equal(out, ref), float((out - ref).abs().max())
-    if pending:
-        assert torch.equal(x_out, xr)
+    # 5-16 rows: the wide kernel with 4 / 2 n-tiles per block (weights on waves 0-3, LayerNorm on waves 4-7) and the one-tile kernel on 8 waves
+    for nt in ((4, 2, 0) if M > 4 else (4,)):
+        with _lib.option_scope(decode_ln_nt=nt):
+            out, x_out = gpt.gemm_ln(x, g1, b1, wp, bias, N, partial=partial, bias_prev=bias_prev)
+        assert torch.equal(out, ref), (nt, float((out - ref).abs().max()))
+        if pending:
+            assert torch.equal(x_out, xr), nt
     assert float(out.abs().mean()) > 1e-2
 
 
@@ -108,12 +112,12 @@ def test_fused_layernorm_decode_steps_equal_unfused(tmp_path):
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuse_ln_probe.py")
     for big in ("1", "0"):
         outs = []
-        for v in ("0", "1", "2"):
+        for v in ("0", "1", "2", "2,decode_ln_nt=2", "2,decode_ln_nt=0"):       # (2 alone: the wide kernel with 4 n-tiles per block at 5-16 rows)
             env = dict(os.environ, PROBE_OPTS=f"decode_fuse_ln={v}", PROBE_BIG=big)
             r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
-        assert outs[0] == outs[1] == outs[2], outs
+        assert len(set(outs)) == 1, outs
 
 
 def test_topk_bisection_equals_radix_select():

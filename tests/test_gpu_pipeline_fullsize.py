@@ -171,3 +171,101 @@ def test_config4_longform_two_segments_streamed_vocoder_vs_oracle_chain():
         print(f"configs[4] segment {b} of 17 ({target} frames): mel max|d| {em:.3e}; streamed-vocoder waveform rms error vs the oracle chain {ew:.3e} "
               f"(signal rms {sig:.3f}); streamed vs one-shot max|d| {float((wav - one).abs().max()):.2e}")
         assert sig > 0.02 and ew <= WAVE_RMS_TOL and em <= 1e-3
+
+
+def test_config3_v2_batch16_latent_pass_waveform_vs_oracle_chain():
+    """BASELINE configs[3] at its stated size: the IndexTTS-2 pipeline class on a batch of 16 segments (two text lengths -> two groups of
+    the teacher-forced latent pass), GPT 24 x 1280 x 20 heads in f32 with the 34 conditioning tokens of model_v2.py:767-773, 350 codes per
+    segment, latent -> gpt_layer (1280 -> 256 -> 128 -> 1024) + vq2emb(codes) -> length regulator (1.72 frames per code) -> 25 CFG Euler
+    steps (fp32x3) -> BigVGAN 1536 channels, through `IndexTTS2._synthesize` (infer_v2.py:558-676 batched).  Checked for two rows of the
+    batch: the latents against `oracle.gpt_oracle.forward_latent` of that row ALONE, and the row's waveform against the CPU oracle chain
+    from the speech codes on (forward_latent -> gpt_layer -> + vq2emb -> regulator -> [prompt | cond] -> CFM -> BigVGAN)."""
+    import torch.nn.functional as F
+    from indextts_amd import gpt, s2mel, synth
+    from indextts_amd.infer_v2 import IndexTTS2 as IndexTTS2V2
+    _threads()
+    w = _weights()
+    _base_engines()
+    gcfg, cc, rc, sc = w["gcfg"], w["cc"], w["rc"], w["sc"]
+    D = gcfg.model_dim
+    gen = torch.Generator().manual_seed(311)
+    sd = dict(w["gsd"])
+    sd["mel_head.bias"] = sd["mel_head.bias"].clone()
+    sd["mel_head.bias"][gcfg.start_mel_token] -= 1e4                  # (the start id is a legal GPT id but not a codebook row)
+    sd["speed_emb.weight"] = torch.randn(2, D, generator=gen) * 0.3
+    lat = torch.randn(1, 32, D, generator=gen) * 0.3
+    emo = torch.randn(1, D, generator=gen) * 0.1
+    gm = gpt.UnifiedVoice(layers=gcfg.layers, model_dim=D, heads=gcfg.heads, max_text_tokens=gcfg.max_text_tokens, max_mel_tokens=gcfg.max_mel_tokens,
+                          number_text_tokens=gcfg.number_text_tokens, precision="fp32", device=DEV, conditioning_fn=lambda x, lengths=None: lat.to(DEV))
+    gm.load_state_dict(sd)
+    gm.post_init_gpt2_config(kv_cache=True)
+    args = dict(DiT=dict(hidden_dim=sc.hidden_dim, num_heads=sc.num_heads, depth=sc.depth, in_channels=sc.in_channels, content_dim=sc.content_dim),
+                wavenet=dict(hidden_dim=sc.wavenet_hidden, num_layers=sc.wavenet_layers, kernel_size=sc.wavenet_kernel,
+                             dilation_rate=sc.wavenet_dilation_rate),
+                style_encoder=dict(dim=sc.style_dim),
+                length_regulator=dict(channels=rc.channels, sampling_ratios=(1, 1, 1, 1), is_discrete=False, in_channels=rc.in_channels,
+                                      content_codebook_size=rc.codebook_size))
+    gl = synth.gpt_layer_weights((D, 256, 128, cc.hidden_size), seed=77)
+    mm = s2mel.MyModel(args, use_gpt_latent=True, precision="fp32x3", device=DEV)
+    mm.models["gpt_layer"] = s2mel.GptLayer((D, 256, 128, cc.hidden_size), device=DEV)
+    mm.load_state_dict({"cfm": w["ssd"], "length_regulator": w["rsd"], "gpt_layer": gl})
+    tts = IndexTTS2V2(cfg={"gpt": {"stop_mel_token": 8193}, "version": 2.0}, device=DEV, frontend=NoFrontend(), gpt=gm, bigvgan=_CACHE["voc"],
+                      semantic_codec=_CACHE["codec"], s2mel=mm)
+    B, n_gen, Tp = 16, 350, 150
+    bundle = dict(_bundle(Tp, 312), emo_cond_emb=torch.zeros(1, 4, 1024, device=DEV))
+    segs = []
+    for b in range(B):
+        n = 40 if b % 2 == 0 else 56
+        segs.append(torch.cat([torch.randint(2, 12000, (n,), generator=gen), torch.tensor([1])]).to(torch.int32))     # the Frontend protocol's stop id
+    target = int(n_gen * 1.72)
+    noise = torch.randn(B, 80, Tp + target, generator=gen)
+    seen = {}
+    inner = tts.codes_latent_to_mel
+
+    def spy(codes, code_lens, latent, bundle_, *a, **k):
+        seen.update(codes=codes.cpu(), code_lens=[int(x) for x in code_lens], latent=latent.float().cpu())
+        return inner(codes, code_lens, latent, bundle_, noise=noise.to(DEV))
+    tts.codes_latent_to_mel = spy
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                                # "generation stopped due to exceeding max_mel_tokens": the fixed-length decode
+        wavs = tts._synthesize(segs, [0] * B, bundle, emo.to(DEV), 1.0, dict(num_beams=1, top_k=1, max_mel_tokens=n_gen), 120)
+    assert len(wavs) == B and seen["code_lens"] == [n_gen] * B and int(seen["codes"].max()) < cc.codebook_size
+    se = sd["speed_emb.weight"]
+    conds = torch.cat((lat + emo.unsqueeze(1), se[1].reshape(1, 1, D), se[0].reshape(1, 1, D)), 1)        # model_v2.py:767-773
+    P = "quantizer.quantizers.0."
+    csd = w["csd"]
+    v_, g_ = csd[P + "out_project.weight_v"], csd[P + "out_project.weight_g"]
+    w_out = v_ * (g_ / v_.reshape(v_.shape[0], -1).norm(dim=1).reshape(g_.shape))
+
+    def chain(b, latent_row):
+        """gpt_layer(latent) + vq2emb(codes) -> regulator -> [prompt | cond] -> 25-step CFM -> BigVGAN, row b alone (infer_v2.py:653-676)"""
+        x = latent_row
+        for i in range(3):
+            x = F.linear(x, gl[f"{i}.weight"], gl[f"{i}.bias"])
+        emb = csd[P + "codebook.weight"][seen["codes"][b:b + 1].long()].transpose(1, 2)
+        S = F.conv1d(emb, w_out, csd[P + "out_project.bias"]).transpose(1, 2) + x
+        cond, _ = CO.length_regulator(w["rsd"], rc, S, torch.tensor([target]))
+        cat = torch.cat([bundle["prompt_condition"].cpu(), cond], 1)
+        T = Tp + target
+        mel = SO.cfm_solve_euler(w["ssd"], sc, noise[b:b + 1, :, :T], torch.tensor([T]), bundle["ref_mel"].cpu(), cat, bundle["style"].cpu(), 25, 0.7)
+        return BO.bigvgan_forward(w["bsd"], mel[:, :, Tp:].contiguous(), w["h"])
+
+    for b in (0, 9):
+        ids = segs[b][:-1].long()[None]
+        with torch.no_grad():
+            lat_ref = G.forward_latent(sd, gcfg, conds, ids, torch.tensor([ids.shape[1]]), seen["codes"][b:b + 1], torch.tensor([n_gen]))
+            e_lat = float((seen["latent"][b:b + 1, :n_gen] - lat_ref).abs().max())
+            wav = (wavs[b].float() / 32767.0)[..., : target * 256]
+            ref_e = chain(b, seen["latent"][b:b + 1, :n_gen])
+            ew_e, sig = rms(wav - ref_e), rms(ref_e)
+            line = (f"configs[3] (IndexTTS-2, B = 16) row {b} ({ids.shape[1]} text tokens, {n_gen} codes, {target} frames): latent max|d| vs the oracle alone "
+                    f"{e_lat:.3e} (rms {rms(lat_ref):.3f}); waveform rms error vs the oracle chain from the engine's latents {ew_e:.3e}")
+            if b == 0:
+                ref_o = chain(b, lat_ref)
+                ew_o = rms(wav - ref_o)
+                line += f", from the oracle's own latents {ew_o:.3e}"
+            print(line + f" (signal rms {sig:.3f})")
+        assert e_lat <= 2e-3 and sig > 0.02 and ew_e <= WAVE_RMS_TOL
+        if b == 0:
+            assert ew_o <= 5e-4
