@@ -34,7 +34,7 @@ int itts_device_count(void);
  * in); options marked "at create" are sampled when a model handle is created.  The reference has no counterpart (its kernels are
  * picked by PyTorch's dispatcher); the table exists for A/B tests and measurement tools.
  *   name              default  range    meaning
- *   decode_fuse_ln       1     0..2    GPT decode: LayerNorm inside the consuming GEMM, 1: at 1-4 rows, 2: up to 16 rows, 0: ln_kernel launches
+ *   decode_fuse_ln       1     0..2    GPT decode: LayerNorm inside the consuming GEMM, 1: at 1-8 rows, 2: up to 16 rows, 0: ln_kernel launches
  *   decode_gemm          1     0..1    bf16 decode GEMMs on the LDS-DMA slab kernel (0: register-path kernel)
  *   decode_rot           1     0..1    per-block rotation of the slab DMA issue order
  *   decode_wnt           0     0..1    non-temporal policy on the decode weight stream
@@ -55,7 +55,7 @@ int itts_device_count(void);
  *   aa_act               2     0..2    anti-aliased activation kernel variant
  *   conv_bm              0     0..128  force the co-tile height of the vocoder conv kernel
  *   h3_kernel            1     0..1    f16x3 vocoder conv: window kernel / two-stage kernel
- *   decode_ln_nt         4     0..4    LayerNorm-fused decode GEMM at 5-16 rows: n-tiles per block of the wide kernel (2 / 4; 0: one-tile kernel)
+ *   decode_ln_nt         2     2..4    LayerNorm-fused decode GEMM at 5-16 rows: n-tiles per block (2 or 4)
  * itts_option_count / _name / _doc / _default enumerate the table (index 0 .. count-1).
  * ---------------------------------------------------------------------------------------------------------- */
 int itts_set_option(const char* name, int value);      /* ITTS_ERR_ARG: unknown name or value out of range */

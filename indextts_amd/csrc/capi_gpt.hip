@@ -428,15 +428,14 @@ static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bo
     const int D = c.model_dim, prec = c.precision, rows = nseq * S;
     int rc;
     const float* pend_bias = nullptr;   // bias of a GEMM whose partials are pending reduction
-    // Decode steps of 1-4 rows (one utterance, its beams): the two LayerNorm launches of a layer are fused into the GEMMs that consume them
-    // (gemm_decode_ln_kernel: same arithmetic, bitwise the same results; option decode_fuse_ln = 0 is the A/B switch).  The fused kernel's block 0
-    // writes the updated residual to the OTHER buffer (its sibling blocks still read the current one): cur / alt alternate.
-    // Measured (profiles/r04a/decode_bench.log, ms per token at 560 tokens, fused / separate): 1 row 0.776 / 0.915, 4 rows 0.874 / 0.957 -- but 8 rows
-    // 1.056 / 0.982 and 16 rows 1.375 / 1.141: every block repeats the LayerNorm of every row (25 KB of L2 reads per row with the split-K partials,
-    // and the 200 registers of ln_row's one-phase loads leave one 8-wave block per CU, so the 320-block fc launch runs in two rounds: 14.6 us against
-    // 5 + 7).  So the fusion is the default up to 4 rows only; decode_fuse_ln = 2 keeps the 5-16-row form reachable (bitwise equal, tested).
+    // Decode steps of 1-8 rows (one utterance, its beams, the 8-utterance shard of an 8-GPU run): the two LayerNorm launches of a layer are fused into
+    // the GEMMs that consume them (gemm_decode_ln_kernel at 1-4 rows, gemm_decode_lnw_kernel at 5-8: same arithmetic, bitwise the same results; option
+    // decode_fuse_ln = 0 is the A/B switch).  The fused kernel's block 0 writes the updated residual to the OTHER buffer (its sibling blocks still read
+    // the current one): cur / alt alternate.  Measured (profiles/r04a, r04h; ms per token at 560 tokens, fused / separate): 1 row 0.776 / 0.915, 4 rows
+    // 0.874 / 0.957, 5 rows 0.935 / 0.963, 8 rows 0.977 / 0.986 -- and 12 rows 1.110 / 1.016, 16 rows 1.294 / 1.099: every block repeats the LayerNorm
+    // of every row, which outgrows the launch it removes.  decode_fuse_ln = 2 keeps the 9-16-row form reachable (bitwise equal, tested).
     const int fuse_opt = itts_opt(OPT_DECODE_FUSE_LN);
-    const bool fuse_ln = fuse_opt != 0 && rows <= (fuse_opt >= 2 ? 16 : 4) && !prefill && S == 1 && prec == PREC_BF16 &&
+    const bool fuse_ln = fuse_opt != 0 && rows <= (fuse_opt >= 2 ? 16 : 8) && !prefill && S == 1 && prec == PREC_BF16 &&
                          gemm_decode_ln_ok(rows, D, EPI_QKV) && w.x2 != nullptr;
     float *cur = w.x, *alt = w.x2;
     for (int l = 0; l < c.layers; ++l) {

@@ -2278,9 +2278,10 @@ static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
 // ================================================================================================================
 // Decode GEMM with the LayerNorm in front of it fused into the operand staging, for at most 16 rows (one utterance, its beams, the
 // 8-utterance shard a rank of the 8-GPU run decodes): at that size a token step is a chain of 172 launches of 4-6 us each and the two
-// LayerNorm launches of a layer are a quarter of it.  (Round 3: 1-4 rows on 4 waves; round 4: up to 16 rows on 8 waves, one or two rows per
-// wave -- at 16 rows every block reads 16 x 25 KB of L2-resident operands, still cheaper than a 5 us launch; above that the redundant
-// LayerNorm work outgrows the launch it removes.)
+// LayerNorm launches of a layer are a quarter of it.  Two kernels: this one for 1-4 rows (4 waves, one row and one quarter of the K split per
+// wave), gemm_decode_lnw_kernel below for 5-16 rows.  Measured (profiles/r04a, r04h; ms per token at 560 tokens, fused / separate launches):
+// 1 row 0.776 / 0.915, 4 rows 0.874 / 0.957, 5 rows 0.935 / 0.963, 8 rows 0.977 / 0.986, 12 rows 1.110 / 1.016, 16 rows 1.294 / 1.099 -- every
+// block repeats the LayerNorm of every row (25 KB of L2 reads per row with the split-K partials), which outgrows the launch it removes above 8 rows.
 //   Same decomposition as gemm_decode64_kernel<1, 1> (one 16-column n-tile per block, K <= 1280 split over the 4 waves by k-block, LDS
 //   reduce, decode_epilogue), but the activation slab is not DMA'd from a LayerNorm kernel's output: wave w < M computes row w itself with
 //   ln_row (ln_kernel's arithmetic: split-K reduce of the previous GEMM's 4 partials + its bias + residual, then the normalisation) and
@@ -2290,8 +2291,8 @@ static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
 //   are still reading ln_x), and the host alternates the two.  Rows M..15 of the MFMA tile hold whatever the LDS held: MFMA rows are
 //   independent and their outputs are never stored.  Same bf16 operands, same MFMAs in the same order -> bitwise the unfused path.
 // ================================================================================================================
-template <int NV, int EPI, int FLAGS, int NWV>       // NWV waves per block (4 for <= 4 rows, else 8): wave w normalises rows w, w + NWV;
-                                                    // the MFMA phase and its 4-way K split stay on waves 0-3 at every size
+template <int NV, int EPI, int FLAGS, int NWV>       // NWV = 4 waves per block: wave w normalises row w and runs its quarter of the K split
+                                                    // (1-4 rows; 5-16 rows: gemm_decode_lnw_kernel below)
 __global__ __launch_bounds__(NWV * 64) void gemm_decode_ln_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];     // [kp][2 row groups][1 KiB]; reused for the reduction
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -2481,19 +2482,19 @@ static int launch_gemm_decode_ln_e(const GemmArgs& a, hipStream_t st) {
         if (part) hipLaunchKernelGGL((gemm_decode_ln_kernel<NV, EPI, LN_PARTIAL | LN_BIAS, NWV_>), dim3(ntiles), dim3(NWV_ * 64), lds, st, a); \
         else hipLaunchKernelGGL((gemm_decode_ln_kernel<NV, EPI, 0, NWV_>), dim3(ntiles), dim3(NWV_ * 64), lds, st, a);                     \
     } while (0)
-    // 5-16 rows: option decode_ln_nt = n-tiles per block of the wide kernel (2 / 4; 0: the one-tile kernel on 8 waves, the A/B record)
-    const int wide_nt = a.M > 4 ? itts_opt(OPT_DECODE_LN_NT) : 0;
+    // 5-16 rows: the wide kernel; option decode_ln_nt = its n-tiles per block (2, the default, or 4)
+    const int wide_nt = itts_opt(OPT_DECODE_LN_NT);
 #define LNW_GEMM_LAUNCH(NT_)                                                                                                             \
     do {                                                                                                                                 \
         const dim3 grid(ceil_div(ntiles, NT_));                                                                                          \
         if (part) hipLaunchKernelGGL((gemm_decode_lnw_kernel<NV, EPI, LN_PARTIAL | LN_BIAS, NT_>), grid, dim3(512), lds, st, a);          \
         else hipLaunchKernelGGL((gemm_decode_lnw_kernel<NV, EPI, 0, NT_>), grid, dim3(512), lds, st, a);                                  \
     } while (0)
-    if (lds < 16384) lds = 16384;                                   // wide kernel's reduction scratch: 4 waves x 4 tiles x 1 KiB
-    if (a.M <= 4) LN_GEMM_LAUNCH(4);                               // (16 waves would cap the kernel at 128 registers: ln_row's one-phase loads need 200)
-    else if (wide_nt == 2) LNW_GEMM_LAUNCH(2);
-    else if (wide_nt == 4) LNW_GEMM_LAUNCH(4);
-    else LN_GEMM_LAUNCH(8);
+    if (a.M <= 4) LN_GEMM_LAUNCH(4);
+    else {
+        if (lds < 16384) lds = 16384;                               // reduction scratch: 4 waves x 4 tiles x 1 KiB
+        if (wide_nt == 4) LNW_GEMM_LAUNCH(4); else LNW_GEMM_LAUNCH(2);
+    }
 #undef LNW_GEMM_LAUNCH
 #undef LN_GEMM_LAUNCH
     HIP_TRY(hipGetLastError());

@@ -16,7 +16,7 @@ struct OptDef {
 };
 // order == the OPT_* enum of common.h
 const OptDef kDefs[OPT_COUNT] = {
-    {"decode_fuse_ln", 1, 0, 2, "GPT decode: LayerNorm (+ split-K reduce, bias, residual) inside the consuming GEMM -- 1: steps of 1-4 rows (measured faster), 2: up to 16 rows (measured slower, kept for the A/B record), 0: separate ln_kernel launches; bitwise equal"},
+    {"decode_fuse_ln", 1, 0, 2, "GPT decode: LayerNorm (+ split-K reduce, bias, residual) inside the consuming GEMM -- 1: steps of 1-8 rows (measured faster), 2: up to 16 rows (measured slower above 8, kept for the A/B record), 0: separate ln_kernel launches; bitwise equal"},
     {"decode_gemm", 1, 0, 1, "bf16 decode GEMMs on the LDS-DMA slab kernel (0: register-path gemm_kernel; bitwise equal)"},
     {"decode_rot", 1, 0, 1, "per-block rotation of the slab DMA issue order in the decode GEMM (same bytes, same LDS image)"},
     {"decode_wnt", 0, 0, 1, "non-temporal policy on the decode GEMM's weight stream"},
@@ -37,7 +37,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"aa_act", 2, 0, 2, "anti-aliased activation kernel variant (2: swizzled LDS tiles)"},
     {"conv_bm", 0, 0, 128, "force the co-tile height of conv_mfma_kernel (0: pick by channel count)"},
     {"h3_kernel", 1, 0, 1, "f16x3 vocoder conv: 1 window kernel, 0 two-stage kernel"},
-    {"decode_ln_nt", 4, 0, 4, "LayerNorm-fused decode GEMM at 5-16 rows: n-tiles per block of the wide kernel (2 / 4: weights on waves 0-3, LayerNorm on waves 4-7; 0: the one-tile kernel on 8 waves; bitwise equal)"},
+    {"decode_ln_nt", 2, 2, 4, "LayerNorm-fused decode GEMM at 5-16 rows (weights on waves 0-3, LayerNorm on waves 4-7): n-tiles per block, 2 or 4 (bitwise equal)"},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::atomic<unsigned> g_epoch{1};

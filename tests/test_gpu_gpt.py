@@ -75,7 +75,7 @@ def test_layernorm_vs_torch():
                                    (5, 1280, 3840), (8, 1280, 5120), (11, 1280, 3840), (16, 1280, 5120), (13, 256, 96), (16, 512, 1536)])
 @pytest.mark.parametrize("pending", [False, True])
 def test_layernorm_fused_decode_gemm_is_bitwise_the_two_launches(M, K, N, pending):
-    """gemm_decode_ln_kernel (decode steps of 1-16 rows -- 4 waves up to 4 rows, 8 waves above, two rows per wave from 9: LayerNorm computed inside the consuming GEMM's operand staging, with the split-K reduce of
+    """gemm_decode_ln_kernel / gemm_decode_lnw_kernel (decode steps of 1-16 rows -- 4 waves up to 4 rows, the wide kernel above: LayerNorm computed inside the consuming GEMM's operand staging, with the split-K reduce of
     the previous GEMM's partials + bias + residual) against the two launches it replaces -- itts_layernorm_forward -> bf16 -> itts_gemm_forward
     (the 16-row slab kernel): output BITWISE equal, and so is the updated residual row it writes back."""
     from indextts_amd import gpt
@@ -93,8 +93,8 @@ def test_layernorm_fused_decode_gemm_is_bitwise_the_two_launches(M, K, N, pendin
         xr = (x + ((partial[0] + partial[1]) + (partial[2] + partial[3]))) + bias_prev          # ln_row's order of additions (exact IEEE adds)
     from indextts_amd import _lib
     ref = gpt.gemm(gpt.layernorm(xr, g1, b1).bfloat16(), wp, bias, N, 1)
-    # 5-16 rows: the wide kernel with 4 / 2 n-tiles per block (weights on waves 0-3, LayerNorm on waves 4-7) and the one-tile kernel on 8 waves
-    for nt in ((4, 2, 0) if M > 4 else (4,)):
+    # 5-16 rows: the wide kernel with 2 / 4 n-tiles per block (weights on waves 0-3, LayerNorm on waves 4-7)
+    for nt in ((2, 4) if M > 4 else (2,)):
         with _lib.option_scope(decode_ln_nt=nt):
             out, x_out = gpt.gemm_ln(x, g1, b1, wp, bias, N, partial=partial, bias_prev=bias_prev)
         assert torch.equal(out, ref), (nt, float((out - ref).abs().max()))
@@ -105,14 +105,14 @@ def test_layernorm_fused_decode_gemm_is_bitwise_the_two_launches(M, K, N, pendin
 
 def test_fused_layernorm_decode_steps_equal_unfused(tmp_path):
     """Whole decode loops of 1 .. 17 rows (greedy, sampled, 3-beam beam-sample of one utterance) with the LayerNorm-fused GEMMs (default 1: steps of
-    1-4 rows on 4 waves; 2: up to 16 rows on 8 waves, one or two rows per wave) and without (option decode_fuse_ln = 0): identical ids -- at the
+    1-8 rows; 2: up to 16 rows) and without (option decode_fuse_ln = 0): identical ids -- at the
     production width (K = 1280: NV = 5) and at 256."""
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuse_ln_probe.py")
     for big in ("1", "0"):
         outs = []
-        for v in ("0", "1", "2", "2,decode_ln_nt=2", "2,decode_ln_nt=0"):       # (2 alone: the wide kernel with 4 n-tiles per block at 5-16 rows)
+        for v in ("0", "1", "2", "2,decode_ln_nt=4"):       # (1: fused up to 8 rows; 2: up to 16, wide kernel with 2 / 4 n-tiles per block)
             env = dict(os.environ, PROBE_OPTS=f"decode_fuse_ln={v}", PROBE_BIG=big)
             r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
