@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 8
+#define ITTS_ABI_VERSION 9
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -372,6 +372,14 @@ int itts_s2mel_solve(itts_s2mel* h, float* x_state, const float* const_in, const
  * reported), [1] attention, [2] the wall span of every estimator call (element-wise time = [2] - [0] - [1]). */
 int itts_s2mel_set_profiling(itts_s2mel* h, int enable);
 int itts_s2mel_profile_read(itts_s2mel* h, double* ms, double* launches, double* flops);
+
+/* Diagnostics: a 64-bit order-independent checksum of every stage's output buffer of the following estimator / solve calls, in launch order, into
+ * dev_u64 (capacity zeroed 64-bit words on the handle's device; NULL clears).  Each call restarts at entry 0; itts_s2mel_trace_count = entries
+ * written by the last call, itts_s2mel_trace_label = what entry i is.  Two runs on the same inputs compared entry by entry name the first stage
+ * that is not bit-stable (tools/s2mel_trace.py).  The reference has no counterpart. */
+int itts_s2mel_set_trace(itts_s2mel* h, void* dev_u64, int capacity);
+int itts_s2mel_trace_count(const itts_s2mel* h);
+const char* itts_s2mel_trace_label(const itts_s2mel* h, int index);
 
 /* Dead-row elimination for the following itts_s2mel_solve calls.  The Euler step never reads the estimator's output at prompt frames
  * (flow_matching.py:107 zeroes them) and everything after the DiT's last attention is row-wise except the WaveNet's few frames of

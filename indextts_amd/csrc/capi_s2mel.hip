@@ -65,7 +65,20 @@ struct itts_s2mel {
     const int* tail_src = nullptr;         // [tail.n_tok] full-layout row of each tail row
     const int* tail_base = nullptr;        // [n_seq] tail row of frame t of sequence s = tail_base[s] + t
     bool tail_set = false;
+    // Diagnostics (itts_s2mel_set_trace): a checksum of every stage's output buffer of the following estimator / solve calls, in launch order, into a
+    // caller-provided device array -- two runs on the same inputs are compared entry by entry to find the first stage that is not bit-stable.
+    unsigned long long* trace = nullptr;
+    int trace_cap = 0, trace_n = 0;
+    std::vector<const char*> trace_labels;
 };
+
+// record the checksum of a stage output (no-op unless a trace buffer is set)
+static int s2_trace(itts_s2mel* h, hipStream_t st, const char* label, const void* p, size_t bytes) {
+    if (!h->trace || h->trace_n >= h->trace_cap) return ITTS_OK;
+    if ((int)h->trace_labels.size() <= h->trace_n) h->trace_labels.push_back(label);
+    else h->trace_labels[h->trace_n] = label;
+    return launch_trace_hash(p, bytes, h->trace + h->trace_n++, st);
+}
 
 enum { S2_GEMM = 0, S2_ATTN = 1, S2_OTHER = 2, S2_CLASSES = 3 };
 
@@ -139,6 +152,20 @@ extern "C" int itts_s2mel_set_profiling(itts_s2mel* h, int enable) {
     h->profiling = enable != 0;
     h->recs.clear();
     return ITTS_OK;
+}
+
+// Diagnostics: dev_u64 = capacity zeroed 64-bit words on the handle's device (nullptr clears).  Every following estimator / solve call restarts
+// at entry 0 and adds one checksum per stage output (itts_s2mel_trace_count entries, itts_s2mel_trace_label names them).
+extern "C" int itts_s2mel_set_trace(itts_s2mel* h, void* dev_u64, int capacity) {
+    if (!h || capacity < 0) { itts_set_error("s2mel_set_trace: bad args"); return ITTS_ERR_ARG; }
+    h->trace = (unsigned long long*)dev_u64;
+    h->trace_cap = dev_u64 ? capacity : 0;
+    h->trace_n = 0;
+    return ITTS_OK;
+}
+extern "C" int itts_s2mel_trace_count(const itts_s2mel* h) { return h ? h->trace_n : 0; }
+extern "C" const char* itts_s2mel_trace_label(const itts_s2mel* h, int i) {
+    return (h && i >= 0 && i < (int)h->trace_labels.size()) ? h->trace_labels[i] : nullptr;
 }
 
 // Totals of the last solve / estimator call per class (0 GEMMs on the MFMA tile kernels, 1 attention, 2 everything else):
@@ -402,10 +429,15 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     const size_t kv_plane = (size_t)tab.n_seq * nh * t_pad * 64;
     int rc;
     float *X = w.X, *X2 = w.X2;
+    const size_t esz = prec == PREC_BF16 ? 2 : 4;                  // activation element size
+    const size_t kvb = kv_plane * (prec == PREC_F32X3 ? (x3_attn ? 6 : 4) : esz);
+#define S2_TRACE(label, ptr, bytes) do { if (h->trace && (rc = s2_trace(h, st, label, ptr, bytes))) return rc; } while (0)
     // x_in = cond_x_merge_linear([x^T | prompt | cond | style]): the x columns here, the rest (+ bias) is const_in
     if ((rc = launch_cast_pad(x_src, w.XA, N, src_rows, C, Kx, prec, st))) return rc;
     HIP_TRY(hipMemcpyAsync(X, const_in, (size_t)N * H * 4, hipMemcpyDeviceToDevice, st));
+    S2_TRACE("cast_pad(x) -> XA", w.XA, (size_t)N * Kx * esz);
     if ((rc = s2_gemm(h, w.XA, Kx, h->w_x, nullptr, X, H, N, H, Kx, EPI_RESIDUAL, st))) return rc;
+    S2_TRACE("x_in GEMM -> X", X, (size_t)N * H * 4);
     int n_skip = 0;
     for (int i = 0; i < c.depth; ++i) {
         const S2Layer& L = h->layers[i];
@@ -414,9 +446,11 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
             --n_skip;
             if ((rc = s2_gemm(h, w.HB, H, L.w_skip_a, L.b_skip, X2, H, N, H, H, EPI_STORE_F32, st))) return rc;
             if ((rc = s2_gemm(h, w.SK + w.sk_stride * n_skip, H, L.w_skip_b, nullptr, X2, H, N, H, H, EPI_RESIDUAL, st))) return rc;
+            S2_TRACE("skip_in GEMMs -> X", X2, (size_t)N * H * 4);
             float* tmp = X; X = X2; X2 = tmp;
         }
         if ((rc = launch_ada_rmsnorm(X, L.g_attn, mods + (size_t)i * 4 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
+        S2_TRACE("ada_rmsnorm(attn) -> HB", w.HB, (size_t)N * H * esz);
         if (fused) {                                               // wqkv + RoPE + Q / K / V^T scatter in one epilogue
             GemmArgs g{};
             g.A = w.HB; g.lda = H; g.Wp = L.w_qkv; g.M = N; g.N = 3 * H; g.K = H; g.nsplit = 1; g.epi = EPI_QKV_ROPE;
@@ -428,12 +462,18 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
             if ((rc = s2_gemm(h, w.HB, H, L.w_qkv, nullptr, w.BIG, 3 * H, N, 3 * H, H, EPI_STORE_F32, st))) return rc;
             if ((rc = launch_rope_split(w.BIG, rope, w.QA, w.KC, w.VC, tab, nh, t_pad, prec, st))) return rc;
         }
+        S2_TRACE("wqkv -> Q", w.QA, (size_t)N * H * esz);
+        S2_TRACE("wqkv -> K", w.KC, kvb);
+        S2_TRACE("wqkv -> V^T", w.VC, kvb);
         { S2Prof ps(h, st, S2_ATTN, attn_flops);
           if (x3_attn) rc = launch_s2mel_attention_x3(w.QA, w.KC, w.VC, w.AO, tab, nh, t_pad, st);
           else rc = launch_s2mel_attention(w.QA, w.KC, w.VC, w.AO, tab, nh, t_pad, prec, st);
           if (rc) return rc; }
+        S2_TRACE("attention -> AO", w.AO, (size_t)N * H * esz);
         if ((rc = s2_gemm(h, w.AO, H, L.w_o, nullptr, X, H, N, H, H, EPI_RESIDUAL, st))) return rc;
+        S2_TRACE("wo GEMM -> X", X, (size_t)N * H * 4);
         if ((rc = launch_ada_rmsnorm(X, L.g_ffn, mods + (size_t)i * 4 * H + 2 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
+        S2_TRACE("ada_rmsnorm(ffn) -> HB", w.HB, (size_t)N * H * esz);
         if (fused) {                                               // [w1 ; w3] GEMM with the SwiGLU combine in the epilogue
             GemmArgs g{};
             g.A = w.HB; g.lda = H; g.Wp = L.w_13; g.M = N; g.N = 2 * I; g.K = H; g.nsplit = 1; g.epi = EPI_SWIGLU; g.out_act = w.FC; g.D = I;
@@ -447,7 +487,9 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
         void* shadow = nullptr;
         if (fused && i < c.depth / 2) shadow = w.SK + w.sk_stride * n_skip;
         else if (fused && i + 1 < c.depth && i + 1 > c.depth / 2) shadow = w.HB;
+        S2_TRACE("w13 + SwiGLU -> FC", w.FC, (size_t)N * I * esz);
         if ((rc = s2_gemm(h, w.FC, I, L.w_2, nullptr, X, H, N, H, I, EPI_RESIDUAL, st, shadow))) return rc;
+        S2_TRACE("w2 GEMM -> X", X, (size_t)N * H * 4);
         if (i < c.depth / 2) {
             if (!fused && (rc = launch_cast_pad(X, w.SK + w.sk_stride * n_skip, N, N, H, H, prec, st))) return rc;
             ++n_skip;
@@ -467,10 +509,13 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     const int NT = tt.n_tok;
     // x_res = skip_linear([transformer.norm(x) | x^T])
     if ((rc = launch_ada_rmsnorm(X, h->g_norm, m_norm, w.HB, NT, H, c.norm_eps, prec, st, tail ? tail_src : nullptr))) return rc;
+    S2_TRACE("final ada_rmsnorm -> HB", w.HB, (size_t)NT * H * esz);
     if ((rc = s2_gemm(h, w.HB, H, h->w_sl_a, h->b_sl, X2, H, NT, H, H, EPI_STORE_F32, st))) return rc;
     if ((rc = s2_gemm(h, XAt, Kx, h->w_sl_b, nullptr, X2, H, NT, H, Kx, EPI_RESIDUAL, st, fused ? w.HB : nullptr))) return rc;
     if (!fused && (rc = launch_cast_pad(X2, w.HB, NT, NT, H, H, prec, st))) return rc;
+    S2_TRACE("skip_linear -> X2", X2, (size_t)NT * H * 4);
     if ((rc = s2_gemm(h, w.HB, H, h->w_c1, h->b_c1, w.WX, W, NT, W, H, EPI_STORE_F32, st, fused ? w.WXA : nullptr))) return rc;
+    S2_TRACE("conv1 -> WX", w.WX, (size_t)NT * W * 4);
     if ((rc = s2_gemm(h, w.HB, H, h->w_rp, h->b_rp, w.RP, W, NT, W, H, EPI_STORE_F32, st))) return rc;
     // WaveNet (wavenet.py:143-166)
     int dil = 1;
@@ -492,7 +537,10 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
             r.A = w.FC; r.lda = W; r.Wp = Wn.w_rs; r.bias = Wn.b_rs; r.M = NT; r.N = ro; r.K = W; r.nsplit = 1; r.epi = EPI_WN_RS;
             r.out_f32 = w.WX; r.out2 = w.OUT; r.D = W; r.wn_first = i == 0; r.wn_last = last; r.out_act2 = last ? nullptr : w.WXA;
             r.tok_seq = tt.tok_seq; r.tok_t = tt.tok_t; r.seq_len = tt.seq_len;
+            S2_TRACE("wavenet in_layer + gate -> FC", w.FC, (size_t)NT * W * esz);
             if ((rc = s2_launch_gemm(h, r, st))) return rc;
+            S2_TRACE("wavenet res_skip -> WX", w.WX, (size_t)NT * W * 4);
+            S2_TRACE("wavenet res_skip -> OUT", w.OUT, (size_t)NT * W * 4);
         } else {
             if ((rc = s2_gemm(h, w.COL, c.wavenet_kernel * W, Wn.w_in, Wn.b_in, w.BIG, 2 * W, NT, 2 * W, c.wavenet_kernel * W, EPI_STORE_F32, st))) return rc;
             if ((rc = launch_wn_gate(w.BIG, m_gc + (size_t)i * 2 * W, w.FC, NT, W, prec, st))) return rc;
@@ -505,7 +553,11 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     if ((rc = launch_final_ln_mod(w.OUT, w.RP, m_fl, w.HB, tt, W, prec, st))) return rc;
     if ((rc = s2_gemm(h, w.HB, W, h->w_fl, h->b_fl, w.BIG, W, NT, W, W, EPI_STORE_F32, st, fused ? w.FC : nullptr))) return rc;
     if (!fused && (rc = launch_cast_pad(w.BIG, w.FC, NT, NT, W, W, prec, st))) return rc;
-    return s2_gemm(h, w.FC, W, h->w_c2, h->b_c2, d_out, C, NT, C, W, EPI_STORE_F32, st);
+    S2_TRACE("final_layer -> FC", w.FC, (size_t)NT * W * esz);
+    if ((rc = s2_gemm(h, w.FC, W, h->w_c2, h->b_c2, d_out, C, NT, C, W, EPI_STORE_F32, st))) return rc;
+    S2_TRACE("conv2 -> output", d_out, (size_t)NT * C * 4);
+    return ITTS_OK;
+#undef S2_TRACE
 }
 
 static int s2_check(const itts_s2mel* h, const void* a, const void* b, const char* who) {
@@ -548,6 +600,7 @@ extern "C" int itts_s2mel_estimator(itts_s2mel* h, const float* x, const float* 
     const SeqTab tab = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tok, t_max);
     h->recs.clear();
     h->prof_stream = st;
+    h->trace_n = 0;
     return s2_estimator(h, w, tab, t_pad, x, n_tok, const_in, mods, rope, d_out, st);
 }
 
@@ -578,6 +631,7 @@ extern "C" int itts_s2mel_solve(itts_s2mel* h, float* x_state, const float* cons
     const int mps = itts_s2mel_mods_per_step(h);
     h->recs.clear();
     h->prof_stream = st;
+    h->trace_n = 0;
     for (int step = 0; step < n_steps; ++step) {                   // flow_matching.py:84-113
         const bool use_tail = h->tail_set && h->tail.n_seq == n_seq && h->tail.n_tok > 0 && h->tail.n_tok <= n_tok && h->tail.n_tok % n_branch == 0;
         int rc = s2_estimator(h, w, tab, t_pad, x_state, n_tok / n_branch, const_in, mods + (size_t)step * mps, rope, w.D, st, 0.0,

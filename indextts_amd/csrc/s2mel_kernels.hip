@@ -303,11 +303,12 @@ __device__ __forceinline__ float fa_colmax(float x) {
                  : "+v"(a), "+v"(b));
     return a;
 }
-__device__ __forceinline__ float fa_max3(float a, float b, float c) {       // no NaN canonicalisation (scores are finite or -inf)
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// max of three as compiler-generated code (one v_max3_f32).  NOT inline asm: in the kernels' non-tail path this is the first reader of S^T
+// accumulators written one to three MFMAs earlier, and hipcc's hazard recognizer pads only instructions it generated itself ("XDL write VGPR ->
+// VALU read": s_nop 7 in front of its own consumer, nothing in front of an asm statement -- tools/microbench/mfma_asm_hazard.hip).  The asm form
+// read accumulators inside that window: a row maximum taken from stale registers still gives a valid softmax (the maximum is only a shift), but
+// one whose rounding depends on how the waves of a SIMD happened to interleave.
+__device__ __forceinline__ float fa_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 template <int QS>
 __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_attn_bf16_kernel(const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ Vt,
@@ -874,6 +875,25 @@ __global__ __launch_bounds__(512) void flash_attn_x3_kernel(const float* __restr
                 *(f32x4*)(orow + mt * 16) = f32x4{o[qs][mt][0] * inv, o[qs][mt][1] * inv, o[qs][mt][2] * inv, o[qs][mt][3] * inv};
         }
     }
+}
+
+// Order-independent 64-bit checksum of a buffer (diagnostics: itts_s2mel_set_trace): sum over the 32-bit words of word * (odd function of the word
+// index), accumulated with integer atomics -- associative, so the value does not depend on which wave adds first.
+__global__ __launch_bounds__(256) void trace_hash_kernel(const uint32_t* __restrict__ p, size_t n_words, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256)
+        acc += (unsigned long long)p[i] * (2 * (unsigned long long)i + 0x9E3779B97F4A7C15ull | 1ull);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+int launch_trace_hash(const void* p, size_t bytes, unsigned long long* out, hipStream_t st) {
+    const size_t n = bytes / 4;
+    if (!n) return ITTS_OK;
+    const unsigned blocks = (unsigned)((n + 256 * 16 - 1) / (256 * 16) < 2048 ? (n + 256 * 16 - 1) / (256 * 16) : 2048);
+    hipLaunchKernelGGL(trace_hash_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, (const uint32_t*)p, n, out);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
 }
 
 // f32 [n] -> three bf16 planes (plane p at out + p * n): the unit-level entry point's path to the x3 attention operands
