@@ -48,7 +48,7 @@ int itts_device_count(void);
  *   sample_radix        -1    -1..1    top-k threshold: -1 per-kernel default, 0 ballot bisection, 1 radix select
  *   gpt_compact          1     0..1    row compaction of ragged decode batches
  *   attn_waves           0     0..16   waves per block of the KV-cache attention kernel (0: by shape; 4 / 8 / 16)
- *   s2mel_fused          1     0..1    bf16 / f32 s2mel: fused GEMM epilogues (at create)
+ *   s2mel_fused          1     0..2    s2mel: fused GEMM epilogues (at create); 1: the bf16 mode keeps wqkv + RoPE / scatter as two launches, 2: everything fused, 0: none
  *   fa_qs                0     0..4    bf16 flash attention: query sub-tiles per wave (0: by shape)
  *   f32_attn_scalar      0     0..1    f32 s2mel attention on the one-wave-per-query reference kernel
  *   fa32_qs              2     1..2    f32 flash attention: query sub-tiles per wave

@@ -30,7 +30,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"sample_radix", -1, -1, 1, "top-k threshold: -1 per-kernel default (radix select in sample_kernel, ballot bisection in the beam kernels), 0 bisection, 1 radix select (identical ids)"},
     {"gpt_compact", 1, 0, 1, "row compaction of ragged decode batches (0 disables it for every handle; identical ids)"},
     {"attn_waves", 0, 0, 16, "waves per block of the KV-cache attention kernel: 0 pick by shape, else 4 / 8 / 16 (the 16 canonical key streams are mapped onto them; bitwise equal)"},
-    {"s2mel_fused", 1, 0, 1, "bf16 s2mel: fused GEMM epilogues (0: separate element-wise kernels)"},
+    {"s2mel_fused", 1, 0, 2, "s2mel: fused GEMM epilogues, sampled when a handle is created -- 1: fused (the bf16 mode keeps its wqkv GEMM + RoPE / scatter as two launches: its fused epilogue is not bit-stable run to run), 2: everything fused, 0: separate element-wise kernels"},
     {"fa_qs", 0, 0, 4, "bf16 flash attention: query sub-tiles per wave (0: pick by shape)"},
     {"f32_attn_scalar", 0, 0, 1, "f32 s2mel attention on the one-wave-per-query reference kernel (the A/B path of the f32 flash kernel)"},
     {"fa32_qs", 2, 1, 2, "f32 flash attention: query sub-tiles per wave"},
