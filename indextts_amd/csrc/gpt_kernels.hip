@@ -2261,6 +2261,16 @@ static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
         if (l2 < (size_t)mt * 4096) l2 = (size_t)mt * 4096;
         return mt == 1 ? launch_gemm_decode64_nt<1, 1>(a, ntiles, l2, st) : launch_gemm_decode64_nt<1, 2>(a, ntiles, l2, st);
     }
+    if (itts_opt(OPT_DECODE_MT) == 2) {                            // A/B: 32-row blocks at every batch size (80 KiB slabs, two blocks per CU; each weight
+        const int blocks = ntiles * ceil_div(a.M, 32) * a.nsplit;  // tile is then streamed by ceil(M / 32) blocks); bitwise the 64-row form
+        size_t l2 = (size_t)((slice_kb + 1) / 2) * 4096;
+        if (blocks > 512) {
+            if (l2 < 16384) l2 = 16384;
+            return launch_gemm_decode64_nt<2, 2>(a, ntiles, l2, st);
+        }
+        if (l2 < 8192) l2 = 8192;
+        return launch_gemm_decode64_nt<1, 2>(a, ntiles, l2, st);
+    }
     size_t lds = (size_t)((slice_kb + 1) / 2) * 8192;
     const int other = ceil_div(a.M, 64) * a.nsplit;
     const int force_nt = itts_opt(OPT_DECODE_NT);
