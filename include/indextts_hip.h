@@ -56,7 +56,6 @@ int itts_device_count(void);
  *   conv_bm              0     0..128  force the co-tile height of the vocoder conv kernel
  *   h3_kernel            1     0..1    f16x3 vocoder conv: window kernel / two-stage kernel
  *   decode_ln_nt         2     2..4    LayerNorm-fused decode GEMM at 5-16 rows: n-tiles per block (2 or 4)
- *   decode_mt            0     0..2    bf16 decode GEMM above 32 rows: 64-row blocks (0) or 32-row blocks (2)
  * itts_option_count / _name / _doc / _default enumerate the table (index 0 .. count-1).
  * ---------------------------------------------------------------------------------------------------------- */
 int itts_set_option(const char* name, int value);      /* ITTS_ERR_ARG: unknown name or value out of range */

@@ -2250,6 +2250,8 @@ static int launch_gemm_decode64_nt(const GemmArgs& a, int ntiles, size_t lds, hi
     return wnt ? launch_gemm_decode64_w<NT, MT, true>(a, ntiles, lds, st) : launch_gemm_decode64_w<NT, MT, false>(a, ntiles, lds, st);
 }
 
+// (32-row blocks above 32 rows -- 80 KiB slabs, two blocks per CU, every weight tile streamed by ceil(M / 32) blocks -- measured 0.5-0.7 % SLOWER
+// at 40 / 48 / 64 rows, profiles/r04n: closed.)
 // n-tiles per block: the slab is 160 KiB of LDS, i.e. ONE block per CU, so a grid above 256 blocks runs in rounds; take the
 // smallest NT (1, 2, 4) that fits the launch into a single round (more columns per block also amortise the slab DMA).
 static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
@@ -2260,16 +2262,6 @@ static int launch_gemm_decode64(const GemmArgs& a, hipStream_t st) {
         size_t l2 = (size_t)((slice_kb + 1) / 2) * 2048 * mt;
         if (l2 < (size_t)mt * 4096) l2 = (size_t)mt * 4096;
         return mt == 1 ? launch_gemm_decode64_nt<1, 1>(a, ntiles, l2, st) : launch_gemm_decode64_nt<1, 2>(a, ntiles, l2, st);
-    }
-    if (itts_opt(OPT_DECODE_MT) == 2) {                            // A/B: 32-row blocks at every batch size (80 KiB slabs, two blocks per CU; each weight
-        const int blocks = ntiles * ceil_div(a.M, 32) * a.nsplit;  // tile is then streamed by ceil(M / 32) blocks); bitwise the 64-row form
-        size_t l2 = (size_t)((slice_kb + 1) / 2) * 4096;
-        if (blocks > 512) {
-            if (l2 < 16384) l2 = 16384;
-            return launch_gemm_decode64_nt<2, 2>(a, ntiles, l2, st);
-        }
-        if (l2 < 8192) l2 = 8192;
-        return launch_gemm_decode64_nt<1, 2>(a, ntiles, l2, st);
     }
     size_t lds = (size_t)((slice_kb + 1) / 2) * 8192;
     const int other = ceil_div(a.M, 64) * a.nsplit;

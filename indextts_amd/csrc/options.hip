@@ -38,7 +38,6 @@ const OptDef kDefs[OPT_COUNT] = {
     {"conv_bm", 0, 0, 128, "force the co-tile height of conv_mfma_kernel (0: pick by channel count)"},
     {"h3_kernel", 1, 0, 1, "f16x3 vocoder conv: 1 window kernel, 0 two-stage kernel"},
     {"decode_ln_nt", 2, 2, 4, "LayerNorm-fused decode GEMM at 5-16 rows (weights on waves 0-3, LayerNorm on waves 4-7): n-tiles per block, 2 or 4 (bitwise equal)"},
-    {"decode_mt", 0, 0, 2, "bf16 decode GEMM above 32 rows: 0 = 64-row blocks (160 KiB slab, one block per CU), 2 = 32-row blocks (80 KiB, two per CU); bitwise equal"},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::atomic<unsigned> g_epoch{1};
