@@ -2844,48 +2844,8 @@ __device__ __forceinline__ uint32_t topk_kth_key(const float* sl, int V, int k, 
         key[j] = i < V ? f2key(sl[i]) : 0u;
     }
     uint32_t T = 0;
-#ifdef ITTS_TOPK_V2
-    // Variant for tools/microbench/sample_stamps.hip (-DITTS_TOPK_V2; NOT in the product until measured and GPU-tested): the stamps put the plain
-    // bisection below at 17.9 us -- 32 rounds x 33 (v_cmp -> s_bcnt1 -> s_add) at ~41 cycles each.  Bound the wave's k-th largest key from below
-    // first: L = the k-th largest of the 64 per-lane maxima (the lane maxima themselves are k keys >= L, so T_w >= L): 33 VALU max + a bisection
-    // with ONE ballot per round.  The keys >= L (about k..2k of the wave's 2112) are compacted through LDS to at most two per lane, and the full
-    // bisection runs on those: a candidate c <= L is feasible without counting, a candidate c > L is counted over the live keys only.
-    // More than 128 live keys (heavy ties): the plain bisection.
-    bool v2_done = false;
-    uint32_t c0 = 0, c1 = 0;
-    {
-        __shared__ uint32_t topk_live[4 * 128];
-        uint32_t mx = 0;
-#pragma unroll
-        for (int j = 0; j < TOPK_KPT; ++j) mx = key[j] > mx ? key[j] : mx;
-        uint32_t L = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t c = L | (1u << bit);
-            if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(mx >= c)) >= k) L = c;
-        }
-        int n_live = 0;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-        for (int j = 0; j < TOPK_KPT; ++j) {
-            const bool keep = key[j] >= L && L != 0u;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-            if (keep) { const int o = n_live + __builtin_popcountll(m & lt); if (o < 128) topk_live[w * 128 + o] = key[j]; }
-            n_live += __builtin_popcountll(m);
-        }
-        if (L != 0u && n_live <= 128) {                              // wave-uniform
-            __builtin_amdgcn_wave_barrier();
-            c0 = lane < n_live ? topk_live[w * 128 + lane] : 0u;
-            c1 = 64 + lane < n_live ? topk_live[w * 128 + 64 + lane] : 0u;
-            for (int bit = 31; bit >= 0; --bit) {
-                const uint32_t c = T | (1u << bit);
-                const bool feas = c <= L || __builtin_popcountll(__builtin_amdgcn_ballot_w64(c0 >= c)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(c1 >= c)) >= k;
-                if (feas) T = c;
-            }
-            v2_done = true;
-        }
-    }
-    if (!v2_done)
-#endif
+    // (A lower bound from the per-lane maxima + compaction of the keys above it before the bisection -- about 170 ballot rounds instead of 1056 --
+    // gave identical ids and no measurable gain at 1 / 8 / 64 rows, profiles/r04p: removed.)
     for (int bit = 31; bit >= 0; --bit) {
         const uint32_t c = T | (1u << bit);
         int cnt = 0;
@@ -3054,30 +3014,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     const bool pen = a.rep_penalty != 1.0f;
     const bool temp = a.do_sample && a.temperature != 1.0f;
     const bool typical = a.typical_mass > 0.f;
-#ifdef ITTS_SAMPLE_ROWS_V2
-    // microbench variant (tools/microbench/sample_stamps.hip, -DITTS_SAMPLE_ROWS_V2; not in the product until measured by the stamps and
-    // GPU-tested): every load of the row (score + seen flag) issued before the first use.  Written as one loop, `if (pen && seen[i])`
-    // compiles to a load, a wait and a branch per element -- 33 dependent round trips: the stamps put this phase at 6.5 us.
-    if (V <= 256 * TOPK_KPT) {
-        float xv[TOPK_KPT];
-        unsigned char sv[TOPK_KPT];
-#pragma unroll
-        for (int j = 0; j < TOPK_KPT; ++j) {
-            const int i = tid + 256 * j, ic = i < V ? i : V - 1;
-            xv[j] = lg[ic];
-            sv[j] = seen[ic];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < TOPK_KPT; ++j) {
-            const int i = tid + 256 * j;
-            float x = xv[j];
-            if (pen && sv[j]) x = x < 0.f ? x * a.rep_penalty : x / a.rep_penalty;
-            if (temp && !typical) x = x / a.temperature;
-            if (i < V) sl[i] = x;
-        }
-    } else
-#endif
+    // (Issuing every load of the row before the first use -- the stamps put this phase at 6.5 us of 33 dependent round trips -- changed nothing
+    // measurable at token level, profiles/r03x: removed.)
     for (int i = tid; i < V; i += 256) {
         float x = lg[i];
         if (pen && seen[i]) x = x < 0.f ? x * a.rep_penalty : x / a.rep_penalty;

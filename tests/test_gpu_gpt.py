@@ -133,7 +133,7 @@ def test_topk_bisection_equals_radix_select():
         r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
-    assert outs[0] == outs[1], outs
+    assert len(set(outs)) == 1, outs
 
 
 def test_attention_geometries_agree():
