@@ -1790,20 +1790,33 @@ static int launch_gemm_prefill_f32(const GemmArgs& a, hipStream_t st) {
 #define X3_LDS PF_LDS            // 2 x 16 KiB of A stages; the epilogue's transposed image (+ row metadata) is the larger
 #define X3_LDS_ONE (96 * 1024)   // an LDS request that admits ONE block per CU (launch_gemm_x3_e: the variants that are not the shipped one)
 
+// a - b as ONE scalar v_sub_f32 that the SLP vectoriser cannot pair up: this file is built with SLP vectorisation (build.py: the GPT sampler's
+// bit-exact fixtures depend on it), which turns the split's adjacent subtractions into v_pk_add_f32 + s_nop -- and a packed f32 op beside MFMAs
+// costs ~13 cycles more than the two scalar ops it replaces (MI355X guide; flash_attn_x3_kernel, built without SLP, keeps the matrix pipe 64 %
+// busy against 45 % here, profiles/r04q).  Plain VALU -> VALU dependencies: hardware-interlocked, no software hazard.
+__device__ __forceinline__ float x3_sub(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <bool SCALAR = false>
 __device__ __forceinline__ void x3_split8(const f32x4 p0, const f32x4 p1, v4u& H, v4u& M, v4u& L) {
     const float x[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float a = x[2 * i], b = x[2 * i + 1];
         const uint32_t h = pf_cvt2(a, b);
-        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);      // exact
+        float ra, rb, sa, sb;
+        if constexpr (SCALAR) { ra = x3_sub(a, __uint_as_float(h << 16)); rb = x3_sub(b, __uint_as_float(h & 0xffff0000u)); }
+        else { ra = a - __uint_as_float(h << 16); rb = b - __uint_as_float(h & 0xffff0000u); }              // exact
         const uint32_t m = pf_cvt2(ra, rb);
-        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);    // exact
+        if constexpr (SCALAR) { sa = x3_sub(ra, __uint_as_float(m << 16)); sb = x3_sub(rb, __uint_as_float(m & 0xffff0000u)); }
+        else { sa = ra - __uint_as_float(m << 16); sb = rb - __uint_as_float(m & 0xffff0000u); }            // exact
         H[i] = h; M[i] = m; L[i] = pf_cvt2(sa, sb);
     }
 }
 
-template <int EPI, bool CONV = false, int NPROD = 8, bool SCHED = true>
+template <int EPI, bool CONV = false, int NPROD = 8, bool SCHED = true, bool SCALAR = false>      // SCALAR: the operand split on scalar v_sub_f32 (x3_sub)
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB] operand stages; the epilogue image is the larger
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1909,14 +1922,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
         {
             const f32x4 p0 = *(const f32x4*)(base + a_wave + a_off[0]);
             const f32x4 p1 = *(const f32x4*)(base + a_wave + a_off[1]);
-            x3_split8(p0, p1, ap[0], ap[1], ap[2]);
+            x3_split8<SCALAR>(p0, p1, ap[0], ap[1], ap[2]);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             if (mt < 3) {
                 const f32x4 p0 = *(const f32x4*)(base + a_wave + (mt + 1) * 2048 + a_off[0]);
                 const f32x4 p1 = *(const f32x4*)(base + a_wave + (mt + 1) * 2048 + a_off[1]);
-                x3_split8(p0, p1, an[0], an[1], an[2]);
+                x3_split8<SCALAR>(p0, p1, an[0], an[1], an[2]);
             }
             // plane pairs, smallest terms first; four independent accumulators between two MFMAs on the same one
             constexpr int PA[8] = {2, 1, 2, 0, 1, 1, 0, 0};
@@ -1984,6 +1997,7 @@ static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
         attr_set = true;
     }
     const dim3 grid(per * 8), blk(256);
@@ -1993,7 +2007,8 @@ static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
     // same kernels soaked clean; one block per CU: bit-stable, cause not found) -- they are A/B and accuracy-study paths, so they are pinned to
     // one block per CU by an LDS request above half a CU's 160 KiB.
     const size_t lds = (nprod == 6 && sched) ? X3_LDS : X3_LDS_ONE;
-    if (nprod == 6 && sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true>), grid, blk, lds, st, a);
+    if (nprod == 6 && sched && itts_opt(OPT_X3_SPLIT) == 1) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true, true>), grid, blk, lds, st, a);
+    else if (nprod == 6 && sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true>), grid, blk, lds, st, a);
     else if (nprod == 6) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, false>), grid, blk, lds, st, a);
     else if (sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, true>), grid, blk, lds, st, a);
     else hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, false>), grid, blk, lds, st, a);

@@ -1,0 +1,46 @@
+#!/bin/bash
+# GPU box: how busy is the matrix pipe under the fp32x3 kernels, and at what clock?  One rocprofv3 counter pass (SQ_VALU_MFMA_BUSY_CYCLES,
+# GRBM_GUI_ACTIVE, SQ_BUSY_CYCLES; --kernel-trace only) over tools/s2mel_bench.py at B utterances x (517 + 1926) frames, two Euler steps, per kernel family:
+#   mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE)          -- fraction of the kernel's own clock cycles with the pipe busy
+#   clock     = GRBM_GUI_ACTIVE / kernel duration                                   -- the effective engine clock while it ran (DVFS)
+# usage: tools/pmc_x3.sh [B=8]  ->  gpurun_out/pmc_x3/x3_pmc.json
+set -u
+B=${1:-8}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/pmc_x3
+mkdir -p "$OUT"
+rm -f "$OUT/x3_pmc.json"
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/raw" -o p -- python $ROOT/tools/s2mel_bench.py $B 517 1926 2 fp32x3 fp32 > "$OUT/run.log" 2>&1
+grep -q "finite=True" "$OUT/run.log" || { echo "pmc_x3: workload failed: $(tail -3 "$OUT/run.log")" >&2; exit 1; }
+cp "$(find "$OUT/raw" -name '*counter_collection.csv' | head -1)" "$OUT/cc.csv" 2>/dev/null
+cp "$(find "$OUT/raw" -name '*kernel_trace.csv' | head -1)" "$OUT/kt.csv" 2>/dev/null
+rm -rf "$OUT/raw"
+python3 - "$OUT" "$B" <<'PY'
+import csv, json, sys, collections
+out, B = sys.argv[1], int(sys.argv[2])
+FAM = ("gemm_x3_kernel", "flash_attn_x3_kernel", "gemm_prefill_kernel", "flash_attn_f32_kernel")
+def fam(n):
+    for k in FAM:
+        if k in n: return k
+    return None
+dur = collections.defaultdict(lambda: [0.0, 0])
+for r in csv.DictReader(open(f"{out}/kt.csv")):
+    k = fam(r["Kernel_Name"])
+    if k: dur[k][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); dur[k][1] += 1
+cnt = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in csv.DictReader(open(f"{out}/cc.csv")):
+    k = fam(r["Kernel_Name"])
+    if k: cnt[k][r["Counter_Name"]] += float(r["Counter_Value"])
+res = {"B": B, "frames": 517 + 1926, "note": "sums over the launches of two CFG Euler steps per mode (fp32x3 then fp32) inside ONE counter pass: durations under "
+       "counter collection are inflated and are used only for the ratio clock = GRBM_GUI_ACTIVE / duration"}
+for k in FAM:
+    if dur[k][1] == 0: continue
+    busy, gui, ns = cnt[k]["SQ_VALU_MFMA_BUSY_CYCLES"], cnt[k]["GRBM_GUI_ACTIVE"], dur[k][0]
+    res[k] = {"dispatches": dur[k][1], "duration_ns": ns, "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": gui,
+              "mfma_busy_of_own_cycles": busy / (1024.0 * gui) if gui else None, "effective_clock_GHz": gui / ns if ns else None,
+              "mfma_busy_at_2p4GHz": busy / (1024.0 * ns * 2.4) if ns else None}
+if "gemm_x3_kernel" not in res: print("pmc_x3: no gemm_x3_kernel dispatches", file=sys.stderr); sys.exit(1)
+json.dump(res, open(f"{out}/x3_pmc.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
