@@ -57,6 +57,7 @@ int itts_device_count(void);
  *   h3_kernel            1     0..1    f16x3 vocoder conv: window kernel / two-stage kernel
  *   decode_ln_nt         2     2..4    LayerNorm-fused decode GEMM at 5-16 rows: n-tiles per block (2 or 4)
  *   x3_split             1     0..1    fp32x3 GEMM: operand split on scalar v_sub_f32 (1) or the SLP-packed form (0)
+ *   x3_aplanes           0     0..1    fp32x3 s2mel: adaptive-norm outputs as bf16 planes, wqkv / w1|w3 GEMMs without an operand split
  * itts_option_count / _name / _doc / _default enumerate the table (index 0 .. count-1).
  * ---------------------------------------------------------------------------------------------------------- */
 int itts_set_option(const char* name, int value);      /* ITTS_ERR_ARG: unknown name or value out of range */

@@ -356,7 +356,8 @@ static size_t s_a256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct S2Ws {
     float *X, *X2, *BIG, *WX, *OUT, *RP, *D;
-    char *HB, *QA, *AO, *FC, *COL, *XA, *SK, *KC, *VC, *WXA, *ZR;
+    char *HB, *QA, *AO, *FC, *COL, *XA, *SK, *KC, *VC, *WXA, *ZR, *HBP;
+    size_t hbp_stride;                                             // f32x3: plane stride (u16 elements) of HBP, the adaptive-norm output as three bf16 planes
     size_t sk_stride, total;
 };
 
@@ -385,6 +386,8 @@ static S2Ws s2_carve(const itts_s2mel* h, char* base, int n_tok, int n_seq, int 
     w.sk_stride = s_a256(N * H * esz);
     w.SK = take(w.sk_stride * (size_t)(c.depth / 2));
     w.WXA = take(N * W * esz);                                     // act-dtype shadow of WX: the tap-mode GEMM's A operand
+    w.hbp_stride = (N * H + 127) / 128 * 128;
+    w.HBP = take(c.precision == PREC_F32X3 ? w.hbp_stride * 6 : 0);  // f32x3: the two per-layer adaptive-RMSNorm outputs as bf16 planes
     // K / V^T images: act dtype, or -- fp32x3 -- room for the three bf16 planes of every element (6 bytes; the f32 image of option
     // x3_attn = 0 fits in the same buffer)
     const size_t kv = (size_t)n_seq * c.num_heads * t_pad * 64 * (c.precision == PREC_F32X3 ? 6 : esz);
@@ -429,6 +432,9 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
     const bool fused = s2_fused(prec, h->opt_fused);
     const bool x3_attn = prec == PREC_F32X3 && itts_opt(OPT_X3_ATTN) != 0;      // attention products on bf16 planes (flash_attn_x3_kernel)
     const size_t kv_plane = (size_t)tab.n_seq * nh * t_pad * 64;
+    // f32x3: the adaptive-RMSNorm outputs (the A operands of wqkv and w1|w3) leave the norm kernel as three bf16 planes in fragment order, so those
+    // two GEMMs issue no operand split at all (option x3_aplanes = 0: f32 rows + the in-register split; bitwise the same results)
+    const bool a_planes = prec == PREC_F32X3 && fused && itts_opt(OPT_X3_APLANES) != 0 && itts_opt(OPT_X3_PRODUCTS) == 6 && itts_opt(OPT_X3_SCHED) != 0 && H % 32 == 0;
     int rc;
     float *X = w.X, *X2 = w.X2;
     const size_t esz = prec == PREC_BF16 ? 2 : 4;                  // activation element size
@@ -451,8 +457,13 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
             S2_TRACE("skip_in GEMMs -> X", X2, (size_t)N * H * 4);
             float* tmp = X; X = X2; X2 = tmp;
         }
-        if ((rc = launch_ada_rmsnorm(X, L.g_attn, mods + (size_t)i * 4 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
-        S2_TRACE("ada_rmsnorm(attn) -> HB", w.HB, (size_t)N * H * esz);
+        if (a_planes) {
+            if ((rc = launch_ada_rmsnorm_planes(X, L.g_attn, mods + (size_t)i * 4 * H, w.HBP, w.hbp_stride, N, H, c.norm_eps, st))) return rc;
+            S2_TRACE("ada_rmsnorm(attn) -> HB planes", w.HBP, w.hbp_stride * 6);
+        } else {
+            if ((rc = launch_ada_rmsnorm(X, L.g_attn, mods + (size_t)i * 4 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
+            S2_TRACE("ada_rmsnorm(attn) -> HB", w.HB, (size_t)N * H * esz);
+        }
         // bf16 mode: the fused wqkv epilogue of the bf16 tile kernels is NOT bit-stable run to run at production depth -- the engine's stage trace
         // (tools/s2mel_trace.py, profiles/r04j) puts the first differing checksum in its Q / K tiles in about one estimator call of two (24 / 24
         // stable with the plain-store GEMM + rope_split, and in the f32 / f32x3 instantiations; the symptom also vanishes under unrelated
@@ -460,6 +471,7 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
         if (fused && h->opt_fused_qkv) {                           // wqkv + RoPE + Q / K / V^T scatter in one epilogue
             GemmArgs g{};
             g.A = w.HB; g.lda = H; g.Wp = L.w_qkv; g.M = N; g.N = 3 * H; g.K = H; g.nsplit = 1; g.epi = EPI_QKV_ROPE;
+            if (a_planes) { g.A = w.HBP; g.a_planes = w.hbp_stride; }
             g.out_act = w.QA; g.kcache = w.KC; g.vcache = w.VC; g.D = H; g.H = nh; g.Tmax = t_pad;
             g.tok_seq = tab.tok_seq; g.tok_t = tab.tok_t; g.rope = rope;
             g.kv_planes = x3_attn ? kv_plane : 0;
@@ -478,11 +490,17 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
         S2_TRACE("attention -> AO", w.AO, (size_t)N * H * esz);
         if ((rc = s2_gemm(h, w.AO, H, L.w_o, nullptr, X, H, N, H, H, EPI_RESIDUAL, st))) return rc;
         S2_TRACE("wo GEMM -> X", X, (size_t)N * H * 4);
-        if ((rc = launch_ada_rmsnorm(X, L.g_ffn, mods + (size_t)i * 4 * H + 2 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
-        S2_TRACE("ada_rmsnorm(ffn) -> HB", w.HB, (size_t)N * H * esz);
+        if (a_planes) {
+            if ((rc = launch_ada_rmsnorm_planes(X, L.g_ffn, mods + (size_t)i * 4 * H + 2 * H, w.HBP, w.hbp_stride, N, H, c.norm_eps, st))) return rc;
+            S2_TRACE("ada_rmsnorm(ffn) -> HB planes", w.HBP, w.hbp_stride * 6);
+        } else {
+            if ((rc = launch_ada_rmsnorm(X, L.g_ffn, mods + (size_t)i * 4 * H + 2 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
+            S2_TRACE("ada_rmsnorm(ffn) -> HB", w.HB, (size_t)N * H * esz);
+        }
         if (fused) {                                               // [w1 ; w3] GEMM with the SwiGLU combine in the epilogue
             GemmArgs g{};
             g.A = w.HB; g.lda = H; g.Wp = L.w_13; g.M = N; g.N = 2 * I; g.K = H; g.nsplit = 1; g.epi = EPI_SWIGLU; g.out_act = w.FC; g.D = I;
+            if (a_planes) { g.A = w.HBP; g.a_planes = w.hbp_stride; }
             if ((rc = s2_launch_gemm(h, g, st))) return rc;
         } else {
             if ((rc = s2_gemm(h, w.HB, H, L.w_13, nullptr, w.BIG, 2 * I, N, 2 * I, H, EPI_STORE_F32, st))) return rc;

@@ -42,6 +42,8 @@ struct GemmArgs {
     // EPI_QKV: n < D -> qbuf[m][n]; D <= n < 2D -> K cache; else V cache, at cache position *pos_ptr + (m % S)
     float* qbuf; void* kcache; void* vcache;
     const int* pos_ptr; int S, H, Tmax, D;
+    size_t a_planes;                 // f32x3 tile GEMM: when non-zero, A is THREE bf16 planes (plane p at (u16*)A + p * a_planes, rows of lda elements, each
+                                     // 32-column group stored in fragment order: ada_rmsnorm_planes_kernel) instead of f32 rows -- no in-register split
     int kb_slice;                    // filled by the decode-GEMM launcher: 32-wide k-blocks per K slice
     int dma_rot;                     // per-block rotation of the slab DMA issue order (ITTS_DECODE_ROT=0 turns it off: A/B switch)
     // LayerNorm fused into a decode GEMM's operand staging (gemm_decode_ln_kernel: at most 4 rows, K == model_dim, bf16): when ln_x is set the

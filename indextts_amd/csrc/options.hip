@@ -39,6 +39,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"h3_kernel", 1, 0, 1, "f16x3 vocoder conv: 1 window kernel, 0 two-stage kernel"},
     {"decode_ln_nt", 2, 2, 4, "LayerNorm-fused decode GEMM at 5-16 rows (weights on waves 0-3, LayerNorm on waves 4-7): n-tiles per block, 2 or 4 (bitwise equal)"},
     {"x3_split", 1, 0, 1, "fp32x3 GEMM (6 products): operand split on scalar v_sub_f32 (1, measured +2.5 % on the GEMMs) instead of the SLP-packed v_pk_add_f32 form (0); bitwise equal"},
+    {"x3_aplanes", 0, 0, 1, "fp32x3 s2mel: the adaptive-RMSNorm outputs as three bf16 planes in fragment order, wqkv / w1|w3 GEMMs without an operand split (bitwise equal)"},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::atomic<unsigned> g_epoch{1};

@@ -33,6 +33,7 @@ int launch_s2mel_attention(const void* q, const void* k, const void* v, void* ou
 int launch_s2mel_attention_x3(const void* q, const void* kp, const void* vp, void* out, const SeqTab& tab, int heads, int t_pad, hipStream_t st);
 // f32 [n] -> three bf16 planes [3][n] (h + m + l == x exactly)
 int launch_split_planes(const float* in, void* out, size_t n, hipStream_t st);
+int launch_ada_rmsnorm_planes(const float* x, const float* g, const float* wb, void* out, size_t plane_stride, int n_tok, int H, float eps, hipStream_t st);
 int launch_trace_hash(const void* p, size_t bytes, unsigned long long* out, hipStream_t st);
 // SwiGLU combine: in f32 [n][2I] = [w1 x | w3 x] -> act [n][I] = silu(a) * b
 int launch_swiglu(const float* in, void* out, int n_tok, int I, int prec, hipStream_t st);

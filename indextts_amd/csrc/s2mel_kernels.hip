@@ -67,6 +67,55 @@ __global__ __launch_bounds__(256) void ada_rmsnorm_kernel(const float* __restric
     }
 }
 
+// The same normalisation with the output written as the THREE bf16 planes of every f32 value (h = bf16(y), m = bf16(y - h), l = bf16(y - h - m):
+// exact), in the order the f32x3 GEMM's A fragments want them: inside every 32-column group the eight values of k-group kg -- columns 4 kg .. 4 kg + 3
+// and 16 + 4 kg .. + 3, the two 16-byte pieces the f32 tile kernel's lane reads -- are contiguous (16 bytes), so gemm_x3_kernel<..., APL = true> stages
+// plane tiles by LDS-DMA and reads a fragment with one ds_read_b128 per plane instead of splitting the f32 tile in registers for every column block.
+// Plane p of row m at out + p * stride + m * H (u16 elements).  Same arithmetic as ada_rmsnorm_kernel, same planes as x3_split8 -> bitwise the same GEMM.
+__global__ __launch_bounds__(256) void ada_rmsnorm_planes_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ wb,
+                                                                 u16* __restrict__ out, size_t stride, int n, int H, float eps) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + w;
+    if (m >= n) return;
+    const float* xr = x + (size_t)m * H;
+    float ss = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    ss = wave_sum(ss);
+    const float rstd = 1.0f / sqrtf(ss / (float)H + eps);
+    for (int c = lane * 4; c < H; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c), gg = *(const f32x4*)(g + c), ww = *(const f32x4*)(wb + c), bb = *(const f32x4*)(wb + H + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ww[j] * ((v[j] * rstd) * gg[j]) + bb[j];
+        v2u hh, mm, ll;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float a0 = o[2 * i], a1 = o[2 * i + 1];
+            const uint32_t h = pack_bf16x2(a0, a1);
+            const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);      // exact
+            const uint32_t mi = pack_bf16x2(r0, r1);
+            const float s0 = r0 - __uint_as_float(mi << 16), s1 = r1 - __uint_as_float(mi & 0xffff0000u);   // exact
+            hh[i] = h; mm[i] = mi; ll[i] = pack_bf16x2(s0, s1);
+        }
+        const int q = c & 31;
+        u16* dst = out + (size_t)m * H + (c & ~31) + (((q & 15) >> 2) << 3) + ((q >> 4) << 2);
+        *(v2u*)dst = hh;
+        *(v2u*)(dst + stride) = mm;
+        *(v2u*)(dst + 2 * stride) = ll;
+    }
+}
+
+int launch_ada_rmsnorm_planes(const float* x, const float* g, const float* wb, void* out, size_t plane_stride, int n_tok, int H, float eps, hipStream_t st) {
+    if (n_tok <= 0) return ITTS_OK;
+    if (H % 32 || plane_stride % 8) { itts_set_error("ada_rmsnorm_planes: hidden size %d must be a multiple of 32 and the plane stride of 8", H); return ITTS_ERR_ARG; }
+    hipLaunchKernelGGL(ada_rmsnorm_planes_kernel, dim3(ceil_div(n_tok, 4)), dim3(256), 0, st, x, g, wb, (u16*)out, plane_stride, n_tok, H, eps);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
 int launch_ada_rmsnorm(const float* x, const float* g, const float* wb, void* out, int n_tok, int H, float eps, int prec, hipStream_t st,
                        const int* row_map) {
     if (n_tok <= 0) return ITTS_OK;

@@ -378,3 +378,31 @@ def test_bf16_estimator_is_bit_stable_run_to_run_with_stage_trace():
     firsts = [next((labels[i] for i in range(len(major)) if r[i] != major[i]), "length") for r in runs if r != major]
     print(f"bf16 estimator, {len(major)} stage checksums per call: {cnt} of {len(runs)} calls agree on all of them; first differing stages: {firsts}")
     assert len(major) > 100 and cnt == len(runs), firsts
+
+
+def test_x3_plane_operands_are_bitwise_the_in_register_split():
+    """fp32x3, option x3_aplanes = 1: the adaptive-RMSNorm outputs leave the norm kernel as three bf16 planes in fragment order and the wqkv / w1|w3
+    GEMMs stage plane tiles instead of splitting f32 tiles in registers ("carry the planes across kernels").  Same planes, same
+    MFMAs in the same order: the estimator's output is BITWISE the default path's, at the production architecture on a ragged pair of utterances.
+    (Measured: +0.8 % on the solve -- the matrix pipe's idle cycles are not the split's, profiles/r04q -- so the option stays off by default.)"""
+    from indextts_amd import _lib, s2mel, synth
+    args = synth.S2MEL_V2
+    g = torch.Generator().manual_seed(3)
+    B, Tp, T = 2, 100, 100 + 411
+    x = torch.randn(B, 80, T, generator=g).to(DEV)
+    mu = torch.randn(B, T, args["DiT"]["content_dim"], generator=g).to(DEV)
+    prompt = (torch.randn(1, 80, Tp, generator=g) * 0.5 - 1.0).to(DEV)
+    style = torch.randn(1, args["style_encoder"]["dim"], generator=g).to(DEV)
+    lens = torch.tensor([T, T - 37])
+    px = torch.zeros_like(x)
+    px[..., :Tp] = prompt
+    outs = []
+    for ap in (0, 1):
+        with _lib.option_scope(x3_aplanes=ap):
+            m = s2mel.CFM(args, precision="fp32x3", device=DEV)
+            m.load_state_dict(synth.s2mel_weights(args, seed=1234))
+            outs.append(m.estimator(torch.cat([x, x]), torch.cat([px, torch.zeros_like(px)]), lens, torch.full((2 * B,), 0.3),
+                                    torch.cat([style.expand(B, -1), torch.zeros(B, style.shape[1], device=DEV)]), torch.cat([mu, torch.zeros_like(mu)]),
+                                    frame_lens=[T, T - 37] * 2).cpu())
+            del m
+    assert rms(outs[0]) > 1e-3 and torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
