@@ -174,3 +174,27 @@ def test_golden_tools_import_without_the_reference():
            "\n".join(f"import tools.{m}" for m in sorted(used)) + "\nassert not any('reference' in p for p in sys.path), sys.path"
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_x3_plane_layout_is_the_fragment_order_of_the_tile_kernel():
+    """CPU restatement of the layout `ada_rmsnorm_planes_kernel` writes and `gemm_x3_kernel<..., APL>` reads (s2mel_kernels.hip / gpt_kernels.hip): inside
+    every 32-column group the producer puts column c at offset  8 * ((c & 15) >> 2) + 4 * (c >> 4) + (c & 3)  -- a bijection of 0..31 -- so that the
+    16-byte piece kg holds, in order, columns 4 kg .. 4 kg + 3 and 16 + 4 kg .. + 3: the eight k-values the f32 tile kernel's lane (row, kg) reads as
+    its two f32 pieces and x3_split8 packs into one MFMA operand.  And the LDS image: DMA lane l of a 16-row chunk carries (row l >> 2, source piece
+    (l & 3) ^ ((l >> 4) & 3)); the reader of (row16, kg) looks in slot kg ^ ((row16 >> 2) & 3) and must find source piece kg, and the sixteen lanes
+    of one k-group must touch sixteen different 16-byte bank quads of the 1 KiB chunk (conflict-free ds_read_b128)."""
+    off = [8 * ((c & 15) >> 2) + 4 * (c >> 4) + (c & 3) for c in range(32)]
+    assert sorted(off) == list(range(32))
+    inv = {o: c for c, o in enumerate(off)}
+    for kg in range(4):
+        assert [inv[8 * kg + j] for j in range(8)] == [4 * kg + j for j in range(4)] + [16 + 4 * kg + j for j in range(4)]
+    lds = {}                                                   # slot index inside the chunk -> (row, source piece)
+    for lane in range(64):
+        lds[lane] = (lane >> 2, (lane & 3) ^ ((lane >> 4) & 3))
+    for kg in range(4):
+        quads = set()
+        for row16 in range(16):
+            slot = row16 * 4 + (kg ^ ((row16 >> 2) & 3))
+            assert lds[slot] == (row16, kg)
+            quads.add(slot % 16)
+        assert len(quads) == 16
