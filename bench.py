@@ -468,7 +468,8 @@ def main():
     g = torch.Generator().manual_seed(100)
     n_text_ids, n_mels, D_model = (12000, 80, 1280) if stub else (eng.gcfg["number_text_tokens"], eng.bh["num_mels"], eng.gcfg["model_dim"])
     text_all = torch.randint(2, n_text_ids, (n_total, n_text), generator=g)
-    mine = D.shard_utterances(n_total, rank, world, lengths=[n_text] * n_total)
+    shards = [D.shard_utterances(n_total, r, world, lengths=[n_text] * n_total) for r in range(world)]     # the same table on every rank
+    mine = shards[rank]
     B = len(mine)
     text = text_all[mine].to(dev)
     langs = torch.full((B,), 3, dtype=torch.long, device=dev)
@@ -486,7 +487,7 @@ def main():
     def one_step(record):
         bundle = D.broadcast_speaker_bundle(bundle0, src=0, device=dev) if dist is not None else bundle0
         wav16 = eng.step(text, langs, mel, bundle, n_gen, record)
-        return D.gather_waveform_tensor(wav16, mine, n_total, dst=0) if dist is not None else wav16
+        return D.gather_waveform_tensor(wav16, mine, n_total, dst=0, shards=shards) if dist is not None else wav16
 
     def barrier():
         if not stub:
@@ -554,7 +555,7 @@ def main():
                 codes.record_stream(torch.cuda.current_stream())
             tw = time.perf_counter()
             wav16 = eng.render(codes, mel, cur_bundle, n_gen, True)
-            out = D.gather_waveform_tensor(wav16, mine, n_total, dst=0) if dist is not None else wav16
+            out = D.gather_waveform_tensor(wav16, mine, n_total, dst=0, shards=shards) if dist is not None else wav16
             if rank == 0 and not stub:
                 log(f"[bench] overlap: render of step {k} enqueued / finished on the host after {time.perf_counter() - tw:.2f}s")
         return out

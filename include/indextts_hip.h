@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 9
+#define ITTS_ABI_VERSION 10
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -58,6 +58,7 @@ int itts_device_count(void);
  *   decode_ln_nt         2     2..4    LayerNorm-fused decode GEMM at 5-16 rows: n-tiles per block (2 or 4)
  *   x3_split             1     0..1    fp32x3 GEMM: operand split on scalar v_sub_f32 (1) or the SLP-packed form (0)
  *   x3_aplanes           0     0..1    fp32x3 s2mel: adaptive-norm outputs as bf16 planes, wqkv / w1|w3 GEMMs without an operand split
+ *   x3_pin               1     0..1    fp32x3 GEMM: the variants that are not the shipped one pinned to one block per CU (0: diagnostic, two blocks)
  * itts_option_count / _name / _doc / _default enumerate the table (index 0 .. count-1).
  * ---------------------------------------------------------------------------------------------------------- */
 int itts_set_option(const char* name, int value);      /* ITTS_ERR_ARG: unknown name or value out of range */
@@ -376,12 +377,18 @@ int itts_s2mel_set_profiling(itts_s2mel* h, int enable);
 int itts_s2mel_profile_read(itts_s2mel* h, double* ms, double* launches, double* flops);
 
 /* Diagnostics: a 64-bit order-independent checksum of every stage's output buffer of the following estimator / solve calls, in launch order, into
- * dev_u64 (capacity zeroed 64-bit words on the handle's device; NULL clears).  Each call restarts at entry 0; itts_s2mel_trace_count = entries
+ * dev_u64 (capacity 64-bit words on the handle's device; NULL clears).  Each call clears the words and restarts at entry 0; itts_s2mel_trace_count = entries
  * written by the last call, itts_s2mel_trace_label = what entry i is.  Two runs on the same inputs compared entry by entry name the first stage
  * that is not bit-stable (tools/s2mel_trace.py).  The reference has no counterpart. */
 int itts_s2mel_set_trace(itts_s2mel* h, void* dev_u64, int capacity);
 int itts_s2mel_trace_count(const itts_s2mel* h);
+int itts_s2mel_trace_wanted(const itts_s2mel* h);   /* entries the last call asked for; > trace_count: the trace stopped at its capacity */
 const char* itts_s2mel_trace_label(const itts_s2mel* h, int index);
+/* ... and a COPY of the output of every traced stage whose label starts with label_prefix, packed into dev_buf in launch order (256-byte aligned;
+ * stages that no longer fit are skipped): the checksums name the stage that differed between two runs, the images say which elements and how
+ * (tools/s2mel_capture.py).  itts_s2mel_capture_offset = byte offset of trace entry `index` of the last call in dev_buf (-1: not captured). */
+int itts_s2mel_set_capture(itts_s2mel* h, void* dev_buf, size_t bytes, const char* label_prefix);
+long long itts_s2mel_capture_offset(const itts_s2mel* h, int index, size_t* bytes);
 
 /* Dead-row elimination for the following itts_s2mel_solve calls.  The Euler step never reads the estimator's output at prompt frames
  * (flow_matching.py:107 zeroes them) and everything after the DiT's last attention is row-wise except the WaveNet's few frames of

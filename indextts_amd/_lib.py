@@ -43,7 +43,7 @@ class GPTConfig(C.Structure):
                 ("stop_mel_token", C.c_int32), ("ln_eps", C.c_float)]
 
 
-ABI_VERSION = 9          # include/indextts_hip.h ITTS_ABI_VERSION
+ABI_VERSION = 10         # include/indextts_hip.h ITTS_ABI_VERSION
 
 
 class GenParams(C.Structure):
@@ -132,7 +132,10 @@ SIGNATURES = {
     "itts_s2mel_profile_read": (C.c_int, [vp, vp, vp, vp]),
     "itts_s2mel_set_trace": (C.c_int, [vp, vp, C.c_int]),
     "itts_s2mel_trace_count": (C.c_int, [vp]),
+    "itts_s2mel_trace_wanted": (C.c_int, [vp]),
     "itts_s2mel_trace_label": (C.c_char_p, [vp, C.c_int]),
+    "itts_s2mel_set_capture": (C.c_int, [vp, vp, C.c_size_t, C.c_char_p]),
+    "itts_s2mel_capture_offset": (C.c_longlong, [vp, C.c_int, C.POINTER(C.c_size_t)]),
     "itts_s2mel_attention_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "itts_s2mel_attention_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
                                                C.c_size_t, vp]),

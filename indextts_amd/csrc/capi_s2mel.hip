@@ -70,15 +70,42 @@ struct itts_s2mel {
     // caller-provided device array -- two runs on the same inputs are compared entry by entry to find the first stage that is not bit-stable.
     unsigned long long* trace = nullptr;
     int trace_cap = 0, trace_n = 0;
+    int trace_wanted = 0;                  // entries the last call asked for (> trace_cap: the trace stopped at capacity)
     std::vector<const char*> trace_labels;
+    // ... and, for the stages whose label starts with capture_prefix, a copy of the stage's output bytes (itts_s2mel_set_capture): the stage
+    // checksums say WHICH stage differed between two runs, the captured images say which elements and how.
+    char* capture = nullptr;
+    size_t capture_bytes = 0, capture_used = 0;
+    std::string capture_prefix;
+    std::vector<long long> capture_off;    // per trace entry: byte offset of its image in the capture buffer, or -1
+    std::vector<size_t> capture_len;
 };
 
 // record the checksum of a stage output (no-op unless a trace buffer is set)
 static int s2_trace(itts_s2mel* h, hipStream_t st, const char* label, const void* p, size_t bytes) {
-    if (!h->trace || h->trace_n >= h->trace_cap) return ITTS_OK;
-    if ((int)h->trace_labels.size() <= h->trace_n) h->trace_labels.push_back(label);
-    else h->trace_labels[h->trace_n] = label;
+    if (!h->trace) return ITTS_OK;
+    ++h->trace_wanted;
+    if (h->trace_n >= h->trace_cap) return ITTS_OK;
+    if ((int)h->trace_labels.size() <= h->trace_n) { h->trace_labels.push_back(label); h->capture_off.push_back(-1); h->capture_len.push_back(0); }
+    else { h->trace_labels[h->trace_n] = label; h->capture_off[h->trace_n] = -1; h->capture_len[h->trace_n] = 0; }
+    if (h->capture && !h->capture_prefix.empty() && strncmp(label, h->capture_prefix.c_str(), h->capture_prefix.size()) == 0) {
+        const size_t at = (h->capture_used + 255) & ~(size_t)255;
+        if (at + bytes <= h->capture_bytes) {
+            HIP_TRY(hipMemcpyAsync(h->capture + at, p, bytes, hipMemcpyDeviceToDevice, st));
+            h->capture_off[h->trace_n] = (long long)at;
+            h->capture_len[h->trace_n] = bytes;
+            h->capture_used = at + bytes;
+        }
+    }
     return launch_trace_hash(p, bytes, h->trace + h->trace_n++, st);
+}
+// a call starts: entry 0 again, the checksum words cleared (the hash kernel ADDS into its word)
+static int s2_trace_begin(itts_s2mel* h, hipStream_t st) {
+    h->trace_n = 0;
+    h->trace_wanted = 0;
+    h->capture_used = 0;
+    if (h->trace && h->trace_cap > 0) HIP_TRY(hipMemsetAsync(h->trace, 0, (size_t)h->trace_cap * 8, st));
+    return ITTS_OK;
 }
 
 enum { S2_GEMM = 0, S2_ATTN = 1, S2_OTHER = 2, S2_CLASSES = 3 };
@@ -166,6 +193,24 @@ extern "C" int itts_s2mel_set_trace(itts_s2mel* h, void* dev_u64, int capacity) 
     return ITTS_OK;
 }
 extern "C" int itts_s2mel_trace_count(const itts_s2mel* h) { return h ? h->trace_n : 0; }
+// entries the last call WANTED to write: larger than itts_s2mel_trace_count when the trace stopped at its capacity
+extern "C" int itts_s2mel_trace_wanted(const itts_s2mel* h) { return h ? h->trace_wanted : 0; }
+// Diagnostics: besides its checksum, keep a COPY of every traced stage output whose label starts with `label_prefix` (packed into dev_buf in
+// launch order, 256-byte aligned; stages that no longer fit are skipped).  Needs a trace (itts_s2mel_set_trace); nullptr clears.
+extern "C" int itts_s2mel_set_capture(itts_s2mel* h, void* dev_buf, size_t bytes, const char* label_prefix) {
+    if (!h || (dev_buf && !label_prefix)) { itts_set_error("s2mel_set_capture: bad args"); return ITTS_ERR_ARG; }
+    h->capture = (char*)dev_buf;
+    h->capture_bytes = dev_buf ? bytes : 0;
+    h->capture_used = 0;
+    h->capture_prefix = dev_buf ? label_prefix : "";
+    return ITTS_OK;
+}
+// byte offset in the capture buffer of trace entry `index` of the last call (-1: not captured) and its length
+extern "C" long long itts_s2mel_capture_offset(const itts_s2mel* h, int index, size_t* bytes) {
+    if (!h || index < 0 || index >= (int)h->capture_off.size() || index >= h->trace_n) return -1;
+    if (bytes) *bytes = h->capture_len[index];
+    return h->capture_off[index];
+}
 extern "C" const char* itts_s2mel_trace_label(const itts_s2mel* h, int i) {
     return (h && i >= 0 && i < (int)h->trace_labels.size()) ? h->trace_labels[i] : nullptr;
 }
@@ -624,7 +669,7 @@ extern "C" int itts_s2mel_estimator(itts_s2mel* h, const float* x, const float* 
     const SeqTab tab = s2_tab(tok_seq, tok_t, seq_start, seq_T, seq_len, n_seq, n_tok, t_max);
     h->recs.clear();
     h->prof_stream = st;
-    h->trace_n = 0;
+    if (int rc = s2_trace_begin(h, st)) return rc;
     return s2_estimator(h, w, tab, t_pad, x, n_tok, const_in, mods, rope, d_out, st);
 }
 
@@ -655,7 +700,7 @@ extern "C" int itts_s2mel_solve(itts_s2mel* h, float* x_state, const float* cons
     const int mps = itts_s2mel_mods_per_step(h);
     h->recs.clear();
     h->prof_stream = st;
-    h->trace_n = 0;
+    if (int rc = s2_trace_begin(h, st)) return rc;
     for (int step = 0; step < n_steps; ++step) {                   // flow_matching.py:84-113
         const bool use_tail = h->tail_set && h->tail.n_seq == n_seq && h->tail.n_tok > 0 && h->tail.n_tok <= n_tok && h->tail.n_tok % n_branch == 0;
         int rc = s2_estimator(h, w, tab, t_pad, x_state, n_tok / n_branch, const_in, mods + (size_t)step * mps, rope, w.D, st, 0.0,

@@ -2042,7 +2042,7 @@ static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
     // 8-product solve differed from run to run in scattered token rows by up to 1e-2 at >= 9.7 k rows while every plain-store GEMM launch of the
     // same kernels soaked clean; one block per CU: bit-stable, cause not found) -- they are A/B and accuracy-study paths, so they are pinned to
     // one block per CU by an LDS request above half a CU's 160 KiB.
-    const size_t lds = (nprod == 6 && sched) ? X3_LDS : X3_LDS_ONE;
+    const size_t lds = ((nprod == 6 && sched) || itts_opt(OPT_X3_PIN) == 0) ? X3_LDS : X3_LDS_ONE;
     if constexpr (!CONV && (EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU)) {     // the two GEMMs behind an adaptive RMSNorm: A as bf16 planes
         if (a.a_planes) {
             if (nprod != 6 || !sched) { itts_set_error("gemm (f32x3): the plane-operand form exists for the shipped variant only (6 products, interleaved)"); return ITTS_ERR_ARG; }

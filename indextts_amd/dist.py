@@ -39,48 +39,74 @@ def shard_utterances(n_utts: int, rank_: Optional[int] = None, world_: Optional[
     return [i for i in range(n_utts) if owner[i] == r]
 
 
-# fixed key order + shapes so every rank can allocate the receive buffers without a metadata exchange
+# fixed key order so that the header of the flat buffer is position-coded
 BUNDLE_KEYS = ("style", "emo_vec", "spk_cond_emb", "emo_cond_emb", "ref_mel", "prompt_condition")
+_HDR_INTS = len(BUNDLE_KEYS) * 5 + 1                                # (ndim, 4 dims) per key + the payload length in floats
+_HDR_BYTES = (_HDR_INTS * 8 + 255) // 256 * 256
+# room for the largest bundle the pipeline produces: the reference truncates reference audio to 15 s (infer_v2.py:466-470), i.e. 750-frame
+# w2v-bert / emotion sequences (1024 wide), a 1292-frame mel (80) and prompt condition (512), a 192-wide style vector: 9.2 MB of float32
+BUNDLE_CAPACITY = 12 << 20
 
 
-def broadcast_speaker_bundle(bundle: Optional[Dict[str, torch.Tensor]], src: int = 0, device=None) -> Dict[str, torch.Tensor]:
-    """One broadcast per tensor of the per-speaker conditioning computed on `src` (SURVEY.md section 8e payload list).
+def _group_active() -> bool:
+    return dist.is_available() and dist.is_initialized()
 
-    Shapes differ per reference clip, so `src` first broadcasts a small int64 header (ndim + dims per key, -1 for an
-    absent key); the payload follows as float32.  <= ~9 MB per speaker; latency-bound on xGMI.
-    """
-    if world() == 1:
+
+def broadcast_speaker_bundle(bundle: Optional[Dict[str, torch.Tensor]], src: int = 0, device=None,
+                             capacity: int = BUNDLE_CAPACITY) -> Dict[str, torch.Tensor]:
+    """ONE broadcast of the per-speaker conditioning computed on `src` (SURVEY.md section 8e payload list): a flat byte buffer of fixed
+    `capacity` = [int64 header: ndim + dims per key (-1 for an absent key), payload length | float32 payload of every present tensor in
+    BUNDLE_KEYS order].  Shapes differ per reference clip, the capacity does not, so the receivers post their buffer without a size
+    exchange; <= ~9 MB per speaker, outside the decode loop.  Runs whenever a process group exists (world size 1 included: the RCCL path
+    is then exercised on one device); without a group it returns `bundle`."""
+    if not _group_active():
         assert bundle is not None
         return bundle
     r = rank()
-    hdr = torch.full((len(BUNDLE_KEYS), 5), -1, dtype=torch.int64, device=device)
+    buf = torch.empty(capacity, dtype=torch.uint8, device=device)
+    hdr = torch.full((_HDR_INTS,), -1, dtype=torch.int64)
     if r == src:
+        parts = []
+        n_float = 0
         for i, k in enumerate(BUNDLE_KEYS):
             t = bundle.get(k) if bundle else None
-            if t is not None:
-                assert t.dim() <= 4
-                hdr[i, 0] = t.dim()
-                for d, s in enumerate(t.shape):
-                    hdr[i, 1 + d] = s
-    dist.broadcast(hdr, src)
+            if t is None:
+                continue
+            assert t.dim() <= 4
+            hdr[5 * i] = t.dim()
+            for d, s_ in enumerate(t.shape):
+                hdr[5 * i + 1 + d] = s_
+            parts.append(t.detach().to(device=device, dtype=torch.float32).reshape(-1))
+            n_float += t.numel()
+        hdr[-1] = n_float
+        if _HDR_BYTES + 4 * n_float > capacity:
+            hdr[-1] = -2                                             # every rank raises instead of deadlocking on a short buffer
+        else:
+            buf[_HDR_BYTES:_HDR_BYTES + 4 * n_float].view(torch.float32).copy_(torch.cat(parts) if parts else torch.empty(0, device=device))
+        buf[: _HDR_INTS * 8].view(torch.int64).copy_(hdr)
+    dist.broadcast(buf, src)
+    hdr = buf[: _HDR_INTS * 8].view(torch.int64).cpu()
+    if int(hdr[-1]) == -2:
+        raise ValueError(f"broadcast_speaker_bundle: the bundle does not fit the {capacity}-byte buffer (pass a larger `capacity` on every rank)")
+    payload = buf[_HDR_BYTES:_HDR_BYTES + 4 * int(hdr[-1])].view(torch.float32)
     out: Dict[str, torch.Tensor] = {}
+    at = 0
     for i, k in enumerate(BUNDLE_KEYS):
-        nd = int(hdr[i, 0])
+        nd = int(hdr[5 * i])
         if nd < 0:
             continue
-        shape = [int(x) for x in hdr[i, 1:1 + nd]]
-        if r == src:
-            t = bundle[k].to(device=device, dtype=torch.float32).contiguous()
-        else:
-            t = torch.empty(shape, dtype=torch.float32, device=device)
-        dist.broadcast(t, src)
-        out[k] = t
+        shape = [int(x) for x in hdr[5 * i + 1:5 * i + 1 + nd]]
+        n = 1
+        for s_ in shape:
+            n *= s_
+        out[k] = payload[at:at + n].view(shape)
+        at += n
     return out
 
 
 def gather_waveforms(wavs: List[torch.Tensor], indices: List[int], n_utts: int, dst: int = 0):
     """Collect per-utterance int16 waveforms on `dst` in utterance order (44 KB per audio-second)."""
-    if world() == 1:
+    if not _group_active():
         return [w for _, w in sorted(zip(indices, wavs))]
     payload = [(int(i), w.detach().to("cpu", torch.int16)) for i, w in zip(indices, wavs)]
     gathered = [None] * world() if rank() == dst else None
@@ -94,26 +120,26 @@ def gather_waveforms(wavs: List[torch.Tensor], indices: List[int], n_utts: int, 
     return out
 
 
-def gather_waveform_tensor(wav: torch.Tensor, indices: Sequence[int], n_utts: int, dst: int = 0) -> Optional[torch.Tensor]:
+def gather_waveform_tensor(wav: torch.Tensor, indices: Sequence[int], n_utts: int, dst: int = 0,
+                           shards: Optional[Sequence[Sequence[int]]] = None) -> Optional[torch.Tensor]:
     """Tensor form of `gather_waveforms` for equal-length rows: every rank hands its (n_local, T) int16 block (device tensor
     for RCCL, CPU tensor for gloo) to `dst`, which returns the (n_utts, T) batch in utterance order.  One `gather` of
     44 KB per audio-second -- the only collective after the speaker-bundle broadcast, and like it outside the decode loop.
-    Ranks may own different numbers of rows (blocks are padded to the largest shard; shard sizes follow from
-    `shard_utterances`, so no size exchange is needed when `counts` is deterministic -- they are exchanged here once as a
-    small int tensor to keep the function self-contained)."""
-    w = world()
-    if w == 1:
+    Ranks may own different numbers of rows (blocks are padded to the largest shard).  `shards[r]` = the utterance indices of rank r:
+    `shard_utterances` is deterministic, so every rank computes the same table and nothing but the waveforms crosses the wire
+    (default: the `rank::world` split).  Runs whenever a process group exists (world size 1 included)."""
+    if not _group_active():
         out = torch.empty((n_utts,) + tuple(wav.shape[1:]), dtype=wav.dtype, device=wav.device)
         out[torch.as_tensor(list(indices), dtype=torch.long, device=wav.device)] = wav
         return out
+    w = world()
     dev = wav.device
     r = rank()
-    meta = torch.full((n_utts + 1,), -1, dtype=torch.int64, device=dev)
-    meta[0] = len(indices)
-    meta[1:1 + len(indices)] = torch.as_tensor(list(indices), dtype=torch.int64, device=dev)
-    metas = [torch.empty_like(meta) for _ in range(w)]
-    dist.all_gather(metas, meta)
-    cmax = max(int(m[0]) for m in metas)
+    if shards is None:
+        shards = [shard_utterances(n_utts, k, w) for k in range(w)]
+    if list(shards[r]) != list(indices) or wav.shape[0] != len(indices):
+        raise ValueError("gather_waveform_tensor: `indices` / the block's rows do not match this rank's entry of `shards`")
+    cmax = max(len(sh) for sh in shards)
     block = torch.zeros((cmax,) + tuple(wav.shape[1:]), dtype=wav.dtype, device=dev)
     block[: wav.shape[0]] = wav
     # bytes on the wire: neither RCCL nor gloo carries int16
@@ -122,10 +148,8 @@ def gather_waveform_tensor(wav: torch.Tensor, indices: Sequence[int], n_utts: in
     dist.gather(wire, parts_b, dst=dst)
     if r != dst:
         return None
-    parts = [p.view(wav.dtype) for p in parts_b]
     out = torch.empty((n_utts,) + tuple(wav.shape[1:]), dtype=wav.dtype, device=dev)
-    for m, part in zip(metas, parts):
-        c = int(m[0])
-        if c:
-            out[m[1:1 + c].to(torch.long)] = part[:c]
+    for sh, part in zip(shards, parts_b):
+        if len(sh):
+            out[torch.as_tensor(list(sh), dtype=torch.long, device=dev)] = part.view(wav.dtype)[: len(sh)]
     return out

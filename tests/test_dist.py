@@ -39,6 +39,21 @@ def _worker(rank, world, port, q):
         ok_gather = None
         if rank == 0:
             ok_gather = all(all_w[i] is not None and all_w[i].numel() == 10 + i and int(all_w[i][0]) == i for i in range(n))
+        # tensor gather with the deterministic LPT shard table (uneven shares: 6 and 5 rows) -- nothing but the blocks crosses the wire
+        shards = [D.shard_utterances(n, r, world, lengths=lengths) for r in range(world)]
+        block = torch.stack([torch.full((7,), 100 + i, dtype=torch.int16) for i in mine])
+        full = D.gather_waveform_tensor(block, mine, n, dst=0, shards=shards)
+        if rank == 0:
+            ok_gather = ok_gather and full.shape == (n, 7) and [int(v) for v in full[:, 0]] == [100 + i for i in range(n)]
+        else:
+            assert full is None
+        # a bundle larger than the flat buffer: every rank raises (no rank is left waiting in a collective)
+        try:
+            D.broadcast_speaker_bundle({"style": torch.zeros(1, 4096)} if rank == 0 else None, src=0, capacity=8192)
+            overflow = False
+        except ValueError:
+            overflow = True
+        assert overflow
         q.put((rank, mine, plain, checksum, sorted(got.keys()), ok_gather,
                sum(lengths[i] for i in mine)))
     finally:

@@ -23,6 +23,10 @@ def test_option_table_roundtrip_and_validation():
         _lib.set_option("no_such_option", 1)
     with pytest.raises(_lib.HipEngineError):
         _lib.set_option("x3_products", 99)
+    # discrete sets: values inside the range that no launcher instantiates are refused (they used to be mapped differently by different launchers)
+    for name, bad in (("x3_products", 7), ("decode_nt", 3), ("fa_qs", 3), ("conv_bm", 48), ("attn_waves", 5), ("decode_ln_nt", 3)):
+        with pytest.raises(_lib.HipEngineError):
+            _lib.set_option(name, bad)
     with _lib.option_scope(tile256=2, fa32_qs=1):
         assert _lib.get_option("tile256") == 2 and _lib.get_option("fa32_qs") == 1
     assert _lib.get_option("tile256") == -1 and _lib.get_option("fa32_qs") == 2
