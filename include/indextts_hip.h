@@ -59,6 +59,7 @@ int itts_device_count(void);
  *   x3_split             1     0..1    fp32x3 GEMM: operand split on scalar v_sub_f32 (1) or the SLP-packed form (0)
  *   x3_aplanes           0     0..1    fp32x3 s2mel: adaptive-norm outputs as bf16 planes, wqkv / w1|w3 GEMMs without an operand split
  *   x3_pin               1     0..1    fp32x3 GEMM: the variants that are not the shipped one pinned to one block per CU (0: diagnostic, two blocks)
+ *   prefill_attn        -1    -1..1    GPT attention of S > 1 passes: -1 causal MFMA kernel (bf16 mode) / canonical streams (f32 mode), 0 canonical, 1 MFMA
  * itts_option_count / _name / _doc / _default enumerate the table (index 0 .. count-1).
  * ---------------------------------------------------------------------------------------------------------- */
 int itts_set_option(const char* name, int value);      /* ITTS_ERR_ARG: unknown name or value out of range */

@@ -673,6 +673,27 @@ __device__ __forceinline__ void pf_stage_meta(const GemmArgs& a, int* meta, int 
     }
 }
 
+// RoPE of two adjacent (even, odd) pairs: y = (v0 c0 - v1 s0, v1 c0 + v0 s0, v2 c1 - v3 s1, v3 c1 + v2 s1), cs = (c0, s0, c1, s1), each component one
+// product rounded and one fma -- bit for bit what hipcc's contraction made of the plain expression.  The products pass through an opaque register
+// barrier so that the SLP vectoriser (this file is built with it) cannot fuse the four components into v_pk_mul_f32 / v_pk_fma_f32 with op_sel
+// operand selection: that packed form -- an IN-PLACE `v_pk_mul_f32 v[n:n+1], v[n:n+1], ... op_sel:[0,1] op_sel_hi:[0,0]` whose low source register
+// feeds both halves, followed by the v_pk_fma_f32 that subtracts its low result -- is where the run-to-run differences of the fused wqkv epilogue
+// came from: in a solve of 13 layers about one quarter-wave (16 lanes, all of one K / Q row) per two calls stored v2 c1 instead of v2 c1 - v3 s1 in
+// exactly the component that in-place product feeds, only while a second block shared the CU (profiles/r05a/capture.log).
+__device__ __forceinline__ f32x4 pf_rope4(const f32x4 v, const f32x4 cs) {
+    float t0 = v[1] * cs[1], t1 = v[1] * cs[0], t2 = v[3] * cs[3], t3 = v[3] * cs[2];
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+    float y0 = __builtin_fmaf(v[0], cs[0], -t0);
+    asm volatile("" : "+v"(y0));
+    float y1 = __builtin_fmaf(v[0], cs[1], t1);
+    asm volatile("" : "+v"(y1));
+    float y2 = __builtin_fmaf(v[2], cs[2], -t2);
+    asm volatile("" : "+v"(y2));
+    float y3 = __builtin_fmaf(v[2], cs[3], t3);
+    asm volatile("" : "+v"(y3));
+    return f32x4{y0, y1, y2, y3};
+}
+
 template <int EPI, int ROWS, int NT, bool F32 = false>            // ROWS x 128 columns of the tile, stored by NT threads (tid < NT)
 __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct, const int* meta, int m0, int n0, int tid) {
     constexpr bool PAIR = (EPI == EPI_SWIGLU || EPI == EPI_GATE);
@@ -772,7 +793,7 @@ __device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct
                 const int sq = meta[row], t = meta[ROWS + row];
                 if (which < 2) {
                     const f32x4 cs = *(const f32x4*)(a.rope + ((size_t)t * 32 + (d >> 1)) * 2);       // (cos, sin) of pairs d/2, d/2 + 1
-                    const f32x4 y{v[0] * cs[0] - v[1] * cs[1], v[1] * cs[0] + v[0] * cs[1], v[2] * cs[2] - v[3] * cs[3], v[3] * cs[2] + v[2] * cs[3]};
+                    const f32x4 y = pf_rope4(v, cs);
                     if (which == 0) pf_store_act4<F32>(a.out_act, (size_t)m * a.D + c, y);
                     else if (F32 && a.kv_planes) pf_store_planes4(a.kcache, a.kv_planes, (((size_t)sq * a.H + hd) * a.Tmax + t) * 64 + d, y);
                     else pf_store_act4<F32>(a.kcache, (((size_t)sq * a.H + hd) * a.Tmax + t) * 64 + d, y);
@@ -2816,6 +2837,210 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs a) {
     }
 }
 
+// ================================================================================================================
+// Causal attention of MANY queries per sequence against the KV cache on the matrix pipe (prefill, the teacher-forced latent pass, any S > 1 pass
+// without a beam row map): one block = (sequence, head, 64 consecutive queries), wave w = 16 of them, flash-style online softmax over 64-key tiles.
+// The reference's counterpart is flash_attn_varlen_func (accel/attention.py:132-141) / the eager causal attention of transformers_gpt2.py:591-667.
+//   S^T = K Q^T (keys as MFMA rows): a lane then owns 4 keys x 1 query, so the per-query maximum / sum is a reduction over its own registers and two
+//   shuffles, and P^T leaves the accumulators already in B-operand order for O^T = V^T P^T.  K fragments come straight from the cache rows (16-byte
+//   pieces of a key's 64 dims); V is staged per tile into LDS transposed ([d][key]) so that a V^T fragment is two 8-byte reads.  Nothing but the
+//   attention output is written: K / V are in the cache from the wqkv epilogue.  Left padding: keys pad[b] .. pos0 + qi, exactly as attn_kernel;
+//   a query left of its sequence's first key (a pad position) gets 0, as there.
+//   BF16 (cache bf16): v_mfma_f32_16x16x32_bf16.  The f32 queries (scaled by 1/8, exact) and the probabilities are carried as bf16 hi + lo pairs -- two
+//   MFMAs each, 16 significant bits -- so the only rounding that differs from attn_kernel's f32 FMAs is the accumulation order.
+//   F32 (cache f32, the parity mode): v_mfma_f32_16x16x4_f32 on exact f32 operands; V through LDS row-major.
+// ================================================================================================================
+#define APF_VROW 68          // bf16 V^T image: [64 d][68] (64 keys + 4 pad: 136-byte rows, 8-byte aligned fragment reads)
+#define APF_VROW32 65        // f32 V image: [64 keys][65]
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char vsm[BF16 ? 64 * APF_VROW * 2 : 64 * APF_VROW32 * 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int sm = a.seq_mul > 1 ? a.seq_mul : 1;
+    const int pb = a.seq_map ? a.seq_map[b] : b * sm;
+    const int first = a.pad ? a.pad[pb] : 0;
+    const int pos0 = *a.pos_ptr;
+    const int qb0 = blockIdx.y * 64;                                  // first query of the block
+    const int q_hi_blk = (qb0 + 63 < a.nq ? qb0 + 63 : a.nq - 1);
+    const int kmax_blk = pos0 + q_hi_blk;                             // last key any query of the block sees (a written cache row)
+    const int qw0 = qb0 + w * 16;
+    const int kmax_w = pos0 + (qw0 + 15 < a.nq ? qw0 + 15 : a.nq - 1);
+    const bool wave_on = qw0 < a.nq;
+    const int qi = qw0 + c16;
+    const bool q_ok = qi < a.nq;
+    const int last_q = pos0 + qi;
+    const size_t qrow = (size_t)b * a.nq + (q_ok ? qi : a.nq - 1);
+    const size_t head_base = ((size_t)pb * a.H + h) * a.Tmax;        // cache row index of key 0 of this (sequence, head)
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the query operand: lane (query c16, k-group g)
+    v4u qh[2], ql[2];
+    f32x4 q4[4];
+    if constexpr (BF16) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* qp = a.qbuf + qrow * a.D + h * 64 + 32 * ks + 8 * g;
+            const f32x4 x0 = *(const f32x4*)qp, x1 = *(const f32x4*)(qp + 4);
+            const float x[8] = {x0[0] * 0.125f, x0[1] * 0.125f, x0[2] * 0.125f, x0[3] * 0.125f, x1[0] * 0.125f, x1[1] * 0.125f, x1[2] * 0.125f, x1[3] * 0.125f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t hi = pf_cvt2(x[2 * i], x[2 * i + 1]);
+                qh[ks][i] = hi;
+                ql[ks][i] = pf_cvt2(x[2 * i] - __uint_as_float(hi << 16), x[2 * i + 1] - __uint_as_float(hi & 0xffff0000u));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            q4[c] = *(const f32x4*)(a.qbuf + qrow * a.D + h * 64 + 16 * c + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q4[c][i] *= 0.125f;
+        }
+    }
+
+    for (int t0 = first; t0 <= kmax_blk; t0 += 64) {
+        __syncthreads();                                              // the previous tile's V image has been read by every wave
+        // ---- stage V of keys t0 .. t0 + 63 (rows past the block's last key are clamped: finite data, weight 0) ----
+        if constexpr (BF16) {
+            u16* vt = (u16*)vsm;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int key = p * 32 + (threadIdx.x >> 3), dg = threadIdx.x & 7;
+                int t = t0 + key;
+                t = t < kmax_blk ? t : kmax_blk;
+                const v4u raw = *(const v4u*)((const u16*)a.vcache + (head_base + t) * 64 + dg * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vt[(dg * 8 + 2 * i) * APF_VROW + key] = (u16)(raw[i] & 0xffffu);
+                    vt[(dg * 8 + 2 * i + 1) * APF_VROW + key] = (u16)(raw[i] >> 16);
+                }
+            }
+        } else {
+            float* v32 = (float*)vsm;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int key = p * 16 + (threadIdx.x >> 4), dq = threadIdx.x & 15;
+                int t = t0 + key;
+                t = t < kmax_blk ? t : kmax_blk;
+                const f32x4 raw = *(const f32x4*)((const float*)a.vcache + (head_base + t) * 64 + dq * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v32[key * APF_VROW32 + dq * 4 + i] = raw[i];
+            }
+        }
+        const bool tile_on = wave_on && t0 <= kmax_w;                 // wave-uniform
+        f32x4 st[4];
+        float sc = 1.f;
+        if (tile_on) {
+            // ---- S^T = K Q^T for the four 16-key tiles ----
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                int t = t0 + 16 * kt + c16;
+                t = t < kmax_blk ? t : kmax_blk;
+                if constexpr (BF16) {
+                    const u16* kp = (const u16*)a.kcache + (head_base + t) * 64 + 8 * g;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const v4u ka = *(const v4u*)(kp + 32 * ks);
+                        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka), __builtin_bit_cast(bf16x8_t, ql[ks]), st[kt], 0, 0, 0);
+                        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ka), __builtin_bit_cast(bf16x8_t, qh[ks]), st[kt], 0, 0, 0);
+                    }
+                } else {
+                    const float* kp = (const float*)a.kcache + (head_base + t) * 64 + 4 * g;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x4 k4 = *(const f32x4*)(kp + 16 * c);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[i], q4[c][i], st[kt], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- mask, online softmax per query column ----
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = t0 + 16 * kt + 4 * g + r;
+                    const bool ok = q_ok && t >= first && t <= last_q;
+                    st[kt][r] = ok ? st[kt][r] : -INFINITY;
+                    mx = fmaxf(mx, st[kt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float nm = fmaxf(m_run, mx);
+            const float mu = nm == -INFINITY ? 0.f : nm;               // a column with no key yet: every exponent below is exp(-inf) = 0
+            sc = exp_sel<BF16>(m_run - mu);
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[kt][r] = exp_sel<BF16>(st[kt][r] - mu); ps += st[kt][r]; }
+            l_run = l_run * sc + ps;                                   // this lane's keys only; the lane groups are added at the end
+            m_run = nm;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[dt][r] *= sc;
+        }
+        __syncthreads();                                              // the V image is complete
+        if (tile_on) {
+            // ---- O^T += V^T P^T ----
+            if constexpr (BF16) {
+                const u16* vt = (const u16*)vsm;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    v4u ph, pl;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4& s = st[2 * jp + (i >> 1)];
+                        const float x0 = s[2 * (i & 1)], x1 = s[2 * (i & 1) + 1];
+                        const uint32_t hi = pf_cvt2(x0, x1);
+                        ph[i] = hi;
+                        pl[i] = pf_cvt2(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const u16* vp = vt + (16 * dt + c16) * APF_VROW + 32 * jp + 4 * g;
+                        const v2u_t lo2 = *(const v2u_t*)vp, hi2 = *(const v2u_t*)(vp + 16);
+                        const v4u va{lo2.x, lo2.y, hi2.x, hi2.y};
+                        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va), __builtin_bit_cast(bf16x8_t, pl), acc[dt], 0, 0, 0);
+                        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va), __builtin_bit_cast(bf16x8_t, ph), acc[dt], 0, 0, 0);
+                    }
+                }
+            } else {
+                const float* v32 = (const float*)vsm;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+                            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v32[(16 * kt + 4 * g + r) * APF_VROW32 + 16 * dt + c16], st[kt][r], acc[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (!q_ok) return;
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    const size_t oo = qrow * a.D + h * 64 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const f32x4 o{acc[dt][0] * inv, acc[dt][1] * inv, acc[dt][2] * inv, acc[dt][3] * inv};
+        if constexpr (BF16) *(v2u_t*)((u16*)a.out + oo + 16 * dt) = v2u_t{(uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16),
+                                                                         (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16)};
+        else *(f32x4*)((float*)a.out + oo + 16 * dt) = o;
+    }
+}
+
 template <bool BF16, int NW>
 static void launch_attention_nw(const AttnArgs& a, dim3 grid, hipStream_t st) {
     if (a.row_map) hipLaunchKernelGGL((attn_kernel<BF16, NW, true>), grid, dim3(NW * 64), 0, st, a);
@@ -2826,6 +3051,16 @@ int launch_attention(const AttnArgs& a, int prec, hipStream_t st) {
     if (a.nseq <= 0 || a.nq <= 0) return ITTS_OK;
     if (a.D != a.H * 64) { itts_set_error("attention: head_dim must be 64 (D=%d H=%d)", a.D, a.H); return ITTS_ERR_ARG; }
     if (a.nq > 65535) { itts_set_error("attention: more than 65535 queries per sequence"); return ITTS_ERR_ARG; }
+    // S > 1 passes without a beam row map: the causal MFMA kernel (option prefill_attn: -1 = the bf16 mode only -- the f32 parity mode keeps the
+    // canonical-stream kernel, whose arithmetic is bit-identical between a prefill and the decode steps that follow it --, 0 never, 1 both precisions)
+    const int pa = itts_opt(OPT_PREFILL_ATTN);
+    if (a.nq > 1 && !a.row_map && (pa == 1 || (pa < 0 && prec == PREC_BF16)) && (a.D % 4) == 0) {
+        dim3 gridp(a.nseq * a.H, (a.nq + 63) / 64);
+        if (prec == PREC_BF16) hipLaunchKernelGGL((attn_prefill_mfma_kernel<true>), gridp, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attn_prefill_mfma_kernel<false>), gridp, dim3(256), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        return ITTS_OK;
+    }
     dim3 grid(a.nseq * a.H, a.nq);
     // waves per block (option attn_waves forces 4 / 8 / 16; every choice gives the same bits).  Measured (profiles/r04a/decode_bench.log,
     // ms per token at 560 tokens, 16 / 8 / 4 waves): 1 row 0.776 / 0.789 / 0.846, 8 rows 1.056 / 1.065 / 1.117, 16 rows 1.376 / 1.331 / 1.356,

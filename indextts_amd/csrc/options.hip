@@ -43,6 +43,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"x3_split", 1, 0, 1, "fp32x3 GEMM (6 products): operand split on scalar v_sub_f32 (1, measured +2.5 % on the GEMMs) instead of the SLP-packed v_pk_add_f32 form (0); bitwise equal"},
     {"x3_aplanes", 0, 0, 1, "fp32x3 s2mel: the adaptive-RMSNorm outputs as three bf16 planes in fragment order, wqkv / w1|w3 GEMMs without an operand split (bitwise equal)"},
     {"x3_pin", 1, 0, 1, "fp32x3 GEMM: pin the variants that are not the shipped one (8 products, burst split) to one block per CU (0: two blocks per CU -- diagnostic only, those variants are not bit-stable run to run there, DESIGN.md section 9)"},
+    {"prefill_attn", -1, -1, 1, "attention of S > 1 passes (prefill, latent pass): -1 causal MFMA kernel in the bf16 mode, canonical-stream kernel in the f32 parity mode; 0 canonical-stream kernel (one block per query) always; 1 MFMA kernel in both precisions"},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::atomic<unsigned> g_epoch{1};

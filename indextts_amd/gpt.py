@@ -210,8 +210,7 @@ class UnifiedVoice:
     def conds_latent(self, campplus_embedding: torch.Tensor, emo_vec: torch.Tensor) -> torch.Tensor:
         """spk_emb_proj(style) + emo_vec, then two zero tokens (model_v2.py:754-755,768)."""
         dev = self.device
-        spk = F.linear(campplus_embedding.to(dev, torch.float32), self._emb["spk_emb_proj.weight"],
-                       self._emb["spk_emb_proj.bias"])
+        spk = linear_f32(campplus_embedding.to(dev, torch.float32), self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
         spk = spk.unsqueeze(0) if spk.ndim != 3 else spk
         emo_vec = emo_vec.to(dev, torch.float32)
         return torch.cat((spk + emo_vec.unsqueeze(1), torch.zeros(spk.size(0), 2, spk.size(2), device=dev)), 1), spk
@@ -649,7 +648,7 @@ class UnifiedVoice:
             conds = torch.cat((spk + emo_vec.to(dev, torch.float32).unsqueeze(1), half.unsqueeze(1), dur.unsqueeze(1)), 1)
             return self.forward_latent(conds, text_inputs, text_lengths, mel_codes, mel_codes_lengths)
         if do_spk_cond:
-            spk = F.linear(spk, self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
+            spk = linear_f32(spk, self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
             if spk.ndim != 3:
                 spk = spk.unsqueeze(1)
         conds = torch.cat((spk + emo_vec.to(dev, torch.float32).unsqueeze(1),
@@ -749,6 +748,27 @@ def gemm(a: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], 
                                                 M, N, K, precision, int(prefill_tiles), 0, _lib.stream_ptr(a.device)),
                    "itts_gemm_forward")
         return out
+
+
+_LINEAR_PACKED: dict = {}
+
+
+def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """`F.linear(x, weight, bias)` on the engine's exact-f32 MFMA GEMM (`itts_gemm_forward`, precision 0) -- the small host-side projections of the
+    hot path (speaker-embedding projection, the flow-matching decoder's per-step conditioning vectors) run on the same hand-written kernels as
+    everything else instead of a vendor BLAS call.  The packed weight is cached per weight tensor; K must be a multiple of 16."""
+    N, K = weight.shape
+    if K % 16:
+        raise _lib.HipEngineError(f"linear_f32: K = {K} is not a multiple of 16")
+    key = (weight.data_ptr(), N, K, str(x.device))
+    hit = _LINEAR_PACKED.get(key)
+    if hit is None:                                                # (the entry keeps the tensor alive, so its address cannot be reused by another weight)
+        hit = (weight, pack_gemm_weight(weight, 0, transposed=True).to(x.device))
+        _LINEAR_PACKED[key] = hit
+    lead = x.shape[:-1]
+    a = x.reshape(-1, K).to(torch.float32).contiguous()
+    out = gemm(a, hit[1], None if bias is None else bias.to(x.device, torch.float32).contiguous(), N, 0)
+    return out.reshape(*lead, N)
 
 
 def gemm_ln(x, g, b, w_packed, bias, N: int, partial=None, bias_prev=None, eps=1e-5):

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from . import _lib
 from .bigvgan import fold_weight_norm
 from .gpt import gemm as engine_gemm
-from .gpt import pack_gemm_weight
+from .gpt import linear_f32, pack_gemm_weight
 
 
 def _get(obj, *path, default=None):
@@ -160,8 +160,8 @@ class CFM:
         p = self._p
         args = 1000 * t[:, None].float() * p[prefix + "freqs"][None]
         emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
-        h = F.silu(F.linear(emb, p[prefix + "mlp.0.weight"], p[prefix + "mlp.0.bias"]))
-        return F.linear(h, p[prefix + "mlp.2.weight"], p[prefix + "mlp.2.bias"])
+        h = F.silu(linear_f32(emb, p[prefix + "mlp.0.weight"], p[prefix + "mlp.0.bias"]))
+        return linear_f32(h, p[prefix + "mlp.2.weight"], p[prefix + "mlp.2.bias"])
 
     def _mods(self, t: torch.Tensor) -> torch.Tensor:
         """t (n_steps,) -> (n_steps, mods_per_step) in the order itts_s2mel_mods_per_step documents."""
@@ -172,11 +172,11 @@ class CFM:
         for i in range(self.depth):
             L = f"transformer.layers.{i}."
             for nm in ("attention_norm.", "ffn_norm."):
-                parts.append(F.linear(t1, p[L + nm + "project_layer.weight"], p[L + nm + "project_layer.bias"]))
-        parts.append(F.linear(t1, p["transformer.norm.project_layer.weight"], p["transformer.norm.project_layer.bias"]))
+                parts.append(linear_f32(t1, p[L + nm + "project_layer.weight"], p[L + nm + "project_layer.bias"]))
+        parts.append(linear_f32(t1, p["transformer.norm.project_layer.weight"], p["transformer.norm.project_layer.bias"]))
         wc = p["wavenet.cond_layer.conv.conv.weight"]
-        parts.append(F.linear(t2, wc.reshape(wc.shape[0], -1), p["wavenet.cond_layer.conv.conv.bias"]))
-        parts.append(F.linear(F.silu(t1), p["final_layer.adaLN_modulation.1.weight"], p["final_layer.adaLN_modulation.1.bias"]))
+        parts.append(linear_f32(t2, wc.reshape(wc.shape[0], -1), p["wavenet.cond_layer.conv.conv.bias"]))
+        parts.append(linear_f32(F.silu(t1), p["final_layer.adaLN_modulation.1.weight"], p["final_layer.adaLN_modulation.1.bias"]))
         out = torch.cat(parts, dim=-1).contiguous()
         assert out.shape[1] == _lib.lib().itts_s2mel_mods_per_step(self._h), out.shape
         return out

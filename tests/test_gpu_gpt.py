@@ -182,6 +182,46 @@ def test_attention_geometries_agree_f32(golden_dir):
     assert float(outs[0][0].abs().mean()) > 1e-3
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_prefill_mfma_attention_vs_canonical_streams(golden_dir, prec):
+    """attn_prefill_mfma_kernel (causal flash attention of S > 1 passes on the matrix pipe: v_mfma_f32_16x16x4_f32 in the f32 engine, bf16 MFMAs with
+    hi + lo query / probability operands in the bf16 engine) against attn_kernel (one block per query, canonical key streams; option prefill_attn = 0):
+    teacher-forced latents of the reference-minted fixture (f32: to accumulation-order noise; bf16: inside one bf16 step of the hidden state), and, f32,
+    the greedy ids of a RAGGED batch (left-padded prefill, pad[b] > 0) with the KV cache and without it -- then every step is an S > 1 pass."""
+    from indextts_amd import _lib
+    z = np.load(os.path.join(golden_dir, "gpt_latent.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]),
+                      max_mel_tokens=int(c[4]), number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))
+    sd["mel_head.bias"][cfg.stop_mel_token] -= 1e4
+    m = engine(cfg, sd, prec)
+    B = z["text"].shape[0]
+    style, emo = torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"])
+    conds, _ = m.conds_latent(style, emo)
+    text, tl = torch.from_numpy(z["text"]), torch.from_numpy(z["text_lens"])
+    assert int(tl.min()) < int(tl.max())                        # ragged: the prefill is left-padded
+    outs = {}
+    for pa in (0, 1):
+        with _lib.option_scope(prefill_attn=pa):
+            lat = m.forward_latent(conds.repeat(B, 1, 1), text, tl, torch.from_numpy(z["mel_codes"]), torch.from_numpy(z["mel_lens"])).cpu()
+            ids = {}
+            for kv in (True, False):
+                m.post_init_gpt2_config(kv_cache=kv)
+                ids[kv], _ = m.inference_speech(None, text, langs=torch.full((B,), 1), emo_vec=emo, campplus_embedding=style, max_generate_length=24,
+                                                do_sample=False, num_beams=1, repetition_penalty=10.0)
+            m.post_init_gpt2_config(kv_cache=True)
+        outs[pa] = (lat, {k: v.cpu() for k, v in ids.items()})
+    lat0, lat1 = outs[0][0], outs[1][0]
+    rel = float((lat1 - lat0).pow(2).mean().sqrt() / lat0.pow(2).mean().sqrt())
+    print(f"prefill MFMA attention vs canonical streams ({prec}): latent rms difference {rel:.3e} of the latent rms")
+    assert torch.isfinite(lat1).all() and float(lat0.abs().mean()) > 1e-3
+    assert rel < (2e-6 if prec == "fp32" else 1.5e-2), rel
+    if prec == "fp32":                                          # (cached and uncached decoding run different GEMM kernels: each is compared with itself)
+        for kv in (True, False):
+            assert torch.equal(outs[1][1][kv], outs[0][1][kv]), kv
+
+
 def run_case(m, z, cfg, sd):
     g = z["gen"]
     kw = dict(do_sample=bool(g[0]), num_beams=int(g[1]), top_p=float(g[2]), top_k=int(g[3]), temperature=float(g[4]),

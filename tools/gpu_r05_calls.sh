@@ -1,0 +1,53 @@
+#!/bin/bash
+# The exact command lists of round 5's GPU sessions (each ran on an MI355X box through gpurun; outputs under gpurun_out/, the summaries that are
+# evidence were copied to profiles/r05*).  usage: tools/gpu_r05_calls.sh <n>      e.g.  gpurun --timeout 1200 -- 'bash tools/gpu_r05_calls.sh 1'
+set -u
+cd "$(dirname "$0")/.."
+ROOT=$PWD
+
+# round 5, GPU call 1: (a) may a VALU op overwrite the A / B operand of the MFMA issued just before it (the x3 GEMM's 8-product variant has that
+# pattern)?  (b) x3 GEMM design space: ablations of the product structure, ring of three, 64-deep K per barrier, 256 x 128 block, W through LDS;
+# (c) the RCCL path at world size 1 (test + one bench step through the collectives); (d) WHAT differs in the not-bit-stable forms (stage images).
+call1() {
+    O=$PWD/gpurun_out/r05a
+    mkdir -p $O
+    timeout 200 tools/microbench/bin/mfma_war_hazard > $O/mfma_war_hazard.log 2>&1; echo "war_hazard rc=$?" | tee $O/status.txt
+    grep -v " 0 of " $O/mfma_war_hazard.log | head -20; echo "(lines with 0 differences: $(grep -c ' 0 of ' $O/mfma_war_hazard.log))"
+    timeout 400 tools/microbench/bin/x3_gemm_lab > $O/x3_gemm_lab.log 2>&1; echo "x3_gemm_lab rc=$?" | tee -a $O/status.txt
+    cat $O/x3_gemm_lab.log
+    timeout 300 python -m pytest tests/test_gpu_dist.py -x -q > $O/pytest_dist.log 2>&1; echo "pytest dist rc=$?" | tee -a $O/status.txt; tail -3 $O/pytest_dist.log
+    ITTS_BENCH_FORCE_DIST=1 timeout 400 python bench.py --steps 1 --warmup 1 --alt-steps 0 --no-configs --no-shards --no-cpu-baseline --no-extras > $O/bench_force_dist.json 2> $O/bench_force_dist.err; echo "bench force_dist rc=$?" | tee -a $O/status.txt
+    python - <<'PY'
+import json
+try:
+    j = json.loads(open("gpurun_out/r05a/bench_force_dist.json").read().strip().splitlines()[-1])
+    print("bench (FORCE_DIST):", j["value"], j["unit"], "ms/step", j["ms_per_step"])
+except Exception as e:
+    print("bench parse failed", e)
+PY
+    tail -3 $O/bench_force_dist.err
+    timeout 500 python tools/s2mel_capture.py 2 517 1926 12 bf16:s2mel_fused=2 fp32x3:x3_attn=0,x3_products=8,x3_pin=0 > $O/capture.log 2>&1; echo "capture rc=$?" | tee -a $O/status.txt
+    head -120 $O/capture.log
+}
+
+# round 5, GPU call 2: (a) the epilogue's SLP-packed RoPE sequence verbatim beside a busy neighbour block (in-place v_pk_mul_f32 vs a separate
+# destination); (b) the formerly unstable forms with the RoPE on scalar fmas: 24 stage traces each; (c) the causal MFMA prefill attention: GPT tests,
+# prefill time at 64 rows; (d) x3 GEMM lab, second round (scalar addressing, tile-group sizes, W-through-LDS ablations); (e) s2mel / x3 GEMM tests.
+call2() {
+    O=$PWD/gpurun_out/r05b
+    mkdir -p $O
+    timeout 300 tools/microbench/bin/pk_inplace_hazard > $O/pk_inplace_hazard.log 2>&1; echo "pk_inplace rc=$?" | tee $O/status.txt
+    cat $O/pk_inplace_hazard.log
+    timeout 900 python tools/s2mel_trace.py 2 517 1926 24 bf16:s2mel_fused=2 fp32x3:x3_attn=0,x3_products=8,x3_pin=0 fp32x3:x3_attn=0,x3_products=8,x3_sched=0,x3_pin=0 fp32x3:x3_attn=0,x3_sched=0,x3_pin=0 fp32x3:x3_products=8,x3_pin=0 fp32x3 > $O/trace.log 2>&1; echo "trace rc=$?" | tee -a $O/status.txt
+    grep -E "repetitions agree|histogram" $O/trace.log
+    timeout 400 tools/microbench/bin/x3_gemm_lab > $O/x3_gemm_lab2.log 2>&1; echo "x3_gemm_lab rc=$?" | tee -a $O/status.txt
+    cat $O/x3_gemm_lab2.log
+    timeout 300 python tools/decode_bench.py 40 1,64 prefill_attn=0 > $O/prefill_bench.log 2>&1; echo "prefill bench rc=$?" | tee -a $O/status.txt
+    grep "^B=" $O/prefill_bench.log
+    timeout 1200 python -m pytest tests/test_gpu_gpt.py tests/test_gpu_edges.py tests/test_gpu_compaction.py -x -q -s > $O/pytest_gpt.log 2>&1; echo "pytest gpt rc=$?" | tee -a $O/status.txt
+    grep -E "prefill MFMA|passed|failed|Error|error" $O/pytest_gpt.log | tail -8
+    timeout 1200 python -m pytest tests/test_gpu_s2mel.py tests/test_gpu_gemm_x3.py -x -q > $O/pytest_s2mel.log 2>&1; echo "pytest s2mel rc=$?" | tee -a $O/status.txt
+    tail -4 $O/pytest_s2mel.log
+}
+
+"call$1"

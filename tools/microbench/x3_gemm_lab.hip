@@ -24,7 +24,7 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-struct Args { const float* A; const char* Wp; float* C; int M, N, K; };
+struct Args { const float* A; const char* Wp; float* C; int M, N, K; int gm; };
 
 __device__ __forceinline__ uint32_t cvt2(float a, float b) {          // (bf16(a), bf16(b)) round to nearest even, a in the low half
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
@@ -45,9 +45,16 @@ __device__ __forceinline__ void split8(const f32x4 p0, const f32x4 p1, v4u& H, v
         H[i] = h; M[i] = m; L[i] = cvt2(sa, sb);
     }
 }
+// a pointer known to be wave-uniform, pinned to SGPRs (keeps loop strength reduction from folding the lane offset into a per-lane 64-bit induction pointer)
+typedef const __attribute__((address_space(1))) char* gptr_t;
+__device__ __forceinline__ gptr_t uni(const char* p) {
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return (gptr_t)(((uint64_t)hi << 32) | lo);
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WM, int NSTAGE, int KB, bool WLDS, int ABL>
+template <int WM, int NSTAGE, int KB, bool WLDS, int ABL, bool SADDR = false>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void x3_lab(Args a) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     constexpr int NT = WM * 2, BMR = WM * 64;                       // waves, block rows
@@ -56,13 +63,16 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void x3_lab(Args a) {
     constexpr int STAGE = KB * (AS + WS);
     constexpr int WPW = 24 / NT;                                    // W pieces per wave and K tile (WLDS)
     constexpr int PA = KB * (4 + (WLDS ? WPW : 0));                 // LDS-DMA pieces per wave and group
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // SADDR: the wave index as a scalar, so that every LDS-DMA destination and every weight base is an SGPR value (no v_readfirstlane / VALU address
+    // arithmetic in the loop), and global addresses as (uniform 64-bit base) + (32-bit lane offset)
+    const int w = SADDR ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     const int wr = w >> 1, wc = w & 1;
     const int n_mt = (a.M + BMR - 1) / BMR, n_nt = a.N / 128;
     const int total = n_mt * n_nt, per = (total + 7) >> 3;
     const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (t >= total) return;
-    constexpr int GM = 8;
+    const int GM = a.gm;
     const int g0 = t / (GM * n_nt), first_m = g0 * GM;
     const int gm = (n_mt - first_m) < GM ? (n_mt - first_m) : GM;
     const int r = t - g0 * GM * n_nt;
@@ -71,6 +81,8 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void x3_lab(Args a) {
     const int nk = a.K >> 5, ng = nk / KB;
 
     const char* asrc[4];
+    uint32_t aoff[4];
+    const char* abase = (const char*)a.A + (size_t)m0 * a.K * 4;       // block-uniform
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = w * 4 + i;
@@ -79,16 +91,21 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void x3_lab(Args a) {
         int m = m0 + row_t;
         m = m < a.M ? m : a.M - 1;
         asrc[i] = (const char*)a.A + (size_t)m * a.K * 4 + piece * 16;
+        aoff[i] = (uint32_t)(m - m0) * (uint32_t)a.K * 4u + piece * 16;
     }
     const v4u* wsrc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) wsrc[nt] = (const v4u*)(a.Wp + (size_t)(nt0 + wc * 4 + nt) * nk * 3072) + lane;
+    const char* wbase[4];
+    const uint32_t lane16 = lane * 16;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wbase[nt] = a.Wp + (size_t)(nt0 + wc * 4 + nt) * nk * 3072;      // wave-uniform
     const char* wdma[WLDS ? WPW : 1];
     if constexpr (WLDS) {
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             const int q = w + NT * i;                                // piece q of the block's 24: n-tile q / 3, plane q % 3
-            wdma[i] = a.Wp + (size_t)(nt0 + q / 3) * nk * 3072 + (q % 3) * 1024 + lane * 16;
+            wdma[i] = a.Wp + (size_t)(nt0 + q / 3) * nk * 3072 + (q % 3) * 1024 + (SADDR ? 0 : lane * 16);
         }
     }
     auto issue = [&](int g, char* stage) {                           // group g (K tiles g KB .. g KB + KB - 1) -> stage
@@ -98,12 +115,12 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void x3_lab(Args a) {
             char* base = stage + s * (AS + WS);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)kt * 128),
+                __builtin_amdgcn_global_load_lds(SADDR ? (const __attribute__((address_space(1))) void*)(uni(abase + (size_t)kt * 128) + aoff[i]) : (const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)kt * 128),
                                                  (__attribute__((address_space(3))) void*)(base + (w * 4 + i) * 1024), 16, 0, 0);
             if constexpr (WLDS) {
 #pragma unroll
                 for (int i = 0; i < WPW; ++i)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wdma[i] + (size_t)kt * 3072),
+                    __builtin_amdgcn_global_load_lds(SADDR ? (const __attribute__((address_space(1))) void*)(uni(wdma[i] + (size_t)kt * 3072) + lane16) : (const __attribute__((address_space(1))) void*)(wdma[i] + (size_t)kt * 3072),
                                                      (__attribute__((address_space(3))) void*)(base + AS + (w + NT * i) * 1024), 16, 0, 0);
             }
         }
@@ -112,7 +129,10 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void x3_lab(Args a) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bw[nt][p] = wsrc[nt][((size_t)kt * 3 + p) * 64];
+            for (int p = 0; p < 3; ++p) {
+                if constexpr (SADDR) bw[nt][p] = *(const __attribute__((address_space(1))) v4u*)(uni(wbase[nt] + (size_t)kt * 3072) + lane16 + p * 1024);
+                else bw[nt][p] = wsrc[nt][((size_t)kt * 3 + p) * 64];
+            }
     };
 
     f32x4 acc[4][4];
@@ -285,14 +305,15 @@ static uint16_t bf16_rne(float f) {
 }
 static float bf16_f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <int WM, int NSTAGE, int KB, bool WLDS, int ABL>
-static double run(const Args& a, const std::vector<float>& Wh, const char* name, double base_ms = 0.0) {
+template <int WM, int NSTAGE, int KB, bool WLDS, int ABL, bool SADDR = false>
+static double run(Args a, const std::vector<float>& Wh, const char* name, double base_ms = 0.0, int gm = 8) {
+    a.gm = gm;
     constexpr int NT = WM * 2, BMR = WM * 64;
     constexpr int STAGE = KB * (BMR * 128 + (WLDS ? 24576 : 0));
     const size_t lds = std::max<size_t>((size_t)NSTAGE * STAGE, (size_t)BMR * 512);
     if ((a.K / 32) % KB) { printf("  %-44s skipped (K tiles not a multiple of KB)\n", name); return 0.0; }
     if (lds > 160 * 1024) { printf("  %-44s skipped (%zu KiB of LDS)\n", name, lds >> 10); return 0.0; }
-    auto kern = x3_lab<WM, NSTAGE, KB, WLDS, ABL>;
+    auto kern = x3_lab<WM, NSTAGE, KB, WLDS, ABL, SADDR>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int n_mt = (a.M + BMR - 1) / BMR, n_nt = a.N / 128;
     const int per = (n_mt * n_nt + 7) / 8;
@@ -371,34 +392,24 @@ int main(int argc, char** argv) {
         char* Wd;
         CK(hipMalloc(&Wd, Wp.size() * 2));
         CK(hipMemcpy(Wd, Wp.data(), Wp.size() * 2, hipMemcpyHostToDevice));
-        Args a{A, Wd, C, M, N, K};
+        Args a{A, Wd, C, M, N, K, 8};
         const double b0 = run<2, 2, 1, false, 0>(a, Wh, "128x128 4w 2 stages KB1 (product structure)");
-        run<2, 2, 1, false, 1>(a, Wh, "  - no A DMA in the loop", b0);
-        run<2, 2, 1, false, 2>(a, Wh, "  - no W loads in the loop", b0);
-        run<2, 2, 1, false, 3>(a, Wh, "  - no A DMA, no W loads", b0);
-        run<2, 2, 1, false, 4>(a, Wh, "  - no waits / barriers", b0);
-        run<2, 2, 1, false, 7>(a, Wh, "  - no DMA, no W loads, no barriers", b0);
-        run<2, 2, 1, false, 8>(a, Wh, "  - no operand split", b0);
-        run<2, 2, 1, false, 16>(a, Wh, "  - no store", b0);
-        run<2, 2, 1, false, 32>(a, Wh, "  - one product instead of six", b0);
-        run<2, 2, 1, false, 64>(a, Wh, "  - no LDS fragment reads", b0);
-        run<2, 2, 1, false, 7 + 16 + 64>(a, Wh, "  - MFMAs + split only", b0);
-        run<2, 2, 1, false, 7 + 8 + 16 + 64>(a, Wh, "  - MFMAs only", b0);
+        run<2, 2, 1, false, 0, true>(a, Wh, "  + scalar bases / wave index (SADDR)", b0);
+        run<2, 2, 1, false, 0>(a, Wh, "  tile groups of 4 m-tiles", b0, 4);
+        run<2, 2, 1, false, 0>(a, Wh, "  tile groups of 16 m-tiles", b0, 16);
+        run<2, 2, 1, false, 0>(a, Wh, "  tile groups of 32 m-tiles", b0, 32);
         run<2, 2, 2, false, 0>(a, Wh, "128x128 4w 2 stages KB2");
-        run<2, 3, 1, false, 0>(a, Wh, "128x128 4w ring of 3 KB1");
-        run<2, 3, 2, false, 0>(a, Wh, "128x128 4w ring of 3 KB2");
-        run<2, 2, 1, true, 0>(a, Wh, "128x128 4w 2 stages KB1, W through LDS");
-        run<2, 3, 1, true, 0>(a, Wh, "128x128 4w ring of 3 KB1, W through LDS");
-        const double b1 = run<4, 2, 1, false, 0>(a, Wh, "256x128 8w 2 stages KB1");
-        run<4, 2, 1, false, 3>(a, Wh, "  - no A DMA, no W loads", b1);
-        run<4, 2, 1, false, 4>(a, Wh, "  - no waits / barriers", b1);
-        run<4, 2, 1, false, 16>(a, Wh, "  - no store", b1);
-        run<4, 2, 2, false, 0>(a, Wh, "256x128 8w 2 stages KB2");
-        run<4, 3, 1, false, 0>(a, Wh, "256x128 8w ring of 3 KB1");
-        run<4, 3, 2, false, 0>(a, Wh, "256x128 8w ring of 3 KB2");
-        run<4, 2, 1, true, 0>(a, Wh, "256x128 8w 2 stages KB1, W through LDS");
-        run<4, 3, 1, true, 0>(a, Wh, "256x128 8w ring of 3 KB1, W through LDS");
-        run<4, 2, 2, true, 0>(a, Wh, "256x128 8w 2 stages KB2, W through LDS");
+        run<2, 2, 2, false, 0, true>(a, Wh, "128x128 4w 2 stages KB2 SADDR");
+        const double b2 = run<2, 2, 1, true, 0>(a, Wh, "128x128 4w 2 stages KB1, W through LDS");
+        run<2, 2, 1, true, 0, true>(a, Wh, "128x128 4w 2 stages KB1, W through LDS, SADDR", b2);
+        run<2, 2, 1, true, 0, true>(a, Wh, "  ... groups of 4 m-tiles", b2, 4);
+        run<2, 2, 1, true, 0, true>(a, Wh, "  ... groups of 16 m-tiles", b2, 16);
+        run<2, 2, 1, true, 1>(a, Wh, "  - no A DMA in the loop", b2);
+        run<2, 2, 1, true, 2>(a, Wh, "  - no W DMA in the loop", b2);
+        run<2, 2, 1, true, 4>(a, Wh, "  - no waits / barriers", b2);
+        run<2, 2, 1, true, 8>(a, Wh, "  - no operand split", b2);
+        run<2, 2, 1, true, 16>(a, Wh, "  - no store", b2);
+        run<4, 2, 1, true, 0, true>(a, Wh, "256x128 8w 2 stages KB1, W through LDS, SADDR");
         CK(hipFree(Wd));
     }
     return 0;
