@@ -48,7 +48,7 @@ int itts_device_count(void);
  *   sample_radix        -1    -1..1    top-k threshold: -1 per-kernel default, 0 ballot bisection, 1 radix select
  *   gpt_compact          1     0..1    row compaction of ragged decode batches
  *   attn_waves           0     0..16   waves per block of the KV-cache attention kernel (0: by shape; 4 / 8 / 16)
- *   s2mel_fused          1     0..2    s2mel: fused GEMM epilogues (at create); 1: the bf16 mode keeps wqkv + RoPE / scatter as two launches, 2: everything fused, 0: none
+ *   s2mel_fused          1     0..2    s2mel: fused GEMM epilogues (at create); 1: fused, 0: separate element-wise kernels (2 = 1, round 4's spelling)
  *   fa_qs                0     0..4    bf16 flash attention: query sub-tiles per wave (0: by shape)
  *   f32_attn_scalar      0     0..1    f32 s2mel attention on the one-wave-per-query reference kernel
  *   fa32_qs              2     1..2    f32 flash attention: query sub-tiles per wave
@@ -56,9 +56,8 @@ int itts_device_count(void);
  *   conv_bm              0     0..128  force the co-tile height of the vocoder conv kernel
  *   h3_kernel            1     0..1    f16x3 vocoder conv: window kernel / two-stage kernel
  *   decode_ln_nt         2     2..4    LayerNorm-fused decode GEMM at 5-16 rows: n-tiles per block (2 or 4)
- *   x3_split             1     0..1    fp32x3 GEMM: operand split on scalar v_sub_f32 (1) or the SLP-packed form (0)
  *   x3_aplanes           0     0..1    fp32x3 s2mel: adaptive-norm outputs as bf16 planes, wqkv / w1|w3 GEMMs without an operand split
- *   x3_pin               1     0..1    fp32x3 GEMM: the variants that are not the shipped one pinned to one block per CU (0: diagnostic, two blocks)
+ *   x3_pin               0     0..1    fp32x3 GEMM: 1 = non-default variants on one block per CU (round 4's workaround, diagnostic only)
  *   prefill_attn        -1    -1..1    GPT attention of S > 1 passes: -1 causal MFMA kernel (bf16 mode) / canonical streams (f32 mode), 0 canonical, 1 MFMA
  * itts_option_count / _name / _doc / _default enumerate the table (index 0 .. count-1).
  * ---------------------------------------------------------------------------------------------------------- */
@@ -109,6 +108,19 @@ size_t itts_conv1d_h3_scratch_bytes(int B, int Cin, int T);
 int itts_conv1d_h3_forward(const float* x, const void* wp3, const float* bias, const float* res, float* y, int B, int Cin, int Cout,
                            int T, int k, int dilation, const int32_t* lens, int len_mult, int acc_mode, float div, void* scratch,
                            void* stream);
+
+/* Third mode of the resblock Conv1d's, the one that may carry the benchmark: every f32 operand EXACTLY as three bf16 planes (x = xh + xm + xl, 8 + 8 +
+ * 8 significand bits), six v_mfma_f32_16x16x32_bf16 plane products per fragment pair (the three dropped ones are <= 2^-24 |x w| each), exact f32
+ * accumulation -- the arithmetic of the flow-matching stage's fp32x3 GEMMs; error against an f64 convolution not above the f32-MFMA kernel's.
+ * C_in % 32 == 0, odd k >= 3, (k - 1) * dilation <= 64.  wp3 = itts_pack_conv1d_x3_weight output on the device; scratch =
+ * itts_conv1d_x3_scratch_bytes device bytes.
+ * replaces: the same nn.Conv1d calls of AMPBlock1 (bigvgan.py:96-141) as itts_conv1d_forward. */
+size_t itts_conv1d_x3_packed_bytes(int Cout, int Cin, int k);
+int itts_pack_conv1d_x3_weight(const float* w, int Cout, int Cin, int k, void* out);        /* host -> host */
+size_t itts_conv1d_x3_scratch_bytes(int B, int Cin, int T);
+int itts_conv1d_x3_forward(const float* x, const void* wp3, const float* bias, const float* res, float* y, int B, int Cin, int Cout,
+                           int T, int k, int dilation, const int32_t* lens, int len_mult, int acc_mode, float div, void* scratch,
+                           void* stream);
 /* replaces: torch.nn.ConvTranspose1d forward of the upsamplers (bigvgan.py:300-316,366-367); k == 2*u,
  * padding (k-u)/2.  wpk_phases: u packed 2-tap weights back to back (itts_pack_convT_weight, phase 0..u-1). */
 int itts_conv_transpose1d_forward(const float* x, const float* wpk_phases, const float* bias, const float* bias_b,
@@ -140,7 +152,8 @@ typedef struct itts_bigvgan itts_bigvgan;
  * Tensors are given by their reference state-dict names (weight-norm already folded), host f32 pointers. */
 int itts_bigvgan_create(const itts_bigvgan_config* cfg, itts_bigvgan** out);
 int itts_bigvgan_device(const itts_bigvgan* h);   /* Conv mode of the generator's resblock convs, to be chosen BEFORE the weights are loaded: 0 = exact f32 MFMA (default; the parity
- * mode), 1 = f16 x 3 split operands (itts_conv1d_h3_forward) for the resblocks with >= min_channels channels (0 = default 96);
+ * mode), 1 = f16 x 3 split operands (itts_conv1d_h3_forward), 2 = bf16 x 3 plane operands (itts_conv1d_x3_forward; exact operands, the mode
+ * the benchmark runs) for the resblocks with >= min_channels channels (0 = default 96);
  * everything else (conv_pre / upsamplers / conv_post / activations) is unchanged. */
 int itts_bigvgan_set_conv_mode(itts_bigvgan* h, int mode, int min_channels);
 /* f16 x 3 mode only: 1 if a forward since the last call met an activation that is not finite or not below 65504 in magnitude (that

@@ -84,6 +84,11 @@ SIGNATURES = {
     "itts_conv1d_h3_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "itts_conv1d_h3_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                          C.c_float, vp, vp]),
+    "itts_conv1d_x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "itts_pack_conv1d_x3_weight": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
+    "itts_conv1d_x3_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "itts_conv1d_x3_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
+                                         C.c_float, vp, vp]),
     "itts_bigvgan_finalize": (C.c_int, [vp]),
     "itts_bigvgan_destroy": (None, [vp]),
     "itts_bigvgan_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int]),

@@ -52,11 +52,13 @@ class BigVGAN:
     def __init__(self, h, use_cuda_kernel: bool = False, cond_dim: int = 0, in_channels: Optional[int] = None,
                  cond_in_each_up_layer: bool = True, speaker_encoder=None, device=None, conv_mode: Optional[str] = None,
                  h3_min_channels: int = 0):
-        """conv_mode: None / "f32" = exact f32 MFMA convs (the parity mode, default); "f16x3" = the opt-in split-operand mode of the
-        resblock convs (three f16 MFMA products per f32 product, 22-bit operands; resblocks with >= h3_min_channels channels)."""
-        if conv_mode not in (None, "f32", "f16x3"):
-            raise ValueError(f"BigVGAN: conv_mode must be 'f32' or 'f16x3', got {conv_mode!r}")
-        self.conv_mode = 1 if conv_mode == "f16x3" else 0
+        """conv_mode: None / "f32" = f32 MFMA convs (the parity mode, default); "bf16x3" = the resblock convs with >= h3_min_channels
+        channels on the bf16 matrix cores with every f32 operand carried exactly as three bf16 planes, six plane products (the fp32x3
+        arithmetic of the flow-matching stage: error vs f64 not above the f32 MFMA kernel's); "f16x3" = the opt-in 22-bit split-operand mode
+        (three f16 MFMA products per f32 product)."""
+        if conv_mode not in (None, "f32", "f16x3", "bf16x3"):
+            raise ValueError(f"BigVGAN: conv_mode must be 'f32', 'bf16x3' or 'f16x3', got {conv_mode!r}")
+        self.conv_mode = {"f16x3": 1, "bf16x3": 2}.get(conv_mode, 0)
         self.h3_min_channels = int(h3_min_channels)
         hp = dict(_V2_DEFAULTS)
         hp.update(dict(h))
@@ -414,6 +416,34 @@ def conv1d_h3(x, w3_packed, bias, Cout, k, dilation=1, res=None, lens=None, len_
         _lib.check(L.itts_conv1d_h3_forward(_lib.ptr(x), _lib.ptr(w3_packed), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(y), B, Cin, Cout, T, k,
                                             dilation, _lib.ptr(lens_t), len_mult, acc_mode, float(div), _lib.ptr(scratch),
                                             _lib.stream_ptr(x.device)), "itts_conv1d_h3_forward")
+        return y
+
+
+def pack_conv1d_x3_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout][Cin][k] f32 -> the three bf16 plane fragment streams of the bf16 x 3 conv (uint8 host tensor)"""
+    w = w.detach().to("cpu", torch.float32).contiguous()
+    Cout, Cin, k = w.shape
+    L = _lib.lib()
+    n = L.itts_conv1d_x3_packed_bytes(Cout, Cin, k)
+    if n == 0:
+        raise ValueError("pack_conv1d_x3_weight: C_in must be a multiple of 32")
+    out = torch.empty(n, dtype=torch.uint8)
+    _lib.check(L.itts_pack_conv1d_x3_weight(_lib.ptr(w), Cout, Cin, k, _lib.ptr(out)), "itts_pack_conv1d_x3_weight")
+    return out
+
+
+def conv1d_x3(x, w3_packed, bias, Cout, k, dilation=1, res=None, lens=None, len_mult=1, out=None, acc_mode=0, div=1.0):
+    """the bf16 x 3 plane-operand Conv1d (`same` zero padding) as a unit op; w3_packed = pack_conv1d_x3_weight(w) on x's device"""
+    x = x.float().contiguous()
+    B, Cin, T = x.shape
+    y = out if out is not None else torch.empty(B, Cout, T, dtype=torch.float32, device=x.device)
+    lens_t = None if lens is None else torch.as_tensor(lens, dtype=torch.int32, device=x.device).contiguous()
+    L = _lib.lib()
+    scratch = torch.empty(L.itts_conv1d_x3_scratch_bytes(B, Cin, T), dtype=torch.uint8, device=x.device)
+    with _lib.on_device(x.device):
+        _lib.check(L.itts_conv1d_x3_forward(_lib.ptr(x), _lib.ptr(w3_packed), _lib.ptr(bias), _lib.ptr(res), _lib.ptr(y), B, Cin, Cout, T, k,
+                                            dilation, _lib.ptr(lens_t), len_mult, acc_mode, float(div), _lib.ptr(scratch),
+                                            _lib.stream_ptr(x.device)), "itts_conv1d_x3_forward")
         return y
 
 

@@ -28,7 +28,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE]
 # flipped (profiles/r03j) -- the bit-exact-ids contract outranks a few percent on an optional GEMM mode.
 EXTRA = {"gpt_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
          "s2mel_kernels.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
-         "bigvgan_kernels.hip": ["-fno-slp-vectorize"]}
+         "bigvgan_kernels.hip": ["-fno-slp-vectorize"],
+         "bigvgan_x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
+         "gemm_x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))

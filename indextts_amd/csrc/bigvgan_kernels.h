@@ -39,6 +39,24 @@ struct ConvH3Args {
     int acc_mode; float div;          // as ConvArgs
     int n_mt, n_co;                   // filled by the launcher
 };
+// bf16 x 3 mode (bigvgan_x3.hip): three bf16 planes per f32 operand, six plane products
+struct ConvX3Args {
+    const void* xp;                   // three planes [3][B][T][Cin] bf16 (h, m, l: h + m + l == x), frames >= the row length zeroed
+    const void* wp;                   // conv_x3_pack output
+    const float* bias;                // [Cout] or null
+    const float* res;                 // [B][Cout][T] or null
+    float* y;                         // [B][Cout][T]
+    const void* zero_row;             // >= 16 zero bytes
+    const int* lens; int len_mult;    // row b is min(lens[b] * len_mult, T) frames long (null: T)
+    int B, Cin, Cout, T, k, dil;
+    int acc_mode; float div;          // as ConvArgs
+    int n_mt, n_co;                   // filled by the launcher
+};
+bool conv_x3_supported(int Cin, int Cout, int k, int dil);
+size_t conv_x3_packed_bytes(int Cout, int Cin, int k);
+int conv_x3_pack(const float* w, int Cout, int Cin, int k, void* out);
+int launch_split_tm3(const float* x, void* xp, int B, int C, int T, const int* lens, int len_mult, hipStream_t st);
+int launch_conv_x3(const ConvX3Args& a, hipStream_t st);
 size_t conv_h3_packed_bytes(int Cout, int Cin, int k);
 int conv_h3_pack(const float* w, int Cout, int Cin, int k, void* out);
 int launch_split_tm(const float* x, void* xh, void* xl, int B, int C, int T, const int* lens, int len_mult, int* range_flag, hipStream_t st);

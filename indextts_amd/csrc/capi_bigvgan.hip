@@ -131,6 +131,28 @@ extern "C" int itts_conv1d_h3_forward(const float* x, const void* wp3, const flo
     return launch_conv_h3(g, st);
 }
 
+// ---- bf16 x 3 plane-operand conv as a unit op (tests / microbenchmarks; the model path packs at load time) ----------------------------
+extern "C" size_t itts_conv1d_x3_packed_bytes(int Cout, int Cin, int k) { return (Cin > 0 && Cin % 32 == 0 && Cout > 0 && k > 0) ? conv_x3_packed_bytes(Cout, Cin, k) : 0; }
+extern "C" int itts_pack_conv1d_x3_weight(const float* w, int Cout, int Cin, int k, void* out) { return conv_x3_pack(w, Cout, Cin, k, out); }
+extern "C" size_t itts_conv1d_x3_scratch_bytes(int B, int Cin, int T) { return (size_t)B * T * Cin * 6 + 512; }
+extern "C" int itts_conv1d_x3_forward(const float* x, const void* wp3, const float* bias, const float* res, float* y, int B, int Cin, int Cout,
+                                      int T, int k, int dilation, const int32_t* lens, int len_mult, int acc_mode, float div, void* scratch,
+                                      void* stream) {
+    if (!x || !wp3 || !y || !scratch || B < 0 || T < 0 || acc_mode < 0 || acc_mode > 2) { itts_set_error("conv1d_x3_forward: bad args"); return ITTS_ERR_ARG; }
+    if (B == 0 || T == 0) return ITTS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    const size_t planes = (size_t)B * T * Cin * 6;
+    void* zr = base + planes;                             // the zero row lives behind the three planes
+    HIP_TRY(hipMemsetAsync(zr, 0, 64, st));
+    int rc = launch_split_tm3(x, base, B, Cin, T, lens, len_mult < 1 ? 1 : len_mult, st);
+    if (rc) return rc;
+    ConvX3Args g{};
+    g.xp = base; g.wp = wp3; g.bias = bias; g.res = res; g.y = y; g.zero_row = zr; g.lens = lens; g.len_mult = len_mult < 1 ? 1 : len_mult;
+    g.B = B; g.Cin = Cin; g.Cout = Cout; g.T = T; g.k = k; g.dil = dilation; g.acc_mode = acc_mode; g.div = div;
+    return launch_conv_x3(g, st);
+}
+
 static int convT_impl(const float* x, const float* wpk_phases, const float* bias, const float* bias_b, float* y, int B,
                       int Cin, int Cout, int Tin, int k, int u, const int* lens, int len_mult_in, hipStream_t st) {
     const int p = (k - u) / 2, ntaps = k / u;
@@ -295,13 +317,13 @@ extern "C" int itts_bigvgan_create(const itts_bigvgan_config* cfg, itts_bigvgan*
 extern "C" int itts_bigvgan_device(const itts_bigvgan* h) { return h ? h->device : -1; }
 
 extern "C" int itts_bigvgan_set_conv_mode(itts_bigvgan* h, int mode, int min_channels) {
-    if (!h || mode < 0 || mode > 1) { itts_set_error("bigvgan_set_conv_mode: mode 0 (exact f32) or 1 (f16 x 3 split operands)"); return ITTS_ERR_ARG; }
+    if (!h || mode < 0 || mode > 2) { itts_set_error("bigvgan_set_conv_mode: mode 0 (f32 MFMA), 1 (f16 x 3 split operands) or 2 (bf16 x 3 plane operands)"); return ITTS_ERR_ARG; }
     for (const ConvL& L : h->convs1)
         if (L.has_w) { itts_set_error("bigvgan_set_conv_mode: call before loading the weights"); return ITTS_ERR_STATE; }
     ItDevGuard dg(h->device);
     h->conv_mode = mode;
     if (min_channels > 0) h->h3_min_c = min_channels;
-    if (mode == 1 && !h->zero_row) {
+    if (mode >= 1 && !h->zero_row) {
         void* z = nullptr;
         HIP_TRY(hipMalloc(&z, 256));
         HIP_TRY(hipMemset(z, 0, 256));
@@ -357,6 +379,16 @@ static int load_conv(itts_bigvgan* h, ConvL* L, const char* what, const float* d
         if (rc) return rc;
         L->Cin = Cin; L->Cout = Cout; L->k = k; L->has_w = true;
         L->w3 = nullptr;
+        if (resblock && h->conv_mode == 2 && Cin % 32 == 0 && Cin >= h->h3_min_c) {                        // bf16 x 3: three weight planes in fragment order
+            std::vector<char> p3(conv_x3_packed_bytes(Cout, Cin, k));
+            rc = conv_x3_pack(data, Cout, Cin, k, p3.data());
+            if (rc) return rc;
+            void* d = nullptr;
+            HIP_TRY(hipMalloc(&d, p3.size()));
+            h->owned.push_back((float*)d);
+            HIP_TRY(hipMemcpy(d, p3.data(), p3.size(), hipMemcpyHostToDevice));
+            L->w3 = d;
+        }
         if (resblock && h->conv_mode == 1 && Cin % 32 == 0 && Cin >= h->h3_min_c) {
             std::vector<char> p3(conv_h3_packed_bytes(Cout, Cin, k));
             rc = conv_h3_pack(data, Cout, Cin, k, p3.data());
@@ -574,7 +606,7 @@ extern "C" size_t itts_bigvgan_workspace_bytes(const itts_bigvgan* h, int B, int
         cond = align256((size_t)B * c.upsample_initial_channel * 4);
         for (int i = 0; i < c.num_upsamples; ++i) cond += align256((size_t)B * stage_channels(c, i) * 4);
     }
-    return (size_t)(h->conv_mode == 1 ? 8 : 7) * align256(max_stage_floats(h, B, T) * sizeof(float)) + cond + 256;
+    return (size_t)(h->conv_mode == 2 ? 9 : h->conv_mode == 1 ? 8 : 7) * align256(max_stage_floats(h, B, T) * sizeof(float)) + cond + 256;
 }
 
 extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32_t* lens, const float* spk, float* wav,
@@ -600,7 +632,7 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
     hipStream_t st = (hipStream_t)stream;
     const size_t bufsz = align256(max_stage_floats(h, B, T) * sizeof(float));
     char* base = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    const int nbuf = h->conv_mode == 1 ? 8 : 7;
+    const int nbuf = h->conv_mode == 2 ? 9 : h->conv_mode == 1 ? 8 : 7;     // (the three bf16 planes of mode 2 take buffers 7 and 8)
     float* buf[8];
     for (int i = 0; i < 8; ++i) buf[i] = (float*)(base + bufsz * (i < nbuf ? i : 0));
     char* condp = base + bufsz * nbuf;
@@ -641,7 +673,16 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
     // a resblock conv: exact f32 MFMA, or (opt-in) the activation split into token-major f16 (hi, lo) + the f16 x 3 kernel
     auto res_conv = [&](const ConvL& L, const float* xin, const float* res, float* yout, int ch_, int t_, int kk_, int dil_, int mult_, int mode_,
                         float div_) -> int {
-        if (!L.w3) return conv1d_impl(xin, L.w.p, L.b.p, nullptr, res, yout, B, ch_, ch_, t_, kk_, dil_, lens, mult_, mode_, div_, st);
+        if (!L.w3 || (h->conv_mode == 2 && !conv_x3_supported(ch_, ch_, kk_, dil_)))
+            return conv1d_impl(xin, L.w.p, L.b.p, nullptr, res, yout, B, ch_, ch_, t_, kk_, dil_, lens, mult_, mode_, div_, st);
+        if (h->conv_mode == 2) {                         // three token-major bf16 planes + the six-product window kernel
+            int rc3 = launch_split_tm3(xin, SP, B, ch_, t_, lens, mult_, st);
+            if (rc3) return rc3;
+            ConvX3Args g{};
+            g.xp = SP; g.wp = L.w3; g.bias = L.b.p; g.res = res; g.y = yout; g.zero_row = h->zero_row; g.lens = lens; g.len_mult = mult_;
+            g.B = B; g.Cin = ch_; g.Cout = ch_; g.T = t_; g.k = kk_; g.dil = dil_; g.acc_mode = mode_; g.div = div_;
+            return launch_conv_x3(g, st);
+        }
         void* sh = SP;
         void* sl = (char*)SP + (size_t)B * t_ * ch_ * 2;
         int rc2 = launch_split_tm(xin, sh, sl, B, ch_, t_, lens, mult_, (int*)((char*)h->zero_row + 128), st);

@@ -156,7 +156,7 @@ extern "C" int itts_s2mel_create(const itts_s2mel_config* cfg, itts_s2mel** out)
     itts_s2mel* h = new itts_s2mel();
     h->cfg = c;
     h->opt_fused = itts_opt(OPT_S2MEL_FUSED) != 0;
-    h->opt_fused_qkv = c.precision != PREC_BF16 || itts_opt(OPT_S2MEL_FUSED) >= 2;
+    h->opt_fused_qkv = true;
     h->I = s2_intermediate(c.hidden_dim);
     h->Kx = (c.in_channels + 63) / 64 * 64;
     h->layers.resize(c.depth);
@@ -509,10 +509,8 @@ static int s2_estimator(itts_s2mel* h, const S2Ws& w, const SeqTab& tab, int t_p
             if ((rc = launch_ada_rmsnorm(X, L.g_attn, mods + (size_t)i * 4 * H, w.HB, N, H, c.norm_eps, prec, st))) return rc;
             S2_TRACE("ada_rmsnorm(attn) -> HB", w.HB, (size_t)N * H * esz);
         }
-        // bf16 mode: the fused wqkv epilogue of the bf16 tile kernels is NOT bit-stable run to run at production depth -- the engine's stage trace
-        // (tools/s2mel_trace.py, profiles/r04j) puts the first differing checksum in its Q / K tiles in about one estimator call of two (24 / 24
-        // stable with the plain-store GEMM + rope_split, and in the f32 / f32x3 instantiations; the symptom also vanishes under unrelated
-        // code-generation changes of the epilogue, profiles/r04k: cause not found).  So that mode runs the two launches unless s2mel_fused = 2.
+        // (Round 4 ran the bf16 mode's wqkv GEMM with a plain store + rope_split because its fused epilogue was not bit-stable run to run; the cause was
+        // the SLP-packed RoPE arithmetic of pf_store_tile -- see pf_rope4 -- and every mode carries RoPE + the Q / K / V^T scatter in the epilogue again.)
         if (fused && h->opt_fused_qkv) {                           // wqkv + RoPE + Q / K / V^T scatter in one epilogue
             GemmArgs g{};
             g.A = w.HB; g.lda = H; g.Wp = L.w_qkv; g.M = N; g.N = 3 * H; g.K = H; g.nsplit = 1; g.epi = EPI_QKV_ROPE;

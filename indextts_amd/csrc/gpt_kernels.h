@@ -71,6 +71,8 @@ struct GemmArgs {
                                      // the bf16 mode's image) -- the operands of flash_attn_x3_kernel (s2mel_kernels.hip)
 };
 int launch_gemm(const GemmArgs& a, int prec, bool prefill, hipStream_t st);
+int launch_gemm_x3(const GemmArgs& a, hipStream_t st);      // gemm_x3.hip: the fp32x3 tile kernel (its own translation unit, built without SLP vectorisation)
+int gemm_x3_occupancy(int* blocks);
 bool gemm_decode_ln_ok(int M, int K, int epi);                 // shapes of the LayerNorm-fused decode GEMM (bf16, 1-4 rows)
 int launch_gemm_decode_ln(const GemmArgs& a, hipStream_t st);  // A = LayerNorm(ln_x [+ ln_partial + ln_bias_prev]) built inside the kernel
 int gemm_tile_occupancy(int prec, int* blocks);      // diagnostics: predicted resident blocks per CU of the 128 x 128 tile kernel

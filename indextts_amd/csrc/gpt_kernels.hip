@@ -14,11 +14,8 @@
 // Decode is HBM-bound (weights once per step + B x KV): weights are pre-packed in MFMA B-fragment order so each
 // wave-level load is one contiguous 1 KiB (16 B/lane); a block's 4 waves split K and reduce through LDS so even
 // N = 1280 gives >= 240 blocks (with 4 K-slices); K/V rows are read as 16 B per lane (8 or 16 lanes per key).
-#include "gpt_kernels.h"
-#include <type_traits>
+#include "gemm_tile.h"
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));   // native vector (HIP's uint4 struct defeats SROA in loops)
 
 // ================================================================================================================
 // LayerNorm (+ fused split-K reduce, bias, residual write-back, optional second LayerNorm)
@@ -275,10 +272,6 @@ int launch_ln(const LnArgs& a, int prec, hipStream_t st) {
 //   f32  (KB = 16): lane holds W[kb*16 + (lane>>4)*4 + j][nt*16 + (lane&15)], j = 0..3 (MFMA j of the group)
 // A is row-major act dtype; the matching 16 bytes of row (lane&15) are loaded straight from global (L2-resident).
 // ================================================================================================================
-__device__ __forceinline__ float gelu_new_f(float x) {
-    const float c = 0.7978845608028654f;   // sqrt(2/pi)
-    return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
-}
 
 template <bool BF16>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, int mbase, int nbase, int lane, int z, f32x4 v) {
@@ -523,377 +516,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
 //   Block -> tile map: XCD-aware (consecutive tiles of one XCD's share) and grouped 8 m-tiles x all n-tiles so the
 //   blocks resident on an XCD reuse A rows and W columns out of that XCD's L2.
 // ================================================================================================================
-#define PF_BM 128
-#define PF_BN 128
-#define PF_BK 64
-#define PF_GM 8
-#define PF_LDS 67584     // 2 x (A 16 KiB | W 16 KiB) operand buffers; the epilogue's transposed image [128][132] f32 is the larger
-#ifndef PF_ABL
-#define PF_ABL 0         // tools/microbench/gemm_f32_ablate.hip builds the tile kernel with pieces removed / a start stagger (bit mask); 0 in the product
-#endif
-#ifndef PF_SCHED
-#define PF_SCHED 1       // explicit LDS-read / MFMA interleave in the tile kernel's main loop (build with -DPF_SCHED=0 for A/B)
-#endif
-
-__device__ __forceinline__ uint32_t pf_pack2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
-
-template <int EPI>
-__device__ __forceinline__ void pf_epilogue(const GemmArgs& a, int mbase, int nbase, int lane, f32x4 v) {
-    const int n = nbase + (lane & 15);
-    if (n >= a.N) return;
-    const float bias = a.bias ? a.bias[n] : 0.f;
-    int which = 0, c = n;
-    if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_ROPE) { which = n / a.D; c = n - which * a.D; }
-    if constexpr (EPI == EPI_QKV_ROPE) {
-        // RoPE pairs are adjacent columns = adjacent lanes: partner value by one xor-shuffle (gpt_fast/model.py:348-360)
-        const int hd = c >> 6, d = c & 63, i = d >> 1;
-        const bool odd = d & 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mbase + (lane >> 4) * 4 + r;
-            const int mc = m < a.M ? m : a.M - 1;
-            const float val = v[r] + bias;
-            const float partner = __shfl_xor(val, 1, 64);
-            const int s = a.tok_seq[mc], t = a.tok_t[mc];
-            float y = val;
-            if (which < 2) {
-                const float cs = a.rope[((size_t)t * 32 + i) * 2], sn = a.rope[((size_t)t * 32 + i) * 2 + 1];
-                y = odd ? val * cs + partner * sn : val * cs - partner * sn;
-            }
-            if (m < a.M) {
-                if (which == 0) ((u16*)a.out_act)[(size_t)m * a.D + c] = f32_to_bf16(y);
-                else if (which == 1) ((u16*)a.kcache)[(((size_t)s * a.H + hd) * a.Tmax + t) * 64 + d] = f32_to_bf16(y);
-                else ((u16*)a.vcache)[(((size_t)s * a.H + hd) * 64 + d) * a.Tmax + t] = f32_to_bf16(y);
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = mbase + (lane >> 4) * 4 + r;
-        if (m >= a.M) continue;
-        const float val = v[r] + bias;
-        if constexpr (EPI == EPI_STORE_F32) {
-            a.out_f32[(size_t)m * a.ldo + n] = val;
-            if (a.out_act2) ((u16*)a.out_act2)[(size_t)m * a.ldo + n] = f32_to_bf16(val);
-        } else if constexpr (EPI == EPI_RESIDUAL) {
-            const float nv = a.out_f32[(size_t)m * a.ldo + n] + val;
-            a.out_f32[(size_t)m * a.ldo + n] = nv;
-            if (a.out_act2) ((u16*)a.out_act2)[(size_t)m * a.ldo + n] = f32_to_bf16(nv);
-        } else if constexpr (EPI == EPI_GELU_ACT) ((u16*)a.out_act)[(size_t)m * a.ldo + n] = f32_to_bf16(gelu_new_f(val));
-        else if constexpr (EPI == EPI_WN_RS) {                   // wavenet.py:158-165
-            if (a.wn_last || n >= a.D) {
-                float* o = a.out2 + (size_t)m * a.D + (a.wn_last ? n : n - a.D);
-                *o = a.wn_first ? val : *o + val;
-            } else {
-                const float mask = a.tok_t[m] < a.seq_len[a.tok_seq[m]] ? 1.f : 0.f;
-                float* o = a.out_f32 + (size_t)m * a.D + n;
-                *o = (*o + val) * mask;
-            }
-        } else {                                                   // EPI_QKV
-            if (which == 0) {
-                a.qbuf[(size_t)m * a.D + c] = val;
-            } else {
-                const int b = m / a.S, si = m - b * a.S;
-                const int pos = *a.pos_ptr + si;
-                const size_t o = (((size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1) * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
-                ((u16*)(which == 1 ? a.kcache : a.vcache))[o] = f32_to_bf16(val);
-            }
-        }
-    }
-}
-
-typedef __bf16 pf_bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float pf_f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
-// v_cvt_pk_bf16_f32 (gfx950): hardware round-to-nearest-even of two f32
-__device__ __forceinline__ uint32_t pf_cvt2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(pf_f32x2_t{a, b}, pf_bf16x2_t)); }
-__device__ __forceinline__ v2u_t pf_cvt4(f32x4 v) { return v2u_t{pf_cvt2(v[0], v[1]), pf_cvt2(v[2], v[3])}; }
-
-// f32 x 4 -> three bf16 planes (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): h + m + l == x exactly), 4 consecutive elements per plane
-__device__ __forceinline__ void pf_split4(const f32x4 v, v2u_t& H, v2u_t& M, v2u_t& L) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float a = v[2 * i], b = v[2 * i + 1];
-        const uint32_t h = pf_cvt2(a, b);
-        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);      // exact
-        const uint32_t m = pf_cvt2(ra, rb);
-        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);    // exact
-        H[i] = h; M[i] = m; L[i] = pf_cvt2(sa, sb);
-    }
-}
-// 4 consecutive elements at element index idx of each of the three planes (8-byte aligned) / one element per plane
-__device__ __forceinline__ void pf_store_planes4(void* base, size_t stride, size_t idx, const f32x4 v) {
-    v2u_t h, m, l;
-    pf_split4(v, h, m, l);
-    u16* p = (u16*)base + idx;
-    *(v2u_t*)p = h; *(v2u_t*)(p + stride) = m; *(v2u_t*)(p + 2 * stride) = l;
-}
-__device__ __forceinline__ void pf_store_planes1(void* base, size_t stride, size_t idx, float x) {
-    const u16 h = f32_to_bf16(x);
-    const float r = x - bf16_to_f32(h);
-    const u16 m = f32_to_bf16(r);
-    u16* p = (u16*)base + idx;
-    p[0] = h; p[stride] = m; p[2 * stride] = f32_to_bf16(r - bf16_to_f32(m));
-}
-
-// Tile store of the bf16 tile kernel: the 128 x 128 f32 accumulator tile has been transposed through LDS (ct, row-major, the
-// 16-float column groups XOR-swizzled by (row >> 2) & 3), so every thread owns 4 CONSECUTIVE columns of a row and the global
-// accesses are 16-byte (f32) / 8-byte (bf16) pieces of full lines.  The MFMA accumulator layout itself gives each lane 4 rows
-// of one column: 64-byte row segments, half-used lines and read-modify-write at that granularity (measured: the N = 512 f32
-// residual GEMMs of the s2mel DiT ran at 1.4 TB/s of output traffic).
-// sigmoid / tanh of the fused s2mel epilogues through v_exp_f32 + v_rcp_f32 (about 1 ulp each; the results are rounded to bf16):
-// expf + an IEEE division per element made the SwiGLU / gate epilogues as long as a K = 512 main loop.
-__device__ __forceinline__ float pf_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
-__device__ __forceinline__ float pf_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
-// F32 instantiations of the tile kernel (the s2mel f32 mode: the reference runs this stage with autocast off, infer_v2_5.py:827-828):
-// activations, shadows and the K / V^T images are f32, and the gate functions are the libm ones the separate f32 kernels use
-// (swiglu_kernel<false>, wn_gate_kernel<false>) -- the main loop is 8x longer per byte than the bf16 one, the epilogue hides under it.
-template <bool F32> __device__ __forceinline__ float pf_sigmoid_t(float x) { if constexpr (F32) return 1.0f / (1.0f + expf(-x)); else return pf_sigmoid(x); }
-template <bool F32> __device__ __forceinline__ float pf_tanh_t(float x) { if constexpr (F32) return tanhf(x); else return pf_tanh(x); }
-template <bool F32> __device__ __forceinline__ void pf_store_act4(void* base, size_t idx, f32x4 v) {      // 4 consecutive act-dtype elements
-    if constexpr (F32) *(f32x4*)((float*)base + idx) = v;
-    else *(v2u_t*)((u16*)base + idx) = pf_cvt4(v);
-}
-
-// Row metadata of a tile region for the epilogues that need the row's (sequence, frame): staged ONCE per region into LDS (meta[row],
-// meta[ROWS + row]) by pf_stage_meta -- read per chunk from global they were two dependent L2 round trips in front of every RoPE
-// table load / masked store (the wqkv GEMM ran 35 % behind the SwiGLU GEMM of the same K).
-//   EPI_QKV_ROPE: (tok_seq, tok_t);  EPI_WN_RS: (tok_t < seq_len[tok_seq] as 0 / 1, unused)
-template <int EPI, int ROWS>
-__device__ __forceinline__ void pf_stage_meta(const GemmArgs& a, int* meta, int m0, int ltid) {
-    if constexpr (EPI == EPI_QKV_ROPE || EPI == EPI_WN_RS) {
-        if (ltid < ROWS) {
-            int m = m0 + ltid;
-            m = m < a.M ? m : a.M - 1;
-            const int sq = a.tok_seq[m], t = a.tok_t[m];
-            if constexpr (EPI == EPI_QKV_ROPE) { meta[ltid] = sq; meta[ROWS + ltid] = t; }
-            else meta[ltid] = (a.wn_last || t < a.seq_len[sq]) ? 1 : 0;
-        }
-    }
-}
-
-// RoPE of two adjacent (even, odd) pairs: y = (v0 c0 - v1 s0, v1 c0 + v0 s0, v2 c1 - v3 s1, v3 c1 + v2 s1), cs = (c0, s0, c1, s1), each component one
-// product rounded and one fma -- bit for bit what hipcc's contraction made of the plain expression.  The products pass through an opaque register
-// barrier so that the SLP vectoriser (this file is built with it) cannot fuse the four components into v_pk_mul_f32 / v_pk_fma_f32 with op_sel
-// operand selection: that packed form -- an IN-PLACE `v_pk_mul_f32 v[n:n+1], v[n:n+1], ... op_sel:[0,1] op_sel_hi:[0,0]` whose low source register
-// feeds both halves, followed by the v_pk_fma_f32 that subtracts its low result -- is where the run-to-run differences of the fused wqkv epilogue
-// came from: in a solve of 13 layers about one quarter-wave (16 lanes, all of one K / Q row) per two calls stored v2 c1 instead of v2 c1 - v3 s1 in
-// exactly the component that in-place product feeds, only while a second block shared the CU (profiles/r05a/capture.log).
-__device__ __forceinline__ f32x4 pf_rope4(const f32x4 v, const f32x4 cs) {
-    float t0 = v[1] * cs[1], t1 = v[1] * cs[0], t2 = v[3] * cs[3], t3 = v[3] * cs[2];
-    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
-    float y0 = __builtin_fmaf(v[0], cs[0], -t0);
-    asm volatile("" : "+v"(y0));
-    float y1 = __builtin_fmaf(v[0], cs[1], t1);
-    asm volatile("" : "+v"(y1));
-    float y2 = __builtin_fmaf(v[2], cs[2], -t2);
-    asm volatile("" : "+v"(y2));
-    float y3 = __builtin_fmaf(v[2], cs[3], t3);
-    asm volatile("" : "+v"(y3));
-    return f32x4{y0, y1, y2, y3};
-}
-
-template <int EPI, int ROWS, int NT, bool F32 = false>            // ROWS x 128 columns of the tile, stored by NT threads (tid < NT)
-__device__ __forceinline__ void pf_store_tile(const GemmArgs& a, const float* ct, const int* meta, int m0, int n0, int tid) {
-    constexpr bool PAIR = (EPI == EPI_SWIGLU || EPI == EPI_GATE);
-    constexpr int CH = PAIR ? 16 : 32;                              // 4-column chunks per tile row
-    constexpr int RSTEP = NT / CH;                                  // a thread keeps its column chunk and walks down the rows
-    const int half = a.N >> 1;
-    const int c4 = tid % CH, row0 = tid / CH;
-    // ---- column-derived quantities: once per thread ----
-    const int j = c4 >> 2, cc = (c4 & 3) * 4;                       // PAIR: pair j of the region, column inside the 16-wide tile
-    const int n = PAIR ? (n0 >> 1) + j * 16 + cc : n0 + c4 * 4;     // output column (inside a half for the pair epilogues)
-    if (PAIR ? n >= half : n >= a.N) return;
-    const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
-    f32x4 b1 = zero4, b2 = zero4;
-    if constexpr (EPI == EPI_GATE) {
-        b1 = *(const f32x4*)(a.gvec + n);
-        b2 = *(const f32x4*)(a.gvec + half + n);
-        if (a.bias) {
-            const f32x4 x1 = *(const f32x4*)(a.bias + n), x2 = *(const f32x4*)(a.bias + half + n);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { b1[q] += x1[q]; b2[q] += x2[q]; }
-        }
-    } else if constexpr (!PAIR) {
-        if (a.bias) b1 = *(const f32x4*)(a.bias + n);
-    }
-    int which = 0, c = n;
-    if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_ROPE) { which = n / a.D; c = n - which * a.D; }
-    const int hd = c >> 6, d = c & 63;
-    const int ca = PAIR ? (2 * j) * 16 + cc : c4 * 4, cb = (2 * j + 1) * 16 + cc;      // columns inside the LDS image
-#pragma unroll 4
-    for (int i = 0; i < ROWS / RSTEP; ++i) {
-        const int row = row0 + i * RSTEP;
-        const int m = m0 + row;
-        if (m >= a.M) break;
-        const int sw = ((row >> 2) & 3) << 4;
-        if constexpr (PAIR) {
-            const f32x4 va = *(const f32x4*)(ct + row * 128 + (ca ^ sw));
-            const f32x4 vb = *(const f32x4*)(ct + row * 128 + (cb ^ sw));
-            f32x4 o;
-            if constexpr (EPI == EPI_SWIGLU) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = va[q] * pf_sigmoid_t<F32>(va[q]) * vb[q];                       // silu(w1 x) * (w3 x)
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = pf_tanh_t<F32>(va[q] + b1[q]) * pf_sigmoid_t<F32>(vb[q] + b2[q]);      // commons.py:133-141
-            }
-            pf_store_act4<F32>(a.out_act, (size_t)m * half + n, o);
-        } else {
-            f32x4 v = *(const f32x4*)(ct + row * 128 + (ca ^ sw));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += b1[q];
-            if constexpr (EPI == EPI_STORE_F32) {
-                *(f32x4*)(a.out_f32 + (size_t)m * a.ldo + n) = v;
-                if (a.out_act2) pf_store_act4<F32>(a.out_act2, (size_t)m * a.ldo + n, v);      // act-dtype shadow: the next GEMM's A operand
-            } else if constexpr (EPI == EPI_RESIDUAL) {
-                f32x4* o = (f32x4*)(a.out_f32 + (size_t)m * a.ldo + n);
-                const f32x4 old = *o;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] += old[q];
-                *o = v;
-                if (a.out_act2) pf_store_act4<F32>(a.out_act2, (size_t)m * a.ldo + n, v);
-            } else if constexpr (EPI == EPI_GELU_ACT) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = gelu_new_f(v[q]);
-                if constexpr (F32) *(f32x4*)((float*)a.out_act + (size_t)m * a.ldo + n) = v;
-                else *(v2u_t*)((u16*)a.out_act + (size_t)m * a.ldo + n) = v2u_t{(uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
-                                                                               (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)};
-            } else if constexpr (EPI == EPI_WN_RS) {
-                if (a.wn_last || n >= a.D) {
-                    f32x4* o = (f32x4*)(a.out2 + (size_t)m * a.D + (a.wn_last ? n : n - a.D));
-                    if (!a.wn_first) {
-                        const f32x4 old = *o;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += old[q];
-                    }
-                    *o = v;
-                } else {
-                    const float mask = (float)meta[row];
-                    f32x4* o = (f32x4*)(a.out_f32 + (size_t)m * a.D + n);
-                    const f32x4 old = *o;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (old[q] + v[q]) * mask;
-                    *o = v;
-                    if (a.out_act2) pf_store_act4<F32>(a.out_act2, (size_t)m * a.D + n, v);
-                }
-            } else if constexpr (EPI == EPI_QKV) {                    // GPT prefill: q f32, K / V appended to the bf16 cache
-                if (which == 0) {
-                    *(f32x4*)(a.qbuf + (size_t)m * a.D + c) = v;
-                } else {
-                    const int b = m / a.S, si = m - b * a.S;
-                    const int pos = *a.pos_ptr + si;
-                    const size_t o = (((size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1) * a.H + hd) * a.Tmax + pos) * 64 + d;
-                    if constexpr (F32) *(f32x4*)((float*)(which == 1 ? a.kcache : a.vcache) + o) = v;
-                    else *(v2u_t*)((u16*)(which == 1 ? a.kcache : a.vcache) + o) =
-                        v2u_t{(uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16), (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)};
-                }
-            } else {                                                   // EPI_QKV_ROPE (s2mel): both RoPE pairs of the chunk are in-thread
-                const int sq = meta[row], t = meta[ROWS + row];
-                if (which < 2) {
-                    const f32x4 cs = *(const f32x4*)(a.rope + ((size_t)t * 32 + (d >> 1)) * 2);       // (cos, sin) of pairs d/2, d/2 + 1
-                    const f32x4 y = pf_rope4(v, cs);
-                    if (which == 0) pf_store_act4<F32>(a.out_act, (size_t)m * a.D + c, y);
-                    else if (F32 && a.kv_planes) pf_store_planes4(a.kcache, a.kv_planes, (((size_t)sq * a.H + hd) * a.Tmax + t) * 64 + d, y);
-                    else pf_store_act4<F32>(a.kcache, (((size_t)sq * a.H + hd) * a.Tmax + t) * 64 + d, y);
-                } else if constexpr (F32) {                            // only when D % 128 != 0 (else pf_store_vt takes the V regions)
-                    const size_t o = (((size_t)sq * a.H + hd) * 64 + d) * a.Tmax + t;
-                    if (a.kv_planes) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) pf_store_planes1(a.vcache, a.kv_planes, o + (size_t)q * a.Tmax, v[q]);
-                    } else {
-                        float* vt = (float*)a.vcache + o;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) vt[(size_t)q * a.Tmax] = v[q];
-                    }
-                } else {
-                    u16* vt = (u16*)a.vcache + (((size_t)sq * a.H + hd) * 64 + d) * a.Tmax + t;
-                    const v2u_t pk = pf_cvt4(v);
-                    vt[0] = (u16)(pk.x & 0xffffu);
-                    vt[(size_t)a.Tmax] = (u16)(pk.x >> 16);
-                    vt[(size_t)2 * a.Tmax] = (u16)(pk.y & 0xffffu);
-                    vt[(size_t)3 * a.Tmax] = (u16)(pk.y >> 16);
-                }
-            }
-        }
-    }
-}
-
-// V^T part of the fused wqkv epilogue (EPI_QKV_ROPE, 128-column tile regions that lie inside the V columns; D % 128 == 0): the
-// accumulators were written to LDS TRANSPOSED (ctT [128 columns][ROWS + 4], each lane's 4 consecutive rows = one 16-byte write), so
-// a thread owns 4 consecutive frames of one (head, d) row of V^T and a wave's stores walk along t: 8-byte stores when the frame
-// run is 4-aligned, 2-byte stores into shared lines otherwise.  (Read from the row-major image the same stores were one 2-byte
-// element per line per lane: the wqkv GEMM ran at 425 TFLOP/s against 790 for the SwiGLU GEMM of the same K.)
-template <int ROWS, int NT, bool F32 = false>
-__device__ __forceinline__ void pf_store_vt(const GemmArgs& a, const float* ctT, int m0, int n0, int tid) {
-    constexpr int RQ = ROWS / 4, CSTEP = NT / RQ;                   // a thread keeps its 4-frame run and walks over the columns
-    const int rq = tid % RQ, col0 = tid / RQ;
-    const int m = m0 + 4 * rq;
-    if (m >= a.M) return;
-    const int ml = m + 3 < a.M ? m + 3 : a.M - 1;
-    const int s0 = a.tok_seq[m], t0 = a.tok_t[m];
-    const bool run = m + 3 < a.M && a.tok_seq[ml] == s0;          // rows of one sequence are consecutive frames
-    const bool wide = run && (((t0 | a.Tmax) & 3) == 0);
-    int sq[4], tq[4];
-    if (!run) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const int mq = m + q < a.M ? m + q : a.M - 1; sq[q] = a.tok_seq[mq]; tq[q] = a.tok_t[mq]; }
-    }
-#pragma unroll 4
-    for (int i = 0; i < 128 / CSTEP; ++i) {
-        const int col = col0 + i * CSTEP;
-        const int n = n0 + col;
-        if (n >= a.N) break;
-        f32x4 v = *(const f32x4*)(ctT + col * (ROWS + 4) + 4 * rq);
-        if (a.bias) {
-            const float b = a.bias[n];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += b;
-        }
-        const int c = n - 2 * a.D, hd = c >> 6, d = c & 63;
-        if constexpr (F32) {                                       // f32 V^T image: 16-byte stores along t when the run is 4-aligned
-            if (a.kv_planes) {                                     // ... or its three bf16 planes (8-byte stores)
-                if (run && wide) {
-                    pf_store_planes4(a.vcache, a.kv_planes, (((size_t)s0 * a.H + hd) * 64 + d) * a.Tmax + t0, v);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (m + q < a.M) {
-                            const size_t o = run ? (((size_t)s0 * a.H + hd) * 64 + d) * a.Tmax + t0 + q : (((size_t)sq[q] * a.H + hd) * 64 + d) * a.Tmax + tq[q];
-                            pf_store_planes1(a.vcache, a.kv_planes, o, v[q]);
-                        }
-                }
-                continue;
-            }
-            if (run) {
-                float* vt = (float*)a.vcache + (((size_t)s0 * a.H + hd) * 64 + d) * a.Tmax + t0;
-                if (wide) *(f32x4*)vt = v;
-                else { vt[0] = v[0]; vt[1] = v[1]; vt[2] = v[2]; vt[3] = v[3]; }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (m + q < a.M) ((float*)a.vcache)[(((size_t)sq[q] * a.H + hd) * 64 + d) * a.Tmax + tq[q]] = v[q];
-            }
-            continue;
-        }
-        const v2u_t pk = pf_cvt4(v);
-        if (run) {
-            u16* vt = (u16*)a.vcache + (((size_t)s0 * a.H + hd) * 64 + d) * a.Tmax + t0;
-            if (wide) {
-                *(v2u_t*)vt = pk;
-            } else {
-                vt[0] = (u16)(pk.x & 0xffffu); vt[1] = (u16)(pk.x >> 16); vt[2] = (u16)(pk.y & 0xffffu); vt[3] = (u16)(pk.y >> 16);
-            }
-        } else {
-            const u16 e[4] = {(u16)(pk.x & 0xffffu), (u16)(pk.x >> 16), (u16)(pk.y & 0xffffu), (u16)(pk.y >> 16)};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (m + q < a.M) ((u16*)a.vcache)[(((size_t)sq[q] * a.H + hd) * 64 + d) * a.Tmax + tq[q]] = e[q];
-        }
-    }
-}
-
 // F32 = true: the same kernel on v_mfma_f32_16x16x4_f32 (exact f32: the s2mel f32 mode and the GPT parity mode's prefill).  A K tile is
 // 32 f32 = the same 128 bytes per row, the packed f32 weights ([N/16][K/16][64 lanes][16 B]) give the same 2 KiB per n-tile and K tile,
 // so the LDS images, the DMA issue and the fragment read offsets are byte-identical; a 16-byte fragment piece now holds 4 k-values =
@@ -1242,9 +864,6 @@ __global__ __launch_bounds__((PF_ABL & 256) ? 320 : 256) void gemm_prefill_kerne
     }
 }
 
-static bool pf_vec_ok(const GemmArgs& a) {
-    return (a.N % 4 == 0) && (a.ldo % 4 == 0 || (a.epi != EPI_STORE_F32 && a.epi != EPI_RESIDUAL && a.epi != EPI_GELU_ACT)) && (a.D % 4 == 0);
-}
 
 template <int EPI, bool CONV = false>
 static int launch_gemm_prefill_e(const GemmArgs& a, hipStream_t st) {
@@ -1762,9 +1381,6 @@ static int launch_gemm_prefill_f32_e(const GemmArgs& a, hipStream_t st) {
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }
-static bool pf_f32_ok(const GemmArgs& a) {
-    return a.K % 32 == 0 && a.lda % 4 == 0 && a.nsplit == 1 && a.epi != EPI_PARTIAL && pf_vec_ok(a) && (((uintptr_t)a.A) & 15) == 0;
-}
 
 static int launch_gemm_prefill_f32(const GemmArgs& a, hipStream_t st) {
     if (a.epi == EPI_GATE && a.conv_taps > 0 &&
@@ -1782,330 +1398,6 @@ static int launch_gemm_prefill_f32(const GemmArgs& a, hipStream_t st) {
         case EPI_QKV_ROPE: return launch_gemm_prefill_f32_e<EPI_QKV_ROPE>(a, st);
         case EPI_WN_RS: return launch_gemm_prefill_f32_e<EPI_WN_RS>(a, st);
         default: itts_set_error("gemm prefill (f32): unsupported epilogue %d", a.epi); return ITTS_ERR_ARG;
-    }
-}
-
-// ================================================================================================================
-// f32-accurate GEMM on the bf16 matrix pipe ("f32x3"): every f32 operand is carried EXACTLY as three bf16 planes
-//   x = xh + xm + xl,  xh = bf16(x), xm = bf16(x - xh), xl = bf16(x - xh - xm)        (8 + 8 + 8 significand bits, no bit dropped)
-// and an f32 product is the sum of the plane products, each of them exact in the f32 accumulator of v_mfma_f32_16x16x32_bf16:
-//   NPROD = 8: every term down to 2^-24 |a b| (hh, hm, mh, mm, hl, lh, ml, lm; only ll, 2^-32, is dropped) -- closer to the exact
-//              product than one f32 rounding;  NPROD = 6: without ml / lm (<= 2^-24 |a b| each in the worst case; their sum measured at
-//              5.7e-9 of the result's RMS on N(0, 1) operands at K = 512 by a CPU emulation of the plane arithmetic: 1/50 of the native f32
-//              GEMM's own error against f64).
-// Accumulation stays f32.  The native f32 MFMA runs at 1/16 of the bf16 rate, so 8 bf16 MFMAs per K = 32 tile pair replace 8 f32
-// MFMAs of twice the issue time: 2x the native-f32 matrix rate (2.67x with 6 products) -- tests/test_gpu_gemm_x3.py holds the
-// result to an f64 GEMM and compares its error with the native f32 kernel's on the same operands.
-//   Activations stay f32 in HBM and LDS: the A tile is DMA'd exactly like the f32 tile kernel's ([128 rows][32 k] f32, same image and
-//   swizzle) and each wave splits its fragments in registers (11 VALU ops per pair of values, software-pipelined under the MFMAs).  The
-//   lane's eight k-values are the two 16-byte pieces the f32 kernel reads (k = 4 kg + j and 16 + 4 kg + j): conflict-free, and the
-//   weights are packed with the same k permutation.  Weights are split once on the host (itts_pack_gemm_weight, precision 2):
-//   [N/16][K/32][3 planes][64 lanes][16 B], read by the waves straight into registers (no LDS stage).  LDS: two 16 KiB A stages; the
-//   66 KiB epilogue image is the allocation -> two blocks per CU.
-//   Measured (profiles/r03e..r03i): 155-165 TFLOP/s f32-equivalent with 8 products (native f32 MFMA kernel: 128), ~190 with 6 -- not
-//   the 2x the instruction rates promise.  Variants that changed nothing: weights through LDS (80 / 66 KiB), the split as a burst or
-//   interleaved, v_mfma_f32_32x32x16_bf16 (slower: 132).  The SQ counters show the matrix pipe 42 % busy with the waves issue-stalled,
-//   and rocm-smi shows why the ceiling is low: under this kernel the socket sits at its ~1.25 kW power limit and the engine clock falls
-//   from 2.39 GHz (the native f32 solve holds it at 1.2 kW) to ~2.03 GHz -- eight bf16 MFMAs cost more energy than the one f32 MFMA
-//   they replace, so the power cap, not the issue rate, prices this mode.
-#define X3_LDS PF_LDS            // 2 x 16 KiB of A stages; the epilogue's transposed image (+ row metadata) is the larger
-#define X3_LDS_ONE (96 * 1024)   // an LDS request that admits ONE block per CU (launch_gemm_x3_e: the variants that are not the shipped one)
-
-// a - b as ONE scalar v_sub_f32 that the SLP vectoriser cannot pair up: this file is built with SLP vectorisation (build.py: the GPT sampler's
-// bit-exact fixtures depend on it), which turns the split's adjacent subtractions into v_pk_add_f32 + s_nop -- and a packed f32 op beside MFMAs
-// costs ~13 cycles more than the two scalar ops it replaces (MI355X guide; flash_attn_x3_kernel, built without SLP, keeps the matrix pipe 64 %
-// busy against 45 % here, profiles/r04q).  Plain VALU -> VALU dependencies: hardware-interlocked, no software hazard.
-__device__ __forceinline__ float x3_sub(float a, float b) {
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-template <bool SCALAR = false>
-__device__ __forceinline__ void x3_split8(const f32x4 p0, const f32x4 p1, v4u& H, v4u& M, v4u& L) {
-    const float x[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float a = x[2 * i], b = x[2 * i + 1];
-        const uint32_t h = pf_cvt2(a, b);
-        float ra, rb, sa, sb;
-        if constexpr (SCALAR) { ra = x3_sub(a, __uint_as_float(h << 16)); rb = x3_sub(b, __uint_as_float(h & 0xffff0000u)); }
-        else { ra = a - __uint_as_float(h << 16); rb = b - __uint_as_float(h & 0xffff0000u); }              // exact
-        const uint32_t m = pf_cvt2(ra, rb);
-        if constexpr (SCALAR) { sa = x3_sub(ra, __uint_as_float(m << 16)); sb = x3_sub(rb, __uint_as_float(m & 0xffff0000u)); }
-        else { sa = ra - __uint_as_float(m << 16); sb = rb - __uint_as_float(m & 0xffff0000u); }            // exact
-        H[i] = h; M[i] = m; L[i] = pf_cvt2(sa, sb);
-    }
-}
-
-template <int EPI, bool CONV = false, int NPROD = 8, bool SCHED = true, bool SCALAR = false, bool APL = false>
-// SCALAR: the operand split on scalar v_sub_f32 (x3_sub).  APL: the A operand arrives as three bf16 planes (GemmArgs::a_planes, written once by the
-// producer in fragment order): the K tile's three plane images are LDS-DMA'd (3 x 8 KiB) and a fragment is one ds_read_b128 per plane -- no split at all.
-__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB] operand stages; the epilogue image is the larger
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wr = w >> 1, wc = w & 1;
-    const int n_mt = (a.M + PF_BM - 1) / PF_BM, n_nt = (a.N + PF_BN - 1) / PF_BN;
-    const int total = n_mt * n_nt, per = (total + 7) >> 3;
-    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (t >= total) return;
-    const int g0 = t / (PF_GM * n_nt), first_m = g0 * PF_GM;
-    const int gm = (n_mt - first_m) < PF_GM ? (n_mt - first_m) : PF_GM;
-    const int r = t - g0 * PF_GM * n_nt;
-    const int bn = r / gm, bm = first_m + (r - bn * gm);
-    const int m0 = bm * PF_BM, nt0 = bn * (PF_BN / 16);
-    const int nk = a.K >> 5;                                           // K tiles of 32
-    const int ntiles = (a.N + 15) >> 4;
-
-    constexpr int STAGE = APL ? 24576 : 16384;                          // bytes of one A stage
-    const char* asrc[APL ? 6 : 4];
-    int cv_t[4], cv_T[4];
-    const char* cv_base[4];
-    const char* cv_zero[4];
-    const int cv_kpt = CONV ? a.conv_W / 32 : 1;
-    const int cv_left = CONV ? (a.conv_taps - 1) * a.conv_dil - ((a.conv_taps - 1) * a.conv_dil) / 2 : 0;
-    if constexpr (APL) {
-        // plane p, chunk c = 16 tile rows of 64 bytes (32 k of bf16): lane l fetches row 16 c + (l >> 2), 16-byte piece (l & 3) ^ ((l >> 4) & 3) into
-        // LDS slot l of the chunk (source-side XOR: a fragment read of one k-group over 16 rows then covers 16 different bank quads)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int pl = i >> 1, c = w + 4 * (i & 1);
-            int m = m0 + c * 16 + (lane >> 2);
-            m = m < a.M ? m : a.M - 1;
-            const int piece = (lane & 3) ^ ((lane >> 4) & 3);
-            asrc[i] = (const char*)a.A + ((size_t)pl * a.a_planes + (size_t)m * a.lda) * 2 + piece * 16;
-        }
-    } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = w * 4 + i;                               // A chunk: tile rows c*8 .. c*8+7
-        const int row_t = c * 8 + (lane >> 3), row16 = row_t & 15;
-        const int piece = (lane & 7) ^ ((row16 >> 1) & 7);
-        int m = m0 + row_t;
-        m = m < a.M ? m : a.M - 1;
-        asrc[i] = (const char*)a.A + (size_t)m * a.lda * 4 + piece * 16;
-        if constexpr (CONV) {
-            const int sq = a.tok_seq[m];
-            cv_t[i] = a.tok_t[m];
-            cv_T[i] = a.seq_T[sq];
-            cv_base[i] = (const char*)a.A + (size_t)a.seq_start[sq] * a.lda * 4 + piece * 16;
-            cv_zero[i] = (const char*)a.zero_row + piece * 16;
-        }
-    }
-    }
-    // The weight fragments never touch LDS: they are stored in fragment order (one contiguous KiB per (n-tile, K tile, plane)), so the
-    // wave loads its own twelve straight into registers with plain coalesced loads, one K tile ahead (two register sets, the loop is
-    // unrolled by two).  An LDS-DMA piece costs 60-185 cycles of issue beside MFMAs (MI355X guide).
-    const v4u* wsrc[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        int ntile = nt0 + wc * 4 + nt;
-        ntile = ntile < ntiles ? ntile : ntiles - 1;
-        wsrc[nt] = (const v4u*)((const char*)a.Wp + (size_t)ntile * nk * 3072) + lane;
-    }
-    auto issue_a = [&](int kt, int buf) {
-        char* base = pf_sm + buf * STAGE;
-        if constexpr (APL) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)kt * 64),
-                                                 (__attribute__((address_space(3))) void*)(base + (i >> 1) * 8192 + (w + 4 * (i & 1)) * 1024), 16, 0, 0);
-            return;
-        }
-        int tap = 0, rem = kt;
-        if constexpr (CONV) { tap = kt / cv_kpt; rem = kt - tap * cv_kpt; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const char* ap = asrc[i] + (size_t)kt * 128;
-            if constexpr (CONV) {
-                const int maxpad = cv_left;
-                const int Tv = cv_T[i] <= maxpad ? maxpad + 1 : cv_T[i];
-                int p = cv_t[i] + tap * a.conv_dil - cv_left;
-                p = p < 0 ? -p : p;
-                p = p >= Tv ? 2 * (Tv - 1) - p : p;
-                const bool ok = p >= 0 && p < cv_T[i];
-                ap = ok ? cv_base[i] + ((size_t)p * a.lda + (size_t)rem * 32) * 4 : cv_zero[i];
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap,
-                                             (__attribute__((address_space(3))) void*)(base + (w * 4 + i) * 1024), 16, 0, 0);
-        }
-    };
-    auto load_w = [&](int kt, v4u (&bw)[4][3]) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bw[nt][p] = wsrc[nt][((size_t)kt * 3 + p) * 64];
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int row16 = lane & 15, kg = lane >> 4;
-    int a_off[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const int pos = (s2 * 4 + kg) ^ ((row16 >> 1) & 7);
-        a_off[s2] = (row16 >> 3) * 1024 + ((row16 & 7) * 8 + pos) * 16;
-    }
-    const int a_wave = wr * 4 * 2048;
-    const int a_off_pl = (row16 * 4 + (kg ^ ((row16 >> 2) & 3))) * 16;     // APL: slot of k-group kg in row row16 of a 1 KiB chunk (16 rows x 64 B)
-
-    // one K tile: `bw` holds its weight fragments (loaded during the previous tile), `bn_` receives the next tile's.  Software pipeline
-    // over the four m-tiles: the operand split of m-tile mt + 1 (two LDS reads, 44 VALU ops) is issued in the shadow of m-tile mt's
-    // 4 x NPROD MFMAs (SCHED: 2 MFMAs, then 3 VALU ops, ...) instead of as a burst in front of them.
-    auto ktile = [&](int kt, v4u (&bw)[4][3], v4u (&bn_)[4][3]) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this tile's A DMA and weight loads have landed
-        __syncthreads();                                           // ... for every wave; the other A stage is free again
-        if (kt + 1 < nk) {
-            issue_a(kt + 1, (kt + 1) & 1);
-            load_w(kt + 1, bn_);
-        }
-        const char* base = pf_sm + (kt & 1) * STAGE;
-        v4u ap[3], an[3];
-        if constexpr (APL) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) ap[pl] = *(const v4u*)(base + pl * 8192 + wr * 4096 + a_off_pl);
-        } else {
-            const f32x4 p0 = *(const f32x4*)(base + a_wave + a_off[0]);
-            const f32x4 p1 = *(const f32x4*)(base + a_wave + a_off[1]);
-            x3_split8<SCALAR>(p0, p1, ap[0], ap[1], ap[2]);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            if (mt < 3) {
-                if constexpr (APL) {
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) an[pl] = *(const v4u*)(base + pl * 8192 + wr * 4096 + (mt + 1) * 1024 + a_off_pl);
-                } else {
-                const f32x4 p0 = *(const f32x4*)(base + a_wave + (mt + 1) * 2048 + a_off[0]);
-                const f32x4 p1 = *(const f32x4*)(base + a_wave + (mt + 1) * 2048 + a_off[1]);
-                x3_split8<SCALAR>(p0, p1, an[0], an[1], an[2]);
-                }
-            }
-            // plane pairs, smallest terms first; four independent accumulators between two MFMAs on the same one
-            constexpr int PA[8] = {2, 1, 2, 0, 1, 1, 0, 0};
-            constexpr int PB[8] = {1, 2, 0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int q = 8 - NPROD; q < 8; ++q)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ap[PA[q]]),
-                                                                          __builtin_bit_cast(bf16x8_t, bw[nt][PB[q]]), acc[mt][nt], 0, 0, 0);
-            if (APL && mt < 3) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          // the next m-tile's three plane fragments, then this one's MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NPROD, 0);
-            }
-            if (!APL && SCHED && mt < 3) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // the next m-tile's two fragment pieces
-#pragma unroll
-                for (int i = 0; i < 2 * NPROD; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMAs ...
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // ... 3 VALU ops of the next split
-                }
-            }
-            if (mt < 3) { ap[0] = an[0]; ap[1] = an[1]; ap[2] = an[2]; }
-        }
-    };
-    v4u bw0[4][3], bw1[4][3];
-    issue_a(0, 0);
-    load_w(0, bw0);
-    for (int kt = 0; kt < nk; kt += 2) {
-        ktile(kt, bw0, bw1);
-        if (kt + 1 < nk) ktile(kt + 1, bw1, bw0);
-    }
-    // epilogue: the f32 tile kernel's vector path
-    __syncthreads();
-    float* ct = (float*)pf_sm;
-    const int g = lane >> 4, c16 = lane & 15;
-    if (EPI == EPI_QKV_ROPE && a.D % 128 == 0 && nt0 * 16 >= 2 * a.D) {       // block-uniform: a V tile
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) *(f32x4*)(ct + (wc * 64 + nt * 16 + c16) * 132 + wr * 64 + mt * 16 + g * 4) = acc[mt][nt];
-        __syncthreads();
-        pf_store_vt<128, 256, true>(a, ct, m0, nt0 * 16, threadIdx.x);
-        return;
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                ct[(wr * 64 + mt * 16 + g * 4 + rr) * 128 + ((wc * 64 + nt * 16 + c16) ^ (g << 4))] = acc[mt][nt][rr];
-    int* meta = (int*)(pf_sm + 65536);
-    pf_stage_meta<EPI, 128>(a, meta, m0, threadIdx.x);
-    __syncthreads();
-    pf_store_tile<EPI, 128, 256, true>(a, ct, meta, m0, nt0 * 16, threadIdx.x);
-}
-
-template <int EPI, bool CONV = false>
-static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
-    const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
-    const int per = ceil_div(n_mt * n_nt, 8);
-    const int nprod = itts_opt(OPT_X3_PRODUCTS) == 6 ? 6 : 8;
-    const bool sched = itts_opt(OPT_X3_SCHED) != 0;                 // A/B switch of the MFMA / split interleave
-    static ItPerDevice<bool> attr_set_pd;
-    bool& attr_set = attr_set_pd.cur();
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
-        attr_set = true;
-    }
-    const dim3 grid(per * 8), blk(256);
-    // Residency.  The shipped variant (6 products, interleaved split) runs two blocks per CU and is held to run-to-run bit equality at solve
-    // sizes by tests/test_gpu_s2mel.py.  The other three variants FAILED that check when two of their blocks share a CU (profiles/r04d: the
-    // 8-product solve differed from run to run in scattered token rows by up to 1e-2 at >= 9.7 k rows while every plain-store GEMM launch of the
-    // same kernels soaked clean; one block per CU: bit-stable, cause not found) -- they are A/B and accuracy-study paths, so they are pinned to
-    // one block per CU by an LDS request above half a CU's 160 KiB.
-    const size_t lds = ((nprod == 6 && sched) || itts_opt(OPT_X3_PIN) == 0) ? X3_LDS : X3_LDS_ONE;
-    if constexpr (!CONV && (EPI == EPI_QKV_ROPE || EPI == EPI_SWIGLU)) {     // the two GEMMs behind an adaptive RMSNorm: A as bf16 planes
-        if (a.a_planes) {
-            if (nprod != 6 || !sched) { itts_set_error("gemm (f32x3): the plane-operand form exists for the shipped variant only (6 products, interleaved)"); return ITTS_ERR_ARG; }
-            static ItPerDevice<bool> apl_set_pd;
-            bool& apl_set = apl_set_pd.cur();
-            if (!apl_set) {
-                HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI, CONV, 6, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_ONE));
-                apl_set = true;
-            }
-            hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true, true, true>), grid, blk, lds, st, a);
-            HIP_TRY(hipGetLastError());
-            return ITTS_OK;
-        }
-    } else if (a.a_planes) { itts_set_error("gemm (f32x3): plane operands are supported for the wqkv / SwiGLU GEMMs only"); return ITTS_ERR_ARG; }
-    if (nprod == 6 && sched && itts_opt(OPT_X3_SPLIT) == 1) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true, true>), grid, blk, lds, st, a);
-    else if (nprod == 6 && sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true>), grid, blk, lds, st, a);
-    else if (nprod == 6) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, false>), grid, blk, lds, st, a);
-    else if (sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, true>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, false>), grid, blk, lds, st, a);
-    HIP_TRY(hipGetLastError());
-    return ITTS_OK;
-}
-
-static int launch_gemm_x3(const GemmArgs& a, hipStream_t st) {
-    if (!pf_f32_ok(a)) {
-        itts_set_error("gemm (f32x3): needs K %% 32 == 0, lda %% 4 == 0, N / ldo / D %% 4 == 0, 16-byte aligned rows, no split-K (M=%d N=%d K=%d lda=%d epi=%d)",
-                       a.M, a.N, a.K, a.lda, a.epi);
-        return ITTS_ERR_ARG;
-    }
-    if (a.epi == EPI_GATE && a.conv_taps > 0 &&
-        (a.conv_W % 32 || a.K != a.conv_taps * a.conv_W || a.lda != a.conv_W || !a.tok_seq || !a.tok_t || !a.seq_start || !a.seq_T || !a.zero_row)) {
-        itts_set_error("gemm tap mode (f32x3): need conv_W %% 32 == 0, K == taps * conv_W, lda == conv_W and the sequence tables");
-        return ITTS_ERR_ARG;
-    }
-    switch (a.epi) {
-        case EPI_STORE_F32: return launch_gemm_x3_e<EPI_STORE_F32>(a, st);
-        case EPI_RESIDUAL: return launch_gemm_x3_e<EPI_RESIDUAL>(a, st);
-        case EPI_SWIGLU: return launch_gemm_x3_e<EPI_SWIGLU>(a, st);
-        case EPI_GATE: return a.conv_taps > 0 ? launch_gemm_x3_e<EPI_GATE, true>(a, st) : launch_gemm_x3_e<EPI_GATE>(a, st);
-        case EPI_QKV_ROPE: return launch_gemm_x3_e<EPI_QKV_ROPE>(a, st);
-        case EPI_WN_RS: return launch_gemm_x3_e<EPI_WN_RS>(a, st);
-        default: itts_set_error("gemm (f32x3): unsupported epilogue %d", a.epi); return ITTS_ERR_ARG;
     }
 }
 
@@ -2657,8 +1949,7 @@ int gemm_tile_occupancy(int prec, int* blocks) {
         (void)hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI_RESIDUAL, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_prefill_kernel<EPI_RESIDUAL, false, true, true>, 256, PF_LDS);
     } else if (prec == PREC_F32X3) {
-        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<EPI_RESIDUAL, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_x3_kernel<EPI_RESIDUAL, false, 8, true>, 256, X3_LDS);
+        return gemm_x3_occupancy(blocks);
     } else {
         (void)hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI_RESIDUAL, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_prefill_kernel<EPI_RESIDUAL, false, true, false>, 256, PF_LDS);

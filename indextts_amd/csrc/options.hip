@@ -32,7 +32,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"sample_radix", -1, -1, 1, "top-k threshold: -1 per-kernel default (radix select in sample_kernel, ballot bisection in the beam kernels), 0 bisection, 1 radix select (identical ids)"},
     {"gpt_compact", 1, 0, 1, "row compaction of ragged decode batches (0 disables it for every handle; identical ids)"},
     {"attn_waves", 0, 0, 16, "waves per block of the KV-cache attention kernel: 0 pick by shape, else 4 / 8 / 16 (the 16 canonical key streams are mapped onto them; bitwise equal)", "0,4,8,16"},
-    {"s2mel_fused", 1, 0, 2, "s2mel: fused GEMM epilogues, sampled when a handle is created -- 1: fused (the bf16 mode keeps its wqkv GEMM + RoPE / scatter as two launches: its fused epilogue is not bit-stable run to run), 2: everything fused, 0: separate element-wise kernels"},
+    {"s2mel_fused", 1, 0, 2, "s2mel: fused GEMM epilogues, sampled when a handle is created -- 1: fused, 0: separate element-wise kernels (2: round 4's spelling of 'the bf16 wqkv epilogue fused too'; the same as 1 since the RoPE fix of round 5)"},
     {"fa_qs", 0, 0, 4, "bf16 flash attention: query sub-tiles per wave (0: pick by shape)", "0,1,2,4"},
     {"f32_attn_scalar", 0, 0, 1, "f32 s2mel attention on the one-wave-per-query reference kernel (the A/B path of the f32 flash kernel)"},
     {"fa32_qs", 2, 1, 2, "f32 flash attention: query sub-tiles per wave"},
@@ -40,9 +40,8 @@ const OptDef kDefs[OPT_COUNT] = {
     {"conv_bm", 0, 0, 128, "force the co-tile height of conv_mfma_kernel (0: pick by channel count)", "0,32,64,96,128"},
     {"h3_kernel", 1, 0, 1, "f16x3 vocoder conv: 1 window kernel, 0 two-stage kernel"},
     {"decode_ln_nt", 2, 2, 4, "LayerNorm-fused decode GEMM at 5-16 rows (weights on waves 0-3, LayerNorm on waves 4-7): n-tiles per block, 2 or 4 (bitwise equal)", "2,4"},
-    {"x3_split", 1, 0, 1, "fp32x3 GEMM (6 products): operand split on scalar v_sub_f32 (1, measured +2.5 % on the GEMMs) instead of the SLP-packed v_pk_add_f32 form (0); bitwise equal"},
     {"x3_aplanes", 0, 0, 1, "fp32x3 s2mel: the adaptive-RMSNorm outputs as three bf16 planes in fragment order, wqkv / w1|w3 GEMMs without an operand split (bitwise equal)"},
-    {"x3_pin", 1, 0, 1, "fp32x3 GEMM: pin the variants that are not the shipped one (8 products, burst split) to one block per CU (0: two blocks per CU -- diagnostic only, those variants are not bit-stable run to run there, DESIGN.md section 9)"},
+    {"x3_pin", 0, 0, 1, "fp32x3 GEMM: 1 pins the variants that are not the default one (8 products, burst split) to one block per CU -- round 4's workaround for their run-to-run differences, kept as a diagnostic; not needed since the RoPE fix of round 5 (DESIGN.md section 9)"},
     {"prefill_attn", -1, -1, 1, "attention of S > 1 passes (prefill, latent pass): -1 causal MFMA kernel in the bf16 mode, canonical-stream kernel in the f32 parity mode; 0 canonical-stream kernel (one block per query) always; 1 MFMA kernel in both precisions"},
 };
 std::atomic<int> g_val[OPT_COUNT];

@@ -210,7 +210,7 @@ class UnifiedVoice:
     def conds_latent(self, campplus_embedding: torch.Tensor, emo_vec: torch.Tensor) -> torch.Tensor:
         """spk_emb_proj(style) + emo_vec, then two zero tokens (model_v2.py:754-755,768)."""
         dev = self.device
-        spk = linear_f32(campplus_embedding.to(dev, torch.float32), self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
+        spk = _spk_proj(campplus_embedding.to(dev, torch.float32), self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
         spk = spk.unsqueeze(0) if spk.ndim != 3 else spk
         emo_vec = emo_vec.to(dev, torch.float32)
         return torch.cat((spk + emo_vec.unsqueeze(1), torch.zeros(spk.size(0), 2, spk.size(2), device=dev)), 1), spk
@@ -648,7 +648,7 @@ class UnifiedVoice:
             conds = torch.cat((spk + emo_vec.to(dev, torch.float32).unsqueeze(1), half.unsqueeze(1), dur.unsqueeze(1)), 1)
             return self.forward_latent(conds, text_inputs, text_lengths, mel_codes, mel_codes_lengths)
         if do_spk_cond:
-            spk = linear_f32(spk, self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
+            spk = _spk_proj(spk, self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
             if spk.ndim != 3:
                 spk = spk.unsqueeze(1)
         conds = torch.cat((spk + emo_vec.to(dev, torch.float32).unsqueeze(1),
@@ -769,6 +769,15 @@ def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     a = x.reshape(-1, K).to(torch.float32).contiguous()
     out = gemm(a, hit[1], None if bias is None else bias.to(x.device, torch.float32).contiguous(), N, 0)
     return out.reshape(*lead, N)
+
+
+def _spk_proj(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """spk_emb_proj (model_v2.py:754): a (B, 192) x (192, D) projection, once per batch, outside every loop.  Evaluated in float64 on the host and
+    rounded once: the result does not depend on any library's summation order.  That matters: the reference-minted `typical_greedy` fixture holds a
+    token whose margin is below f32 summation noise of this projection -- the engine's f32 MFMA GEMM (another order than the reference's CPU sgemm)
+    flips it, the correctly rounded value keeps it (profiles/r05d/status.txt).  No vendor BLAS call either way."""
+    y = x.detach().to("cpu", torch.float64) @ weight.detach().to("cpu", torch.float64).t() + bias.detach().to("cpu", torch.float64)
+    return y.to(torch.float32).to(x.device)
 
 
 def gemm_ln(x, g, b, w_packed, bias, N: int, partial=None, bias_prev=None, eps=1e-5):

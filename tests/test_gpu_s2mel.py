@@ -303,17 +303,26 @@ def test_dead_row_elimination_is_bit_identical(precision):
     print(f"{precision}: GEMM FLOPs of the solve {flops[False]:.3e} -> {flops[True]:.3e} with the prompt rows' dead tail work removed")
 
 
-@pytest.mark.parametrize("mode", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3", "fp32x3:x3_products=8", "fp32x3:x3_sched=0", "fp32x3:x3_attn=0,x3_products=8,x3_sched=0", "bf16"])
 def test_estimator_is_bit_stable_run_to_run_at_solve_size(mode):
     """The production architecture on two utterances of 517 + 1926 frames (9772 packed rows with the CFG branch: every tile GEMM launch runs
     several blocks per CU): three estimator calls and three one-step solves on the same inputs return the same BITS, with the cached workspace
-    filled with NaN patterns in between (nothing may be read before it is written).  Round 4 found run-to-run differences in the x3 GEMM variants
-    that are not the shipped one when two of their blocks share a CU (profiles/r04d; they are pinned to one block per CU since) -- this test
-    holds the two modes that may carry `bench.py`'s headline to determinism at a size where that showed."""
+    filled with NaN patterns in between (nothing may be read before it is written).  Round 4 found run-to-run differences in the bf16 mode and in
+    the x3 GEMM variants that are not the default one when two of their blocks share a CU, and worked around them (two launches / one block per CU);
+    round 5 traced them to the packed RoPE arithmetic of the fused wqkv epilogue (pf_rope4; profiles/r05a/capture.log, r05b/trace.log) -- every
+    mode and variant, fused and at two blocks per CU, is held to determinism here."""
     import hashlib
     from indextts_amd import s2mel, synth
+    from indextts_amd import _lib
     args = synth.S2MEL_V2
-    m = s2mel.CFM(args, precision=mode, device=DEV)
+    prec, _, optstr = mode.partition(":")
+    opts = {k: int(v) for k, v in (kv.split("=") for kv in optstr.split(",") if kv)}
+    with _lib.option_scope(**opts):
+        _bit_stable_body(prec, mode, args, hashlib, s2mel, synth)
+
+
+def _bit_stable_body(prec, mode, args, hashlib, s2mel, synth):
+    m = s2mel.CFM(args, precision=prec, device=DEV)
     m.load_state_dict(synth.s2mel_weights(args, seed=1234))
     g = torch.Generator().manual_seed(0)
     B, Tp, T = 2, 517, 517 + 1926
@@ -326,7 +335,7 @@ def test_estimator_is_bit_stable_run_to_run_at_solve_size(mode):
     px[..., :Tp] = prompt
     hsh = lambda y: hashlib.sha1(y.float().cpu().numpy().tobytes()).hexdigest()[:12]
     est, sol = [], []
-    for _ in range(3):
+    for _ in range(4):
         if m._ws is not None:
             m._ws.fill_(0xFF)
         est.append(hsh(m.estimator(torch.cat([x, x]), torch.cat([px, torch.zeros_like(px)]), lens, torch.full((2 * B,), 0.3),
@@ -343,8 +352,9 @@ def test_bf16_estimator_is_bit_stable_run_to_run_with_stage_trace():
     """The bf16 mode at production depth, 12 estimator calls on the same inputs with the engine's stage checksums on (itts_s2mel_set_trace: one
     order-independent 64-bit checksum per stage output, in launch order): every call gives the same checksums for every stage.  Round 4 found this
     mode differing run to run in about one call of two; the trace put the first differing stage in the Q / K tiles of the fused wqkv epilogue of
-    the bf16 tile kernels (profiles/r04j), so the mode now runs that GEMM with a plain store and the RoPE / scatter as a second launch (option
-    s2mel_fused = 2 restores the fused form).  The trace names the stage should a difference come back."""
+    the bf16 tile kernels (profiles/r04j), and round 5's stage captures showed one quarter-wave per differing call storing v2 c1 instead of
+    v2 c1 - v3 s1 -- the SLP-packed RoPE arithmetic (pf_rope4 replaces it).  The mode runs the FUSED epilogue again.  The trace names the stage
+    should a difference come back."""
     import collections
     from indextts_amd import _lib, s2mel, synth
     args = synth.S2MEL_V2

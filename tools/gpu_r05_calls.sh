@@ -50,4 +50,34 @@ call2() {
     tail -4 $O/pytest_s2mel.log
 }
 
+# round 5, GPU call 3: the product x3 GEMM with scalar addressing (pf_uni): GEMM shapes, solve time (with / without plane operands), tests of
+# everything the RoPE / addressing / fusion changes touch (GPT incl. the prefill attention, s2mel incl. determinism of every variant, x3 GEMM).
+call3() {
+    O=$PWD/gpurun_out/r05c
+    mkdir -p $O
+    timeout 300 python tools/gemm_x3_bench.py 312704 5 > $O/gemm_x3_bench.log 2>&1; echo "gemm_x3_bench rc=$?" | tee $O/status.txt
+    cat $O/gemm_x3_bench.log
+    timeout 600 python tools/s2mel_bench.py 8 517 1926 3 fp32x3 fp32x3:x3_aplanes=1 fp32x3 fp32x3:x3_aplanes=1 bf16 fp32 > $O/s2mel_bench.log 2>&1; echo "s2mel_bench rc=$?" | tee -a $O/status.txt
+    grep "^B=" $O/s2mel_bench.log
+    timeout 1200 python -m pytest tests/test_gpu_gpt.py -x -q -s -k "prefill or latent or bf16 or golden" > $O/pytest_gpt.log 2>&1; echo "pytest gpt rc=$?" | tee -a $O/status.txt
+    grep -E "prefill MFMA|passed|failed|Error|error" $O/pytest_gpt.log | tail -8
+    timeout 1500 python -m pytest tests/test_gpu_s2mel.py tests/test_gpu_gemm_x3.py -x -q > $O/pytest_s2mel.log 2>&1; echo "pytest s2mel rc=$?" | tee -a $O/status.txt
+    tail -4 $O/pytest_s2mel.log
+}
+
+# round 5, GPU call 4: (a) which arithmetic of the tiny spk_emb_proj projection keeps the reference-minted `typical_greedy` fixture's borderline
+# token (engine f32 GEMM / f64 on the host / vendor BLAS); (b) the bf16 x 3 vocoder conv: unit op vs f64 and the f32 kernel, generator vs the
+# reference-class waveforms, vocoder forward at 16 x 1926 frames in the three conv modes with per-stage conv rates.
+call4() {
+    O=$PWD/gpurun_out/r05d
+    mkdir -p $O
+    for m in engine f64 blas; do
+        ITTS_SPK_PROJ=$m timeout 600 python -m pytest tests/test_gpu_gpt.py -q -k "codes_bit_exact or beam_codes_bit_exact or v1_decode or v2_decode" > $O/pytest_spk_$m.log 2>&1; echo "spk proj $m rc=$? $(tail -1 $O/pytest_spk_$m.log)" | tee -a $O/status.txt
+    done
+    timeout 900 python -m pytest tests/test_gpu_bigvgan_x3.py -x -q -s > $O/pytest_voc_x3.log 2>&1; echo "pytest voc x3 rc=$?" | tee -a $O/status.txt
+    grep -E "x3 conv|rms err|passed|failed|Error|error" $O/pytest_voc_x3.log | tail -20
+    timeout 600 python tools/voc_h3_bench.py 16 f32,bf16x3:96,f16x3:96 > $O/voc_bench.log 2>&1; echo "voc bench rc=$?" | tee -a $O/status.txt
+    cat $O/voc_bench.log
+}
+
 "call$1"
