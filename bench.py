@@ -328,7 +328,21 @@ class HipEngine:
                              "unit": "TFLOP/s (f32-equivalent)", "frac": tf / (PEAK_BF16_MFMA_TFLOPS / 3.0)},
                 "rms_vs_f32_mode": float((w3.float() - ref.float()).pow(2).mean().sqrt()),
                 "signal_rms": float(ref.float().pow(2).mean().sqrt())}
-            del v3, w3, ref
+            del v3, w3
+            # ... and the vocoder's other exact-operand conv mode (f32 MFMA <-> bf16 x 3), one forward at the bench shape
+            other = "f32" if self.args.bigvgan_conv != "f32" else "bf16x3"
+            vo = bigvgan.BigVGAN(self.bh, device=self.dev, conv_mode=None if other == "f32" else other)
+            vo.load_state_dict(self.bsd)
+            vo.to(self.dev)
+            vo.set_profiling(True)
+            wo = vo(mel)
+            wo = vo(mel)
+            po = vo.profile()
+            out["bigvgan_other_conv_mode"] = {"conv": other, "ms_per_step": sum(v["ms"] for v in po.values()), "conv_ms_per_step": po["conv1d_mfma"]["ms"],
+                                              "conv_tflops_f32_equivalent": po["conv1d_mfma"]["flops"] / (po["conv1d_mfma"]["ms"] * 1e-3) / 1e12,
+                                              "rms_vs_headline_mode": float((wo.float() - ref.float()).pow(2).mean().sqrt()),
+                                              "signal_rms": float(ref.float().pow(2).mean().sqrt())}
+            del vo, wo, ref
             torch.cuda.empty_cache()
         kw = dict(self.gen_kw, num_beams=3)                    # the reference default: 3-beam beam-sample
         for _ in range(2):
@@ -409,6 +423,10 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the timed lines of BASELINE.json's other configs")
     ap.add_argument("--no-shards", action="store_true", help="skip the timed per-rank shards of the 2 / 4 / 8-GPU runs and the 15 s-prompt line")
     ap.add_argument("--bigvgan-chunk", type=int, default=0, help="utterances per BigVGAN launch group (0 = all)")
+    ap.add_argument("--bigvgan-conv", default="bf16x3", choices=["bf16x3", "f32"],
+                    help="BigVGAN resblock convs: bf16x3 = every f32 operand exactly as three bf16 planes, six plane products on the bf16 matrix pipe, "
+                         "f32 accumulation (the fp32x3 arithmetic of the flow-matching stage; error vs f64 not above the f32-MFMA kernel's, "
+                         "tests/test_gpu_bigvgan_x3.py); f32 = the f32 MFMA kernel everywhere")
     ap.add_argument("--no-s2mel", action="store_true", help="skip codes -> mel (codec, length regulator, 25-step CFM) and vocode a "
                                                            "synthetic mel instead (the round-1 hot-path-only measurement)")
     ap.add_argument("--prompt-frames", type=int, default=517, help="reference-speaker prompt length in mel frames (6 s)")
@@ -596,7 +614,9 @@ def main():
             "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None,
-            "dtype": (("bf16 (GPT GEMM operands / KV cache; f32 accumulate, residual stream, norms: the reference's own GPU mode) + "
+            "dtype": ((lambda d: d if args.bigvgan_conv == "f32" else d.replace("BigVGAN)", "BigVGAN outside the resblock convs) + bf16x3 (BigVGAN resblock "
+                       "convs of the >= 96-channel stages: f32 operands exactly as three bf16 planes, six plane products, f32 accumulation)")
+                       .replace("BigVGAN:", "BigVGAN outside the resblock convs:"))(("bf16 (GPT GEMM operands / KV cache; f32 accumulate, residual stream, norms: the reference's own GPU mode) + "
                        if args.precision == "bf16" else "f32 (GPT) + ")
                       + ("f32 (codec decode, length regulator, flow matching, BigVGAN: the reference runs these with autocast off)"
                          if args.s2mel_precision == "fp32" or args.no_s2mel else
@@ -605,7 +625,7 @@ def main():
                          f"product; softmax, norms, element-wise stages f32) + f32 (codec decode, length regulator, BigVGAN)"
                          if args.s2mel_precision == "fp32x3" else
                          "bf16 (s2mel GEMM operands / K,V / attention probabilities; f32 accumulate, residual streams, norms) + "
-                         "f32 (codec decode, length regulator, BigVGAN)")),
+                         "f32 (codec decode, length regulator, BigVGAN)"))),
             "data": "synthetic (seeded random-init weights of the IndexTTS-2.5 architecture; synthetic text ids, conditioning "
                     "vectors, prompt mel / prompt condition" + ("" if not args.no_s2mel else " and mel") +
                     "; EOS suppressed so every row decodes all tokens)",
@@ -1036,9 +1056,15 @@ def gpu_report(args, eng, B, n_text, n_gen, t_mel):
                                     GBps=(v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0))
                             for k, v in prof_acc.items()},
     }
-    conv_roof = {"bound": "mfma", "kernel": "conv_mfma_kernel (BigVGAN Conv1d implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                 "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+    x3v = getattr(args, "bigvgan_conv", "f32") == "bf16x3"
+    conv_peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if x3v else PEAK_F32_MFMA_TFLOPS
+    conv_roof = {"bound": "mfma",
+                 "kernel": ("BigVGAN Conv1d's: conv_x3w_kernel + split_tm3_kernel on the >= 96-channel resblocks (three bf16 planes per f32 operand, 6 x "
+                            "v_mfma_f32_16x16x32_bf16 per f32-equivalent MFMA; peak = bf16 peak / 6, the split pass's time is inside `achieved`) and "
+                            "conv_mfma_kernel (v_mfma_f32_32x32x2_f32) on conv_pre / the upsamplers / the 48- and 24-channel stages"
+                            if x3v else "conv_mfma_kernel (BigVGAN Conv1d implicit GEMM, v_mfma_f32_32x32x2_f32)"),
+                 "achieved": achieved, "peak": conv_peak, "unit": "TFLOP/s" + (" (f32-equivalent)" if x3v else ""),
+                 "frac": achieved / conv_peak, "traffic": traffic if not x3v else None, "traffic_unit": "bytes/launch",
                  "traffic_source": traffic_src, "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
                  "launches_per_step": conv["launches"] // n_prof, "avg_launch_ms": conv["ms"] / max(1, conv["launches"]),
                  "ms_per_step": conv["ms"] / n_prof}

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 10
+#define ITTS_ABI_VERSION 11
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -273,6 +273,20 @@ int itts_gpt_generate_chunk(itts_gpt* h, const float* prefix_embeds, const int32
                             const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids,
                             const double* uniforms, int64_t* codes_out, int32_t step_limit, int32_t* n_steps_out,
                             void* workspace, size_t workspace_bytes, int use_graph, void* stream);
+/* Admission of new utterances into a suspended itts_gpt_generate_chunk loop (in-flight batching; design reference: backends/trt/serving/
+ *   triton_server.py:96-305, backends/trt/pipeline/pipeline.py:459-548 -- the HF loop itself has no counterpart).  Between two chunk calls every
+ *   live row will next run cache position pos = S + steps - 1.  prefix_embeds [n_new][S_new][D] f32 device, S_new == pos: the new prompts, LEFT-padded
+ *   to that length (pad_lens [n_new] device: pad positions per row), ending with the start-mel row as for itts_gpt_generate.  slots [n_new] host:
+ *   the utterances (rows of the first call) whose cache rows / code rows the new ones take over -- they must have FINISHED.  The new rows are
+ *   prefilled on admit_workspace (itts_gpt_admit_workspace_bytes), their first token lands in column steps - 1 of the slot's code row
+ *   (*first_column_out), and the following chunk calls decode them with the rest -- position embedding, uniform / RNG stream and row limit follow
+ *   the row's own step.  params, penalty ids, uniforms, codes_out, workspace: those of the chunk calls.  The running batch is un-compacted by the
+ *   call.  An admitted row produces bit for bit the ids it produces alone with the same left padding (tests/test_gpu_admission.py). */
+size_t itts_gpt_admit_workspace_bytes(const itts_gpt* h, int n_new, int S_new);
+int itts_gpt_admit_rows(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, const int32_t* slots, int n_new, int S_new,
+                        const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids, const double* uniforms,
+                        int64_t* codes_out, void* workspace, size_t workspace_bytes, void* admit_workspace, size_t admit_bytes,
+                        int32_t* first_column_out, void* stream);
 /* replaces: the same generate() call in beam mode, num_beams > 1 (the reference default is 3-beam beam-sample,
  *   indextts/infer_v2_5.py:732-740) -> vendored GenerationMixin._beam_search (transformers_generation_utils.py:3325-3609),
  *   BeamSearchScorer.process (3rd-party; mirror indextts/gpt/transformers_beam_search.py:215-305,930-1013) and

@@ -88,6 +88,11 @@ __global__ __launch_bounds__(256) void split_tm3_kernel(const float* __restrict_
 template <int N>
 __device__ __forceinline__ void cx3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// NH = co tiles of 96 channels a block runs against ONE staged window (1 or 2): the window of a 32-channel chunk (3 planes x up to 20 KiB) is the larger
+// part of a K tile's LDS-DMA traffic -- at k = 3 a 96-wide block moved 60 + 54 KiB per 6 900 matrix-pipe cycles per SIMD and was bound by the
+// CU's fill rate (~12 B / clk), profiles/r05d/voc_bench.log -- so with NH = 2 the block walks (chunk, co half, tap): two accumulator sets, the same
+// weight bytes as two blocks, half the window bytes.
+template <int NH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x3w_kernel(ConvX3Args a) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -99,13 +104,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tile >= a.n_mt * a.B) return;
     const int b = tile / a.n_mt;
     const int m0 = (tile - b * a.n_mt) * CX3_BM;
-    const int co0 = (slot % a.n_co) * CX3_BN;
+    const int co0 = (slot % a.n_co) * (CX3_BN * NH);
     const int len = a.lens ? min(a.lens[b] * a.len_mult, a.T) : a.T;
     if (m0 >= len) return;
-    const int nkc = a.Cin / CX3_BK, G = a.k * nkc;
+    const int nkc = a.Cin / CX3_BK, G = a.k * nkc * NH;
     const int ntiles = (a.Cout + 15) >> 4;
     const int pad = (a.k - 1) / 2 * a.dil;
-    const int nach = (CX3_BM + 2 * pad + 15) >> 4;                      // row chunks of the window actually needed (<= CX3_ACH)
+    const int nach = (CX3_BM + 2 * pad + 15) >> 4;                      // row chunks of the window actually needed (17 .. CX3_ACH)
 
     // ---- staging sources.  A chunk = 16 frames x 64 bytes of one plane, held K-GROUP MAJOR: piece (frame r, k-group q) at q * 256 + r * 16; the
     // DMA writes lane l to byte 16 l of the chunk, so lane l fetches (frame l & 15, k-group l >> 4).
@@ -113,61 +118,65 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t plane = (size_t)a.B * a.T * a.Cin * 2;                 // bytes of one token-major plane
     const char* x_b = (const char*)a.xp + ((size_t)b * a.T * a.Cin + skp * 8) * 2;
     const char* zr = (const char*)a.zero_row;
-    // three window chunks per wave and plane (a wave past the end repeats the last chunk: same bytes to the same place), so every wave issues the
-    // same number of DMA instructions (9) and the counted waits below hold for all of them
+    // wave w stages window chunks w, w + 8, w + 16 (< nach): 2 or 3 chunks x 3 planes -- the count is wave-uniform and known up front, so the
+    // counted wait below (how many of this wave's own LDS-DMA instructions may stay in flight) is exact per wave
+    const int my_ach = (nach - w + 7) >> 3;
     auto issue_a = [&](int kc_, int buf) {
         char* base = sm + buf * CX3_ABUF;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            int c = w + 8 * i;
-            c = c < nach ? c : nach - 1;
-            const int t = m0 - pad + c * 16 + srow;
-            const bool ok = (unsigned)t < (unsigned)a.T;
-            const size_t o = ((size_t)(ok ? t : 0) * a.Cin + kc_ * CX3_BK) * 2;
+            const int c = w + 8 * i;
+            if (c < nach) {                                              // wave-uniform
+                const int t = m0 - pad + c * 16 + srow;
+                const bool ok = (unsigned)t < (unsigned)a.T;
+                const size_t o = ((size_t)(ok ? t : 0) * a.Cin + kc_ * CX3_BK) * 2;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? x_b + pl * plane + o : zr),
-                                                 (__attribute__((address_space(3))) void*)(base + (pl * CX3_ACH + c) * 1024), 16, 0, 0);
+                for (int pl = 0; pl < 3; ++pl)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? x_b + pl * plane + o : zr),
+                                                     (__attribute__((address_space(3))) void*)(base + (pl * CX3_ACH + c) * 1024), 16, 0, 0);
+            }
         }
     };
-    // weight stage: 6 n-tiles x 3 planes; wave w stages n-tile min(w, 5) (waves 6, 7 repeat the last one), 3 DMA instructions per wave
-    int ntl = w < CX3_NWT ? w : CX3_NWT - 1;
-    int ntg = (co0 >> 4) + ntl;
-    ntg = ntg < ntiles ? ntg : ntiles - 1;
-    const char* wsrc = (const char*)a.wp + (size_t)ntg * G * 1024 + lane * 16;
-    const size_t wstream = (size_t)ntiles * G * 1024;                   // bytes of one weight plane stream
-    auto issue_w = [&](int g) {                                         // K tile g = (chunk g / k, tap g % k); packed index tap * nkc + chunk
-        const int kc_ = g / a.k, j_ = g - kc_ * a.k;
-        const size_t kt = (size_t)j_ * nkc + kc_;
+    // weight stage: 6 n-tiles x 3 planes; waves 0 .. 5 stage one n-tile each (3 DMA instructions), waves 6 and 7 none
+    const bool w_on = w < CX3_NWT;
+    auto issue_w = [&](int g) {                                         // K tile g = (chunk, co half, tap); packed index tap * nkc + chunk
+        if (!w_on) return;
+        const int kc_ = g / (a.k * NH), r_ = g - kc_ * a.k * NH;
+        const int h_ = r_ / a.k, j_ = r_ - h_ * a.k;
+        int ntg = (co0 >> 4) + h_ * CX3_NWT + w;
+        ntg = ntg < ntiles ? ntg : ntiles - 1;
+        const char* wsrc = (const char*)a.wp + ((size_t)ntg * a.k * nkc + (size_t)j_ * nkc + kc_) * 1024 + lane * 16;
+        const size_t wstream = (size_t)ntiles * a.k * nkc * 1024;       // bytes of one weight plane stream
         char* base = sm + 2 * CX3_ABUF + (g & 1) * CX3_WST;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + pl * wstream + kt * 1024),
-                                             (__attribute__((address_space(3))) void*)(base + (pl * CX3_NWT + ntl) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + pl * wstream),
+                                             (__attribute__((address_space(3))) void*)(base + (pl * CX3_NWT + w) * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[CX3_MT][CX3_NT];
+    f32x4 acc[NH][CX3_MT][CX3_NT];
 #pragma unroll
-    for (int i = 0; i < CX3_MT; ++i)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int jn = 0; jn < CX3_NT; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < CX3_MT; ++i)
+#pragma unroll
+            for (int jn = 0; jn < CX3_NT; ++jn) acc[h][i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int row16 = lane & 15, kg = lane >> 4;
     const int b_off = wc * CX3_NT * 1024 + lane * 16;
 
     issue_a(0, 0);
     issue_w(0);
-    // (chunk, tap) of K tile g, kept incrementally; a_recent: the next chunk's window was requested during the previous iteration, after that
-    // iteration's weight request (it may stay in flight across this iteration's wait: 9 DMA instructions per wave)
-    int kc = 0, j = 0;
+    // one K tile: wait, barrier, request the next weight tile (and, at a chunk's first tile, the next chunk's window BEHIND it: a wait for the
+    // weights then never drains the window), 72 MFMAs per wave.  a_recent: the window request of the previous iteration may stay in flight.
     bool a_recent = false;
-    for (int g = 0; g < G; ++g) {
-        if (a_recent) cx3_wait_vm<9>(); else cx3_wait_vm<0>();          // weight tile g (and, when it is due, the window of its chunk) has landed
+    auto ktile = [&](int g, int kc, int j, f32x4 (&ac)[CX3_MT][CX3_NT], bool first_of_chunk) {
+        if (a_recent) { if (my_ach == 3) cx3_wait_vm<9>(); else cx3_wait_vm<6>(); } else cx3_wait_vm<0>();
         __builtin_amdgcn_s_barrier();                                   // ... for every wave; the other weight stage and window buffer are free again
         asm volatile("" ::: "memory");                                  // (raw barrier: __syncthreads' fence would drain the window request in flight)
-        if (g + 1 < G) issue_w(g + 1);                                  // the weights first: their wait must not drain the window behind them
+        if (g + 1 < G) issue_w(g + 1);
         a_recent = false;
-        if (j == 0 && kc + 1 < nkc) { issue_a(kc + 1, (kc + 1) & 1); a_recent = true; }
+        if (first_of_chunk && kc + 1 < nkc) { issue_a(kc + 1, (kc + 1) & 1); a_recent = true; }
         const char* abase = sm + (kc & 1) * CX3_ABUF;
         const char* wbase = sm + 2 * CX3_ABUF + (g & 1) * CX3_WST;
         x3_v4u bf[CX3_NT][3];
@@ -190,18 +199,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int q = 0; q < 6; ++q)
 #pragma unroll
                 for (int nt = 0; nt < CX3_NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x3_bf16x8, af[PA[q]]),
-                                                                          __builtin_bit_cast(x3_bf16x8, bf[nt][PB[q]]), acc[mt][nt], 0, 0, 0);
+                    ac[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x3_bf16x8, af[PA[q]]),
+                                                                         __builtin_bit_cast(x3_bf16x8, bf[nt][PB[q]]), ac[mt][nt], 0, 0, 0);
         }
-        if (++j == a.k) { j = 0; ++kc; }
+    };
+    int g = 0;
+    for (int kc = 0; kc < nkc; ++kc) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+            for (int j = 0; j < a.k; ++j, ++g) ktile(g, kc, j, acc[h], h == 0 && j == 0);
     }
 
     const bool vec = (a.T & 3) == 0;
     float* yb = a.y + (size_t)b * a.Cout * a.T;
     const float* rb = a.res ? a.res + (size_t)b * a.Cout * a.T : nullptr;
 #pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
     for (int nt = 0; nt < CX3_NT; ++nt) {
-        const int co = co0 + (wc * CX3_NT + nt) * 16 + (lane & 15);
+        const int co = co0 + h * CX3_BN + (wc * CX3_NT + nt) * 16 + (lane & 15);
         if (co >= a.Cout) continue;
         const float bias = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (t >= len) continue;
             f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + bias;
+            for (int r = 0; r < 4; ++r) v[r] = acc[h][mt][nt][r] + bias;
             const size_t o = (size_t)co * a.T + t;
             if (vec && t + 3 < len) {
                 if (rb) { const f32x4 rv = *(const f32x4*)(rb + o); v += rv; }
@@ -297,18 +313,21 @@ int launch_conv_x3(const ConvX3Args& a0, hipStream_t st) {
     }
     if ((long long)a0.Cout * a0.T >= (1ll << 31) || (long long)a0.Cin * a0.T >= (1ll << 31)) { itts_set_error("conv_x3: row plane too large"); return ITTS_ERR_ARG; }
     ConvX3Args a = a0;
+    const int nh = a.Cout > CX3_BN ? 2 : 1;                            // two co tiles per staged window where there are two
     a.n_mt = ceil_div(a.T, CX3_BM);
-    a.n_co = ceil_div(a.Cout, CX3_BN);
+    a.n_co = ceil_div(a.Cout, CX3_BN * nh);
     const long long tiles8 = ((long long)a.n_mt * a.B + 7) / 8 * 8;
     const long long nblocks = tiles8 * a.n_co;
     if (nblocks > 2147483647ll) { itts_set_error("conv_x3: grid too large"); return ITTS_ERR_ARG; }
     static ItPerDevice<bool> attr_set_pd;
     bool& attr_set = attr_set_pd.cur();
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)conv_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CX3_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)conv_x3w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CX3_LDS));
+        HIP_TRY(hipFuncSetAttribute((const void*)conv_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CX3_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_x3w_kernel, dim3((unsigned)nblocks), dim3(512), CX3_LDS, st, a);
+    if (nh == 2) hipLaunchKernelGGL(conv_x3w_kernel<2>, dim3((unsigned)nblocks), dim3(512), CX3_LDS, st, a);
+    else hipLaunchKernelGGL(conv_x3w_kernel<1>, dim3((unsigned)nblocks), dim3(512), CX3_LDS, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }

@@ -323,6 +323,7 @@ struct GptWs {
     int* pen_ids;       // [16]
     int* slot_map;      // [nseq] dense row -> utterance (row compaction; unused while the batch is uncompacted)
     int* gather_src;    // [nseq] compaction: the old dense row each new dense row is taken from
+    int* row_step0;     // [nseq] the step at which the utterance joined the running batch (itts_gpt_admit_rows; 0 otherwise)
     // beam search (nb > 1)
     unsigned char* seen2;    // second seen buffer
     int* row_map[2];         // [nseq][Tmax]
@@ -359,6 +360,7 @@ static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tm
     w.pen_ids = (int*)take(64);
     w.slot_map = (int*)take((size_t)nseq * 4);
     w.gather_src = (int*)take((size_t)nseq * 4);
+    w.row_step0 = (int*)take((size_t)nseq * 4);
     w.seen2 = nullptr; w.row_map[0] = w.row_map[1] = nullptr;
     if (nb > 1) {
         const int B = nseq / nb, max_new = Tmax - S;
@@ -531,6 +533,7 @@ static SampleArgs make_sample(itts_gpt* h, const GptWs& w, const itts_gen_params
     s.row_slot = mapped ? w.slot_map : nullptr;
     s.uniforms_stride = n_utts > 0 ? n_utts : nseq;
     s.row_limit = (h->row_limits && h->row_limits_n == s.uniforms_stride) ? h->row_limits : nullptr;
+    s.row_step0 = w.row_step0;
     return s;
 }
 
@@ -596,6 +599,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
     // ---- state init ----
     HIP_TRY(hipMemsetAsync(w.seen, 0, (size_t)nseq * c.vocab, st));
     HIP_TRY(hipMemsetAsync(w.finished, 0, nseq, st));
+    HIP_TRY(hipMemsetAsync(w.row_step0, 0, (size_t)nseq * 4, st));
     if (pad_lens) HIP_TRY(hipMemcpyAsync(w.pad, pad_lens, (size_t)nseq * 4, hipMemcpyDeviceToDevice, st));
     else HIP_TRY(hipMemsetAsync(w.pad, 0, (size_t)nseq * 4, st));
     if (n_penalty_ids > 0) {
@@ -749,6 +753,151 @@ extern "C" int itts_gpt_generate_chunk(itts_gpt* h, const float* prefix_embeds, 
                                        void* workspace, size_t workspace_bytes, int use_graph, void* caller_stream) {
     return gpt_generate_impl(h, prefix_embeds, pad_lens, nseq, S, gpp, penalty_ids, n_penalty_ids, uniforms, codes_out, n_steps_out,
                              workspace, workspace_bytes, use_graph, caller_stream, step_limit, prefix_embeds == nullptr);
+}
+
+// ---- admission of new utterances into a running decode batch -------------------------------------------------------------------------
+// Design reference: the reference's serving path keeps a decode batch running and puts a newly arrived request into a free slot while the other
+// rows keep generating (backends/trt/serving/triton_server.py:96-305, backends/trt/pipeline/pipeline.py:459-548 on TRT-LLM's in-flight batching).
+// Here: between two itts_gpt_generate_chunk calls the loop is suspended with its state on the device; every live row will next run position
+// pos = S + steps - 1.  A new utterance takes the cache row of a FINISHED one: its prompt is given left-padded to exactly `pos` positions, prefilled
+// on an admission workspace of its own (K / V to a scratch cache, copied into the slot's cache rows), its first token is sampled into column
+// steps - 1 of the slot's code row, and row_step0[slot] = steps - 1 makes the sampler index the row's position embedding, uniform / RNG stream and
+// token limit by the row's OWN step.  Left-pad keys are skipped exactly by the attention kernels and a row's arithmetic does not depend on the
+// batch it runs in, so the admitted row generates, bit for bit, the ids it generates alone with the same left padding (tests/test_gpu_admission.py).
+__global__ void admit_state_kernel(const int* __restrict__ slots, const int* __restrict__ pad_new, unsigned char* seen, unsigned char* finished, int* pad,
+                                   int* row_step0, const int* __restrict__ pen_ids, int n_ids, int V, int step0) {
+    const int i = blockIdx.x, u = slots[i];
+    unsigned char* sr = seen + (size_t)u * V;
+    for (int c = threadIdx.x; c < V; c += blockDim.x) sr[c] = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < n_ids) {
+        const int id = pen_ids[threadIdx.x];
+        if (id >= 0 && id < V) sr[id] = 1;
+    }
+    if (threadIdx.x == 0) { finished[u] = 0; pad[u] = pad_new[i]; row_step0[u] = step0; }
+}
+// K / V of positions [0, n_pos) of the admission cache's row i -> the running batch's cache row slots[i] (both [L][rows][H][T][64], own T strides)
+__global__ void copy_kv_rows_kernel(const char* __restrict__ src, char* __restrict__ dst, const int* __restrict__ slots, int H, int T_src, int T_dst,
+                                    int n_pos, int row_bytes, size_t src_layer, size_t dst_layer) {
+    const int i = blockIdx.x / H, hd = blockIdx.x - i * H, l = blockIdx.y;
+    const char* s = src + (size_t)l * src_layer + ((size_t)i * H + hd) * T_src * row_bytes;
+    char* d = dst + (size_t)l * dst_layer + ((size_t)slots[i] * H + hd) * T_dst * row_bytes;
+    const size_t n16 = (size_t)n_pos * row_bytes / 16;
+    for (size_t c = threadIdx.x; c < n16; c += blockDim.x) ((uint4*)d)[c] = ((const uint4*)s)[c];
+}
+// dense rows back to utterance order: tmp[d] = x[src[d]] (zero where the utterance is not in the running batch), then the admitted rows
+__global__ void regather_rows_kernel(const float* __restrict__ x, const int* __restrict__ src, float* __restrict__ tmp, int D) {
+    const int d = blockIdx.x, j = src[d];
+    for (int c = threadIdx.x; c < D; c += blockDim.x) tmp[(size_t)d * D + c] = j >= 0 ? x[(size_t)j * D + c] : 0.f;
+}
+__global__ void place_rows_kernel(const float* __restrict__ xa, const int* __restrict__ slots, float* __restrict__ x, int D) {
+    const int i = blockIdx.x;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) x[(size_t)slots[i] * D + c] = xa[(size_t)i * D + c];
+}
+
+extern "C" size_t itts_gpt_admit_workspace_bytes(const itts_gpt* h, int n_new, int S_new) {
+    if (!h || n_new <= 0 || S_new <= 0) return 0;
+    const int Sb = s_bucket(S_new);
+    return carve(h->cfg, nullptr, n_new, Sb, Sb + 8).total + a256((size_t)n_new * 8) + 512;
+}
+
+extern "C" int itts_gpt_admit_rows(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, const int32_t* slots, int n_new, int S_new,
+                                   const itts_gen_params* gpp, const int32_t* penalty_ids, int n_penalty_ids, const double* uniforms,
+                                   int64_t* codes_out, void* workspace, size_t workspace_bytes, void* admit_workspace, size_t admit_bytes,
+                                   int32_t* first_column_out, void* caller_stream) {
+    if (!h || !prefix_embeds || !pad_lens || !slots || !gpp || !codes_out || !workspace || !admit_workspace) { itts_set_error("gpt_admit_rows: null pointer"); return ITTS_ERR_ARG; }
+    if (!h->finalized) { itts_set_error("gpt_admit_rows: call itts_gpt_finalize first"); return ITTS_ERR_STATE; }
+    ItDevGuard dg(h->device);
+    if (int rcd = check_same_device(h, prefix_embeds, workspace, "gpt_admit_rows")) return rcd;
+    const itts_gpt_config& c = h->cfg;
+    const itts_gen_params gp = *gpp;
+    const int nseq = h->chunk_nseq, S = h->chunk_S, k = h->chunk_steps;
+    if (k < 1 || h->chunk_ws != workspace || gp.max_new_tokens != h->chunk_max_new || gp.num_beams != 1) {
+        itts_set_error("gpt_admit_rows: no suspended itts_gpt_generate_chunk loop on this workspace with these parameters");
+        return ITTS_ERR_STATE;
+    }
+    if (k >= gp.max_new_tokens) { itts_set_error("gpt_admit_rows: the running batch is at its last step (%d of %d)", k, gp.max_new_tokens); return ITTS_ERR_STATE; }
+    if (S_new != S + k - 1) {
+        itts_set_error("gpt_admit_rows: the new rows must be left-padded to the running batch's position: S_new = %d, want %d (= S + steps - 1)", S_new, S + k - 1);
+        return ITTS_ERR_ARG;
+    }
+    if (n_new < 1 || n_new > nseq) { itts_set_error("gpt_admit_rows: n_new = %d outside 1 .. %d", n_new, nseq); return ITTS_ERR_ARG; }
+    if (n_penalty_ids < 0 || n_penalty_ids > 16) { itts_set_error("gpt_admit_rows: at most 16 initial penalty ids"); return ITTS_ERR_ARG; }
+    const int Sb = s_bucket(S), Tmax = Sb + gp.max_new_tokens;
+    const GptWs w0 = carve(c, nullptr, nseq, Sb, Tmax);
+    if (workspace_bytes < w0.total) { itts_set_error("gpt_admit_rows: workspace too small"); return ITTS_ERR_ARG; }
+    const GptWs w = carve(c, (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), nseq, Sb, Tmax);
+    const int Sba = s_bucket(S_new), Ta = Sba + 8;
+    const GptWs wa0 = carve(c, nullptr, n_new, Sba, Ta);
+    if (admit_bytes < wa0.total + a256((size_t)n_new * 8) + 256) { itts_set_error("gpt_admit_rows: admission workspace too small (%zu < %zu)", admit_bytes, wa0.total + a256((size_t)n_new * 8) + 256); return ITTS_ERR_ARG; }
+    char* abase = (char*)(((uintptr_t)admit_workspace + 255) & ~(uintptr_t)255);
+    const GptWs wa = carve(c, abase, n_new, Sba, Ta);
+    int* slots_dev = (int*)(abase + wa0.total);
+    hipStream_t st = h->stream, cs = (hipStream_t)caller_stream;
+    HIP_TRY(hipEventRecord(h->ev_in, cs));
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_in, 0));
+    // the slots must be distinct finished utterances of the running batch
+    if (h->fin_cap < nseq) { itts_set_error("gpt_admit_rows: no finished-flag buffer (run a chunk first)"); return ITTS_ERR_STATE; }
+    HIP_TRY(hipMemcpyAsync(h->host_fin, w.finished, nseq, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<char> taken(nseq, 0);
+    for (int i = 0; i < n_new; ++i) {
+        const int u = slots[i];
+        if (u < 0 || u >= nseq || taken[u] || !h->host_fin[u]) {
+            itts_set_error("gpt_admit_rows: slot %d (entry %d) is out of range, repeated or still generating", u, i);
+            return ITTS_ERR_ARG;
+        }
+        taken[u] = 1;
+    }
+    int rc;
+    HIP_TRY(hipMemcpyAsync(slots_dev, slots, (size_t)n_new * 4, hipMemcpyHostToDevice, st));
+    if (n_penalty_ids > 0) HIP_TRY(hipMemcpyAsync(wa.pen_ids, penalty_ids, (size_t)n_penalty_ids * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(wa.pad, pad_lens, (size_t)n_new * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(admit_state_kernel, dim3(n_new), dim3(256), 0, st, slots_dev, wa.pad, w.seen, w.finished, w.pad, w.row_step0, wa.pen_ids,
+                       n_penalty_ids, c.vocab, k - 1);
+    // prefill of the new rows on the admission workspace: all S_new positions, logits of the last one
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, wa.state, 0, 0);
+    HIP_TRY(hipMemcpyAsync(wa.x, prefix_embeds, (size_t)n_new * S_new * c.model_dim * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+    bool pending = false;
+    if ((rc = run_layers(h, wa, n_new, S_new, Ta, true, wa.state + 1, wa.pad, &pending, st))) return rc;
+    if ((rc = run_head(h, wa, n_new, S_new, S_new - 1, pending, st))) return rc;
+    // first token of every new row: sampled with the running batch's per-utterance state (seen set, finished flag, code row, uniform / RNG stream),
+    // into column steps - 1; the row's own step is 0
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, wa.state, k - 1, S_new);
+    {
+        SampleArgs s = make_sample(h, w, gp, n_new, (long long*)codes_out, uniforms, nseq, false);
+        s.logits = wa.logits; s.x_next = wa.x; s.step_ptr = wa.state; s.row_slot = slots_dev; s.adv_state = nullptr;
+        if ((rc = launch_sample(s, st))) return rc;
+    }
+    // K / V of the prompt into the slots' cache rows
+    {
+        const int rb = 64 * (c.precision == PREC_BF16 ? 2 : 4);
+        hipLaunchKernelGGL(copy_kv_rows_kernel, dim3(n_new * c.heads, c.layers), dim3(256), 0, st, wa.kc, w.kc, slots_dev, c.heads, Ta, Tmax, S_new, rb,
+                           wa.layer_cache_bytes, w.layer_cache_bytes);
+        hipLaunchKernelGGL(copy_kv_rows_kernel, dim3(n_new * c.heads, c.layers), dim3(256), 0, st, wa.vc, w.vc, slots_dev, c.heads, Ta, Tmax, S_new, rb,
+                           wa.layer_cache_bytes, w.layer_cache_bytes);
+    }
+    // the running batch back in utterance order (uncompacted), the admitted rows' next-step inputs in their slots
+    {
+        if (h->map_cap < nseq) { itts_set_error("gpt_admit_rows: no row-map buffer (run a chunk first)"); return ITTS_ERR_STATE; }
+        int* src = h->host_map;
+        for (int d = 0; d < nseq; ++d) src[d] = -1;
+        for (int j = 0; j < (int)h->cur_slots.size(); ++j) src[h->cur_slots[j]] = j;
+        HIP_TRY(hipMemcpyAsync(w.gather_src, src, (size_t)nseq * sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(regather_rows_kernel, dim3(nseq), dim3(256), 0, st, w.x, w.gather_src, w.qbuf, c.model_dim);
+        hipLaunchKernelGGL(copy_rows_kernel, dim3(nseq), dim3(256), 0, st, w.qbuf, w.x, c.model_dim);
+        hipLaunchKernelGGL(place_rows_kernel, dim3(n_new), dim3(256), 0, st, wa.x, slots_dev, w.x, c.model_dim);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(h->ev_out, st));
+    HIP_TRY(hipStreamWaitEvent(cs, h->ev_out, 0));
+    HIP_TRY(hipStreamSynchronize(st));
+    h->cur_slots.resize(nseq);
+    for (int i = 0; i < nseq; ++i) h->cur_slots[i] = i;
+    h->cur_mapped = false;
+    if (first_column_out) *first_column_out = k - 1;
+    return ITTS_OK;
 }
 
 // ---- beam search / beam-sample ------------------------------------------------------------------------------------

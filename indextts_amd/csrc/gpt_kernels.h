@@ -118,6 +118,9 @@ struct SampleArgs {
     unsigned long long* stamps;   // microbench builds only (-DITTS_SAMPLE_STAMPS): [B][8] phase time stamps, else null
     const int* row_limit;    // [utterances] or null: per-utterance cap on generated tokens (a batch merges requests with their own
                              // max_mel_tokens): from token index row_limit[u] on, the row emits the stop token
+    const int* row_step0;    // [utterances] or null: the step at which utterance u joined the running batch (itts_gpt_admit_rows; 0 for the rows of
+                             // the first call).  The token column stays the global step; the row's own step (step - row_step0[u]) indexes its mel
+                             // position embedding, its uniform / RNG stream and its token limit -- what the row would see decoded alone.
 };
 int launch_sample(const SampleArgs& a, hipStream_t st);
 int launch_advance(int* step_ptr, int* pos_ptr, hipStream_t st);

@@ -2600,6 +2600,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     const int step = *a.step_ptr;
     SAMPLE_STAMP(0);
     const int u = a.row_slot ? a.row_slot[b] : b;                   // the utterance this dense row carries
+    const int rstep = step - (a.row_step0 ? a.row_step0[u] : 0);    // the row's own step (rows admitted into a running batch start later)
     const float* lg = a.logits + (size_t)b * V;
     unsigned char* seen = a.seen + (size_t)u * V;
     const bool pen = a.rep_penalty != 1.0f;
@@ -2735,8 +2736,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             if (tid == 0) {
                 double total = 0.0;
                 for (int i = lo; i < n; ++i) total += (double)cand_v[i];
-                const double ur = a.uniforms ? a.uniforms[(size_t)step * (a.uniforms_stride > 0 ? a.uniforms_stride : a.B) + u]
-                                             : rng_uniform(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned long long)step, (unsigned long long)u);
+                const double ur = a.uniforms ? a.uniforms[(size_t)rstep * (a.uniforms_stride > 0 ? a.uniforms_stride : a.B) + u]
+                                             : rng_uniform(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned long long)rstep, (unsigned long long)u);
                 const double tgt = ur * total;
                 double cum = 0.0;
                 int pick = cand_i[n - 1];
@@ -2753,7 +2754,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     if (tid == 0) {
         int tok = s_tok;
         if (a.finished[u]) tok = a.stop_token;               // :3256 finished rows emit pad (= stop)
-        if (a.row_limit && step >= a.row_limit[u]) tok = a.stop_token;          // this utterance's own max_mel_tokens
+        if (a.row_limit && rstep >= a.row_limit[u]) tok = a.stop_token;         // this utterance's own max_mel_tokens
         a.tokens[(size_t)u * a.max_new + step] = tok;
         if (tok == a.stop_token) a.finished[u] = 1;
         seen[tok] = 1;
@@ -2763,7 +2764,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     SAMPLE_STAMP(5);
     if (a.x_next) {
         const int tok = s_tok;
-        int p = step + a.pos_offset;
+        int p = rstep + a.pos_offset;
         p = p < a.n_mel_pos ? p : a.n_mel_pos - 1;
         for (int d = tid; d < a.D; d += 256)
             a.x_next[(size_t)b * a.D + d] = a.mel_emb[(size_t)tok * a.D + d] + a.mel_pos[(size_t)p * a.D + d];

@@ -11,7 +11,7 @@ Prompt encoders (Conformer/Perceiver emotion encoder, CAMPPlus) are out of this 
 `emo_vec=` / `campplus_embedding=` computed by the PyTorch-ROCm modules, as `indextts/infer_v2_5.py:762-781` does.
 """
 import ctypes as C
-from typing import Dict, Optional, Sequence
+from typing import List, Dict, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
@@ -664,6 +664,108 @@ class UnifiedVoice:
                 self._h = C.c_void_p()
         except Exception:
             pass
+
+
+class DecodeSession:
+    """A decode batch that keeps running while its utterances finish and NEW utterances are admitted into the freed slots (design reference: the
+    in-flight batching of the reference's serving path, backends/trt/serving/triton_server.py:96-305, backends/trt/pipeline/pipeline.py:459-548).
+    Built on the suspended-loop API of the engine: `run(n)` advances every live row by n tokens (`itts_gpt_generate_chunk`), `finished()` reports
+    the slots whose row has emitted its stop token, `admit(slots, ...)` prefills new prompts -- left-padded to the batch's current position --
+    into those slots (`itts_gpt_admit_rows`).  A row's arithmetic does not depend on the batch it runs in and left-pad keys are skipped exactly,
+    so an admitted row generates, bit for bit, the ids it generates alone with the same left padding.  Greedy / sampling, num_beams = 1.
+
+    inputs_embeds (B, s, D) / attention_mask (B, s + 1): what `UnifiedVoice.inference_speech_stream` returns for the first batch."""
+
+    def __init__(self, model: "UnifiedVoice", inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int, do_sample=False,
+                 top_p=1.0, top_k=50, temperature=1.0, repetition_penalty=1.0, length_penalty=1.0, seed: Optional[int] = None,
+                 typical_mass: float = 0.0, **unused):
+        model._check_idle("DecodeSession")
+        if unused.get("num_beams", 1) != 1:
+            raise NotImplementedError("DecodeSession: num_beams = 1 only")
+        self.m, self.dev = model, model.device
+        B, s, D = inputs_embeds.shape
+        self.B, self.D, self.max_new = B, D, int(max_new_tokens)
+        self._start = (model._emb["mel_embedding.weight"][model.start_mel_token] + model._emb["mel_pos_embedding.emb.weight"][0])
+        self._x = torch.cat([inputs_embeds.to(self.dev, torch.float32), self._start.expand(B, 1, D)], dim=1).contiguous()
+        self.S = s + 1
+        self._pad = (attention_mask[:, :self.S] == 0).sum(dim=1).to(torch.int32).to(self.dev).contiguous()
+        gp = _lib.GenParams()
+        gp.do_sample, gp.num_beams, gp.top_k = int(bool(do_sample)), 1, int(top_k or 0)
+        gp.min_tokens_to_keep, gp.max_new_tokens = 1, self.max_new
+        gp.pos_offset = 2 if model.kv_cache else 1
+        gp.top_p, gp.temperature = float(top_p), float(temperature)
+        gp.repetition_penalty = float(repetition_penalty if repetition_penalty is not None else 1.0)
+        gp.length_penalty, gp.seed = float(length_penalty), model._seed(seed, do_sample, None)
+        gp.typical_mass = float(typical_mass)
+        self._gp = gp
+        L = _lib.lib()
+        self._ws = model._workspace(L.itts_gpt_workspace_bytes(model._h, B, self.S, self.S + self.max_new))
+        self._codes = model._persistent("codes", (B, self.max_new), torch.int64)
+        self._pen = (C.c_int32 * 2)(1, model.start_mel_token)
+        self.steps = 0                               # tokens generated so far by the rows of the first batch (the global step)
+        self.col0 = [0] * B                          # first code column of the utterance currently in each slot
+        self._first = True
+        self._adm_ws = None
+        model._stream_open = True                    # the workspace holds this session's state until close()
+
+    def run(self, n_tokens: int) -> int:
+        """advance the batch by up to n_tokens tokens; returns the global step (stops early when every row has finished)"""
+        L = _lib.lib()
+        limit = min(self.max_new, self.steps + int(n_tokens))
+        n = C.c_int32(0)
+        _lib.check(L.itts_gpt_generate_chunk(self.m._h, _lib.ptr(self._x) if self._first else None, _lib.ptr(self._pad), self.B, self.S,
+                                             C.byref(self._gp), self._pen, 2, None, _lib.ptr(self._codes), limit, C.byref(n), _lib.ptr(self._ws),
+                                             self._ws.numel(), int(self.m.use_graph), _lib.stream_ptr(self.dev)), "itts_gpt_generate_chunk")
+        self._first = False
+        self.steps = int(n.value)
+        return self.steps
+
+    def codes(self, slot: int) -> torch.Tensor:
+        """the codes of the utterance in `slot` so far (up to, not including, its stop token)"""
+        row = self._codes[slot, self.col0[slot]:self.steps]
+        stop = (row == self.m.stop_mel_token).nonzero()
+        return row[: int(stop[0])].clone() if stop.numel() else row.clone()
+
+    def finished(self) -> List[int]:
+        got = self._codes[:, :self.steps] == self.m.stop_mel_token
+        return [b for b in range(self.B) if bool(got[b, self.col0[b]:].any())]
+
+    def position(self) -> int:
+        """prompt length (with the start-mel row) a new utterance must be left-padded to in order to join now"""
+        return self.S + self.steps - 1
+
+    def admit(self, slots: Sequence[int], inputs_embeds: torch.Tensor, attention_mask: torch.Tensor) -> None:
+        """put new utterances into finished slots: inputs_embeds (n, s', D) / attention_mask (n, s' + 1) as for the first batch, s' + 1 <= position()"""
+        if self._first or self.steps < 1:
+            raise RuntimeError("DecodeSession.admit: run() the first batch before admitting")
+        n, s, D = inputs_embeds.shape
+        S_new = self.position()
+        if s + 1 > S_new:
+            raise ValueError(f"DecodeSession.admit: the prompt ({s + 1} positions) is longer than the batch's position ({S_new}); admit it later")
+        x = torch.cat([inputs_embeds.to(self.dev, torch.float32), self._start.expand(n, 1, D)], dim=1)
+        extra = S_new - (s + 1)
+        x = torch.cat([torch.zeros(n, extra, D, device=self.dev), x], dim=1).contiguous()          # more left padding: skipped exactly by the attention
+        pad = ((attention_mask[:, :s + 1] == 0).sum(dim=1).to(torch.int32).to(self.dev) + extra).contiguous()
+        L = _lib.lib()
+        need = L.itts_gpt_admit_workspace_bytes(self.m._h, n, S_new)
+        if self._adm_ws is None or self._adm_ws.numel() < need:
+            self._adm_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        sl = (C.c_int32 * n)(*[int(v) for v in slots])
+        col = C.c_int32(0)
+        _lib.check(L.itts_gpt_admit_rows(self.m._h, _lib.ptr(x), _lib.ptr(pad), sl, n, S_new, C.byref(self._gp), self._pen, 2, None,
+                                         _lib.ptr(self._codes), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(self._adm_ws), self._adm_ws.numel(),
+                                         C.byref(col), _lib.stream_ptr(self.dev)), "itts_gpt_admit_rows")
+        for v in slots:
+            self.col0[int(v)] = int(col.value)
+
+    def close(self):
+        self.m._stream_open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 class UnifiedVoiceV1(UnifiedVoice):

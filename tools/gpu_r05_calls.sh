@@ -80,4 +80,21 @@ call4() {
     cat $O/voc_bench.log
 }
 
+# round 5, GPU call 5: the fp32x3 GEMM from its own translation unit (no SLP, plain subtractions): GEMM shapes, solve time, s2mel + x3 GEMM tests;
+# GPT fixtures with the f64 speaker projection; vocoder x3 tests again (ragged fixture fixed).
+call5() {
+    O=$PWD/gpurun_out/r05e
+    mkdir -p $O
+    timeout 300 python tools/gemm_x3_bench.py 312704 5 > $O/gemm_x3_bench.log 2>&1; echo "gemm_x3_bench rc=$?" | tee $O/status.txt
+    grep f32x3 $O/gemm_x3_bench.log
+    timeout 600 python tools/s2mel_bench.py 8 517 1926 3 fp32x3 fp32x3:x3_aplanes=1 fp32x3 fp32x3:x3_aplanes=1 > $O/s2mel_bench.log 2>&1; echo "s2mel_bench rc=$?" | tee -a $O/status.txt
+    grep "^B=" $O/s2mel_bench.log
+    timeout 1500 python -m pytest tests/test_gpu_s2mel.py tests/test_gpu_gemm_x3.py tests/test_gpu_attn_x3.py -x -q > $O/pytest_s2mel.log 2>&1; echo "pytest s2mel rc=$?" | tee -a $O/status.txt
+    tail -4 $O/pytest_s2mel.log
+    timeout 1500 python -m pytest tests/test_gpu_gpt.py -x -q > $O/pytest_gpt.log 2>&1; echo "pytest gpt rc=$?" | tee -a $O/status.txt
+    tail -4 $O/pytest_gpt.log
+    timeout 900 python -m pytest tests/test_gpu_bigvgan_x3.py tests/test_gpu_bigvgan.py tests/test_gpu_bigvgan_h3.py -x -q > $O/pytest_voc.log 2>&1; echo "pytest voc rc=$?" | tee -a $O/status.txt
+    tail -4 $O/pytest_voc.log
+}
+
 "call$1"
