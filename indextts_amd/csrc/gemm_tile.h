@@ -18,9 +18,6 @@ __device__ __forceinline__ float gelu_new_f(float x) {
 #define PF_BK 64
 #define PF_GM 8
 #define PF_LDS 67584     // 2 x (A 16 KiB | W 16 KiB) operand buffers; the epilogue's transposed image [128][132] f32 is the larger
-#ifndef PF_ABL
-#define PF_ABL 0         // tools/microbench/gemm_f32_ablate.hip builds the tile kernel with pieces removed / a start stagger (bit mask); 0 in the product
-#endif
 #ifndef PF_SCHED
 #define PF_SCHED 1       // explicit LDS-read / MFMA interleave in the tile kernel's main loop (build with -DPF_SCHED=0 for A/B)
 #endif

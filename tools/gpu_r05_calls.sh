@@ -97,4 +97,33 @@ call5() {
     tail -4 $O/pytest_voc.log
 }
 
+# round 5, GPU call 6: admission into a running decode batch; the two-co-tile form of the x3 vocoder conv (tests + forward time); GPT fixtures with the
+# sampler's row-relative step; then the benchmark as the driver runs it, and the rocprofv3 kernel stats of a short run.
+call6() {
+    O=$PWD/gpurun_out/r05f
+    mkdir -p $O
+    timeout 600 python -m pytest tests/test_gpu_admission.py -x -q -s > $O/pytest_admission.log 2>&1; echo "pytest admission rc=$?" | tee $O/status.txt
+    grep -E "admitted at|passed|failed|Error|error" $O/pytest_admission.log | tail -8
+    timeout 900 python -m pytest tests/test_gpu_bigvgan_x3.py tests/test_gpu_bigvgan.py -x -q -s > $O/pytest_voc.log 2>&1; echo "pytest voc rc=$?" | tee -a $O/status.txt
+    grep -E "x3 conv|rms err|passed|failed|Error|error" $O/pytest_voc.log | tail -16
+    timeout 600 python tools/voc_h3_bench.py 16 f32,bf16x3:96 > $O/voc_bench.log 2>&1; echo "voc bench rc=$?" | tee -a $O/status.txt
+    cat $O/voc_bench.log
+    timeout 1500 python -m pytest tests/test_gpu_gpt.py tests/test_gpu_compaction.py tests/test_gpu_edges.py tests/test_streaming.py -x -q > $O/pytest_gpt.log 2>&1; echo "pytest gpt rc=$?" | tee -a $O/status.txt
+    tail -3 $O/pytest_gpt.log
+    timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/status.txt
+    python - <<'PY'
+import json
+try:
+    j = json.loads(open("gpurun_out/r05f/bench.json").read().strip().splitlines()[-1])
+    st = j["stages"]
+    print("bench:", round(j["value"], 2), j["unit"], "ms/step", round(j["ms_per_step"], 1), "| roofline frac", round(j["roofline"]["frac"], 3), j["roofline"]["achieved"])
+    print("  gpt prefill", round(st["gpt_prefill_ms_per_step"], 1), "decode", round(st["gpt_decode_ms_per_step"], 1), "ms/token", round(st["gpt_decode_ms_per_token"], 3), "bigvgan", round(st["bigvgan_ms_per_step"], 1))
+    s2 = st["s2mel"]
+    print("  s2mel:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in s2.items() if k.startswith("cfm_") or k.endswith("ms_per_step")})
+except Exception as e:
+    print("bench parse failed", e)
+PY
+    tail -3 $O/bench.err
+}
+
 "call$1"

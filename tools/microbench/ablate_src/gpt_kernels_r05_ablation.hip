@@ -524,11 +524,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, KSPLIT ?
 // ascending, MFMAs x, y, z, w) -> bitwise the same results.  Per K tile a wave issues 128 MFMAs x 32 cycles against 16 fragment reads
 // and 32 KiB of DMA per block: MFMA-bound (157 TFLOP/s peak).
 template <int EPI, bool CONV = false, bool VEC = true, bool F32 = false>      // VEC: the LDS-transposed vector epilogue (N, ldo, D multiples of 4)
-__global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
+__global__ __launch_bounds__((PF_ABL & 256) ? 320 : 256) void gemm_prefill_kernel(GemmArgs a) {
     constexpr int ES = F32 ? 4 : 2;                                   // operand element size
+    constexpr bool LOADER = F32 && !CONV && (PF_ABL & 256) != 0;      // microbench variant 256: a fifth wave issues every LDS-DMA piece
     constexpr int BK = 128 / ES;                                      // K tile: 128 bytes per row (64 bf16 / 32 f32)
     extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB | W 16 KiB]
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // scalar: LDS-DMA destinations (M0) need no v_readfirstlane
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int n_mt = (a.M + PF_BM - 1) / PF_BM, n_nt = (a.N + PF_BN - 1) / PF_BN;
     const int total = n_mt * n_nt, per = (total + 7) >> 3;
@@ -541,6 +542,19 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     const int m0 = bm * PF_BM, nt0 = bn * (PF_BN / 16);
     const int nkb = F32 ? a.K >> 4 : a.K >> 5, nk = a.K / BK;
     const int ntiles = (a.N + 15) >> 4;
+    if constexpr (F32 && (PF_ABL & (16 | 64)) != 0) {
+        // start stagger (microbench variants 16 / 64; measured: no effect, profiles/r03n): the two blocks of a CU start together and, with
+        // equal tiles, could stay in lock step -- both in the main loop at half rate, both in prologue / epilogue with the matrix pipe
+        // idle.  Delay one of each pair by half a tile (a K tile is 4096 MFMA cycles per wave alone: nk / 4 sleeps of 127 x 64 cycles).
+        __shared__ int s_late;
+        if (threadIdx.x == 0) {
+            if constexpr ((PF_ABL & 16) != 0) s_late = (int)((blockIdx.x >> 8) & 1);                   // dispatch-order guess
+            else s_late = (int)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 1);       // HW_ID.WAVE_ID bit 0: the wave slot
+        }
+        __syncthreads();
+        if (blockIdx.x < 512 && s_late)
+            for (int i = 0; i < (nk + 3) / 4; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // staging sources of this lane: 4 A chunks (rows) and 4 W chunks per wave per K tile
     const char* asrc[4];
@@ -593,6 +607,18 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
         }
     };
 
+    // one of the 8 LDS-DMA pieces of a K tile (piece p: chunk i = p >> 1, A operand for even p, W for odd): the interleaved schedule
+    // (variant 128) issues them one per MFMA group.  No tap mode here (the implicit-im2col source needs the row tables).
+    auto issue_piece = [&](int kt, int buf, int p) {
+        char* base = pf_sm + buf * 32768;
+        const int i = p >> 1;
+        if ((p & 1) == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)kt * 128),
+                                             (__attribute__((address_space(3))) void*)(base + (w * 4 + i) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (size_t)kt * 2048),
+                                             (__attribute__((address_space(3))) void*)(base + 16384 + ((w * 2 + (i >> 1)) * 2 + (i & 1)) * 1024), 16, 0, 0);
+    };
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -611,18 +637,97 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
     const int a_wave = wr * 4 * 2048;                           // 4 m-blocks of 2 chunks each
     const int b_wave = 16384 + wc * 4 * 2048 + lane * 16;
 
+    if constexpr (LOADER) {
+        // variant 256 (launched with 320 threads): wave 4 stages every K tile -- all 32 pieces -- and waits for them; the four MFMA waves
+        // never issue a VMEM instruction (an LDS-DMA piece blocks its wave's instruction stream for 60-185 cycles, MI355X guide).
+        if (w == 4) {
+            const char* la[16];
+            const char* lb[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int row_t = c * 8 + (lane >> 3), row16 = row_t & 15;
+                const int piece = (lane & 7) ^ ((row16 >> 1) & 7);
+                int m = m0 + row_t;
+                m = m < a.M ? m : a.M - 1;
+                la[c] = (const char*)a.A + (size_t)m * a.lda * ES + piece * 16;
+                int nt = nt0 + (c >> 1);
+                nt = nt < ntiles ? nt : ntiles - 1;
+                lb[c] = (const char*)a.Wp + ((size_t)nt * nkb + (c & 1)) * 1024 + lane * 16;
+            }
+            auto stage = [&](int kt, int buf) {
+                char* base = pf_sm + buf * 32768;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(la[c] + (size_t)kt * 128),
+                                                     (__attribute__((address_space(3))) void*)(base + c * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lb[c] + (size_t)kt * 2048),
+                                                     (__attribute__((address_space(3))) void*)(base + 16384 + c * 1024), 16, 0, 0);
+                }
+            };
+            stage(0, 0);
+            for (int kt = 0; kt < nk; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+            }
+            if constexpr ((PF_ABL & 8) == 0) { __syncthreads(); __syncthreads(); }      // the epilogue's two barriers (plain-store path)
+            return;
+        }
+    } else {
     issue(0, 0);
-    // one K tile: this tile's operands have landed (every wave's pieces: wait + barrier), the next tile is requested into the other stage (a branch:
-    // its own basic block, the DMA burst sits between the barrier and the first fragment read), then the MFMAs
-    auto k_tile = [&](int kt) {
+    if constexpr ((PF_ABL & 1) != 0) issue(0, 1);                   // ablation 1: no in-loop DMA (both stages hold tile 0)
+    }
+    // one K tile; ISSUE: 1 = stage the next tile if there is one (a branch: its own basic block, the DMA burst sits between the barrier
+    // and the first fragment read), 2 = stage it unconditionally (same basic block as the MFMAs: the scheduler may interleave), 0 = none
+    auto k_tile = [&](int kt, auto issue_mode) {
+        constexpr int ISSUE = decltype(issue_mode)::value;          // 3: the MFMA part only (variant 512 does its own staging and barrier)
+        if constexpr (ISSUE != 3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        if constexpr ((PF_ABL & 2) == 0) __syncthreads();            // ablation 2: no barrier in the loop
+        else if (kt == 0) __syncthreads();
+        }
+        constexpr bool MANUAL = F32 && !CONV && (PF_ABL & 128) != 0;   // microbench variant 128: hand-placed schedule, DMA pieces inside the MFMA stream (measured: -1 %, profiles/r03n)
+        if constexpr ((PF_ABL & 1) == 0 && !MANUAL) {
+            if constexpr (ISSUE == 1) { if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1); }
+            else if constexpr (ISSUE == 2) issue(kt + 1, (kt + 1) & 1);
+        }
         const char* base = pf_sm + (kt & 1) * 32768;
+        if constexpr (MANUAL) {
+            v4u af[2][4], bf[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[0][mt] = *(const v4u*)(base + a_wave + mt * 2048 + a_off[0]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bf[0][nt] = *(const v4u*)(base + b_wave + (nt * 2 + 0) * 1024);
+#pragma unroll
+            for (int grp = 0; grp < 8; ++grp) {                       // 8 groups of 16 MFMAs: (k-step s2, element j of the 16-byte pieces)
+                const int s2 = grp >> 2, j = grp & 3;
+                __builtin_amdgcn_sched_barrier(0);
+                if (grp < 4) {                                        // the second k-step's fragments: two reads per group
+                    af[1][grp] = *(const v4u*)(base + a_wave + grp * 2048 + a_off[1]);
+                    bf[1][grp] = *(const v4u*)(base + b_wave + (grp * 2 + 1) * 1024);
+                }
+                if constexpr (ISSUE == 2 && (PF_ABL & 1) == 0) issue_piece(kt + 1, (kt + 1) & 1, grp);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[s2][mt][j]), __uint_as_float(bf[s2][nt][j]), acc[mt][nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         // Both k-steps' fragments are read up front into separate registers and the second step's reads are interleaved with
         // the first step's MFMAs (sched_group_barrier: 2 MFMAs per LDS read): left to itself hipcc emitted read-all / wait /
         // 8 MFMAs / 2 reads / wait / ..., i.e. four exposed LDS round trips per K tile.
         v4u af0[4], bf0[4], af1[4], bf1[4];
+        if constexpr ((PF_ABL & 4) != 0) {                          // ablation 4: no LDS fragment reads (register-made operands)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned u = 0x3f800000u + (unsigned)(kt + q);
+                af0[q] = v4u{u, u + 1, u + 2, u + 3}; bf0[q] = v4u{u + 4, u + 5, u + 6, u + 7};
+                af1[q] = v4u{u + 8, u + 9, u + 10, u + 11}; bf1[q] = v4u{u + 12, u + 13, u + 14, u + 15};
+            }
+        } else {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) af0[mt] = *(const v4u*)(base + a_wave + mt * 2048 + a_off[0]);
 #pragma unroll
@@ -631,6 +736,7 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
         for (int mt = 0; mt < 4; ++mt) af1[mt] = *(const v4u*)(base + a_wave + mt * 2048 + a_off[1]);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) bf1[nt] = *(const v4u*)(base + b_wave + (nt * 2 + 1) * 1024);
+        }
         if constexpr (F32) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -675,10 +781,53 @@ __global__ __launch_bounds__(256) void gemm_prefill_kernel(GemmArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);     // the second k-step's MFMAs
         }
     };
-    for (int kt = 0; kt < nk; ++kt) k_tile(kt);
+    if constexpr (LOADER) {
+        for (int kt = 0; kt < nk; ++kt) k_tile(kt, std::integral_constant<int, 0>{});
+    } else
+    if constexpr (F32 && !CONV && (PF_ABL & 512) != 0) {
+        // variant 512: register staging instead of LDS-DMA -- the next tile's 8 pieces per wave are plain 16-byte global loads issued after
+        // the barrier (a few cycles each; an LDS-DMA piece holds its wave's instruction stream for 60-185 cycles) and written to the other
+        // stage by ds_write_b128 after this tile's MFMAs (same lane-linear LDS image: piece c at c KiB + 16 lane).
+        v4u ra[4], rb[4];
+        auto gload = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ra[i] = *(const v4u*)(asrc[i] + (size_t)kt * 128); rb[i] = *(const v4u*)(bsrc[i] + (size_t)kt * 2048); }
+        };
+        auto lstore = [&](int buf) {
+            char* base = pf_sm + buf * 32768 + lane * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { *(v4u*)(base + (w * 4 + i) * 1024) = ra[i]; *(v4u*)(base + 16384 + (w * 4 + i) * 1024) = rb[i]; }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the DMA of tile 0 issued above (kept so that the prologue is unchanged)
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            __syncthreads();
+            gload(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);                          // keep hipcc from sinking the loads down to their ds_writes
+            k_tile(kt, std::integral_constant<int, 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+            lstore((kt + 1) & 1);
+        }
+        __syncthreads();
+        k_tile(nk - 1, std::integral_constant<int, 3>{});
+    } else
+    if constexpr (F32 && !CONV && (PF_ABL & 128) != 0) {             // variant 128: last tile peeled, the others stage unconditionally
+        for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::integral_constant<int, 2>{});
+        k_tile(nk - 1, std::integral_constant<int, 0>{});
+    } else {
+        for (int kt = 0; kt < nk; ++kt) k_tile(kt, std::integral_constant<int, 1>{});
+    }
     // Epilogue.  Vector path (every shape of the engine except an odd-width GPT head: N, ldo, D multiples of 4): transpose the
     // accumulator tile through LDS and store full-line pieces (pf_store_tile); otherwise (VEC = false instantiations of the
     // GPT epilogues) the per-lane element path.
+    if constexpr ((PF_ABL & 8) != 0) {                              // ablation 8: no epilogue (the store keeps the accumulators alive)
+        float sum = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) sum += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+        if (sum == 1.2345e-30f) a.out_f32[threadIdx.x] = sum;
+        return;
+    }
     if constexpr (VEC) {
         __syncthreads();                                           // every wave is done with the operand buffers
         float* ct = (float*)pf_sm;                                 // [128][128] f32 (row-major) or [128][132] (transposed, V^T tiles)
@@ -1228,7 +1377,7 @@ static int launch_gemm_prefill_f32_e(const GemmArgs& a, hipStream_t st) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_prefill_kernel<EPI, CONV, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_prefill_kernel<EPI, CONV, true, true>), dim3(per * 8), dim3(256), PF_LDS, st, a);
+    hipLaunchKernelGGL((gemm_prefill_kernel<EPI, CONV, true, true>), dim3(per * 8), dim3((!CONV && (PF_ABL & 256)) ? 320 : 256), PF_LDS, st, a);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }

@@ -329,11 +329,16 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 //   The next tile's global loads are in flight while the current one feeds the MFMAs.
 // ================================================================================================================
 #define FA_LD 64          // bf16 elements per LDS row (128 B, pieces swizzled)
-// Three measured choices are built in (A/B and ablation variants live in the frozen copy under tools/microbench/ablate_src/, which
-// tools/microbench/flash_ablate.hip builds): the LDS stage is a compile-time constant (the key loop is unrolled by two: immediate offsets instead
-// of address adds); the accumulators are rescaled only when some query's running maximum moved (wave-uniform branch); the row sums of P ride on
-// the PV MFMAs (a fifth m-tile of ones: the normaliser is the sum of the bf16 probabilities the PV product uses).  Same-box A/B at 64 x 2443 frames
-// x 8 heads, two sub-tiles: none 1284 us, stage + rescale 1200, all three 1180 (160 registers).
+#ifndef FA_OPT
+#define FA_OPT 7          // bit 1: compile-time LDS stage (loop unrolled x2: immediate offsets instead of address adds), bit 4: rescale the
+                          // accumulators only when some query's running maximum moved (wave-uniform branch), bit 2: row sums of P on the
+                          // PV MFMAs (a fifth m-tile of ones; the normaliser is then the sum of the bf16 probabilities the PV product uses).
+                          // Same-box A/B (tools/microbench/flash_ablate.hip, 64 x 2443 frames x 8 heads, two sub-tiles): before the
+                          // V^T read fix 0: 1284 us, 5: 1255, 7: 1359 (176 registers); after it 5: 1200, 7: 1180 (160 registers)
+#endif
+#ifndef FA_ABL
+#define FA_ABL 0          // tools/microbench/flash_ablate.hip builds variants with pieces of the loop removed (bit mask); 0 in the product
+#endif
 
 // QS = 16-query sub-tiles per wave (block = 64 * QS queries).  Every K / V^T fragment read from LDS feeds QS MFMAs: with one
 // sub-tile the kernel is LDS-bound (16 KB of fragment reads per 16 MFMAs per wave), with four the MFMA pipe is the limit.
@@ -393,6 +398,7 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
             const int r = r0 + 32 * i;
             const int pk = (p0 ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1))) * 8;      // r and r + 32 share both swizzles
             const int pv = (p0 ^ ((r >> 1) & 7)) * 8;
+            if (FA_ABL & 256) { asm volatile("" ::"v"(kreg[i]), "v"(vreg[i])); continue; }
             *(v4u*)(ks[buf] + r * FA_LD + pk) = kreg[i];
             *(v4u*)(vs[buf] + r * FA_LD + pv) = vreg[i];
         }
@@ -407,11 +413,12 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
         k_off[kx] = krow * FA_LD + (((kx * 4 + g) ^ ksw) << 3);
         v_off[kx] = c16 * FA_LD + (((kx * 4 + g) ^ vsw) << 3);                                  // keys 32 kx + 8 g .. + 7
     }
-    f32x4 o[QS][4], osum[QS];                                      // osum: row 0 of a fifth V^T m-tile of ones = the row sums of P
-    float m_run[QS];
+    f32x4 o[QS][4], osum[QS];                                      // osum (FA_OPT & 2): row 0 of a fifth V^T m-tile of ones = the row sums of P
+    float m_run[QS], l_run[QS];                                    // l_run: this lane's share of the row sum (reduced after the loop)
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
         m_run[qs] = -INFINITY;
+        l_run[qs] = 0.f;
         osum[qs] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) o[qs][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -428,24 +435,25 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
         asm volatile("" : "+v"(qf[qs][0]));
         asm volatile("" : "+v"(qf[qs][1]));
     }
-    // One key tile; the LDS stage is a compile-time constant (the loop is unrolled by two).
+    // One key tile; the LDS stage is a compile-time constant when the loop is unrolled by two (FA_OPT & 1), else bufc carries it at run time.
     auto tile = [&](auto bufc, int k0) {
         const int BUF = bufc;
-        const bool more = k0 + 64 < len;                           // block-uniform
+        const bool more = (FA_ABL & 1) ? false : k0 + 64 < len;    // block-uniform
         if (more) fetch(k0 + 64);                                  // in flight under this tile's MFMAs
-        const u16* kt_s = ks[BUF];
-        const u16* vt_s = vs[BUF];
+        const u16* kt_s = ks[(FA_ABL & 1) ? 0 : BUF];
+        const u16* vt_s = vs[(FA_ABL & 1) ? 0 : BUF];
         f32x4 st[QS][4];
         // S^T: all four key sub-tiles with the first 32 d, then the second 32 d -- consecutive MFMAs never chain on one accumulator
 #pragma unroll
         for (int kx = 0; kx < 2; ++kx)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const v4u a = *(const v4u*)(kt_s + (32 * (kt >> 1) + 4 * (kt & 1)) * FA_LD + k_off[kx]);
+                const v4u a = (FA_ABL & 64) ? v4u{1u, 2u, 3u, 4u} : *(const v4u*)(kt_s + (32 * (kt >> 1) + 4 * (kt & 1)) * FA_LD + k_off[kx]);
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs)
-                    st[qs][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[qs][kx]),
-                                                                         kx == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : st[qs][kt], 0, 0, 0);
+                    if (FA_ABL & 32) { st[qs][kt] = f32x4{0.f, 1.f, 2.f, 3.f}; asm volatile("" ::"v"(a)); }
+                    else st[qs][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, qf[qs][kx]),
+                                                                              kx == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : st[qs][kt], 0, 0, 0);
             }
         const bool tail = k0 + 64 > len;                           // block-uniform: only the last tile holds masked keys
         v4u pb[QS][2];
@@ -463,23 +471,31 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
             const float t0 = fa_max3(st[qs][0][0], st[qs][0][1], st[qs][0][2]), t1 = fa_max3(st[qs][1][0], st[qs][1][1], st[qs][1][2]);
             const float t2 = fa_max3(st[qs][2][0], st[qs][2][1], st[qs][2][2]), t3 = fa_max3(st[qs][3][0], st[qs][3][1], st[qs][3][2]);
             const float u0 = fa_max3(t0, t1, st[qs][0][3]), u1 = fa_max3(t2, t3, st[qs][1][3]);
-            const float m_new = fa_colmax(fa_max3(u0, u1, fa_max3(st[qs][2][3], st[qs][3][3], m_run[qs])));   // >= m_run, finite
-            if (__builtin_amdgcn_ballot_w64(m_new > m_run[qs]) != 0) {                       // wave-uniform: skipped when no maximum moved
+            const float m_new = (FA_ABL & 8) ? fmaxf(m_run[qs], 0.f)
+                                             : fa_colmax(fa_max3(u0, u1, fa_max3(st[qs][2][3], st[qs][3][3], m_run[qs])));   // >= m_run, finite
+            if (!(FA_OPT & 4) || __builtin_amdgcn_ballot_w64(m_new > m_run[qs]) != 0) {      // (FA_OPT & 4: wave-uniform skip)
                 const float alpha = __builtin_amdgcn_exp2f((m_run[qs] - m_new) * scale_log2e);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[qs][mt][r] *= alpha;
-                osum[qs][0] *= alpha;
+                if (FA_OPT & 2) osum[qs][0] *= alpha; else l_run[qs] *= alpha;
                 m_run[qs] = m_new;
             }
             // plain f32 VALU on purpose (the file is built with -fno-slp-vectorize): beside MFMAs a v_pk_fma/mul/add_f32 costs ~13
             // cycles more than the two scalar ops it replaces (MI355X guide)
             const float off = -m_new * scale_log2e;
+            float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[qs][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qs][kt][r], scale_log2e, off));
+                for (int r = 0; r < 4; ++r) {
+                    const float t = __builtin_fmaf(st[qs][kt][r], scale_log2e, off);
+                    const float p = (FA_ABL & 4) ? t : __builtin_amdgcn_exp2f(t);
+                    st[qs][kt][r] = p;
+                    if (!(FA_OPT & 2)) psum += p;
+                }
+            if (!(FA_OPT & 2)) l_run[qs] += psum;
 #pragma unroll
             for (int kx = 0; kx < 2; ++kx)
                 pb[qs][kx] = v4u{pack_bf16x2(st[qs][2 * kx][0], st[qs][2 * kx][1]), pack_bf16x2(st[qs][2 * kx][2], st[qs][2 * kx][3]),
@@ -489,28 +505,41 @@ __global__ __launch_bounds__(256, (QS == 1 ? 4 : QS == 2 ? 2 : 1)) void flash_at
         for (int kx = 0; kx < 2; ++kx) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const v4u a = *(const v4u*)(vt_s + mt * 16 * FA_LD + v_off[kx]);
+                const v4u a = (FA_ABL & 128) ? v4u{1u, 2u, 3u, 4u} : *(const v4u*)(vt_s + mt * 16 * FA_LD + v_off[kx]);
 #pragma unroll
                 for (int qs = 0; qs < QS; ++qs)
-                    o[qs][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, pb[qs][kx]),
-                                                                        o[qs][mt], 0, 0, 0);
+                    if (FA_ABL & 16) asm volatile("" ::"v"(a), "v"(pb[qs][kx]));
+                    else o[qs][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, pb[qs][kx]),
+                                                                             o[qs][mt], 0, 0, 0);
             }
 #pragma unroll
             for (int qs = 0; qs < QS; ++qs)
-                osum[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones_frag), __builtin_bit_cast(bf16x8_t, pb[qs][kx]),
-                                                                   osum[qs], 0, 0, 0);
+                if ((FA_OPT & 2) && !(FA_ABL & 16)) osum[qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones_frag),
+                                                                                        __builtin_bit_cast(bf16x8_t, pb[qs][kx]), osum[qs], 0, 0, 0);
         }
         if (more) stage(BUF ^ 1);                                  // the other stage was last read one tile ago (barrier below that tile)
-        __syncthreads();
+        if (!(FA_ABL & 2)) __syncthreads();
     };
-    for (int k0 = 0; k0 < len; k0 += 128) {
-        tile(std::integral_constant<int, 0>{}, k0);
-        if (k0 + 64 >= len) break;
-        tile(std::integral_constant<int, 1>{}, k0 + 64);
+    if (FA_OPT & 1) {
+        for (int k0 = 0; k0 < len; k0 += 128) {
+            tile(std::integral_constant<int, 0>{}, k0);
+            if (k0 + 64 >= len) break;
+            tile(std::integral_constant<int, 1>{}, k0 + 64);
+        }
+    } else {
+        int buf = 0;
+        for (int k0 = 0; k0 < len; k0 += 64, buf ^= 1) tile(buf, k0);
     }
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
-        const float ls = __shfl(osum[qs][0], c16, 64);             // row 0 of the ones tile lives in lanes 0..15 (g = 0), element 0
+        float ls;
+        if (FA_OPT & 2) {
+            ls = __shfl(osum[qs][0], c16, 64);                     // row 0 of the ones tile lives in lanes 0..15 (g = 0), element 0
+        } else {
+            ls = l_run[qs];                                        // the four key groups' shares of the row sum
+            ls += __shfl_xor(ls, 16, 64);
+            ls += __shfl_xor(ls, 32, 64);
+        }
         const int qi = q0 + (w * QS + qs) * 16 + c16;
         if (qi < T) {
             const float inv = ls > 0.f ? 1.0f / ls : 0.f;

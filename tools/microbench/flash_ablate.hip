@@ -3,14 +3,14 @@
 //   mask bits: 1 no per-tile global fetch / LDS staging (every tile re-reads stage 0), 2 no barrier, 4 no exp2, 8 no max / permlane,
 //              16 no PV MFMAs, 32 no QK MFMAs
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I indextts_amd/csrc -mllvm -amdgpu-mfma-vgpr-form=1 -DFA_ABL=0 -DQS_=1 \
-//         tools/microbench/flash_ablate.hip -o /tmp/fa_0 && /tmp/fa_0 64 2443
+//         tools/microbench/flash_ablate.hip indextts_amd/csrc/options.hip -o /tmp/fa_0 && /tmp/fa_0 64 2443
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
 #include "../../indextts_amd/csrc/common.h"
 void itts_set_error(const char* fmt, ...) { (void)fmt; }
-#include "../../indextts_amd/csrc/s2mel_kernels.hip"
+#include "ablate_src/s2mel_kernels_r05_ablation.hip"     // frozen copy of the product source that still carries the PF_ABL / FA_ABL / FA_OPT branches
 #ifndef QS_
 #define QS_ 1
 #endif

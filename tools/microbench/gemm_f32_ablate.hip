@@ -6,14 +6,14 @@
 //              128 DMA pieces hand-placed inside the MFMA stream, 256 a fifth (loader) wave stages every piece, 512 register staging
 //              (global_load -> ds_write) instead of LDS-DMA;  -DUSE_T256: the 256 x 256 tile kernel on the f32 MFMA instead
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I indextts_amd/csrc -mllvm -amdgpu-mfma-vgpr-form=1 -DPF_ABL=0 \
-//         tools/microbench/gemm_f32_ablate.hip -o /tmp/ga_0 && /tmp/ga_0 312704
+//         tools/microbench/gemm_f32_ablate.hip indextts_amd/csrc/options.hip indextts_amd/csrc/gemm_x3.hip -o /tmp/ga_0 && /tmp/ga_0 312704
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
 #include "../../indextts_amd/csrc/common.h"
 void itts_set_error(const char* fmt, ...) { (void)fmt; }
-#include "../../indextts_amd/csrc/gpt_kernels.hip"
+#include "ablate_src/gpt_kernels_r05_ablation.hip"     // frozen copy of the product source that still carries the PF_ABL / FA_ABL / FA_OPT branches
 // order-independent fingerprint of the output bits: variants that only move instructions (16, 64, 128) must print the baseline's value
 __global__ void fingerprint_kernel(const unsigned* __restrict__ p, size_t n, unsigned long long* out) {
     unsigned long long h = 0;
