@@ -195,7 +195,7 @@ class HipEngine:
         self.model.use_graph = not args.no_graph
         self.bh = dict(synth.BIGVGAN_V2_22K)
         self.bsd = synth.bigvgan_weights(self.bh, seed=1234)
-        self.voc = bigvgan.BigVGAN(self.bh, device=dev)
+        self.voc = bigvgan.BigVGAN(self.bh, device=dev, conv_mode=None if args.bigvgan_conv == "f32" else args.bigvgan_conv)
         self.voc.load_state_dict(self.bsd)
         self.voc.to(dev)
         self.prof_acc = {}

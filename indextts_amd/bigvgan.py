@@ -250,7 +250,7 @@ class BigVGAN:
         rc = _lib.lib().itts_bigvgan_forward(self._h, _lib.ptr(x), _lib.ptr(lens_t), _lib.ptr(spk), _lib.ptr(wav), B, T,
                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
         _lib.check(rc, "itts_bigvgan_forward")
-        if self.conv_mode:                              # the split mode cannot represent values outside the f16 range: fail, never garble
+        if self.conv_mode == 1:                         # the f16 split mode cannot represent values outside the f16 range: fail, never garble (bf16 planes have the f32 range)
             bad = _lib.lib().itts_bigvgan_range_check(self._h)
             if bad:
                 raise _lib.HipEngineError("BigVGAN(conv_mode='f16x3'): an activation was not finite or outside the f16 range "

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(512) void flash_attn_x3_kernel(const float* __restr
     const int T = tab.seq_T[s], len = tab.seq_len[s];
     if (q0 >= T) return;
     const int H = heads * 64;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: LDS-DMA destinations (M0) without v_readfirstlane
     const int g = lane >> 4, c16 = lane & 15;
     const size_t row0 = (size_t)tab.seq_start[s];
     // plane pairs (A = K or V^T plane, B = Q or P plane), smallest terms first; NPROD = 6 skips the two 2^-24 cross terms ml, lm

@@ -1,8 +1,10 @@
 #!/bin/bash
 # GPU box: how busy is the matrix pipe under the fp32x3 kernels, and at what clock?  One rocprofv3 counter pass (SQ_VALU_MFMA_BUSY_CYCLES,
 # GRBM_GUI_ACTIVE, SQ_BUSY_CYCLES; --kernel-trace only) over tools/s2mel_bench.py at B utterances x (517 + 1926) frames, two Euler steps, per kernel family:
-#   mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE)          -- fraction of the kernel's own clock cycles with the pipe busy
-#   clock     = GRBM_GUI_ACTIVE / kernel duration                                   -- the effective engine clock while it ran (DVFS)
+#   GRBM_GUI_ACTIVE comes back SUMMED over the 8 XCDs (each XCD's GRBM counts its own active cycles), SQ_VALU_MFMA_BUSY_CYCLES summed over all SIMDs:
+#   cycles    = GRBM_GUI_ACTIVE / 8                                                 -- the kernel's own clock cycles (per XCD)
+#   mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)                    -- fraction of those cycles with the matrix pipe busy
+#   clock     = cycles / kernel duration                                            -- the effective engine clock while it ran (DVFS)
 # usage: tools/pmc_x3.sh [B=8]  ->  gpurun_out/pmc_x3/x3_pmc.json
 set -u
 B=${1:-8}
@@ -37,9 +39,10 @@ res = {"B": B, "frames": 517 + 1926, "note": "sums over the launches of two CFG 
 for k in FAM:
     if dur[k][1] == 0: continue
     busy, gui, ns = cnt[k]["SQ_VALU_MFMA_BUSY_CYCLES"], cnt[k]["GRBM_GUI_ACTIVE"], dur[k][0]
-    res[k] = {"dispatches": dur[k][1], "duration_ns": ns, "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": gui,
-              "mfma_busy_of_own_cycles": busy / (1024.0 * gui) if gui else None, "effective_clock_GHz": gui / ns if ns else None,
-              "mfma_busy_at_2p4GHz": busy / (1024.0 * ns * 2.4) if ns else None}
+    cyc = gui / 8.0                                                  # per-XCD: the counter is summed over the 8 XCDs
+    res[k] = {"dispatches": dur[k][1], "duration_ns": ns, "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE_sum_over_8_xcds": gui,
+              "cycles_per_xcd": cyc, "mfma_busy_of_own_cycles": busy / (1024.0 * cyc) if cyc else None,
+              "effective_clock_GHz": cyc / ns if ns else None, "mfma_busy_at_2p4GHz": busy / (1024.0 * ns * 2.4) if ns else None}
 if "gemm_x3_kernel" not in res: print("pmc_x3: no gemm_x3_kernel dispatches", file=sys.stderr); sys.exit(1)
 json.dump(res, open(f"{out}/x3_pmc.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
