@@ -43,8 +43,8 @@ def test_admitted_row_equals_the_row_alone(golden_dir, prec):
     max_new = 96
 
     def prep(t):
-        return m.inference_speech_stream(None, t, langs=torch.full((t.shape[0],), 1), emo_vec=emo[:1].expand(t.shape[0], -1),
-                                         campplus_embedding=style[:1].expand(t.shape[0], -1), max_generate_length=max_new, **kw)
+        return m.inference_speech_stream(None, t, langs=torch.full((t.shape[0],), 1), emo_vec=emo, campplus_embedding=style,
+                                         max_generate_length=max_new, **kw)
 
     emb, mask, mn, hf = prep(text)
     emb_n, mask_n, _, _ = prep(new_text)

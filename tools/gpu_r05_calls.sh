@@ -126,4 +126,46 @@ PY
     tail -3 $O/bench.err
 }
 
+# round 5, GPU call 7: admission test (fixed inputs); SAME-BOX A/B of round 4's library (tools/ab/r04_tree, built from commit 43a1160, not committed)
+# against this round's: the 64-utterance flow-matching solve and the vocoder forward; the benchmark with the bf16 x 3 vocoder convs; rocprofv3
+# kernel stats of a one-step run; the matrix-pipe PMC pass with per-XCD-normalised fields.
+call7() {
+    O=$PWD/gpurun_out/r05g
+    mkdir -p $O
+    timeout 600 python -m pytest tests/test_gpu_admission.py -x -q -s > $O/pytest_admission.log 2>&1; echo "pytest admission rc=$?" | tee $O/status.txt
+    grep -E "admitted at|passed|failed|Error|error" $O/pytest_admission.log | tail -8
+    for rep in 1 2; do
+        (cd tools/ab/r04_tree && timeout 300 python tools/s2mel_bench.py 64 517 1926 1 fp32x3) > $O/ab_r04_solve_$rep.log 2>&1; grep "^B=" $O/ab_r04_solve_$rep.log | sed 's/^/r04: /'
+        timeout 300 python tools/s2mel_bench.py 64 517 1926 1 fp32x3 > $O/ab_r05_solve_$rep.log 2>&1; grep "^B=" $O/ab_r05_solve_$rep.log | sed 's/^/r05: /'
+    done
+    (cd tools/ab/r04_tree && timeout 300 python tools/voc_h3_bench.py 64 f32) > $O/ab_r04_voc.log 2>&1; grep "^B=" $O/ab_r04_voc.log | sed 's/^/r04: /'
+    timeout 300 python tools/voc_h3_bench.py 64 f32,bf16x3 > $O/ab_r05_voc.log 2>&1; grep "^B=" $O/ab_r05_voc.log | sed 's/^/r05: /'
+    echo "ab rc=0" | tee -a $O/status.txt
+    timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/status.txt
+    python - <<'PY'
+import json
+try:
+    j = json.loads(open("gpurun_out/r05g/bench.json").read().strip().splitlines()[-1])
+    st = j["stages"]
+    print("bench:", round(j["value"], 2), j["unit"], "ms/step", round(j["ms_per_step"], 1), "| roofline frac", round(j["roofline"]["frac"], 3), round(j["roofline"]["achieved"], 1))
+    print("  gpt prefill", round(st["gpt_prefill_ms_per_step"], 1), "decode", round(st["gpt_decode_ms_per_step"], 1), "ms/token", round(st["gpt_decode_ms_per_token"], 3), "bigvgan", round(st["bigvgan_ms_per_step"], 1))
+    s2 = st["s2mel"]
+    print("  s2mel:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in s2.items() if k.startswith("cfm_") or k.endswith("ms_per_step")})
+    print("  other conv mode:", st.get("bigvgan_other_conv_mode"))
+except Exception as e:
+    print("bench parse failed", e)
+PY
+    cd /tmp && export TMPDIR=/tmp
+    timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $ROOT/bench.py --steps 1 --warmup 1 --alt-steps 0 --no-configs --no-shards --no-cpu-baseline --no-extras > $O/bench_profiled_run.json 2> $O/bench_profiled.err; echo "rocprof rc=$?" | tee -a $O/status.txt
+    cd $ROOT
+    cp "$(find $O/prof -name '*kernel_stats.csv' | head -1)" $O/bench_kernel_stats.csv 2>/dev/null; rm -rf $O/prof
+    head -14 $O/bench_kernel_stats.csv | cut -c1-150
+    timeout 900 bash tools/pmc_x3.sh 8 > $O/pmc_x3.log 2>&1; echo "pmc_x3 rc=$?" | tee -a $O/status.txt; cp gpurun_out/pmc_x3/x3_pmc.json $O/ 2>/dev/null
+    python -c "
+import json; j=json.load(open('$O/x3_pmc.json'))
+for k,v in j.items():
+    if isinstance(v, dict): print(k, 'busy', round(v['mfma_busy_of_own_cycles'],3), 'clock', round(v['effective_clock_GHz'],3))
+" 2>/dev/null
+}
+
 "call$1"
