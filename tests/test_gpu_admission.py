@@ -38,15 +38,24 @@ def test_admitted_row_equals_the_row_alone(golden_dir, prec):
     B = text.shape[0]
     assert B >= 3
     g = torch.Generator().manual_seed(77)
-    new_text = torch.randint(2, cfg.number_text_tokens - 2, (1, 9), generator=g)     # the utterance that arrives later
+    cand = torch.randint(2, cfg.number_text_tokens - 2, (8, 9), generator=g)         # candidates for the utterance that arrives later
     kw = dict(do_sample=False, num_beams=1, repetition_penalty=10.0)
-    max_new = 96
+    max_new = min(96, cfg.max_mel_tokens - 2)                    # the fixture model's mel position table is short
 
     def prep(t):
         return m.inference_speech_stream(None, t, langs=torch.full((t.shape[0],), 1), emo_vec=emo, campplus_embedding=style,
                                          max_generate_length=max_new, **kw)
 
     emb, mask, mn, hf = prep(text)
+    # the late utterance: the candidate that decodes longest on its own (the fixture model's EOS bias stops many rows within a few tokens)
+    emb_c, mask_c, _, _ = prep(cand)
+    with gpt.DecodeSession(m, emb_c, mask_c, mn, **hf) as sc:
+        while sc.steps < max_new and len(sc.finished()) < cand.shape[0]:
+            sc.run(8)
+        clens = [int(sc.codes(b).numel()) for b in range(cand.shape[0])]
+    pick = int(np.argmax(clens))
+    assert clens[pick] >= 6, clens
+    new_text = cand[pick:pick + 1]
     emb_n, mask_n, _, _ = prep(new_text)
 
     # (1) the batch alone, to its end
@@ -55,7 +64,7 @@ def test_admitted_row_equals_the_row_alone(golden_dir, prec):
             s0.run(8)
         alone_batch = [s0.codes(b).cpu() for b in range(B)]
     lens = [int(v.numel()) for v in alone_batch]
-    assert min(lens) < max_new - 16, f"no row finishes early enough to free a slot: {lens}"
+    assert min(lens) < max_new - 12, f"no row finishes early enough to free a slot: {lens}"
 
     # (2) the same batch; as soon as a row has finished the new utterance takes its slot
     with gpt.DecodeSession(m, emb, mask, mn, **hf) as s1:
@@ -84,5 +93,5 @@ def test_admitted_row_equals_the_row_alone(golden_dir, prec):
         solo = s2.codes(0).cpu()
     n = min(int(solo.numel()), int(admitted.numel()))
     print(f"{prec}: admitted at step {k} into slot {slot} (position {S_new}): {admitted.numel()} codes, alone {solo.numel()}; first ids {admitted[:8].tolist()}")
-    assert n >= 4 and torch.equal(admitted[:n], solo[:n])
+    assert n >= 6 and torch.equal(admitted[:n], solo[:n])
     assert admitted.numel() == solo.numel() or admitted.numel() >= max_new - k     # (the admitted row may run into the batch's token budget)
