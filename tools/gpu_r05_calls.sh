@@ -168,4 +168,25 @@ for k,v in j.items():
 " 2>/dev/null
 }
 
+# round 5, GPU call 8: admission test; rocprofv3 kernel stats of a one-step bench run (csv)
+call8() {
+    O=$PWD/gpurun_out/r05h
+    mkdir -p $O
+    timeout 600 python -m pytest tests/test_gpu_admission.py -x -q -s > $O/pytest_admission.log 2>&1; echo "pytest admission rc=$?" | tee $O/status.txt
+    grep -E "admitted at|passed|failed|Error|error" $O/pytest_admission.log | tail -8
+    timeout 1200 bash tools/profile.sh r05h --alt-steps 0 --no-configs --no-shards --no-extras > $O/profile.log 2>&1; echo "profile rc=$?" | tee -a $O/status.txt
+    cp gpurun_out/prof_r05h/kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null; cp gpurun_out/prof_r05h/bench.json $O/bench_profiled_run.json 2>/dev/null
+    head -16 $O/bench_kernel_stats.csv | cut -c1-170
+}
+
+# round 5, GPU call 9: the whole GPU suite + smoke at the current code
+call9() {
+    O=$PWD/gpurun_out/r05i
+    mkdir -p $O
+    timeout 2400 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; echo "pytest -m gpu rc=$?" | tee $O/status.txt
+    tail -6 $O/pytest_gpu.log
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/status.txt
+    tail -4 $O/smoke.log
+}
+
 "call$1"
