@@ -37,14 +37,15 @@ def test_admitted_row_equals_the_row_alone(golden_dir, prec):
     text = torch.from_numpy(z["text"])
     B = text.shape[0]
     assert B >= 3
-    kw = dict(do_sample=False, num_beams=1, repetition_penalty=10.0)
+    gen = z["gen"]                                               # the fixture's own generation settings (greedy): its rows stop at steps 0 / 21 / 6
+    kw = dict(do_sample=bool(gen[0]), num_beams=1, top_p=float(gen[2]), top_k=int(gen[3]), temperature=float(gen[4]), repetition_penalty=float(gen[5]))
+    langs = torch.from_numpy(z["langs"])
     max_new = min(96, cfg.max_mel_tokens - 2)                    # the fixture model's mel position table is short
 
-    def prep(t):
-        return m.inference_speech_stream(None, t, langs=torch.full((t.shape[0],), 1), emo_vec=emo, campplus_embedding=style,
-                                         max_generate_length=max_new, **kw)
+    def prep(t, lg):
+        return m.inference_speech_stream(None, t, langs=lg, emo_vec=emo, campplus_embedding=style, max_generate_length=max_new, **kw)
 
-    emb, mask, mn, hf = prep(text)
+    emb, mask, mn, hf = prep(text, langs)
     # the late utterance: the text of the fixture's longest-running row once more (random texts stop at once under this model's EOS bias)
     ref_codes = z["codes"]
     stop = int(ref_codes.max())
@@ -52,7 +53,7 @@ def test_admitted_row_equals_the_row_alone(golden_dir, prec):
     long_row = int(np.argmax(ref_lens))
     assert ref_lens[long_row] >= 6, ref_lens
     new_text = text[long_row:long_row + 1].contiguous()          # (trailing pad ids are stripped by prepare_gpt_inputs)
-    emb_n, mask_n, _, _ = prep(new_text)
+    emb_n, mask_n, _, _ = prep(new_text, langs[long_row:long_row + 1])
 
     # (1) the batch alone, to its end
     with gpt.DecodeSession(m, emb, mask, mn, **hf) as s0:

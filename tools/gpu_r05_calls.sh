@@ -183,7 +183,7 @@ call8() {
 call9() {
     O=$PWD/gpurun_out/r05i
     mkdir -p $O
-    timeout 2400 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; echo "pytest -m gpu rc=$?" | tee $O/status.txt
+    timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest -m gpu rc=$?" | tee $O/status.txt
     tail -6 $O/pytest_gpu.log
     timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/status.txt
     tail -4 $O/smoke.log
