@@ -167,31 +167,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     issue_a(0, 0);
     issue_w(0);
-    // one K tile: wait, barrier, request the next weight tile (and, at a chunk's first tile, the next chunk's window BEHIND it: a wait for the
+    // window fragments of one K tile: tap j of chunk kc, three planes per m-tile
+    auto read_a = [&](int kc, int j, x3_v4u (&af)[CX3_MT][3]) {
+        const char* abase = sm + (kc & 1) * CX3_ABUF;
+        const int rbase = wr * CX3_MT * 16 + row16 + j * a.dil;         // window row of this lane's first frame for tap j
+#pragma unroll
+        for (int mt = 0; mt < CX3_MT; ++mt) {
+            const int rr = rbase + mt * 16;
+            const char* ap = abase + (rr >> 4) * 1024 + kg * 256 + (rr & 15) * 16;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[mt][pl] = *(const x3_v4u*)(ap + pl * CX3_ACH * 1024);
+        }
+    };
+    // One K tile: wait, barrier, request the next weight tile (and, at a chunk's first tile, the next chunk's window BEHIND it: a wait for the
     // weights then never drains the window), 72 MFMAs per wave.  a_recent: the window request of the previous iteration may stay in flight.
+    // The window fragments of the NEXT K tile are read during this tile's MFMAs (m-tile by m-tile, into the registers that m-tile's MFMAs have just
+    // consumed): all eight waves leave the barrier together, and with the
+    // 12 window reads + 9 weight reads per wave issued behind it the LDS was busy ~1 300 cycles per K tile before the first MFMA could start
+    // (profiles/r05d: 213 TFLOP/s on the 768-channel stage); the next tile's window is resident by then -- the same chunk's, or the next chunk's,
+    // which was requested k NH >= 3 tiles earlier and waited for (vmcnt(0) + barrier) two tiles after its request.
     bool a_recent = false;
-    auto ktile = [&](int g, int kc, int j, f32x4 (&ac)[CX3_MT][CX3_NT], bool first_of_chunk) {
+    x3_v4u afc[CX3_MT][3];                                              // this tile's window fragments (read during the previous tile)
+    auto ktile = [&](int g, int kc, int kc_n, int j_n, f32x4 (&ac)[CX3_MT][CX3_NT], bool first_of_chunk) {
         if (a_recent) { if (my_ach == 3) cx3_wait_vm<9>(); else cx3_wait_vm<6>(); } else cx3_wait_vm<0>();
         __builtin_amdgcn_s_barrier();                                   // ... for every wave; the other weight stage and window buffer are free again
         asm volatile("" ::: "memory");                                  // (raw barrier: __syncthreads' fence would drain the window request in flight)
         if (g + 1 < G) issue_w(g + 1);
         a_recent = false;
         if (first_of_chunk && kc + 1 < nkc) { issue_a(kc + 1, (kc + 1) & 1); a_recent = true; }
-        const char* abase = sm + (kc & 1) * CX3_ABUF;
         const char* wbase = sm + 2 * CX3_ABUF + (g & 1) * CX3_WST;
         x3_v4u bf[CX3_NT][3];
 #pragma unroll
         for (int nt = 0; nt < CX3_NT; ++nt)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = *(const x3_v4u*)(wbase + pl * CX3_NWT * 1024 + b_off + nt * 1024);
-        const int rbase = wr * CX3_MT * 16 + row16 + j * a.dil;         // window row of this lane's first frame for tap j
+        if (g == 0) read_a(0, 0, afc);                                  // the first tile's own fragments (its window landed with this barrier)
+        const char* abase_n = sm + (kc_n & 1) * CX3_ABUF;
+        const int rbase_n = wr * CX3_MT * 16 + row16 + j_n * a.dil;
+        const bool more = g + 1 < G;
 #pragma unroll
         for (int mt = 0; mt < CX3_MT; ++mt) {
-            const int rr = rbase + mt * 16;
-            const char* ap = abase + (rr >> 4) * 1024 + kg * 256 + (rr & 15) * 16;
-            x3_v4u af[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) af[pl] = *(const x3_v4u*)(ap + pl * CX3_ACH * 1024);
             // plane pairs, smallest terms first (x plane, w plane): l h, h l, m m, m h, h m, h h
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
             constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
@@ -199,15 +214,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int q = 0; q < 6; ++q)
 #pragma unroll
                 for (int nt = 0; nt < CX3_NT; ++nt)
-                    ac[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x3_bf16x8, af[PA[q]]),
+                    ac[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(x3_bf16x8, afc[mt][PA[q]]),
                                                                          __builtin_bit_cast(x3_bf16x8, bf[nt][PB[q]]), ac[mt][nt], 0, 0, 0);
+            if (more) {                                                 // this m-tile's fragments of the NEXT K tile, into the registers just consumed
+                const int rr = rbase_n + mt * 16;
+                const char* ap = abase_n + (rr >> 4) * 1024 + kg * 256 + (rr & 15) * 16;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) afc[mt][pl] = *(const x3_v4u*)(ap + pl * CX3_ACH * 1024);
+            }
         }
     };
-    int g = 0;
-    for (int kc = 0; kc < nkc; ++kc) {
+    {
+        // K tiles in (chunk, co half, tap) order
+        int g = 0;
+        for (int kc = 0; kc < nkc; ++kc) {
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
-            for (int j = 0; j < a.k; ++j, ++g) ktile(g, kc, j, acc[h], h == 0 && j == 0);
+            for (int h = 0; h < NH; ++h)
+                for (int j = 0; j < a.k; ++j, ++g) {
+                    int j_n = j + 1, kc_n = kc;                          // the successor tile's tap and chunk (the co half does not matter to the window)
+                    if (j_n == a.k) { j_n = 0; if (h == NH - 1) kc_n = kc + 1; }
+                    ktile(g, kc, kc_n, j_n, acc[h], h == 0 && j == 0);
+                }
+        }
     }
 
     const bool vec = (a.T & 3) == 0;

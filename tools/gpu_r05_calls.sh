@@ -189,4 +189,14 @@ call9() {
     tail -4 $O/smoke.log
 }
 
+# round 5, GPU call 10: x3 vocoder conv with the next tile's window fragments read under the MFMAs: tests + forward time
+call10() {
+    O=$PWD/gpurun_out/r05j
+    mkdir -p $O
+    timeout 900 python -m pytest tests/test_gpu_bigvgan_x3.py -x -q -s > $O/pytest_voc.log 2>&1; echo "pytest voc rc=$?" | tee $O/status.txt
+    grep -E "x3 conv|rms err|passed|failed|Error|error" $O/pytest_voc.log | tail -14
+    timeout 600 python tools/voc_h3_bench.py 16 bf16x3:96,f32 > $O/voc_bench.log 2>&1; echo "voc bench rc=$?" | tee -a $O/status.txt
+    cat $O/voc_bench.log
+}
+
 "call$1"
