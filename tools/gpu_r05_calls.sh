@@ -199,4 +199,23 @@ call10() {
     cat $O/voc_bench.log
 }
 
+# round 5, GPU call 11: operand split on v_dot2c_f32_bf16 (7 instead of 11 VALU ops per pair): bit check of the planes, x3 tests, same-box A/B
+# against the previous build (tools/ab/base_tree, not committed)
+call11() {
+    O=$PWD/gpurun_out/r05k
+    mkdir -p $O
+    timeout 300 tools/microbench/bin/split_dot2 > $O/split_dot2.log 2>&1; echo "split_dot2 rc=$?" | tee $O/status.txt
+    cat $O/split_dot2.log
+    timeout 900 python -m pytest tests/test_gpu_gemm_x3.py tests/test_gpu_attn_x3.py tests/test_gpu_bigvgan_x3.py -x -q > $O/pytest_x3.log 2>&1; echo "pytest x3 rc=$?" | tee -a $O/status.txt
+    tail -3 $O/pytest_x3.log
+    timeout 900 python -m pytest tests/test_gpu_s2mel.py -x -q > $O/pytest_s2mel.log 2>&1; echo "pytest s2mel rc=$?" | tee -a $O/status.txt
+    tail -3 $O/pytest_s2mel.log
+    for rep in 1 2; do
+        timeout 300 python tools/gemm_x3_bench.py > $O/gemm_x3_bench_$rep.log 2>&1; grep "^M=" $O/gemm_x3_bench_$rep.log | sed 's/^/dot2: /'
+        (cd tools/ab/base_tree && timeout 300 python tools/gemm_x3_bench.py) > $O/ab_base_gemm_$rep.log 2>&1; grep "^M=" $O/ab_base_gemm_$rep.log | sed 's/^/base: /'
+        timeout 300 python tools/s2mel_bench.py 64 517 1926 1 fp32x3 > $O/solve_$rep.log 2>&1; grep "^B=" $O/solve_$rep.log | sed 's/^/dot2: /'
+        (cd tools/ab/base_tree && timeout 300 python tools/s2mel_bench.py 64 517 1926 1 fp32x3) > $O/ab_base_solve_$rep.log 2>&1; grep "^B=" $O/ab_base_solve_$rep.log | sed 's/^/base: /'
+    done
+}
+
 "call$1"
