@@ -770,6 +770,10 @@ def configs_leg(args, eng, bundle0, dev):
             audio = sum(int(w.shape[-1]) for w in wavs) / SR
             res = {"ms": dt * 1e3, "audio_seconds": audio, "audio_seconds_per_sec": audio / dt, "rtf_per_stream": dt / (audio / len(wavs)),
                    "stage_seconds": {k: round(float(v), 4) for k, v in tts.last_timing.items()}}
+            gt = getattr(eng.model, "last_timing", None) or {}
+            if "prefill_ms" in gt:                               # device events around the prefill launch train, which ends with the first sampled code
+                res["time_to_first_token_ms"] = round(float(gt["prefill_ms"]), 3)
+                res["decode_ms_per_token"] = round(float(gt["decode_ms"]) / max(1, int(gt.get("steps", 1))), 4)
         return res
 
     style, emo_vec = bundle0["style"], bundle0["emo_vec"]

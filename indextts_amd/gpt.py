@@ -602,6 +602,78 @@ class UnifiedVoice:
         hf["uniforms"] = uniforms
         return inputs_embeds, attention_mask, max_new, hf
 
+    def inference_speech_inflight(self, speech_condition, text_inputs, langs=None, cond_lengths=None, emo_vec=None, campplus_embedding=None,
+                                  max_generate_length=None, typical_sampling=False, typical_mass=.9, conds_latent=None, slots=8,
+                                  chunk_tokens=16, admit_room=None, **hf_generate_kwargs):
+        """`inference_speech` for MORE utterances than decode slots: `slots` rows decode at a time and, whenever rows have emitted their stop
+        token, waiting utterances are prefilled into the freed slots (`DecodeSession.admit`) instead of waiting for the whole batch to drain --
+        the in-flight batching of the reference's serving path (backends/trt/serving/triton_server.py:96-305, pipeline.py:459-548) as a
+        scheduling loop around the engine's suspended decode loop.  A row's ids do not depend on the batch it runs in or on when it joins
+        (greedy: bit for bit the ids of `inference_speech` over all utterances at once; sampling: slot- and row-step-keyed random stream).
+
+        The running batch shares one position counter, bounded by the mel position table; an utterance is admitted while `admit_room`
+        (default: max_generate_length) more tokens fit under that bound, otherwise it waits for the next session.  Rows are polled every
+        `chunk_tokens` tokens.  Returns (codes (N, L) padded with the stop token, speech_conditioning_latent); `last_inflight` holds the
+        schedule's counters.  num_beams = 1."""
+        emb, mask, max_new, hf, spk_lat = self._prepare_inference(
+            speech_condition, text_inputs, langs, cond_lengths, emo_vec, campplus_embedding, None, 1, max_generate_length, typical_sampling,
+            typical_mass, conds_latent, hf_generate_kwargs)
+        if hf.get("num_beams", 1) != 1:
+            raise NotImplementedError("inference_speech_inflight: num_beams = 1 only")
+        N, slots, chunk = emb.shape[0], max(1, int(slots)), max(1, int(chunk_tokens))
+        table = int(self._emb["mel_pos_embedding.emb.weight"].shape[0]) + 1 - (2 if self.kv_cache else 1)      # the engine's bound on a session's steps
+        if max_new > table:
+            raise ValueError(f"max_generate_length = {max_new} exceeds the mel position table ({table} steps)")
+        room = max_new if admit_room is None else max(1, min(int(admit_room), max_new))
+        session_max = table if N > slots else max_new
+        stop = self.stop_mel_token
+        results: List[Optional[torch.Tensor]] = [None] * N
+        stats = dict(sessions=0, admitted=0, steps=0, row_steps=0, truncated=0)
+        pending = list(range(N))
+        while pending:
+            first, pending = pending[:slots], pending[slots:]
+            B = len(first)
+            owner: List[Optional[int]] = list(first)
+            stats["sessions"] += 1
+            with DecodeSession(self, emb[first], mask[first], session_max, **hf) as sess:
+                while any(o is not None for o in owner):
+                    before = sess.steps
+                    sess.run(chunk)
+                    stats["row_steps"] += (sess.steps - before) * sum(o is not None for o in owner)
+                    fin = set(sess.finished())
+                    if sess.steps == before:
+                        raise _lib.HipEngineError("inference_speech_inflight: the decode session made no progress")
+                    exhausted = sess.steps >= session_max
+                    for b in range(B):
+                        if owner[b] is None:
+                            continue
+                        n_row = sess.steps - sess.col0[b]
+                        if b in fin or n_row >= max_new or exhausted:
+                            c = sess.codes(b)[:max_new]
+                            if b in fin and c.numel() < max_new:
+                                c = torch.cat([c, c.new_full((1,), stop)])
+                            else:
+                                stats["truncated"] += 1
+                            results[owner[b]] = c
+                            owner[b] = None
+                    if exhausted:
+                        break
+                    free = [b for b in range(B) if owner[b] is None]
+                    if free and pending and sess.steps + room <= session_max:
+                        take, pending = pending[:len(free)], pending[len(free):]
+                        free = free[:len(take)]
+                        sess.admit(free, emb[take], mask[take])
+                        for b, i in zip(free, take):
+                            owner[b] = i
+                        stats["admitted"] += len(take)
+                stats["steps"] += sess.steps
+        self.last_inflight = stats
+        width = max(int(c.numel()) for c in results)
+        codes = torch.full((N, width), stop, dtype=torch.int64, device=self.device)
+        for i, c in enumerate(results):
+            codes[i, : c.numel()] = c
+        return codes, spk_lat
+
     # ---- teacher-forced latent pass (model_v2.py:596-646) ----------------------------------------------------------
     def forward_latent(self, conds: torch.Tensor, text_inputs: torch.Tensor, text_lengths: torch.Tensor,
                        mel_codes: torch.Tensor, mel_codes_lengths: torch.Tensor) -> torch.Tensor:

@@ -510,12 +510,21 @@ class IndexTTS2:
         for i, t in enumerate(segment_tokens):
             text[i, : t.numel()] = t.reshape(-1).to(torch.int32)
         langs = torch.tensor(lang_ids, dtype=torch.long)
+        inflight_slots = gk.pop("inflight_slots", None)    # engine extension: decode `inflight_slots` rows at a time, admit waiting segments into
+        inflight_kw = {k: gk.pop(k) for k in ("chunk_tokens", "admit_room") if k in gk}            # slots whose row has stopped
         t0 = time.perf_counter()
-        codes, _ = self.gpt.inference_speech(bundle["spk_cond_emb"], text.to(dev), langs.to(dev), emo_vec=emovec,
-                                             campplus_embedding=bundle["style"], do_sample=True, top_p=top_p, top_k=top_k,
-                                             temperature=temperature, num_return_sequences=1, length_penalty=length_penalty,
-                                             num_beams=num_beams, repetition_penalty=repetition_penalty,
-                                             max_generate_length=max_mel_tokens, **gk)
+        if inflight_slots and num_beams == 1 and len(segment_tokens) > int(inflight_slots):
+            codes, _ = self.gpt.inference_speech_inflight(bundle["spk_cond_emb"], text.to(dev), langs.to(dev), emo_vec=emovec,
+                                                          campplus_embedding=bundle["style"], do_sample=True, top_p=top_p, top_k=top_k,
+                                                          temperature=temperature, length_penalty=length_penalty, num_beams=1,
+                                                          repetition_penalty=repetition_penalty, max_generate_length=max_mel_tokens,
+                                                          slots=int(inflight_slots), **inflight_kw, **gk)
+        else:
+            codes, _ = self.gpt.inference_speech(bundle["spk_cond_emb"], text.to(dev), langs.to(dev), emo_vec=emovec,
+                                                 campplus_embedding=bundle["style"], do_sample=True, top_p=top_p, top_k=top_k,
+                                                 temperature=temperature, num_return_sequences=1, length_penalty=length_penalty,
+                                                 num_beams=num_beams, repetition_penalty=repetition_penalty,
+                                                 max_generate_length=max_mel_tokens, **gk)
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         t1 = time.perf_counter()
         if codes.shape[1] > 0 and (codes[:, -1] != self.stop_mel_token).any():

@@ -55,8 +55,11 @@ class DynamicBatcher:
     `max_batch` of them wait or the oldest has waited `max_wait_ms`, and runs them as ONE `infer_batch` call.  Groups are served
     oldest-first; a failing batch fails exactly its own futures."""
 
-    def __init__(self, tts, max_batch: int = 64, max_wait_ms: float = 10.0):
+    def __init__(self, tts, max_batch: int = 64, max_wait_ms: float = 10.0, inflight_slots: Optional[int] = None):
+        """inflight_slots: decode at most that many rows at a time and admit the batch's waiting utterances into the slots of rows that have
+        stopped (`UnifiedVoice.inference_speech_inflight`, num_beams = 1) -- `max_batch` can then exceed what one decode batch should hold."""
         self.tts, self.max_batch, self.max_wait = tts, int(max_batch), float(max_wait_ms) / 1000.0
+        self.inflight_slots = None if not inflight_slots else int(inflight_slots)
         self._q: List[_Request] = []
         self._cv = threading.Condition()
         self._stop = False
@@ -108,7 +111,10 @@ class DynamicBatcher:
             _, _, emo_alpha, lang, gen = key
             self.batches.append(len(reqs))
             try:
-                res = list(self.tts.infer_batch(spk, [r.text for r in reqs], lang, emo_audio_prompt=emo, emo_alpha=emo_alpha, **dict(gen)))
+                gen = dict(gen)
+                if self.inflight_slots and gen.get("num_beams", 3) == 1:
+                    gen.setdefault("inflight_slots", self.inflight_slots)
+                res = list(self.tts.infer_batch(spk, [r.text for r in reqs], lang, emo_audio_prompt=emo, emo_alpha=emo_alpha, **gen))
                 if len(res) != len(reqs):
                     raise RuntimeError(f"infer_batch returned {len(res)} results for {len(reqs)} requests")
                 for r, out in zip(reqs, res):

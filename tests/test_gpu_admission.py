@@ -92,3 +92,34 @@ def test_admitted_row_equals_the_row_alone(golden_dir, prec):
     print(f"{prec}: admitted at step {k} into slot {slot} (position {S_new}): {admitted.numel()} codes, alone {solo.numel()}; first ids {admitted[:8].tolist()}")
     assert n >= 6 and torch.equal(admitted[:n], solo[:n])
     assert admitted.numel() == solo.numel() or admitted.numel() >= max_new - k     # (the admitted row may run into the batch's token budget)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_inflight_equals_one_batch(golden_dir, prec):
+    """`inference_speech_inflight` (2 decode slots, freed slots refilled from the waiting utterances) returns, bit for bit, the ids of
+    `inference_speech` over all utterances in one batch (greedy)."""
+    z = np.load(os.path.join(golden_dir, "gpt_greedy.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]), max_mel_tokens=int(c[4]),
+                      number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))
+    sd["mel_head.bias"][cfg.stop_mel_token] += float(z["eos_bias"])
+    m = _engine(cfg, sd, prec)
+    style, emo = torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"])
+    order = [1, 0, 2, 1, 2, 0, 1]                                # the fixture's rows stop after 0 / 21 / 6 ids
+    text = torch.from_numpy(z["text"])[order].contiguous()
+    langs = torch.from_numpy(z["langs"])[order].contiguous()
+    gen = z["gen"]
+    kw = dict(do_sample=bool(gen[0]), num_beams=1, top_p=float(gen[2]), top_k=int(gen[3]), temperature=float(gen[4]), repetition_penalty=float(gen[5]))
+    max_new = min(48, cfg.max_mel_tokens - 2)
+    n = len(order)
+    assert style.shape[0] == 1 and emo.shape[0] == 1 and n == 7              # one voice / emotion vector for every row, as in the fixture
+    ref, _ = m.inference_speech(None, text, langs, emo_vec=emo, campplus_embedding=style, max_generate_length=max_new, **kw)
+    got, _ = m.inference_speech_inflight(None, text, langs, emo_vec=emo, campplus_embedding=style, max_generate_length=max_new, slots=2,
+                                         chunk_tokens=4, admit_room=24, **kw)
+    st = m.last_inflight
+    print(f"{prec}: in-flight schedule {st}; one batch {tuple(ref.shape)}, in flight {tuple(got.shape)}")
+    assert st["admitted"] >= 2 and st["truncated"] == 0
+    assert got.shape == ref.shape and torch.equal(got.cpu(), ref.cpu())
+    again, _ = m.inference_speech(None, text[:3], langs[:3], emo_vec=emo, campplus_embedding=style, max_generate_length=max_new, **kw)
+    assert torch.equal(again.cpu()[:, : ref.shape[1]], ref.cpu()[:3, : again.shape[1]])          # the engine is idle and usable again

@@ -1,0 +1,138 @@
+"""The in-flight batching schedule of `UnifiedVoice.inference_speech_inflight` (design reference: backends/trt/serving/triton_server.py:96-305,
+backends/trt/pipeline/pipeline.py:459-548) on a SIMULATED decode session: every utterance's ids are a function of the utterance alone, so the test
+can check that each one comes back complete, in order and exactly once whatever the slot count, poll interval and admission window -- and that the
+schedule really reuses freed slots.  (The engine-level contract -- an admitted row's ids equal the row decoded alone -- is the GPU test
+tests/test_gpu_admission.py; the schedule against the real engine: test_inflight_equals_one_batch there.)"""
+import pytest
+import torch
+
+from indextts_amd import gpt, serving
+
+STOP = 99
+
+
+def _ids(utt, length):
+    return [(7 * utt + 3 * t) % 90 for t in range(length)]
+
+
+class _FakeSession:
+    """Rows emit _ids(utt, len) then STOP for ever; one shared step counter; admit() starts a row at column steps - 1 (as the engine does)."""
+    log = []
+
+    def __init__(self, model, emb, mask, max_new, **kw):
+        self.utts = [int(v) for v in emb[:, 0, 0].tolist()]
+        self.lens = {u: int(emb[i, 0, 1]) for i, u in enumerate(self.utts)}
+        self.B, self.max_new, self.steps = len(self.utts), int(max_new), 0
+        self.col0 = [0] * self.B
+        self._codes = torch.full((self.B, self.max_new), STOP, dtype=torch.int64)
+        self.S = emb.shape[1] + 1
+        _FakeSession.log.append(("open", list(self.utts), self.max_new))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        _FakeSession.log.append(("close", self.steps))
+
+    def run(self, n):
+        limit = min(self.max_new, self.steps + n)
+        for col in range(self.steps, limit):
+            for b, u in enumerate(self.utts):
+                t = col - self.col0[b]
+                self._codes[b, col] = _ids(u, self.lens[u])[t] if t < self.lens[u] else STOP
+        self.steps = limit
+        return self.steps
+
+    def finished(self):
+        return [b for b in range(self.B) if bool((self._codes[b, self.col0[b]:self.steps] == STOP).any())]
+
+    def codes(self, b):
+        row = self._codes[b, self.col0[b]:self.steps]
+        hit = (row == STOP).nonzero()
+        return row[: int(hit[0])].clone() if hit.numel() else row.clone()
+
+    def position(self):
+        return self.S + self.steps - 1
+
+    def admit(self, slots, emb, mask):
+        assert self.steps >= 1 and emb.shape[1] + 1 <= self.position()
+        for b, i in zip(slots, range(emb.shape[0])):
+            u = int(emb[i, 0, 0])
+            assert b in self.finished(), "admitted into a slot whose row is still running"
+            self.utts[b], self.lens[u], self.col0[b] = u, int(emb[i, 0, 1]), self.steps - 1
+            self._codes[b, self.steps - 1:] = STOP
+            # the admitted row's first id is sampled by the admission prefill into column steps - 1
+            self._codes[b, self.steps - 1] = _ids(u, self.lens[u])[0] if self.lens[u] > 0 else STOP
+        _FakeSession.log.append(("admit", list(slots), self.steps))
+
+
+def _model(lengths, table=400):
+    m = object.__new__(gpt.UnifiedVoice)
+    m.kv_cache, m.stop_mel_token, m.device = True, STOP, "cpu"
+    m._emb = {"mel_pos_embedding.emb.weight": torch.zeros(table + 1, 4)}          # -> `table` steps per session with kv_cache
+
+    def prep(speech_condition, text_inputs, langs, cond_lengths, emo_vec, campplus_embedding, input_tokens, nret, max_generate_length, *rest):
+        n = len(lengths)
+        emb = torch.zeros(n, 5, 4)
+        emb[:, 0, 0] = torch.arange(n, dtype=torch.float32)
+        emb[:, 0, 1] = torch.tensor(lengths, dtype=torch.float32)
+        return emb, torch.ones(n, 6, dtype=torch.long), int(max_generate_length), dict(rest[-1]), None
+    m._prepare_inference = prep
+    return m
+
+
+@pytest.mark.parametrize("slots,chunk", [(1, 4), (2, 8), (3, 5), (4, 16), (8, 3)])
+def test_every_utterance_comes_back_complete_and_in_order(monkeypatch, slots, chunk):
+    monkeypatch.setattr(gpt, "DecodeSession", _FakeSession)
+    lengths = [30, 3, 0, 17, 40, 8, 8, 1, 25, 12, 5]
+    m = _model(lengths)
+    _FakeSession.log = []
+    codes, _ = m.inference_speech_inflight(None, None, max_generate_length=64, slots=slots, chunk_tokens=chunk, do_sample=False)
+    assert codes.shape[0] == len(lengths) and codes.shape[1] == max(lengths) + 1
+    for u, n in enumerate(lengths):
+        assert codes[u, :n].tolist() == _ids(u, n) and bool((codes[u, n:] == STOP).all()), u
+    st = m.last_inflight
+    opened = [e for e in _FakeSession.log if e[0] == "open"]
+    assert st["sessions"] == len(opened) and st["truncated"] == 0
+    assert st["admitted"] + sum(len(e[1]) for e in opened) == len(lengths)          # every utterance entered exactly once
+    if slots < len(lengths):
+        assert st["admitted"] > 0                                                    # freed slots were reused
+        assert all(len(e[1]) <= slots for e in opened)
+    # in-flight beats draining: fewer decode steps than running ceil(N / slots) batches to their longest row
+    drained = sum(max(lengths[i:i + slots]) + 1 for i in range(0, len(lengths), slots))
+    assert st["steps"] <= drained + chunk * len(opened) + chunk * st["admitted"]
+
+
+def test_row_budget_and_session_budget(monkeypatch):
+    monkeypatch.setattr(gpt, "DecodeSession", _FakeSession)
+    lengths = [50, 20, 20, 20, 20, 20]
+    m = _model(lengths, table=60)                            # a session holds 60 steps
+    _FakeSession.log = []
+    codes, _ = m.inference_speech_inflight(None, None, max_generate_length=30, slots=2, chunk_tokens=4, do_sample=False)
+    st = m.last_inflight
+    assert st["truncated"] == 1                              # utterance 0 runs into its own 30-token budget: no stop token in its row
+    assert codes.shape[1] == 30 and codes[0].tolist() == _ids(0, 50)[:30]
+    for u in range(1, 6):
+        assert codes[u, :20].tolist() == _ids(u, 20) and int(codes[u, 20]) == STOP
+    assert st["sessions"] >= 2                               # admissions stop when fewer than 30 steps are left under the table; the rest start a new session
+    for e in _FakeSession.log:
+        if e[0] == "admit":
+            assert e[2] + 30 <= 60
+    with pytest.raises(ValueError):
+        m.inference_speech_inflight(None, None, max_generate_length=61, slots=2)
+    with pytest.raises(NotImplementedError):
+        m.inference_speech_inflight(None, None, max_generate_length=30, slots=2, num_beams=3)
+
+
+def test_batcher_passes_the_slot_count_for_single_beam_requests():
+    class TTS:
+        calls = []
+
+        def infer_batch(self, spk, texts, lang, emo_audio_prompt=None, emo_alpha=1.0, **gen):
+            TTS.calls.append(dict(gen))
+            return [(22050, None)] * len(texts)
+    b = serving.DynamicBatcher(TTS(), max_batch=4, max_wait_ms=5, inflight_slots=2)
+    b.submit(b"A", "one", "en", num_beams=1).result(timeout=10)
+    b.submit(b"A", "two", "en").result(timeout=10)                                   # reference default: 3 beams -> the plain batch path
+    b.close()
+    assert TTS.calls == [{"num_beams": 1, "inflight_slots": 2}, {}]

@@ -218,4 +218,12 @@ call11() {
     done
 }
 
+# round 5, GPU call 12: in-flight schedule against the engine (inference_speech_inflight == one batch), admission test again
+call12() {
+    O=$PWD/gpurun_out/r05l
+    mkdir -p $O
+    timeout 900 python -m pytest tests/test_gpu_admission.py -q -s > $O/pytest_admission.log 2>&1; echo "pytest admission rc=$?" | tee $O/status.txt
+    grep -E "in-flight|admitted at|passed|failed|Error|assert" $O/pytest_admission.log | tail -20
+}
+
 "call$1"
