@@ -56,6 +56,8 @@ bool conv_x3_supported(int Cin, int Cout, int k, int dil);
 size_t conv_x3_packed_bytes(int Cout, int Cin, int k);
 int conv_x3_pack(const float* w, int Cout, int Cin, int k, void* out);
 int launch_split_tm3(const float* x, void* xp, int B, int C, int T, const int* lens, int len_mult, hipStream_t st);
+int launch_aa_act_planes(const float* x, void* xp, const float* alpha, const float* beta, const float* fu, const float* fd,
+                         int B, int C, int T, const int* lens, int len_mult, int logscale, hipStream_t st);
 int launch_conv_x3(const ConvX3Args& a, hipStream_t st);
 size_t conv_h3_packed_bytes(int Cout, int Cin, int k);
 int conv_h3_pack(const float* w, int Cout, int Cin, int k, void* out);

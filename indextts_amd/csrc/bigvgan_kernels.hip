@@ -208,6 +208,174 @@ __global__ __launch_bounds__(256) void aa_act_kernel_v2(const float* __restrict_
 }
 
 // --------------------------------------------------------------------------------------------------------------
+// The same activation written straight into the bf16 x 3 conv's operand: three bf16 planes [B][T][C] (h, m, l: h + m + l == the f32 activation
+// exactly; frames >= the row's length are zeros) instead of f32 [B][C][T] -- the producer side of the x3 window kernel (bigvgan_x3.hip), so that the
+// f32 activation tensor and the transposing split pass (split_tm3_kernel: 4 B read + 6 B written per element, one more launch per conv) disappear.
+// Arithmetic per element = aa_act_kernel_v2<4, true> (same windows, same fmaf order, same reduced v_sin) followed by split_tm3_kernel's split:
+// the planes are bit-identical to the two-kernel path (tests/test_gpu_bigvgan_x3.py).
+// Block = 32 channels x 128 frames, 4 waves; a wave runs 2 channels at a time on 32 lanes each (a lane owns 4 consecutive frames of one channel, as
+// in the v2 kernel) through windows of its own -- no block barrier inside the four rounds, the next round's input is requested before this round's
+// arithmetic --; the block's result is transposed through an LDS image [plane][frame][channel] and leaves as 64-byte rows.
+// Measured (profiles/r05m, 16 x 1926 frames): 0.78 ms per launch against 0.36 (v2 kernel) + 0.49 (split pass as it was) -- the 27 KiB image holds the
+// kernel to 3 blocks per CU.  Two other forms lost: a 64 x 64 tile with block barriers (0.83 ms), and keeping the split results in registers and
+// storing each lane's 8-byte pieces directly (no LDS image, 4 blocks per CU: 1.45 ms -- scattered 8-byte stores).
+// --------------------------------------------------------------------------------------------------------------
+#define AAP_TT 128
+#define AAP_CB 32
+#define AAP_RS 36           // u16 per frame row of the LDS image (18 dwords: 32 consecutive row slots fall on 32 different even banks)
+__device__ __forceinline__ uint32_t aap_cvt2(float a, float b) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, bf2));
+}
+// LDS traffic between the lanes of ONE wave: the LDS executes a wave's instructions in order, the fence keeps the compiler from moving them
+__device__ __forceinline__ void aap_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// row slot of frame tt in the LDS image: the four frames of a lane are 32 slots apart, the 32 lanes of a channel take consecutive slots
+__device__ __forceinline__ int aap_slot(int tt) { return (tt & 3) * 32 + (tt >> 2); }
+
+__global__ __launch_bounds__(256) void aa_act_planes_kernel(const float* __restrict__ x, u16* __restrict__ xh, u16* __restrict__ xm, u16* __restrict__ xl,
+                                                            const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                            const float* __restrict__ fu, const float* __restrict__ fd,
+                                                            int C, int T, const int* __restrict__ lens, int len_mult, int logscale) {
+    // windows start 64 dwords apart modulo the bank row, so the 16 lanes of a ds_*_b128 group meet the v2 kernel's conflict-free pattern (its 2x-rate
+    // window swizzle aa_sw included)
+    __shared__ __attribute__((aligned(256))) float xs[4][2][192];
+    __shared__ __attribute__((aligned(256))) float vs[4][2][320];
+    __shared__ __attribute__((aligned(16))) u16 ot[3][AAP_TT][AAP_RS];
+    const int b = blockIdx.z, c0 = blockIdx.y * AAP_CB, t0 = blockIdx.x * AAP_TT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, sub = lane >> 5, pos = lane & 31;
+    const int len = lens ? min(lens[b] * len_mult, T) : T;
+    const int n_out = len - t0 < AAP_TT ? (len - t0 < 0 ? 0 : len - t0) : AAP_TT;       // frames of this tile inside the row
+    if (n_out > 0) {
+        float fus[12], fds[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) { fus[j] = 2.0f * fu[j]; fds[j] = fd[j]; }
+        float* xw_ = xs[w][sub];
+        float* vw_ = vs[w][sub];
+        // x window of a round: xw_[i] = x[clamp(t0 - 6 + i)], i in [0, TT + 12): five values per lane
+        int toff[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int t = t0 - 6 + pos + 32 * k;
+            toff[k] = t < 0 ? 0 : (t > len - 1 ? len - 1 : t);
+        }
+        auto chan = [&](int it) { const int c = c0 + w * 8 + it * 2 + sub; return c < C ? c : C - 1; };
+        float xn[5];
+        {
+            const float* xr = x + ((size_t)b * C + chan(0)) * T;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) xn[k] = xr[toff[k]];
+        }
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            const int cl = w * 8 + it * 2 + sub;
+            const bool c_ok = c0 + cl < C;
+            float a_e = alpha[chan(it)], b_e = beta[chan(it)];
+            if (logscale) { a_e = expf(a_e); b_e = expf(b_e); }
+            const float inv_b = 1.0f / (b_e + 1e-9f);
+            aap_wave_sync();                         // the previous round's reads of both windows are done
+#pragma unroll
+            for (int k = 0; k < 5; ++k) xw_[pos + 32 * k] = xn[k];
+            if (it < 3) {
+                const float* xr = x + ((size_t)b * C + chan(it + 1)) * T;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) xn[k] = xr[toff[k]];
+            }
+            aap_wave_sync();
+            auto snake8 = [&](int vb, float* v) {
+                float xw[12];
+                *(f32x4*)&xw[0] = *(const f32x4*)&xw_[(vb >> 1)];
+                *(f32x4*)&xw[4] = *(const f32x4*)&xw_[(vb >> 1) + 4];
+                *(f32x4*)&xw[8] = *(const f32x4*)&xw_[(vb >> 1) + 8];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float ue = 0.f, uo = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        ue = fmaf(fus[1 + 2 * j], xw[p + 5 - j], ue);
+                        uo = fmaf(fus[2 * j], xw[p + 6 - j], uo);
+                    }
+                    const float se = sin_reduced(ue * a_e);
+                    const float so = sin_reduced(uo * a_e);
+                    v[2 * p] = fmaf(inv_b * se, se, ue);
+                    v[2 * p + 1] = fmaf(inv_b * so, so, uo);
+                }
+            };
+            {
+                float v[8];
+                const int vb = 8 * pos;
+                snake8(vb, v);
+                *(f32x4*)&vw_[aa_sw(vb)] = *(const f32x4*)&v[0];
+                *(f32x4*)&vw_[aa_sw(vb + 4)] = *(const f32x4*)&v[4];
+            }
+            if (pos < 2) {                       // tail: 2x-rate samples 2 TT .. 2 TT + 15
+                float vt[8];
+                snake8(2 * AAP_TT + 8 * pos, vt);
+                *(f32x4*)&vw_[aa_sw(2 * AAP_TT + 8 * pos)] = *(const f32x4*)&vt[0];
+                *(f32x4*)&vw_[aa_sw(2 * AAP_TT + 8 * pos + 4)] = *(const f32x4*)&vt[4];
+            }
+            aap_wave_sync();
+            // replicate padding at the 2x rate (5 left / 6 right)
+            if (t0 == 0 && pos < 6) vw_[aa_sw(pos)] = vw_[aa_sw(6)];
+            const int vi_end = (2 * len - 1) - (2 * t0 - 6);
+            if (vi_end < 2 * AAP_TT + 12 - 1) {
+                const int vi = vi_end + 1 + pos;
+                if (pos < 8 && vi < 2 * AAP_TT + 16) vw_[aa_sw(vi)] = vw_[aa_sw(vi_end)];
+            }
+            aap_wave_sync();
+            float vw[20];
+            const int base = 8 * pos;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) *(f32x4*)&vw[4 * k] = *(const f32x4*)&vw_[aa_sw(base + 4 * k)];
+            float o[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) acc = fmaf(fds[j], vw[2 * p + j + 1], acc);
+                o[p] = (4 * pos + p < n_out && c_ok) ? acc : 0.f;
+            }
+            // split (split_tm3_kernel's arithmetic) into the LDS image
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float f0 = o[2 * e], f1 = o[2 * e + 1];
+                const uint32_t h = aap_cvt2(f0, f1);
+                const float r0 = f0 - __uint_as_float(h << 16), r1 = f1 - __uint_as_float(h & 0xffff0000u);          // exact
+                const uint32_t m = aap_cvt2(r0, r1);
+                const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);          // exact
+                const uint32_t l = aap_cvt2(s0, s1);
+                const int sa = aap_slot(4 * pos + 2 * e), sb = aap_slot(4 * pos + 2 * e + 1);
+                ot[0][sa][cl] = (u16)h; ot[0][sb][cl] = (u16)(h >> 16);
+                ot[1][sa][cl] = (u16)m; ot[1][sb][cl] = (u16)(m >> 16);
+                ot[2][sa][cl] = (u16)l; ot[2][sb][cl] = (u16)(l >> 16);
+            }
+        }
+    }
+    __syncthreads();
+    // rows of 32 channels x 2 B: 4 lanes x 16 B per (plane, frame); 64 rows per pass
+    const size_t plane_row = (size_t)b * T;
+    const int q = tid & 3;
+#pragma unroll 1
+    for (int r = tid >> 2; r < 3 * AAP_TT; r += 64) {
+        const int p = r / AAP_TT, tt = r - p * AAP_TT;
+        const int t = t0 + tt;
+        if (t >= T || c0 + 8 * q >= C) continue;
+        uint2 lo = {0u, 0u}, hi = {0u, 0u};
+        if (n_out > 0) {
+            const u16* src = &ot[p][aap_slot(tt)][8 * q];
+            lo = *(const uint2*)src;
+            hi = *(const uint2*)(src + 4);
+        }
+        u16* dst = (p == 0 ? xh : (p == 1 ? xm : xl)) + (plane_row + t) * C + c0 + 8 * q;
+        *(uint4*)dst = uint4{lo.x, lo.y, hi.x, hi.y};
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.
 //   out[b, co, n(m)] = epi( sum_{j<k} sum_{ci} w[co][ci][j] * x[b, ci, m + tap_base + j*tap_step] )
 //   n(m) = m*ostride + ooff.   Regular Conv1d: tap_base = -(k-1)/2*d, tap_step = d, ostride 1, ooff 0.
@@ -509,6 +677,19 @@ int launch_aa_act(const float* x, float* y, const float* alpha, const float* bet
     else if (mode == 1) hipLaunchKernelGGL((aa_act_kernel_v2<4, false>), dim3(ceil_div(T, 1024), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
     else if (mode == 2) hipLaunchKernelGGL((aa_act_kernel_v2<4, true>), dim3(ceil_div(T, 1024), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
     else hipLaunchKernelGGL((aa_act_kernel_v2<8, true>), dim3(ceil_div(T, 2048), C, B), dim3(256), 0, st, x, y, alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
+    HIP_TRY(hipGetLastError());
+    return ITTS_OK;
+}
+
+// the activation as the x3 conv's operand planes (aa_act_planes_kernel); xp = [3][B][T][C] bf16
+int launch_aa_act_planes(const float* x, void* xp, const float* alpha, const float* beta, const float* fu, const float* fd,
+                         int B, int C, int T, const int* lens, int len_mult, int logscale, hipStream_t st) {
+    if (B <= 0 || C <= 0 || T <= 0) return ITTS_OK;
+    if (C % 8) { itts_set_error("aa_act_planes: C %% 8 != 0"); return ITTS_ERR_ARG; }
+    u16* p = (u16*)xp;
+    const size_t plane = (size_t)B * T * C;
+    hipLaunchKernelGGL(aa_act_planes_kernel, dim3(ceil_div(T, AAP_TT), ceil_div(C, AAP_CB), B), dim3(256), 0, st, x, p, p + plane, p + 2 * plane,
+                       alpha, beta, fu, fd, C, T, lens, len_mult, logscale);
     HIP_TRY(hipGetLastError());
     return ITTS_OK;
 }

@@ -62,16 +62,18 @@ __global__ __launch_bounds__(256) void split_tm3_kernel(const float* __restrict_
         tile[w * 16 + i][lane] = (c < C && t < len) ? xb[(size_t)c * T + t] : 0.f;
     }
     __syncthreads();
-    const int t = t0 + (tid >> 2), cq = tid & 3;
-    if (t >= T) return;
+    // 8 lanes x 16 B = the 128 contiguous bytes of a frame's 64 channels in a plane; 32 frames per pass.  (First version: 4 lanes per frame, each
+    // writing channels [16 q, 16 q + 8) and then [16 q + 8, 16 q + 16): every store instruction left 16-byte holes in its 32-byte sectors.)
+    const int cb = (tid & 7) * 8;
+    if (c0 + cb >= C) return;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-        const int cb = cq * 16 + hf * 8;
-        if (c0 + cb >= C) break;
+        const int tl = (tid >> 3) + 32 * hf, t = t0 + tl;
+        if (t >= T) break;
         x3_v4u ph, pm, pl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float f0 = tile[cb + 2 * e][tid >> 2], f1 = tile[cb + 2 * e + 1][tid >> 2];
+            const float f0 = tile[cb + 2 * e][tl], f1 = tile[cb + 2 * e + 1][tl];
             const uint32_t h = cx3_cvt2(f0, f1);
             const float r0 = f0 - __uint_as_float(h << 16), r1 = f1 - __uint_as_float(h & 0xffff0000u);          // exact
             const uint32_t m = cx3_cvt2(r0, r1);

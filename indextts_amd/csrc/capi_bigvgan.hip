@@ -671,12 +671,16 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
     if (rc) return rc;
 
     // a resblock conv: exact f32 MFMA, or (opt-in) the activation split into token-major f16 (hi, lo) + the f16 x 3 kernel
+    // x3 mode: the activation in front of an x3 conv writes the conv's operand planes itself (aa_act_planes_kernel: no f32 activation tensor, no
+    // split pass; bit-identical planes).  Option voc_act_planes = 0 keeps the two-kernel path for the A/B test.
+    const bool act_planes = h->conv_mode == 2 && itts_opt(OPT_VOC_ACT_PLANES) != 0 && itts_opt(OPT_AA_ACT) == 2;
+    auto x3_conv = [&](const ConvL& L, int ch_, int kk_, int dil_) { return L.w3 && h->conv_mode == 2 && conv_x3_supported(ch_, ch_, kk_, dil_); };
     auto res_conv = [&](const ConvL& L, const float* xin, const float* res, float* yout, int ch_, int t_, int kk_, int dil_, int mult_, int mode_,
-                        float div_) -> int {
+                        float div_, bool planes_ready) -> int {
         if (!L.w3 || (h->conv_mode == 2 && !conv_x3_supported(ch_, ch_, kk_, dil_)))
             return conv1d_impl(xin, L.w.p, L.b.p, nullptr, res, yout, B, ch_, ch_, t_, kk_, dil_, lens, mult_, mode_, div_, st);
         if (h->conv_mode == 2) {                         // three token-major bf16 planes + the six-product window kernel
-            int rc3 = launch_split_tm3(xin, SP, B, ch_, t_, lens, mult_, st);
+            int rc3 = planes_ready ? ITTS_OK : launch_split_tm3(xin, SP, B, ch_, t_, lens, mult_, st);
             if (rc3) return rc3;
             ConvX3Args g{};
             g.xp = SP; g.wp = L.w3; g.bias = L.b.p; g.res = res; g.y = yout; g.zero_row = h->zero_row; g.lens = lens; g.len_mult = mult_;
@@ -711,19 +715,22 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
                 const ActL& a2 = h->acts[(size_t)n * 2 * ND + 2 * d + 1];
                 const ConvL& c1 = h->convs1[(size_t)n * ND + d];
                 const ConvL& c2 = h->convs2[(size_t)n * ND + d];
+                const bool p1 = act_planes && x3_conv(c1, ch, kk, c.resblock_dilations[j][d]), p2 = act_planes && x3_conv(c2, ch, kk, 1);
                 { ProfScope ps(h, st, PC_ACT, 0, tensor_bytes(2 * ch, t_cur));
-                  rc = launch_aa_act(cur, T1, a1.alpha.p, a1.beta.p, a1.fu.p, a1.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st); }
+                  rc = p1 ? launch_aa_act_planes(cur, SP, a1.alpha.p, a1.beta.p, a1.fu.p, a1.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st)
+                          : launch_aa_act(cur, T1, a1.alpha.p, a1.beta.p, a1.fu.p, a1.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st); }
                 if (rc) return rc;
                 { ProfScope ps(h, st, PC_CONV, conv_flops(ch, ch, kk, t_cur), tensor_bytes(2 * ch, t_cur));
-                  rc = res_conv(c1, T1, nullptr, T2, ch, t_cur, kk, c.resblock_dilations[j][d], mult, 0, 1.f); }
+                  rc = res_conv(c1, T1, nullptr, T2, ch, t_cur, kk, c.resblock_dilations[j][d], mult, 0, 1.f, p1); }
                 if (rc) return rc;
                 { ProfScope ps(h, st, PC_ACT, 0, tensor_bytes(2 * ch, t_cur));
-                  rc = launch_aa_act(T2, T1, a2.alpha.p, a2.beta.p, a2.fu.p, a2.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st); }
+                  rc = p2 ? launch_aa_act_planes(T2, SP, a2.alpha.p, a2.beta.p, a2.fu.p, a2.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st)
+                          : launch_aa_act(T2, T1, a2.alpha.p, a2.beta.p, a2.fu.p, a2.fd.p, B, ch, t_cur, lens, mult, c.snake_logscale, st); }
                 if (rc) return rc;
                 if (d < ND - 1) {
                     float* nxt = (cur == RA) ? RB : RA;
                     { ProfScope ps(h, st, PC_CONV, conv_flops(ch, ch, kk, t_cur), tensor_bytes(3 * ch, t_cur));
-                      rc = res_conv(c2, T1, cur, nxt, ch, t_cur, kk, 1, mult, 0, 1.f); }
+                      rc = res_conv(c2, T1, cur, nxt, ch, t_cur, kk, 1, mult, 0, 1.f, p2); }
                     if (rc) return rc;
                     cur = nxt;
                 } else {
@@ -731,7 +738,7 @@ extern "C" int itts_bigvgan_forward(itts_bigvgan* h, const float* x, const int32
                     int mode = (j == 0) ? 0 : 1;
                     if (j == c.num_kernels - 1) mode = (c.num_kernels == 1) ? 0 : 2;
                     { ProfScope ps(h, st, PC_CONV, conv_flops(ch, ch, kk, t_cur), tensor_bytes((mode ? 4 : 3) * ch, t_cur));
-                      rc = res_conv(c2, T1, cur, XS, ch, t_cur, kk, 1, mult, mode, (float)c.num_kernels); }
+                      rc = res_conv(c2, T1, cur, XS, ch, t_cur, kk, 1, mult, mode, (float)c.num_kernels, p2); }
                     if (rc) return rc;
                 }
             }

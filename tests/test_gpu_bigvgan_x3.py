@@ -112,3 +112,31 @@ def test_generator_bf16x3_ragged_rows_equal_solo():
     for b, n in enumerate(lens):
         solo = m(mel[b:b + 1, :, :n].to(DEV)).cpu()
         assert float((wav[b, ..., : n * 256] - solo[0]).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("frames,lens", [(40, [40, 23, 7]), (67, [67, 1, 66]), (5, [5, 3, 2])])
+def test_activation_written_as_operand_planes_is_bit_identical(frames, lens):
+    """`voc_act_planes` (default): the activation in front of an x3 conv writes the conv's three bf16 operand planes itself (aa_act_planes_kernel)
+    instead of an f32 tensor + the split pass.  Same arithmetic per element -> the waveform is bit-identical to the two-kernel path, ragged rows,
+    frame counts that are not a multiple of the 128-frame tile included."""
+    from indextts_amd import _lib, bigvgan as bv
+    h = dict(O.V2_HPARAMS, upsample_initial_channel=1536)        # stage widths 768 ... 24: 768 / 384 / 192 / 96 / (32-multiples only) on the x3 kernel
+    sd = O.synth_weights(h, seed=5)
+    m = bv.BigVGAN(h, conv_mode="bf16x3", h3_min_channels=32)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    g = torch.Generator().manual_seed(frames)
+    mel = torch.randn(3, 80, frames, generator=g)
+    for b, n in enumerate(lens):
+        mel[b, :, n:] = 0
+    out = {}
+    try:
+        for v in (1, 0):
+            _lib.set_option("voc_act_planes", v)
+            out[v] = m(mel.to(DEV), lens=torch.tensor(lens)).cpu()
+    finally:
+        _lib.reset_options()
+    for b, n in enumerate(lens):
+        a, c = out[1][b, ..., : n * 256], out[0][b, ..., : n * 256]
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+        assert torch.equal(a, c), f"row {b}: max |d| {float((a - c).abs().max()):.3e}"

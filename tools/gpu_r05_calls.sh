@@ -226,4 +226,14 @@ call12() {
     grep -E "in-flight|admitted at|passed|failed|Error|assert" $O/pytest_admission.log | tail -20
 }
 
+# round 5, GPU call 13: activation written as the x3 conv's operand planes: bit-identity test, vocoder tests, forward time with / without
+call13() {
+    O=$PWD/gpurun_out/r05m
+    mkdir -p $O
+    timeout 900 python -m pytest tests/test_gpu_bigvgan_x3.py -x -q > $O/pytest_voc_x3.log 2>&1; echo "pytest voc x3 rc=$?" | tee $O/status.txt
+    tail -5 $O/pytest_voc_x3.log
+    timeout 600 python tools/voc_h3_bench.py 16 bf16x3:96,bf16x3:96:voc_act_planes=0 > $O/voc_bench.log 2>&1; echo "voc bench rc=$?" | tee -a $O/status.txt
+    cat $O/voc_bench.log
+}
+
 "call$1"

@@ -8,7 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from indextts_amd import bigvgan, synth  # noqa: E402
+from indextts_amd import _lib, bigvgan, synth  # noqa: E402
 
 B, T = int(sys.argv[1]) if len(sys.argv) > 1 else 16, 1926
 MODES = sys.argv[2].split(",") if len(sys.argv) > 2 else ["f32", "f16x3:96", "f16x3:192"]
@@ -17,7 +17,11 @@ sd = synth.bigvgan_weights(bh)
 mel = (torch.randn(B, 80, T, generator=torch.Generator().manual_seed(0)) * 2 - 4).cuda()
 ref = None
 for spec in MODES:
-    mode, _, minc = spec.partition(":")
+    mode, _, rest = spec.partition(":")                      # mode[:min_channels[:option=value[+option=value...]]]
+    minc, _, opts = rest.partition(":")
+    _lib.reset_options()
+    for kv in filter(None, opts.split("+")):
+        _lib.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     voc = bigvgan.BigVGAN(bh, conv_mode=mode, h3_min_channels=int(minc or 0))
     voc.load_state_dict(sd)
     voc.to("cuda:0")
