@@ -831,6 +831,47 @@ def configs_leg(args, eng, bundle0, dev):
                                  decode_only=dec, decode_speedup=dec["compaction_off"]["decode_ms"] / max(1e-9, dec["compaction_on"]["decode_ms"]))
     except Exception as e:
         out["ragged_b64"] = {"error": repr(e)}
+    try:
+        # in-flight batching of the GPT stage: 128 utterances of ragged length on 64 decode slots, freed slots refilled from the waiting utterances
+        # (UnifiedVoice.inference_speech_inflight), against the same utterances as two drained batches of 64 (row compaction on in both)
+        g = torch.Generator().manual_seed(308)
+        n_utt = 128
+        caps = torch.randint(120, 561, (n_utt,), generator=g).tolist()
+        text = torch.stack(segments(n_utt, 128, 309)).to(dev)
+        langs = torch.full((n_utt,), 3, dtype=torch.long, device=dev)
+        eng.model.set_compaction(True, 8)
+        kw = dict(emo_vec=emo_vec, campplus_embedding=style, max_generate_length=560, do_sample=True, num_beams=1, **sample)
+
+        def drained():
+            return [eng.model.inference_speech(None, text[i:i + 64], langs=langs[i:i + 64], row_max_new=caps[i:i + 64], **kw)[0] for i in range(0, n_utt, 64)]
+
+        def inflight():
+            return eng.model.inference_speech_inflight(None, text, langs=langs, slots=64, chunk_tokens=32, min_free=8, row_max_new=caps, **kw)[0]
+
+        def wall(f):
+            best, res = None, None
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = f()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            return best, res
+        t_d, c_d = wall(drained)
+        t_i, c_i = wall(inflight)
+        st = dict(eng.model.last_inflight)
+
+        def lens_of(c):
+            return [int((r == eng.model.stop_mel_token).nonzero()[0]) if bool((r == eng.model.stop_mel_token).any()) else int(r.numel()) for r in c]
+        ok = [n for c in c_d for n in lens_of(c)] == caps and lens_of(c_i) == caps
+        out["inflight_b128"] = {"utterances": n_utt, "slots": 64, "text_tokens": 128, "code_lengths": "uniform 120..560 (seeded), mean %.0f" % (sum(caps) / n_utt),
+                                "tokens": int(sum(caps)), "drained_two_batches_s": round(t_d, 4), "inflight_s": round(t_i, 4),
+                                "drained_tokens_per_s": round(sum(caps) / t_d, 1), "inflight_tokens_per_s": round(sum(caps) / t_i, 1),
+                                "speedup": round(t_d / t_i, 3), "schedule": st, "lengths_as_capped": bool(ok),
+                                "what": "GPT stage only (prefill + decode + admissions, host wall time), sampling, EOS suppressed so every utterance runs to its cap"}
+    except Exception as e:
+        out["inflight_b128"] = {"error": repr(e)}
     try:                                                           # configs[0]: IndexTTS-1.5, one utterance, greedy
         out["config0_v15_single"] = config0_leg(args, dev)
     except Exception as e:

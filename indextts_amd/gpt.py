@@ -604,17 +604,19 @@ class UnifiedVoice:
 
     def inference_speech_inflight(self, speech_condition, text_inputs, langs=None, cond_lengths=None, emo_vec=None, campplus_embedding=None,
                                   max_generate_length=None, typical_sampling=False, typical_mass=.9, conds_latent=None, slots=8,
-                                  chunk_tokens=16, admit_room=None, **hf_generate_kwargs):
+                                  chunk_tokens=16, admit_room=None, min_free=1, row_max_new: Optional[Sequence[int]] = None,
+                                  **hf_generate_kwargs):
         """`inference_speech` for MORE utterances than decode slots: `slots` rows decode at a time and, whenever rows have emitted their stop
         token, waiting utterances are prefilled into the freed slots (`DecodeSession.admit`) instead of waiting for the whole batch to drain --
         the in-flight batching of the reference's serving path (backends/trt/serving/triton_server.py:96-305, pipeline.py:459-548) as a
         scheduling loop around the engine's suspended decode loop.  A row's ids do not depend on the batch it runs in or on when it joins
         (greedy: bit for bit the ids of `inference_speech` over all utterances at once; sampling: slot- and row-step-keyed random stream).
 
-        The running batch shares one position counter, bounded by the mel position table; an utterance is admitted while `admit_room`
-        (default: max_generate_length) more tokens fit under that bound, otherwise it waits for the next session.  Rows are polled every
-        `chunk_tokens` tokens.  Returns (codes (N, L) padded with the stop token, speech_conditioning_latent); `last_inflight` holds the
-        schedule's counters.  num_beams = 1."""
+        The running batch shares one position counter, bounded by the mel position table; an utterance is admitted while its own budget -- its
+        `row_max_new` cap, else `admit_room` (default: max_generate_length) -- still fits under that bound, otherwise it waits for the next session.  Rows are polled every
+        `chunk_tokens` tokens; an admission (one prefill launch train for all the utterances it places) waits until `min_free` slots are free
+        -- or nothing is running.  `row_max_new`: per-utterance token caps as in `generate`.  Returns (codes (N, L) padded with the stop token,
+        speech_conditioning_latent); `last_inflight` holds the schedule's counters.  num_beams = 1."""
         emb, mask, max_new, hf, spk_lat = self._prepare_inference(
             speech_condition, text_inputs, langs, cond_lengths, emo_vec, campplus_embedding, None, 1, max_generate_length, typical_sampling,
             typical_mass, conds_latent, hf_generate_kwargs)
@@ -627,15 +629,21 @@ class UnifiedVoice:
         room = max_new if admit_room is None else max(1, min(int(admit_room), max_new))
         session_max = table if N > slots else max_new
         stop = self.stop_mel_token
+        if row_max_new is not None and len(row_max_new) != N:
+            raise ValueError(f"row_max_new must have one entry per utterance ({N}), got {len(row_max_new)}")
+        cap = [max_new if row_max_new is None else max(0, min(max_new, int(v))) for v in (row_max_new if row_max_new is not None else range(N))]
+        caps_of = lambda idx: [cap[i] for i in idx]          # always enforced by the engine's sampler: a row at its cap emits the stop token, which
+                                                               # is what frees its slot (admission needs the engine to have the row as finished)
+        min_free = max(1, int(min_free))
         results: List[Optional[torch.Tensor]] = [None] * N
-        stats = dict(sessions=0, admitted=0, steps=0, row_steps=0, truncated=0)
+        stats = dict(sessions=0, admitted=0, admissions=0, steps=0, row_steps=0, truncated=0)
         pending = list(range(N))
         while pending:
             first, pending = pending[:slots], pending[slots:]
             B = len(first)
             owner: List[Optional[int]] = list(first)
             stats["sessions"] += 1
-            with DecodeSession(self, emb[first], mask[first], session_max, **hf) as sess:
+            with DecodeSession(self, emb[first], mask[first], session_max, row_max_new=caps_of(first), **hf) as sess:
                 while any(o is not None for o in owner):
                     before = sess.steps
                     sess.run(chunk)
@@ -647,25 +655,32 @@ class UnifiedVoice:
                     for b in range(B):
                         if owner[b] is None:
                             continue
-                        n_row = sess.steps - sess.col0[b]
-                        if b in fin or n_row >= max_new or exhausted:
-                            c = sess.codes(b)[:max_new]
+                        if b in fin or exhausted:
+                            c = sess.codes(b)[:cap[owner[b]]]
+                            if c.numel() >= cap[owner[b]] or b not in fin:
+                                stats["truncated"] += 1              # ran into its cap (or the session's end) before a stop token of its own
                             if b in fin and c.numel() < max_new:
                                 c = torch.cat([c, c.new_full((1,), stop)])
-                            else:
-                                stats["truncated"] += 1
                             results[owner[b]] = c
                             owner[b] = None
                     if exhausted:
                         break
                     free = [b for b in range(B) if owner[b] is None]
-                    if free and pending and sess.steps + room <= session_max:
-                        take, pending = pending[:len(free)], pending[len(free):]
+                    # an utterance joins while its own budget (its cap when per-utterance caps were given, else admit_room) still fits under the
+                    # session's step bound; the others wait for the next session
+                    left = session_max - sess.steps
+                    fits = [i for i in pending if (cap[i] if row_max_new is not None else room) <= left]
+                    enough = len(free) >= min(min_free, len(fits)) or len(free) == B
+                    if free and fits and enough:
+                        take = fits[:len(free)]
+                        taken = set(take)
+                        pending = [i for i in pending if i not in taken]
                         free = free[:len(take)]
-                        sess.admit(free, emb[take], mask[take])
+                        sess.admit(free, emb[take], mask[take], row_max_new=caps_of(take))
                         for b, i in zip(free, take):
                             owner[b] = i
                         stats["admitted"] += len(take)
+                        stats["admissions"] += 1
                 stats["steps"] += sess.steps
         self.last_inflight = stats
         width = max(int(c.numel()) for c in results)
@@ -750,7 +765,9 @@ class DecodeSession:
 
     def __init__(self, model: "UnifiedVoice", inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int, do_sample=False,
                  top_p=1.0, top_k=50, temperature=1.0, repetition_penalty=1.0, length_penalty=1.0, seed: Optional[int] = None,
-                 typical_mass: float = 0.0, **unused):
+                 typical_mass: float = 0.0, row_max_new: Optional[Sequence[int]] = None, **unused):
+        """row_max_new: per-utterance caps on generated tokens (`generate`'s engine extension): the utterance in a slot emits the stop token from
+        its own token index row_max_new[b] on; `admit(..., row_max_new=)` sets the caps of the utterances it places."""
         model._check_idle("DecodeSession")
         if unused.get("num_beams", 1) != 1:
             raise NotImplementedError("DecodeSession: num_beams = 1 only")
@@ -778,6 +795,13 @@ class DecodeSession:
         self.col0 = [0] * B                          # first code column of the utterance currently in each slot
         self._first = True
         self._adm_ws = None
+        self._lim = None
+        if row_max_new is not None:
+            if len(row_max_new) != B:
+                raise ValueError(f"row_max_new must have one entry per row ({B}), got {len(row_max_new)}")
+            self._lim = model._persistent("row_limits", (B,), torch.int32)     # persistent: its address is part of the decode graph's key
+            self._lim.copy_(torch.as_tensor([int(v) for v in row_max_new], dtype=torch.int32))
+            _lib.check(L.itts_gpt_set_row_limits(model._h, _lib.ptr(self._lim), B), "itts_gpt_set_row_limits")
         model._stream_open = True                    # the workspace holds this session's state until close()
 
     def run(self, n_tokens: int) -> int:
@@ -799,18 +823,31 @@ class DecodeSession:
         return row[: int(stop[0])].clone() if stop.numel() else row.clone()
 
     def finished(self) -> List[int]:
-        got = self._codes[:, :self.steps] == self.m.stop_mel_token
-        return [b for b in range(self.B) if bool(got[b, self.col0[b]:].any())]
+        """slots whose utterance has emitted its stop token (one device reduction, one host synchronisation)"""
+        if self.steps < 1:
+            return []
+        col0 = torch.as_tensor(self.col0, device=self.dev)
+        live_cols = torch.arange(self.steps, device=self.dev)[None, :] >= col0[:, None]
+        got = ((self._codes[:, :self.steps] == self.m.stop_mel_token) & live_cols).any(dim=1)
+        return [b for b, v in enumerate(got.tolist()) if v]
 
     def position(self) -> int:
         """prompt length (with the start-mel row) a new utterance must be left-padded to in order to join now"""
         return self.S + self.steps - 1
 
-    def admit(self, slots: Sequence[int], inputs_embeds: torch.Tensor, attention_mask: torch.Tensor) -> None:
+    def admit(self, slots: Sequence[int], inputs_embeds: torch.Tensor, attention_mask: torch.Tensor,
+              row_max_new: Optional[Sequence[int]] = None) -> None:
         """put new utterances into finished slots: inputs_embeds (n, s', D) / attention_mask (n, s' + 1) as for the first batch, s' + 1 <= position()"""
         if self._first or self.steps < 1:
             raise RuntimeError("DecodeSession.admit: run() the first batch before admitting")
         n, s, D = inputs_embeds.shape
+        if (row_max_new is not None) != (self._lim is not None):
+            raise ValueError("DecodeSession.admit: row_max_new must be given exactly when the session was opened with per-row caps")
+        if row_max_new is not None:
+            if len(row_max_new) != n:
+                raise ValueError(f"row_max_new must have one entry per admitted row ({n}), got {len(row_max_new)}")
+            self._lim[torch.as_tensor([int(v) for v in slots], device=self.dev)] = torch.as_tensor([int(v) for v in row_max_new], dtype=torch.int32,
+                                                                                                     device=self.dev)
         S_new = self.position()
         if s + 1 > S_new:
             raise ValueError(f"DecodeSession.admit: the prompt ({s + 1} positions) is longer than the batch's position ({S_new}); admit it later")
@@ -831,6 +868,9 @@ class DecodeSession:
             self.col0[int(v)] = int(col.value)
 
     def close(self):
+        if self._lim is not None:
+            _lib.lib().itts_gpt_set_row_limits(self.m._h, None, 0)
+            self._lim = None
         self.m._stream_open = False
 
     def __enter__(self):

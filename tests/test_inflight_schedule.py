@@ -19,9 +19,13 @@ class _FakeSession:
     """Rows emit _ids(utt, len) then STOP for ever; one shared step counter; admit() starts a row at column steps - 1 (as the engine does)."""
     log = []
 
-    def __init__(self, model, emb, mask, max_new, **kw):
+    def __init__(self, model, emb, mask, max_new, row_max_new=None, **kw):
         self.utts = [int(v) for v in emb[:, 0, 0].tolist()]
         self.lens = {u: int(emb[i, 0, 1]) for i, u in enumerate(self.utts)}
+        if row_max_new is not None:                          # a capped row emits the stop token from its cap on, as the engine's sampler does
+            for u, c in zip(self.utts, row_max_new):
+                self.lens[u] = min(self.lens[u], int(c))
+        self.capped = row_max_new is not None
         self.B, self.max_new, self.steps = len(self.utts), int(max_new), 0
         self.col0 = [0] * self.B
         self._codes = torch.full((self.B, self.max_new), STOP, dtype=torch.int64)
@@ -54,12 +58,15 @@ class _FakeSession:
     def position(self):
         return self.S + self.steps - 1
 
-    def admit(self, slots, emb, mask):
+    def admit(self, slots, emb, mask, row_max_new=None):
         assert self.steps >= 1 and emb.shape[1] + 1 <= self.position()
+        assert (row_max_new is not None) == self.capped
         for b, i in zip(slots, range(emb.shape[0])):
             u = int(emb[i, 0, 0])
             assert b in self.finished(), "admitted into a slot whose row is still running"
             self.utts[b], self.lens[u], self.col0[b] = u, int(emb[i, 0, 1]), self.steps - 1
+            if row_max_new is not None:
+                self.lens[u] = min(self.lens[u], int(row_max_new[i]))
             self._codes[b, self.steps - 1:] = STOP
             # the admitted row's first id is sampled by the admission prefill into column steps - 1
             self._codes[b, self.steps - 1] = _ids(u, self.lens[u])[0] if self.lens[u] > 0 else STOP
@@ -110,7 +117,7 @@ def test_row_budget_and_session_budget(monkeypatch):
     _FakeSession.log = []
     codes, _ = m.inference_speech_inflight(None, None, max_generate_length=30, slots=2, chunk_tokens=4, do_sample=False)
     st = m.last_inflight
-    assert st["truncated"] == 1                              # utterance 0 runs into its own 30-token budget: no stop token in its row
+    assert st["truncated"] == 1                              # utterance 0 runs into its own 30-token budget: no stop token of its own
     assert codes.shape[1] == 30 and codes[0].tolist() == _ids(0, 50)[:30]
     for u in range(1, 6):
         assert codes[u, :20].tolist() == _ids(u, 20) and int(codes[u, 20]) == STOP
@@ -136,3 +143,21 @@ def test_batcher_passes_the_slot_count_for_single_beam_requests():
     b.submit(b"A", "two", "en").result(timeout=10)                                   # reference default: 3 beams -> the plain batch path
     b.close()
     assert TTS.calls == [{"num_beams": 1, "inflight_slots": 2}, {}]
+
+
+def test_per_utterance_caps_and_admission_batching(monkeypatch):
+    monkeypatch.setattr(gpt, "DecodeSession", _FakeSession)
+    lengths = [40] * 12                                      # nothing stops on its own within the caps
+    caps = [5, 33, 9, 12, 30, 7, 21, 3, 16, 11, 8, 2]
+    m = _model(lengths)
+    _FakeSession.log = []
+    codes, _ = m.inference_speech_inflight(None, None, max_generate_length=36, slots=4, chunk_tokens=4, min_free=2, row_max_new=caps, do_sample=False)
+    for u, n in enumerate(caps):
+        assert codes[u, :n].tolist() == _ids(u, 40)[:n] and bool((codes[u, n:] == STOP).all()), u
+    st = m.last_inflight
+    assert st["truncated"] == 12 and st["admitted"] == 8 and st["admissions"] <= 4         # every row ends at its cap; at least two slots per admission
+    for e in _FakeSession.log:
+        if e[0] == "admit":
+            assert len(e[1]) >= 2 or e is [x for x in _FakeSession.log if x[0] == "admit"][-1]
+    with pytest.raises(ValueError):
+        m.inference_speech_inflight(None, None, max_generate_length=36, slots=4, row_max_new=caps[:3])

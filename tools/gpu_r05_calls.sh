@@ -236,4 +236,15 @@ call13() {
     cat $O/voc_bench.log
 }
 
+# round 5, GPU call 14: per-utterance caps in the decode session, admission tests again, in-flight vs drained batches at production width
+call14() {
+    O=$PWD/gpurun_out/r05n
+    mkdir -p $O
+    timeout 900 python -m pytest tests/test_gpu_admission.py -q -s > $O/pytest_admission.log 2>&1; echo "pytest admission rc=$?" | tee $O/status.txt
+    grep -E "in-flight|passed|failed|Error" $O/pytest_admission.log | tail -8
+    timeout 600 python tools/inflight_bench.py 512 64 32 8 > $O/inflight_bench.log 2>&1; echo "inflight bench rc=$?" | tee -a $O/status.txt
+    timeout 600 python tools/inflight_bench.py 512 64 32 8 280 560 >> $O/inflight_bench.log 2>&1
+    grep -E "^N=|Error|error" $O/inflight_bench.log | tail -8
+}
+
 "call$1"
