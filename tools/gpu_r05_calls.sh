@@ -247,4 +247,25 @@ call14() {
     grep -E "^N=|Error|error" $O/inflight_bench.log | tail -8
 }
 
+# round 5, final validation A: the whole GPU suite + smoke at the final code
+call15() {
+    O=$PWD/gpurun_out/r05o
+    mkdir -p $O
+    timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest -m gpu rc=$?" | tee $O/status.txt
+    tail -6 $O/pytest_gpu.log
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/status.txt
+    tail -4 $O/smoke.log
+}
+
+# round 5, final validation B: the bench line (every leg; 5 timed steps) + rocprofv3 kernel stats of the same command without the extra legs
+call16() {
+    O=$PWD/gpurun_out/r05p
+    mkdir -p $O
+    timeout 1500 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/status.txt
+    tail -c 1800 $O/bench.json
+    timeout 900 bash tools/profile.sh r05p --alt-steps 0 --no-configs --no-shards --no-extras > $O/profile.log 2>&1; echo "profile rc=$?" | tee -a $O/status.txt
+    cp gpurun_out/prof_r05p/kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null; cp gpurun_out/prof_r05p/bench.json $O/bench_profiled_run.json 2>/dev/null
+    head -12 $O/bench_kernel_stats.csv | cut -c1-150
+}
+
 "call$1"
