@@ -613,9 +613,9 @@ class UnifiedVoice:
         (greedy: bit for bit the ids of `inference_speech` over all utterances at once; sampling: slot- and row-step-keyed random stream).
 
         The running batch shares one position counter, bounded by the mel position table; an utterance is admitted while its own budget -- its
-        `row_max_new` cap, else `admit_room` (default: max_generate_length) -- still fits under that bound, otherwise it waits for the next session.  Rows are polled every
-        `chunk_tokens` tokens; an admission (one prefill launch train for all the utterances it places) waits until `min_free` slots are free
-        -- or nothing is running.  `row_max_new`: per-utterance token caps as in `generate`.  Returns (codes (N, L) padded with the stop token,
+        `row_max_new` cap, else `admit_room` (default: max_generate_length) -- still fits under that bound, otherwise it waits for the next
+        session.  Rows are polled every `chunk_tokens` tokens; an admission (one prefill launch train for all the utterances it places) waits
+        until `min_free` slots are free -- or nothing is running.  `row_max_new`: per-utterance token caps as in `generate`.  Returns (codes (N, L) padded with the stop token,
         speech_conditioning_latent); `last_inflight` holds the schedule's counters.  num_beams = 1."""
         emb, mask, max_new, hf, spk_lat = self._prepare_inference(
             speech_condition, text_inputs, langs, cond_lengths, emo_vec, campplus_embedding, None, 1, max_generate_length, typical_sampling,

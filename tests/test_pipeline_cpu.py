@@ -191,3 +191,31 @@ def test_engine_stages_are_built_from_the_frontends_state_dicts(monkeypatch):
     made.clear()
     IndexTTS2(cfg=cfg, device="cpu", frontend=FE(False), gpt=FakeGPT(), bigvgan=FakeVoc(), semantic_codec=mine, s2mel=mine)
     assert made == []                                                                            # both injected: nothing is built
+
+
+def test_inflight_slots_route_the_gpt_stage_through_the_inflight_call():
+    """`infer_batch(..., num_beams=1, inflight_slots=S)` with more segments than slots -> `inference_speech_inflight(slots=S, ...)`; fewer segments,
+    several beams or no `inflight_slots` -> the plain batch call.  The scheduling kwargs never reach the engine's generate kwargs."""
+    class GPT(FakeGPT):
+        def __init__(self):
+            super().__init__()
+            self.inflight = []
+
+        def inference_speech_inflight(self, cond, text, langs, slots=None, chunk_tokens=16, admit_room=None, **kw):
+            self.inflight.append((text.shape[0], slots, chunk_tokens, admit_room, kw))
+            return FakeGPT.inference_speech(self, cond, text, langs, **kw)
+
+    fe = StubFrontend(64)
+    tts = IndexTTS2(cfg={"gpt": {"stop_mel_token": 8193}}, device="cpu", frontend=fe, gpt=GPT(), bigvgan=FakeVoc())
+    texts = ["one.", "two two.", "three three three.", "four.", "five five."]
+    out = tts.infer_batch("spk.wav", texts, "en", num_beams=1, inflight_slots=2, chunk_tokens=8)
+    assert len(out) == 5 and len(tts.gpt.inflight) == 1
+    n, slots, chunk, room, kw = tts.gpt.inflight[0]
+    assert (n, slots, chunk, room) == (5, 2, 8, None) and kw["num_beams"] == 1 and "inflight_slots" not in kw and "chunk_tokens" not in kw
+    plain = len(tts.gpt.calls)
+    tts.infer_batch("spk.wav", texts, "en", num_beams=1, inflight_slots=8)           # everything fits the slots: one ordinary batch
+    tts.infer_batch("spk.wav", texts, "en", num_beams=3, inflight_slots=2)           # the reference's default beam search: ordinary batch
+    tts.infer_batch("spk.wav", texts, "en", num_beams=1)
+    assert len(tts.gpt.inflight) == 1 and len(tts.gpt.calls) == plain + 3
+    for _, kw in tts.gpt.calls[plain:]:
+        assert "inflight_slots" not in kw
