@@ -226,6 +226,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 4 * NPROD, 0);
             }
             if (!APL && SCHED && mt < 3) {
+                // A REQUEST, not a guarantee: hipcc's group solver does not resolve this pipeline (ISA of this build: the splits come out as bursts of
+                // 36 / 52 / 44 / 44 VALU ops between clumps of 24 MFMAs; the two waves a SIMD holds overlap each other's bursts instead).  An exact-fit
+                // request -- 22 x (1 MFMA, 2 VALU ops) + the rest, one scheduling region per m-tile -- is resolved and measures the same (DESIGN
+                // section 8 item 1b, profiles/r05r): the matrix pipe is not waiting for VALU work.
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // the next m-tile's two fragment pieces
 #pragma unroll
                 for (int i = 0; i < 2 * NPROD; ++i) {

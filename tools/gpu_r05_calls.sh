@@ -268,4 +268,29 @@ call16() {
     head -12 $O/bench_kernel_stats.csv | cut -c1-150
 }
 
+# round 5, GPU call 18: x3 GEMM with the split really interleaved under the MFMAs (per-m-tile scheduling regions, 1 MFMA : 2 VALU): same-box A/B
+# against the previous build (tools/ab/base_tree), bits of the solve, x3 GEMM tests, s2mel tests
+call18() {
+    O=$PWD/gpurun_out/r05r
+    mkdir -p $O
+    timeout 300 python tools/gemm_x3_bench.py > $O/gemm_x3_bench.log 2>&1; grep "^M=.*f32x3" $O/gemm_x3_bench.log | sed 's/^/new:  /'
+    (cd tools/ab/base_tree && timeout 300 python tools/gemm_x3_bench.py) > $O/ab_base_gemm.log 2>&1; grep "^M=.*f32x3" $O/ab_base_gemm.log | sed 's/^/base: /'
+    timeout 300 python tools/s2mel_bench.py 64 517 1926 1 fp32x3 > $O/solve.log 2>&1; grep "^B=" $O/solve.log | sed 's/^/new:  /'
+    (cd tools/ab/base_tree && timeout 300 python tools/s2mel_bench.py 64 517 1926 1 fp32x3) > $O/ab_base_solve.log 2>&1; grep "^B=" $O/ab_base_solve.log | sed 's/^/base: /'
+    timeout 600 python -m pytest tests/test_gpu_gemm_x3.py tests/test_gpu_s2mel.py -x -q > $O/pytest_x3_s2mel.log 2>&1; echo "pytest rc=$?" | tee $O/status.txt
+    tail -3 $O/pytest_x3_s2mel.log
+}
+
+# round 5, GPU call 19: the exact interleave on the plain GEMM instantiations only (tap-mode conv keeps its form): same-box A/B, bits of the solve
+call19() {
+    O=$PWD/gpurun_out/r05s
+    mkdir -p $O
+    timeout 300 python tools/gemm_x3_bench.py > $O/gemm_x3_bench.log 2>&1; grep "^M=.*f32x3" $O/gemm_x3_bench.log | sed 's/^/new:  /'
+    (cd tools/ab/base_tree && timeout 300 python tools/gemm_x3_bench.py) > $O/ab_base_gemm.log 2>&1; grep "^M=.*f32x3" $O/ab_base_gemm.log | sed 's/^/base: /'
+    for rep in 1 2; do
+        timeout 300 python tools/s2mel_bench.py 64 517 1926 1 fp32x3 > $O/solve_$rep.log 2>&1; grep "^B=" $O/solve_$rep.log | sed 's/^/new:  /'
+        (cd tools/ab/base_tree && timeout 300 python tools/s2mel_bench.py 64 517 1926 1 fp32x3) > $O/ab_base_solve_$rep.log 2>&1; grep "^B=" $O/ab_base_solve_$rep.log | sed 's/^/base: /'
+    done
+}
+
 "call$1"
