@@ -161,3 +161,24 @@ def test_per_utterance_caps_and_admission_batching(monkeypatch):
             assert len(e[1]) >= 2 or e is [x for x in _FakeSession.log if x[0] == "admit"][-1]
     with pytest.raises(ValueError):
         m.inference_speech_inflight(None, None, max_generate_length=36, slots=4, row_max_new=caps[:3])
+
+
+def test_session_finished_and_codes_respect_the_slot_columns():
+    """`DecodeSession.finished()` / `codes()` look only at the columns of the utterance that occupies the slot NOW (from `col0` on): the stop tokens a
+    previous occupant left in the row do not count."""
+    class M:
+        stop_mel_token = STOP
+    s = object.__new__(gpt.DecodeSession)
+    s.m, s.dev, s.B = M(), "cpu", 4
+    s._codes = torch.tensor([[1, 2, STOP, STOP, STOP, STOP, STOP, STOP],      # slot 0: first occupant stopped after 2 ids
+                             [1, 2, 3, 4, 5, 6, 7, 8],                          # slot 1: still running
+                             [STOP, STOP, STOP, 7, 8, 9, STOP, STOP],           # slot 2: an utterance admitted at column 3, stopped after 3 ids
+                             [4, STOP, STOP, STOP, 5, 6, 7, 8]], dtype=torch.int64)   # slot 3: admitted at column 4, still running
+    s.col0 = [0, 0, 3, 4]
+    s.steps = 8
+    assert s.finished() == [0, 2]
+    assert s.codes(0).tolist() == [1, 2] and s.codes(2).tolist() == [7, 8, 9] and s.codes(3).tolist() == [5, 6, 7, 8] and s.codes(1).numel() == 8
+    s.steps = 5                                                                  # earlier in time: slot 2 has produced 7, 8 so far, slot 3 its first id
+    assert s.finished() == [0] and s.codes(2).tolist() == [7, 8] and s.codes(3).tolist() == [5]
+    s.steps = 0
+    assert s.finished() == []
