@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define ITTS_ABI_VERSION 11
+#define ITTS_ABI_VERSION 12
 
 int itts_abi_version(void);
 const char* itts_last_error(void);
@@ -269,25 +269,31 @@ int itts_gpt_generate(itts_gpt* h, const float* prefix_embeds, const int32_t* pa
  *   non-NULL -- prefill + decode until `step_limit` tokens exist (or every row finished).  Later calls: prefix_embeds NULL --
  *   the decode loop continues from the device state left in the SAME workspace (KV cache, step / position, finished flags,
  *   repetition set) up to the new step_limit; nseq, S, params->max_new_tokens, codes_out, uniforms must be those of the first
- *   call.  *n_steps_out = tokens generated so far (< step_limit only when every row has finished). */
+ *   call.  *n_steps_out = steps run so far (< step_limit only when every row has finished).  The first call clamps step_limit to
+ *   params->max_new_tokens; a later call may run past it (sessions with itts_gpt_admit_rows): each row is bounded by its OWN step -- from its step
+ *   max_new_tokens on it emits the stop token and stores nothing. */
 int itts_gpt_generate_chunk(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, int nseq, int S,
                             const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids,
                             const double* uniforms, int64_t* codes_out, int32_t step_limit, int32_t* n_steps_out,
                             void* workspace, size_t workspace_bytes, int use_graph, void* stream);
 /* Admission of new utterances into a suspended itts_gpt_generate_chunk loop (in-flight batching; design reference: backends/trt/serving/
- *   triton_server.py:96-305, backends/trt/pipeline/pipeline.py:459-548 -- the HF loop itself has no counterpart).  Between two chunk calls every
- *   live row will next run cache position pos = S + steps - 1.  prefix_embeds [n_new][S_new][D] f32 device, S_new == pos: the new prompts, LEFT-padded
- *   to that length (pad_lens [n_new] device: pad positions per row), ending with the start-mel row as for itts_gpt_generate.  slots [n_new] host:
- *   the utterances (rows of the first call) whose cache rows / code rows the new ones take over -- they must have FINISHED.  The new rows are
- *   prefilled on admit_workspace (itts_gpt_admit_workspace_bytes), their first token lands in column steps - 1 of the slot's code row
- *   (*first_column_out), and the following chunk calls decode them with the rest -- position embedding, uniform / RNG stream and row limit follow
- *   the row's own step.  params, penalty ids, uniforms, codes_out, workspace: those of the chunk calls.  The running batch is un-compacted by the
- *   call.  An admitted row produces bit for bit the ids it produces alone with the same left padding (tests/test_gpu_admission.py). */
+ *   triton_server.py:96-305, backends/trt/pipeline/pipeline.py:459-548 -- the HF loop itself has no counterpart).  prefix_embeds [n_new][S_new][D]
+ *   f32 device: the new prompts at their OWN length (left-padded among themselves, pad_lens [n_new] device: pad positions per row; 1 <= S_new <= the
+ *   session's prompt bucket), ending with the start-mel row as for itts_gpt_generate.  slots [n_new] host: the utterances (rows of the first call)
+ *   whose cache rows / code rows the new ones take over -- they must have FINISHED.  row_limits_new [n_new] host: the new utterances' token caps,
+ *   given exactly when limits are installed (itts_gpt_set_row_limits over the first call's rows; the call writes them into that device array once
+ *   every check has passed).  The new rows are prefilled on admit_workspace (itts_gpt_admit_workspace_bytes), keep their keys at their own cache
+ *   positions (a per-row shift under the batch's position counter), their code row is refilled with the stop token and their first token lands in
+ *   its column 0; the following chunk calls decode them with the rest -- token column, position embedding, uniform / RNG stream and row limit follow
+ *   the row's own step; the session's step counter may run past params->max_new_tokens (itts_gpt_generate_chunk), each ROW stops at its own
+ *   step max_new_tokens.  params, penalty ids, uniforms, codes_out,
+ *   workspace: those of the chunk calls.  The running batch is un-compacted by the call.  An admitted row produces bit for bit the ids it produces
+ *   decoded alone, whatever step it joins at (tests/test_gpu_admission.py). */
 size_t itts_gpt_admit_workspace_bytes(const itts_gpt* h, int n_new, int S_new);
 int itts_gpt_admit_rows(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, const int32_t* slots, int n_new, int S_new,
-                        const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids, const double* uniforms,
-                        int64_t* codes_out, void* workspace, size_t workspace_bytes, void* admit_workspace, size_t admit_bytes,
-                        int32_t* first_column_out, void* stream);
+                        const int32_t* row_limits_new, const itts_gen_params* params, const int32_t* penalty_ids, int n_penalty_ids,
+                        const double* uniforms, int64_t* codes_out, void* workspace, size_t workspace_bytes, void* admit_workspace,
+                        size_t admit_bytes, void* stream);
 /* replaces: the same generate() call in beam mode, num_beams > 1 (the reference default is 3-beam beam-sample,
  *   indextts/infer_v2_5.py:732-740) -> vendored GenerationMixin._beam_search (transformers_generation_utils.py:3325-3609),
  *   BeamSearchScorer.process (3rd-party; mirror indextts/gpt/transformers_beam_search.py:215-305,930-1013) and

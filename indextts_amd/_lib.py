@@ -43,7 +43,7 @@ class GPTConfig(C.Structure):
                 ("stop_mel_token", C.c_int32), ("ln_eps", C.c_float)]
 
 
-ABI_VERSION = 11         # include/indextts_hip.h ITTS_ABI_VERSION
+ABI_VERSION = 12         # include/indextts_hip.h ITTS_ABI_VERSION
 
 
 class GenParams(C.Structure):
@@ -116,7 +116,7 @@ SIGNATURES = {
     "itts_gpt_generate_beam": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(GenParams), c_i32p, C.c_int, vp,
                                          vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int32), vp, C.c_size_t, C.c_int, vp]),
     "itts_gpt_admit_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int]),
-    "itts_gpt_admit_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, vp]),
+    "itts_gpt_admit_rows": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp]),
     "itts_gpt_last_timing": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "itts_gpt_graph_stats": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "itts_gpt_set_compaction": (C.c_int, [vp, C.c_int, C.c_int]),

@@ -86,7 +86,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
     os.replace(LIB + ".tmp", LIB)
+    check_isa()
     return LIB
+
+
+def check_isa() -> None:
+    """Fail the build when hipcc has emitted, in a kernel that stages its accumulator tile through LDS (gemm_tile.h's tile store), the in-place
+    packed-f32 form behind round 4's run-to-run differences (tools/check_isa.py: rule and history).  The bit-stability of the flow-matching solve
+    rests on that form being absent; SLP vectorisation stays on in gpt_kernels.hip (bit-exact sampler fixtures), so the generated code is checked."""
+    tool = os.path.join(os.path.dirname(HERE), "tools", "check_isa.py")
+    if not os.path.exists(tool):
+        return
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("ISA check failed (in-place packed f32 op with a half selection in a tile-store kernel):\n" + r.stdout + r.stderr)
 
 
 if __name__ == "__main__":

@@ -324,6 +324,8 @@ struct GptWs {
     int* slot_map;      // [nseq] dense row -> utterance (row compaction; unused while the batch is uncompacted)
     int* gather_src;    // [nseq] compaction: the old dense row each new dense row is taken from
     int* row_step0;     // [nseq] the step at which the utterance joined the running batch (itts_gpt_admit_rows; 0 otherwise)
+    int* row_shift;     // [nseq] batch position counter - the cache row's own position (0 for the rows of the first call; admitted rows keep their
+                        // keys at their own positions 0 .. prompt + generated, whatever the running batch's counter says)
     // beam search (nb > 1)
     unsigned char* seen2;    // second seen buffer
     int* row_map[2];         // [nseq][Tmax]
@@ -361,6 +363,7 @@ static GptWs carve(const itts_gpt_config& c, char* base, int nseq, int S, int Tm
     w.slot_map = (int*)take((size_t)nseq * 4);
     w.gather_src = (int*)take((size_t)nseq * 4);
     w.row_step0 = (int*)take((size_t)nseq * 4);
+    w.row_shift = (int*)take((size_t)nseq * 4);
     w.seen2 = nullptr; w.row_map[0] = w.row_map[1] = nullptr;
     if (nb > 1) {
         const int B = nseq / nb, max_new = Tmax - S;
@@ -425,7 +428,8 @@ __global__ void copy_rows_kernel(const float* __restrict__ tmp, float* __restric
 // decode: split-K partials reduced inside the next LayerNorm kernel.
 // x_cur (optional out): the buffer that holds the residual stream after the pass (w.x, or w.x2 when the LayerNorm-fused decode GEMMs ran)
 static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bool prefill, const int* pos_ptr, const int* pad,
-                      bool* pending, hipStream_t st, bool beam = false, int seq_mul = 1, const int* seq_map = nullptr, float** x_cur = nullptr) {
+                      bool* pending, hipStream_t st, bool beam = false, int seq_mul = 1, const int* seq_map = nullptr, float** x_cur = nullptr,
+                      const int* pos_shift = nullptr) {
     const itts_gpt_config& c = h->cfg;
     const int D = c.model_dim, prec = c.precision, rows = nseq * S;
     int rc;
@@ -451,7 +455,7 @@ static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bo
         GemmArgs g{};
         g.A = w.hbuf; g.lda = D; g.Wp = L.w_qkv; g.bias = L.b_qkv; g.M = rows; g.N = 3 * D; g.K = D; g.nsplit = 1; g.epi = EPI_QKV;
         g.qbuf = w.qbuf; g.kcache = w.kc + w.layer_cache_bytes * l; g.vcache = w.vc + w.layer_cache_bytes * l;
-        g.pos_ptr = pos_ptr; g.S = S; g.H = c.heads; g.Tmax = Tmax; g.D = D; g.seq_mul = seq_mul; g.seq_map = seq_map;
+        g.pos_ptr = pos_ptr; g.S = S; g.H = c.heads; g.Tmax = Tmax; g.D = D; g.seq_mul = seq_mul; g.seq_map = seq_map; g.pos_shift = pos_shift;
         if (fuse_ln) {
             g.ln_x = cur; g.ln_partial = ln.partial; g.ln_bias_prev = pend_bias; g.ln_g = L.ln1_g; g.ln_b = L.ln1_b; g.ln_eps = c.ln_eps;
             g.ln_x_out = pend_bias ? alt : nullptr;
@@ -461,7 +465,7 @@ static int run_layers(itts_gpt* h, const GptWs& w, int nseq, int S, int Tmax, bo
         pend_bias = nullptr;
 
         AttnArgs at{};
-        at.qbuf = w.qbuf; at.kcache = g.kcache; at.vcache = g.vcache; at.pad = pad; at.pos_ptr = pos_ptr;
+        at.qbuf = w.qbuf; at.kcache = g.kcache; at.vcache = g.vcache; at.pad = pad; at.pos_ptr = pos_ptr; at.pos_shift = pos_shift;
         at.row_map = beam ? w.row_map[0] : nullptr; at.row_map_alt = beam ? w.row_map[1] : nullptr; at.step_ptr = beam ? w.state : nullptr;
         at.out = w.attn; at.nseq = nseq; at.H = c.heads; at.nq = S; at.Tmax = Tmax; at.D = D; at.seq_mul = seq_mul; at.seq_map = seq_map;
         if ((rc = launch_attention(at, prec, st))) return rc;
@@ -542,7 +546,7 @@ static int decode_step(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, i
                        const double* uniforms, hipStream_t st) {
     bool pending = false;
     float* xc = w.x;
-    int rc = run_layers(h, w, rows, 1, Tmax, false, w.state + 1, w.pad, &pending, st, false, 1, mapped ? w.slot_map : nullptr, &xc);
+    int rc = run_layers(h, w, rows, 1, Tmax, false, w.state + 1, w.pad, &pending, st, false, 1, mapped ? w.slot_map : nullptr, &xc, w.row_shift);
     if (rc) return rc;
     if ((rc = run_head(h, w, rows, 1, 0, pending, st, xc))) return rc;
     SampleArgs s = make_sample(h, w, gp, rows, tokens, uniforms, n_utts, mapped);
@@ -563,7 +567,10 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
     const itts_gpt_config& c = h->cfg;
     const itts_gen_params gp = *gpp;
     if (nseq <= 0 || S <= 0 || gp.max_new_tokens <= 0) { itts_set_error("gpt_generate: nseq, S, max_new_tokens must be > 0"); return ITTS_ERR_ARG; }
-    if (step_limit < 1 || step_limit > gp.max_new_tokens) step_limit = gp.max_new_tokens;
+    // The first call's step counter is bounded by max_new_tokens.  A resumed loop's is not: every row is bounded by its OWN step (the sampler emits
+    // the stop token from the row's step max_new_tokens / its row limit on and stores nothing; a finished row's K / V stay inside its cache row), so a
+    // session runs for as long as the caller keeps admitting rows (itts_gpt_admit_rows).
+    if (step_limit < 1 || (step_limit > gp.max_new_tokens && !resume)) step_limit = gp.max_new_tokens;
     if (resume && (h->chunk_steps < 1 || h->chunk_nseq != nseq || h->chunk_S != S || h->chunk_max_new != gp.max_new_tokens ||
                    h->chunk_ws != workspace)) {
         itts_set_error("gpt_generate_chunk: resume without a matching first chunk (same workspace, nseq, S, max_new_tokens)");
@@ -600,6 +607,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
     HIP_TRY(hipMemsetAsync(w.seen, 0, (size_t)nseq * c.vocab, st));
     HIP_TRY(hipMemsetAsync(w.finished, 0, nseq, st));
     HIP_TRY(hipMemsetAsync(w.row_step0, 0, (size_t)nseq * 4, st));
+    HIP_TRY(hipMemsetAsync(w.row_shift, 0, (size_t)nseq * 4, st));
     if (pad_lens) HIP_TRY(hipMemcpyAsync(w.pad, pad_lens, (size_t)nseq * 4, hipMemcpyDeviceToDevice, st));
     else HIP_TRY(hipMemsetAsync(w.pad, 0, (size_t)nseq * 4, st));
     if (n_penalty_ids > 0) {
@@ -758,23 +766,31 @@ extern "C" int itts_gpt_generate_chunk(itts_gpt* h, const float* prefix_embeds, 
 // ---- admission of new utterances into a running decode batch -------------------------------------------------------------------------
 // Design reference: the reference's serving path keeps a decode batch running and puts a newly arrived request into a free slot while the other
 // rows keep generating (backends/trt/serving/triton_server.py:96-305, backends/trt/pipeline/pipeline.py:459-548 on TRT-LLM's in-flight batching).
-// Here: between two itts_gpt_generate_chunk calls the loop is suspended with its state on the device; every live row will next run position
-// pos = S + steps - 1.  A new utterance takes the cache row of a FINISHED one: its prompt is given left-padded to exactly `pos` positions, prefilled
-// on an admission workspace of its own (K / V to a scratch cache, copied into the slot's cache rows), its first token is sampled into column
-// steps - 1 of the slot's code row, and row_step0[slot] = steps - 1 makes the sampler index the row's position embedding, uniform / RNG stream and
-// token limit by the row's OWN step.  Left-pad keys are skipped exactly by the attention kernels and a row's arithmetic does not depend on the
-// batch it runs in, so the admitted row generates, bit for bit, the ids it generates alone with the same left padding (tests/test_gpu_admission.py).
+// Here: between two itts_gpt_generate_chunk calls the loop is suspended with its state on the device; the batch's position counter stands at
+// pos = S + steps - 1.  A new utterance takes the cache row of a FINISHED one and keeps its OWN positions: its prompt (S_new positions, at most the
+// session's prompt bucket) is prefilled on an admission workspace of its own (K / V to a scratch cache, copied to positions 0 .. S_new - 1 of the
+// slot's cache rows), row_shift[slot] = pos - S_new lets the QKV epilogue and the attention kernel find the row's own position under the shared
+// counter, its first token is sampled into column 0 of the slot's code row (refilled with the stop token), and row_step0[slot] = steps - 1 makes
+// the sampler index the row's token column, position embedding, uniform / RNG stream and token limit by the row's OWN step.  Nothing of the row
+// depends on the step it joined at -- the attention's key streams are laid out from the row's first valid key -- so the admitted row generates,
+// bit for bit, the ids it generates alone (tests/test_gpu_admission.py), and a session is not bounded by the mel position table: only each row is.
 __global__ void admit_state_kernel(const int* __restrict__ slots, const int* __restrict__ pad_new, unsigned char* seen, unsigned char* finished, int* pad,
-                                   int* row_step0, const int* __restrict__ pen_ids, int n_ids, int V, int step0) {
+                                   int* row_step0, int* row_shift, const int* __restrict__ pen_ids, int n_ids, int V, int step0, int shift,
+                                   long long* tokens, int max_new, long long stop_token, int* row_limit, const int* __restrict__ limits_new) {
     const int i = blockIdx.x, u = slots[i];
     unsigned char* sr = seen + (size_t)u * V;
     for (int c = threadIdx.x; c < V; c += blockDim.x) sr[c] = 0;
+    long long* tr = tokens + (size_t)u * max_new;
+    for (int c = threadIdx.x; c < max_new; c += blockDim.x) tr[c] = stop_token;
     __syncthreads();
     if ((int)threadIdx.x < n_ids) {
         const int id = pen_ids[threadIdx.x];
         if (id >= 0 && id < V) sr[id] = 1;
     }
-    if (threadIdx.x == 0) { finished[u] = 0; pad[u] = pad_new[i]; row_step0[u] = step0; }
+    if (threadIdx.x == 0) {
+        finished[u] = 0; pad[u] = pad_new[i]; row_step0[u] = step0; row_shift[u] = shift;
+        if (row_limit && limits_new) row_limit[u] = limits_new[i];
+    }
 }
 // K / V of positions [0, n_pos) of the admission cache's row i -> the running batch's cache row slots[i] (both [L][rows][H][T][64], own T strides)
 __global__ void copy_kv_rows_kernel(const char* __restrict__ src, char* __restrict__ dst, const int* __restrict__ slots, int H, int T_src, int T_dst,
@@ -802,9 +818,9 @@ extern "C" size_t itts_gpt_admit_workspace_bytes(const itts_gpt* h, int n_new, i
 }
 
 extern "C" int itts_gpt_admit_rows(itts_gpt* h, const float* prefix_embeds, const int32_t* pad_lens, const int32_t* slots, int n_new, int S_new,
-                                   const itts_gen_params* gpp, const int32_t* penalty_ids, int n_penalty_ids, const double* uniforms,
-                                   int64_t* codes_out, void* workspace, size_t workspace_bytes, void* admit_workspace, size_t admit_bytes,
-                                   int32_t* first_column_out, void* caller_stream) {
+                                   const int32_t* row_limits_new, const itts_gen_params* gpp, const int32_t* penalty_ids, int n_penalty_ids,
+                                   const double* uniforms, int64_t* codes_out, void* workspace, size_t workspace_bytes, void* admit_workspace,
+                                   size_t admit_bytes, void* caller_stream) {
     if (!h || !prefix_embeds || !pad_lens || !slots || !gpp || !codes_out || !workspace || !admit_workspace) { itts_set_error("gpt_admit_rows: null pointer"); return ITTS_ERR_ARG; }
     if (!h->finalized) { itts_set_error("gpt_admit_rows: call itts_gpt_finalize first"); return ITTS_ERR_STATE; }
     ItDevGuard dg(h->device);
@@ -816,14 +832,18 @@ extern "C" int itts_gpt_admit_rows(itts_gpt* h, const float* prefix_embeds, cons
         itts_set_error("gpt_admit_rows: no suspended itts_gpt_generate_chunk loop on this workspace with these parameters");
         return ITTS_ERR_STATE;
     }
-    if (k >= gp.max_new_tokens) { itts_set_error("gpt_admit_rows: the running batch is at its last step (%d of %d)", k, gp.max_new_tokens); return ITTS_ERR_STATE; }
-    if (S_new != S + k - 1) {
-        itts_set_error("gpt_admit_rows: the new rows must be left-padded to the running batch's position: S_new = %d, want %d (= S + steps - 1)", S_new, S + k - 1);
+    const int Sb = s_bucket(S), Tmax = Sb + gp.max_new_tokens;
+    if (S_new < 1 || S_new > Sb) {      // a cache row holds Sb prompt positions + max_new_tokens generated ones
+        itts_set_error("gpt_admit_rows: S_new = %d outside 1 .. %d (the session's prompt bucket)", S_new, Sb);
+        return ITTS_ERR_ARG;
+    }
+    const bool limited = h->row_limits && h->row_limits_n == nseq;
+    if (limited != (row_limits_new != nullptr)) {
+        itts_set_error("gpt_admit_rows: row_limits_new must be given exactly when per-utterance limits are installed (itts_gpt_set_row_limits, %d entries)", nseq);
         return ITTS_ERR_ARG;
     }
     if (n_new < 1 || n_new > nseq) { itts_set_error("gpt_admit_rows: n_new = %d outside 1 .. %d", n_new, nseq); return ITTS_ERR_ARG; }
     if (n_penalty_ids < 0 || n_penalty_ids > 16) { itts_set_error("gpt_admit_rows: at most 16 initial penalty ids"); return ITTS_ERR_ARG; }
-    const int Sb = s_bucket(S), Tmax = Sb + gp.max_new_tokens;
     const GptWs w0 = carve(c, nullptr, nseq, Sb, Tmax);
     if (workspace_bytes < w0.total) { itts_set_error("gpt_admit_rows: workspace too small"); return ITTS_ERR_ARG; }
     const GptWs w = carve(c, (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255), nseq, Sb, Tmax);
@@ -833,6 +853,7 @@ extern "C" int itts_gpt_admit_rows(itts_gpt* h, const float* prefix_embeds, cons
     char* abase = (char*)(((uintptr_t)admit_workspace + 255) & ~(uintptr_t)255);
     const GptWs wa = carve(c, abase, n_new, Sba, Ta);
     int* slots_dev = (int*)(abase + wa0.total);
+    int* limits_dev = slots_dev + n_new;
     hipStream_t st = h->stream, cs = (hipStream_t)caller_stream;
     HIP_TRY(hipEventRecord(h->ev_in, cs));
     HIP_TRY(hipStreamWaitEvent(st, h->ev_in, 0));
@@ -851,10 +872,13 @@ extern "C" int itts_gpt_admit_rows(itts_gpt* h, const float* prefix_embeds, cons
     }
     int rc;
     HIP_TRY(hipMemcpyAsync(slots_dev, slots, (size_t)n_new * 4, hipMemcpyHostToDevice, st));
+    if (limited) HIP_TRY(hipMemcpyAsync(limits_dev, row_limits_new, (size_t)n_new * 4, hipMemcpyHostToDevice, st));
     if (n_penalty_ids > 0) HIP_TRY(hipMemcpyAsync(wa.pen_ids, penalty_ids, (size_t)n_penalty_ids * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(wa.pad, pad_lens, (size_t)n_new * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(admit_state_kernel, dim3(n_new), dim3(256), 0, st, slots_dev, wa.pad, w.seen, w.finished, w.pad, w.row_step0, wa.pen_ids,
-                       n_penalty_ids, c.vocab, k - 1);
+    // (the limits are written here, after every check above has passed: a rejected call leaves the running rows' caps alone)
+    hipLaunchKernelGGL(admit_state_kernel, dim3(n_new), dim3(256), 0, st, slots_dev, wa.pad, w.seen, w.finished, w.pad, w.row_step0, w.row_shift,
+                       wa.pen_ids, n_penalty_ids, c.vocab, k - 1, S + k - 1 - S_new, (long long*)codes_out, gp.max_new_tokens,
+                       (long long)c.stop_mel_token, limited ? (int*)h->row_limits : nullptr, limited ? limits_dev : nullptr);
     // prefill of the new rows on the admission workspace: all S_new positions, logits of the last one
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, wa.state, 0, 0);
     HIP_TRY(hipMemcpyAsync(wa.x, prefix_embeds, (size_t)n_new * S_new * c.model_dim * 4, hipMemcpyDeviceToDevice, st));
@@ -863,7 +887,7 @@ extern "C" int itts_gpt_admit_rows(itts_gpt* h, const float* prefix_embeds, cons
     if ((rc = run_layers(h, wa, n_new, S_new, Ta, true, wa.state + 1, wa.pad, &pending, st))) return rc;
     if ((rc = run_head(h, wa, n_new, S_new, S_new - 1, pending, st))) return rc;
     // first token of every new row: sampled with the running batch's per-utterance state (seen set, finished flag, code row, uniform / RNG stream),
-    // into column steps - 1; the row's own step is 0
+    // into column 0 of the slot's code row: the row's own step is 0
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, wa.state, k - 1, S_new);
     {
         SampleArgs s = make_sample(h, w, gp, n_new, (long long*)codes_out, uniforms, nseq, false);
@@ -896,7 +920,6 @@ extern "C" int itts_gpt_admit_rows(itts_gpt* h, const float* prefix_embeds, cons
     h->cur_slots.resize(nseq);
     for (int i = 0; i < nseq; ++i) h->cur_slots[i] = i;
     h->cur_mapped = false;
-    if (first_column_out) *first_column_out = k - 1;
     return ITTS_OK;
 }
 

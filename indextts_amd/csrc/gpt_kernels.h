@@ -39,9 +39,11 @@ struct GemmArgs {
     float* out_f32; int ldo;         // EPI_STORE_F32 / EPI_RESIDUAL (in-place add)
     void* out_act;                   // EPI_GELU_ACT: act dtype [M][ldo]
     float* partial;                  // EPI_PARTIAL: [nsplit][M][N]
-    // EPI_QKV: n < D -> qbuf[m][n]; D <= n < 2D -> K cache; else V cache, at cache position *pos_ptr + (m % S)
+    // EPI_QKV: n < D -> qbuf[m][n]; D <= n < 2D -> K cache; else V cache, at cache position *pos_ptr + (m % S) [- pos_shift[cache row]]
     float* qbuf; void* kcache; void* vcache;
     const int* pos_ptr; int S, H, Tmax, D;
+    const int* pos_shift;            // [cache rows] or null (decode steps only): the batch's position counter runs ahead of cache row r's OWN position by
+                                     // pos_shift[r] -- a row admitted into a running batch (itts_gpt_admit_rows) keeps its keys at its own positions
     size_t a_planes;                 // f32x3 tile GEMM: when non-zero, A is THREE bf16 planes (plane p at (u16*)A + p * a_planes, rows of lda elements, each
                                      // 32-column group stored in fragment order: ada_rmsnorm_planes_kernel) instead of f32 rows -- no in-register split
     int kb_slice;                    // filled by the decode-GEMM launcher: 32-wide k-blocks per K slice
@@ -86,6 +88,7 @@ struct AttnArgs {
     const int* row_map_alt;  // second buffer: the map in use is (*step_ptr & 1) ? row_map_alt : row_map
     const int* step_ptr;
     const int* pos_ptr;      // cache index of query 0
+    const int* pos_shift;    // [cache rows] or null: query 0 of cache row r sits at *pos_ptr - pos_shift[r] (GemmArgs::pos_shift)
     void* out;               // [nseq*nq][D] act dtype
     int nseq, H, nq, Tmax, D;
     int seq_mul;             // sequence b reads cache row / pad entry b * seq_mul when no row map is given (0/1 = identity)
@@ -119,8 +122,9 @@ struct SampleArgs {
     const int* row_limit;    // [utterances] or null: per-utterance cap on generated tokens (a batch merges requests with their own
                              // max_mel_tokens): from token index row_limit[u] on, the row emits the stop token
     const int* row_step0;    // [utterances] or null: the step at which utterance u joined the running batch (itts_gpt_admit_rows; 0 for the rows of
-                             // the first call).  The token column stays the global step; the row's own step (step - row_step0[u]) indexes its mel
-                             // position embedding, its uniform / RNG stream and its token limit -- what the row would see decoded alone.
+                             // the first call).  The row's own step (step - row_step0[u]) indexes its token column, its mel position embedding,
+                             // its uniform / RNG stream and its token limit -- what the row would see decoded alone; from its own step max_new
+                             // on a row emits the stop token and stores nothing (a session's step counter may run past max_new).
 };
 int launch_sample(const SampleArgs& a, hipStream_t st);
 int launch_advance(int* step_ptr, int* pos_ptr, hipStream_t st);

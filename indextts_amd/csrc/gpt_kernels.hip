@@ -299,10 +299,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, int mbase, int 
                 if (which == 0) {
                     a.qbuf[(size_t)m * a.D + c] = val;
                 } else {
-                    const int pos = *a.pos_ptr + si;
                     const size_t pb = a.seq_map ? (size_t)a.seq_map[b] : (size_t)b * (a.seq_mul > 1 ? a.seq_mul : 1);
+                    const int pos = *a.pos_ptr + si - (a.pos_shift ? a.pos_shift[pb] : 0);
                     const size_t o = ((pb * a.H + (c >> 6)) * a.Tmax + pos) * 64 + (c & 63);
                     void* cache = which == 1 ? a.kcache : a.vcache;
+                    if (pos >= a.Tmax) break;                   // a finished row of a long-running session (its slot awaits an admission): nothing to keep
                     if (BF16) ((u16*)cache)[o] = f32_to_bf16(val);
                     else ((float*)cache)[o] = val;
                 }
@@ -1305,7 +1306,9 @@ __device__ __forceinline__ void decode_epilogue(const GemmArgs& a, int mbase, in
                     int b = m, si = 0;
                     if (a.S != 1) { b = m / a.S; si = m - b * a.S; }          // uniform; decode has S == 1
                     const size_t pb = a.seq_map ? (size_t)a.seq_map[b] : (size_t)b * sm;
-                    cache[pb * a.H * a.Tmax * 64 + head_off + (size_t)(pos + si) * 64] = f32_to_bf16(v[r] + bias);
+                    const int own = pos + si - (a.pos_shift ? a.pos_shift[pb] : 0);          // the cache row's own position (admitted rows)
+                    if (own < a.Tmax)                                                          // (past it: a finished row of a long-running session)
+                        cache[pb * a.H * a.Tmax * 64 + head_off + (size_t)own * 64] = f32_to_bf16(v[r] + bias);
                 }
             }
         }
@@ -1857,9 +1860,10 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
     const int qi = blockIdx.y;
-    const int last = *a.pos_ptr + qi;
     const int sm = a.seq_mul > 1 ? a.seq_mul : 1;
     const int pb = a.seq_map ? a.seq_map[b] : b * sm;              // physical cache row / pad entry of this sequence
+    int last = *a.pos_ptr + qi - (a.pos_shift ? a.pos_shift[pb] : 0);
+    last = last < a.Tmax ? last : a.Tmax - 1;                      // (a finished row of a long-running session stays inside its cache row)
     const int first = a.pad ? a.pad[pb] : 0;
     const int sub = lane % LPK, grp = lane / LPK;
     const size_t qrow = (size_t)b * a.nq + qi;
@@ -2587,7 +2591,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             if (tid == 0) {
                 double total = 0.0;
                 for (int i = lo; i < n; ++i) total += (double)cand_v[i];
-                const double ur = a.uniforms ? a.uniforms[(size_t)rstep * (a.uniforms_stride > 0 ? a.uniforms_stride : a.B) + u]
+                const double ur = a.uniforms ? a.uniforms[(size_t)(rstep < a.max_new ? rstep : a.max_new - 1) * (a.uniforms_stride > 0 ? a.uniforms_stride : a.B) + u]
                                              : rng_uniform(a.seed_ptr ? *a.seed_ptr : a.seed, (unsigned long long)rstep, (unsigned long long)u);
                 const double tgt = ur * total;
                 double cum = 0.0;
@@ -2606,7 +2610,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         int tok = s_tok;
         if (a.finished[u]) tok = a.stop_token;               // :3256 finished rows emit pad (= stop)
         if (a.row_limit && rstep >= a.row_limit[u]) tok = a.stop_token;         // this utterance's own max_mel_tokens
-        a.tokens[(size_t)u * a.max_new + step] = tok;
+        if (rstep >= a.max_new) tok = a.stop_token;                             // (a session's step counter runs past max_new: the row's own step bounds it)
+        else a.tokens[(size_t)u * a.max_new + rstep] = tok;
         if (tok == a.stop_token) a.finished[u] = 1;
         seen[tok] = 1;
         s_tok = tok;

@@ -26,7 +26,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"prefill_gemm", 1, 0, 1, "bf16 prefill GEMMs on the LDS-DMA tile kernels (0: register-path gemm_kernel; bitwise equal)"},
     {"tile256", -1, -1, 2, "bf16 tile GEMM: -1 pick by shape, 0 always 128x128, 1 always 256x256, 2 always 256x128 (bitwise equal)"},
     {"f32_tile", 1, 0, 1, "f32 GEMMs with plain epilogues on the f32-MFMA tile kernel (0: register-path kernel; bitwise equal)"},
-    {"x3_products", 6, 6, 8, "plane products per f32 product of the fp32x3 GEMMs and attention: 6 (hh, hm, mh, hl, lh, mm; drops m*l and l*m, 2^-24 |ab| each: measured error vs f64 <= the native f32-MFMA kernels' on every benchmarked shape) or 8 (every term down to 2^-24 |ab|; GEMM launches of this variant are pinned to one block per CU, see launch_gemm_x3_e)", "6,8"},
+    {"x3_products", 6, 6, 8, "plane products per f32 product of the fp32x3 GEMMs and attention: 6 (hh, hm, mh, hl, lh, mm; drops m*l and l*m, 2^-24 |ab| each: measured error vs f64 <= the native f32-MFMA kernels' on every benchmarked shape) or 8 (every term down to 2^-24 |ab|; two blocks per CU like the default since the packed-RoPE fix -- option x3_pin = 1 restores round 4's one-block pin as a diagnostic)", "6,8"},
     {"x3_sched", 1, 0, 1, "fp32x3 GEMM: interleave the operand split with the MFMAs (0: split as a burst; bitwise equal)"},
     {"x3_attn", 1, 0, 1, "fp32x3 s2mel: attention products on bf16 planes too (K / V^T written as three planes by the wqkv epilogue, flash_attn_x3_kernel); 0: the f32-MFMA flash kernel"},
     {"sample_radix", -1, -1, 1, "top-k threshold: -1 per-kernel default (radix select in sample_kernel, ballot bisection in the beam kernels), 0 bisection, 1 radix select (identical ids)"},

@@ -207,10 +207,19 @@ class UnifiedVoice:
         fake_inputs[:, -1] = self.start_mel_token
         return fake_inputs, out, attention_mask
 
+    def _spk_proj_params(self):
+        """float64 host copies of spk_emb_proj's weight / bias, made once per loaded state dict (`_spk_proj`)"""
+        w = self._emb["spk_emb_proj.weight"]
+        hit = getattr(self, "_spk64", None)
+        if hit is None or hit[0] is not w:
+            hit = (w, w.detach().to("cpu", torch.float64), self._emb["spk_emb_proj.bias"].detach().to("cpu", torch.float64))
+            self._spk64 = hit
+        return hit[1], hit[2]
+
     def conds_latent(self, campplus_embedding: torch.Tensor, emo_vec: torch.Tensor) -> torch.Tensor:
         """spk_emb_proj(style) + emo_vec, then two zero tokens (model_v2.py:754-755,768)."""
         dev = self.device
-        spk = _spk_proj(campplus_embedding.to(dev, torch.float32), self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
+        spk = _spk_proj(campplus_embedding.to(dev, torch.float32), *self._spk_proj_params())
         spk = spk.unsqueeze(0) if spk.ndim != 3 else spk
         emo_vec = emo_vec.to(dev, torch.float32)
         return torch.cat((spk + emo_vec.unsqueeze(1), torch.zeros(spk.size(0), 2, spk.size(2), device=dev)), 1), spk
@@ -604,30 +613,28 @@ class UnifiedVoice:
 
     def inference_speech_inflight(self, speech_condition, text_inputs, langs=None, cond_lengths=None, emo_vec=None, campplus_embedding=None,
                                   max_generate_length=None, typical_sampling=False, typical_mass=.9, conds_latent=None, slots=8,
-                                  chunk_tokens=16, admit_room=None, min_free=1, row_max_new: Optional[Sequence[int]] = None,
-                                  **hf_generate_kwargs):
+                                  chunk_tokens=16, min_free=1, row_max_new: Optional[Sequence[int]] = None, **hf_generate_kwargs):
         """`inference_speech` for MORE utterances than decode slots: `slots` rows decode at a time and, whenever rows have emitted their stop
         token, waiting utterances are prefilled into the freed slots (`DecodeSession.admit`) instead of waiting for the whole batch to drain --
         the in-flight batching of the reference's serving path (backends/trt/serving/triton_server.py:96-305, pipeline.py:459-548) as a
         scheduling loop around the engine's suspended decode loop.  A row's ids do not depend on the batch it runs in or on when it joins
         (greedy: bit for bit the ids of `inference_speech` over all utterances at once; sampling: slot- and row-step-keyed random stream).
 
-        The running batch shares one position counter, bounded by the mel position table; an utterance is admitted while its own budget -- its
-        `row_max_new` cap, else `admit_room` (default: max_generate_length) -- still fits under that bound, otherwise it waits for the next
-        session.  Rows are polled every `chunk_tokens` tokens; an admission (one prefill launch train for all the utterances it places) waits
-        until `min_free` slots are free -- or nothing is running.  `row_max_new`: per-utterance token caps as in `generate`.  Returns (codes (N, L) padded with the stop token,
-        speech_conditioning_latent); `last_inflight` holds the schedule's counters.  num_beams = 1."""
+        ONE session serves the whole call: every slot keeps its own cache position and its own step (position embedding, token cap), so an
+        utterance can join at any step with its full budget (`max_generate_length`, or its `row_max_new` cap) -- nothing of the session is
+        bounded by the mel position table, only each row is.  Rows are polled every `chunk_tokens` tokens; an admission (one prefill launch
+        train for all the utterances it places) waits until `min_free` slots are free -- or nothing is running.  `row_max_new`: per-utterance
+        token caps as in `generate`.  Returns (codes (N, L) padded with the stop token, speech_conditioning_latent); `last_inflight` holds the
+        schedule's counters.  num_beams = 1."""
         emb, mask, max_new, hf, spk_lat = self._prepare_inference(
             speech_condition, text_inputs, langs, cond_lengths, emo_vec, campplus_embedding, None, 1, max_generate_length, typical_sampling,
             typical_mass, conds_latent, hf_generate_kwargs)
         if hf.get("num_beams", 1) != 1:
             raise NotImplementedError("inference_speech_inflight: num_beams = 1 only")
         N, slots, chunk = emb.shape[0], max(1, int(slots)), max(1, int(chunk_tokens))
-        table = int(self._emb["mel_pos_embedding.emb.weight"].shape[0]) + 1 - (2 if self.kv_cache else 1)      # the engine's bound on a session's steps
+        table = int(self._emb["mel_pos_embedding.emb.weight"].shape[0]) + 1 - (2 if self.kv_cache else 1)      # the engine's bound on a ROW's steps
         if max_new > table:
             raise ValueError(f"max_generate_length = {max_new} exceeds the mel position table ({table} steps)")
-        room = max_new if admit_room is None else max(1, min(int(admit_room), max_new))
-        session_max = table if N > slots else max_new
         stop = self.stop_mel_token
         if row_max_new is not None and len(row_max_new) != N:
             raise ValueError(f"row_max_new must have one entry per utterance ({N}), got {len(row_max_new)}")
@@ -636,52 +643,38 @@ class UnifiedVoice:
                                                                # is what frees its slot (admission needs the engine to have the row as finished)
         min_free = max(1, int(min_free))
         results: List[Optional[torch.Tensor]] = [None] * N
-        stats = dict(sessions=0, admitted=0, admissions=0, steps=0, row_steps=0, truncated=0)
-        pending = list(range(N))
-        while pending:
-            first, pending = pending[:slots], pending[slots:]
-            B = len(first)
-            owner: List[Optional[int]] = list(first)
-            stats["sessions"] += 1
-            with DecodeSession(self, emb[first], mask[first], session_max, row_max_new=caps_of(first), **hf) as sess:
-                while any(o is not None for o in owner):
-                    before = sess.steps
-                    sess.run(chunk)
-                    stats["row_steps"] += (sess.steps - before) * sum(o is not None for o in owner)
-                    fin = set(sess.finished())
-                    if sess.steps == before:
-                        raise _lib.HipEngineError("inference_speech_inflight: the decode session made no progress")
-                    exhausted = sess.steps >= session_max
-                    for b in range(B):
-                        if owner[b] is None:
-                            continue
-                        if b in fin or exhausted:
-                            c = sess.codes(b)[:cap[owner[b]]]
-                            if c.numel() >= cap[owner[b]] or b not in fin:
-                                stats["truncated"] += 1              # ran into its cap (or the session's end) before a stop token of its own
-                            if b in fin and c.numel() < max_new:
-                                c = torch.cat([c, c.new_full((1,), stop)])
-                            results[owner[b]] = c
-                            owner[b] = None
-                    if exhausted:
-                        break
-                    free = [b for b in range(B) if owner[b] is None]
-                    # an utterance joins while its own budget (its cap when per-utterance caps were given, else admit_room) still fits under the
-                    # session's step bound; the others wait for the next session
-                    left = session_max - sess.steps
-                    fits = [i for i in pending if (cap[i] if row_max_new is not None else room) <= left]
-                    enough = len(free) >= min(min_free, len(fits)) or len(free) == B
-                    if free and fits and enough:
-                        take = fits[:len(free)]
-                        taken = set(take)
-                        pending = [i for i in pending if i not in taken]
-                        free = free[:len(take)]
-                        sess.admit(free, emb[take], mask[take], row_max_new=caps_of(take))
-                        for b, i in zip(free, take):
-                            owner[b] = i
-                        stats["admitted"] += len(take)
-                        stats["admissions"] += 1
-                stats["steps"] += sess.steps
+        stats = dict(sessions=1, admitted=0, admissions=0, steps=0, row_steps=0, truncated=0)
+        first, pending = list(range(N))[:slots], list(range(N))[slots:]
+        B = len(first)
+        owner: List[Optional[int]] = list(first)
+        with DecodeSession(self, emb[first], mask[first], max_new, row_max_new=caps_of(first), **hf) as sess:
+            while any(o is not None for o in owner):
+                before = sess.steps
+                sess.run(chunk)
+                stats["row_steps"] += (sess.steps - before) * sum(o is not None for o in owner)
+                if sess.steps == before:
+                    raise _lib.HipEngineError("inference_speech_inflight: the decode session made no progress")
+                for b in sess.finished():
+                    if owner[b] is None:
+                        continue
+                    c = sess.codes(b)[:cap[owner[b]]]
+                    if c.numel() >= cap[owner[b]]:
+                        stats["truncated"] += 1              # ran into its cap before a stop token of its own
+                    if c.numel() < max_new:
+                        c = torch.cat([c, c.new_full((1,), stop)])
+                    results[owner[b]] = c
+                    owner[b] = None
+                free = [b for b in range(B) if owner[b] is None]
+                enough = len(free) >= min(min_free, len(pending)) or len(free) == B
+                if free and pending and enough:
+                    take, pending = pending[:len(free)], pending[len(free):]
+                    free = free[:len(take)]
+                    sess.admit(free, emb[take], mask[take], row_max_new=caps_of(take))
+                    for b, i in zip(free, take):
+                        owner[b] = i
+                    stats["admitted"] += len(take)
+                    stats["admissions"] += 1
+            stats["steps"] = sess.steps
         self.last_inflight = stats
         width = max(int(c.numel()) for c in results)
         codes = torch.full((N, width), stop, dtype=torch.int64, device=self.device)
@@ -735,7 +728,7 @@ class UnifiedVoice:
             conds = torch.cat((spk + emo_vec.to(dev, torch.float32).unsqueeze(1), half.unsqueeze(1), dur.unsqueeze(1)), 1)
             return self.forward_latent(conds, text_inputs, text_lengths, mel_codes, mel_codes_lengths)
         if do_spk_cond:
-            spk = _spk_proj(spk, self._emb["spk_emb_proj.weight"], self._emb["spk_emb_proj.bias"])
+            spk = _spk_proj(spk, *self._spk_proj_params())
             if spk.ndim != 3:
                 spk = spk.unsqueeze(1)
         conds = torch.cat((spk + emo_vec.to(dev, torch.float32).unsqueeze(1),
@@ -757,20 +750,27 @@ class DecodeSession:
     """A decode batch that keeps running while its utterances finish and NEW utterances are admitted into the freed slots (design reference: the
     in-flight batching of the reference's serving path, backends/trt/serving/triton_server.py:96-305, backends/trt/pipeline/pipeline.py:459-548).
     Built on the suspended-loop API of the engine: `run(n)` advances every live row by n tokens (`itts_gpt_generate_chunk`), `finished()` reports
-    the slots whose row has emitted its stop token, `admit(slots, ...)` prefills new prompts -- left-padded to the batch's current position --
-    into those slots (`itts_gpt_admit_rows`).  A row's arithmetic does not depend on the batch it runs in and left-pad keys are skipped exactly,
-    so an admitted row generates, bit for bit, the ids it generates alone with the same left padding.  Greedy / sampling, num_beams = 1.
+    the slots whose row has emitted its stop token, `admit(slots, ...)` prefills new prompts into those slots (`itts_gpt_admit_rows`).  Every slot
+    keeps its OWN cache position and its OWN step: an admitted utterance's keys sit at positions 0 .. of its cache row, its codes start at column
+    0 of its code row, its position embeddings, random stream and token cap count from its first token -- so it generates, bit for bit, the ids
+    it generates decoded alone, whatever step it joins at, and the session runs for as long as utterances keep arriving (only a ROW is bounded,
+    by `max_new_tokens`).  Greedy / sampling, num_beams = 1.
 
     inputs_embeds (B, s, D) / attention_mask (B, s + 1): what `UnifiedVoice.inference_speech_stream` returns for the first batch."""
 
     def __init__(self, model: "UnifiedVoice", inputs_embeds: torch.Tensor, attention_mask: torch.Tensor, max_new_tokens: int, do_sample=False,
                  top_p=1.0, top_k=50, temperature=1.0, repetition_penalty=1.0, length_penalty=1.0, seed: Optional[int] = None,
-                 typical_mass: float = 0.0, row_max_new: Optional[Sequence[int]] = None, **unused):
+                 typical_mass: float = 0.0, row_max_new: Optional[Sequence[int]] = None, uniforms=None, **unused):
         """row_max_new: per-utterance caps on generated tokens (`generate`'s engine extension): the utterance in a slot emits the stop token from
-        its own token index row_max_new[b] on; `admit(..., row_max_new=)` sets the caps of the utterances it places."""
+        its own token index row_max_new[b] on; `admit(..., row_max_new=)` passes the caps of the utterances it places."""
         model._check_idle("DecodeSession")
         if unused.get("num_beams", 1) != 1:
             raise NotImplementedError("DecodeSession: num_beams = 1 only")
+        if uniforms is not None:        # a uniform stream is laid out per (step, row) of ONE batch; slots here change utterances
+            raise NotImplementedError("DecodeSession: `uniforms` is not supported (rows are re-occupied); use `seed`")
+        altering = sorted(k for k in unused if k in _UNSUPPORTED_GENERATE_KWARGS and unused[k] is not None)
+        if altering:                    # as `generate`: never drop kwargs that change the ids silently
+            raise NotImplementedError(f"DecodeSession: {altering} would change the generated ids and the device loop does not implement them")
         self.m, self.dev = model, model.device
         B, s, D = inputs_embeds.shape
         self.B, self.D, self.max_new = B, D, int(max_new_tokens)
@@ -791,8 +791,8 @@ class DecodeSession:
         self._ws = model._workspace(L.itts_gpt_workspace_bytes(model._h, B, self.S, self.S + self.max_new))
         self._codes = model._persistent("codes", (B, self.max_new), torch.int64)
         self._pen = (C.c_int32 * 2)(1, model.start_mel_token)
-        self.steps = 0                               # tokens generated so far by the rows of the first batch (the global step)
-        self.col0 = [0] * B                          # first code column of the utterance currently in each slot
+        self.steps = 0                               # steps of the session (= tokens generated by the rows of the first batch while they run)
+        self.step0 = [0] * B                         # the session step at which the utterance currently in each slot produced its first token
         self._first = True
         self._adm_ws = None
         self._lim = None
@@ -805,9 +805,9 @@ class DecodeSession:
         model._stream_open = True                    # the workspace holds this session's state until close()
 
     def run(self, n_tokens: int) -> int:
-        """advance the batch by up to n_tokens tokens; returns the global step (stops early when every row has finished)"""
+        """advance the batch by up to n_tokens steps; returns the session's step count (stops early when every row has finished)"""
         L = _lib.lib()
-        limit = min(self.max_new, self.steps + int(n_tokens))
+        limit = self.steps + int(n_tokens) if not self._first else min(self.max_new, int(n_tokens))
         n = C.c_int32(0)
         _lib.check(L.itts_gpt_generate_chunk(self.m._h, _lib.ptr(self._x) if self._first else None, _lib.ptr(self._pad), self.B, self.S,
                                              C.byref(self._gp), self._pen, 2, None, _lib.ptr(self._codes), limit, C.byref(n), _lib.ptr(self._ws),
@@ -816,56 +816,54 @@ class DecodeSession:
         self.steps = int(n.value)
         return self.steps
 
+    def _own_steps(self, slot: int) -> int:
+        """tokens the utterance in `slot` has produced so far (its code columns 0 .. that - 1)"""
+        return max(0, min(self.max_new, self.steps - self.step0[slot]))
+
     def codes(self, slot: int) -> torch.Tensor:
         """the codes of the utterance in `slot` so far (up to, not including, its stop token)"""
-        row = self._codes[slot, self.col0[slot]:self.steps]
+        row = self._codes[slot, :self._own_steps(slot)]
         stop = (row == self.m.stop_mel_token).nonzero()
         return row[: int(stop[0])].clone() if stop.numel() else row.clone()
 
     def finished(self) -> List[int]:
-        """slots whose utterance has emitted its stop token (one device reduction, one host synchronisation)"""
+        """slots whose utterance has emitted its stop token or used up its max_new_tokens (one device reduction, one host synchronisation)"""
         if self.steps < 1:
             return []
-        col0 = torch.as_tensor(self.col0, device=self.dev)
-        live_cols = torch.arange(self.steps, device=self.dev)[None, :] >= col0[:, None]
-        got = ((self._codes[:, :self.steps] == self.m.stop_mel_token) & live_cols).any(dim=1)
+        own = torch.as_tensor([self.steps - self.step0[b] for b in range(self.B)], device=self.dev)
+        live_cols = torch.arange(self.max_new, device=self.dev)[None, :] < own[:, None]
+        got = ((self._codes == self.m.stop_mel_token) & live_cols).any(dim=1) | (own > self.max_new)      # (past its last column the engine has the row
+                                                                                                          # as stopped: the sampler emits the stop token there)
         return [b for b, v in enumerate(got.tolist()) if v]
-
-    def position(self) -> int:
-        """prompt length (with the start-mel row) a new utterance must be left-padded to in order to join now"""
-        return self.S + self.steps - 1
 
     def admit(self, slots: Sequence[int], inputs_embeds: torch.Tensor, attention_mask: torch.Tensor,
               row_max_new: Optional[Sequence[int]] = None) -> None:
-        """put new utterances into finished slots: inputs_embeds (n, s', D) / attention_mask (n, s' + 1) as for the first batch, s' + 1 <= position()"""
+        """put new utterances into finished slots: inputs_embeds (n, s', D) / attention_mask (n, s' + 1) as for the first batch, s' <= the first
+        batch's s (a cache row holds that prompt + max_new_tokens)"""
         if self._first or self.steps < 1:
             raise RuntimeError("DecodeSession.admit: run() the first batch before admitting")
         n, s, D = inputs_embeds.shape
         if (row_max_new is not None) != (self._lim is not None):
             raise ValueError("DecodeSession.admit: row_max_new must be given exactly when the session was opened with per-row caps")
-        if row_max_new is not None:
-            if len(row_max_new) != n:
-                raise ValueError(f"row_max_new must have one entry per admitted row ({n}), got {len(row_max_new)}")
-            self._lim[torch.as_tensor([int(v) for v in slots], device=self.dev)] = torch.as_tensor([int(v) for v in row_max_new], dtype=torch.int32,
-                                                                                                     device=self.dev)
-        S_new = self.position()
-        if s + 1 > S_new:
-            raise ValueError(f"DecodeSession.admit: the prompt ({s + 1} positions) is longer than the batch's position ({S_new}); admit it later")
-        x = torch.cat([inputs_embeds.to(self.dev, torch.float32), self._start.expand(n, 1, D)], dim=1)
-        extra = S_new - (s + 1)
-        x = torch.cat([torch.zeros(n, extra, D, device=self.dev), x], dim=1).contiguous()          # more left padding: skipped exactly by the attention
-        pad = ((attention_mask[:, :s + 1] == 0).sum(dim=1).to(torch.int32).to(self.dev) + extra).contiguous()
+        if row_max_new is not None and len(row_max_new) != n:
+            raise ValueError(f"row_max_new must have one entry per admitted row ({n}), got {len(row_max_new)}")
+        if len(slots) != n:
+            raise ValueError(f"DecodeSession.admit: {len(slots)} slots for {n} utterances")
+        if s + 1 > self.S:
+            raise ValueError(f"DecodeSession.admit: the prompt ({s + 1} positions) is longer than the session's cache rows hold ({self.S})")
+        x = torch.cat([inputs_embeds.to(self.dev, torch.float32), self._start.expand(n, 1, D)], dim=1).contiguous()
+        pad = (attention_mask[:, :s + 1] == 0).sum(dim=1).to(torch.int32).to(self.dev).contiguous()
         L = _lib.lib()
-        need = L.itts_gpt_admit_workspace_bytes(self.m._h, n, S_new)
+        need = L.itts_gpt_admit_workspace_bytes(self.m._h, n, s + 1)
         if self._adm_ws is None or self._adm_ws.numel() < need:
             self._adm_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         sl = (C.c_int32 * n)(*[int(v) for v in slots])
-        col = C.c_int32(0)
-        _lib.check(L.itts_gpt_admit_rows(self.m._h, _lib.ptr(x), _lib.ptr(pad), sl, n, S_new, C.byref(self._gp), self._pen, 2, None,
+        lim = None if row_max_new is None else (C.c_int32 * n)(*[int(v) for v in row_max_new])     # written to the live limits by the engine,
+        _lib.check(L.itts_gpt_admit_rows(self.m._h, _lib.ptr(x), _lib.ptr(pad), sl, n, s + 1, lim, C.byref(self._gp), self._pen, 2, None,   # after its checks
                                          _lib.ptr(self._codes), _lib.ptr(self._ws), self._ws.numel(), _lib.ptr(self._adm_ws), self._adm_ws.numel(),
-                                         C.byref(col), _lib.stream_ptr(self.dev)), "itts_gpt_admit_rows")
+                                         _lib.stream_ptr(self.dev)), "itts_gpt_admit_rows")
         for v in slots:
-            self.col0[int(v)] = int(col.value)
+            self.step0[int(v)] = self.steps - 1
 
     def close(self):
         if self._lim is not None:
@@ -964,33 +962,33 @@ def gemm(a: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], 
         return out
 
 
-_LINEAR_PACKED: dict = {}
-
-
-def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], cache: Optional[dict] = None, key=None) -> torch.Tensor:
     """`F.linear(x, weight, bias)` on the engine's exact-f32 MFMA GEMM (`itts_gemm_forward`, precision 0) -- the small host-side projections of the
-    hot path (speaker-embedding projection, the flow-matching decoder's per-step conditioning vectors) run on the same hand-written kernels as
-    everything else instead of a vendor BLAS call.  The packed weight is cached per weight tensor; K must be a multiple of 16."""
+    hot path (the flow-matching decoder's per-step conditioning vectors) run on the same hand-written kernels as everything else instead of a
+    vendor BLAS call.  `cache` / `key`: a dict OWNED BY THE CALLER'S MODEL and the parameter's name -- the packed weight is kept there, so it lives
+    and dies with the model that owns the parameter (no process-wide table keyed by addresses); without a cache the weight is packed per call.
+    K not a multiple of 16 (no shape of the shipped models): `F.linear`."""
     N, K = weight.shape
     if K % 16:
-        raise _lib.HipEngineError(f"linear_f32: K = {K} is not a multiple of 16")
-    key = (weight.data_ptr(), N, K, str(x.device))
-    hit = _LINEAR_PACKED.get(key)
-    if hit is None:                                                # (the entry keeps the tensor alive, so its address cannot be reused by another weight)
-        hit = (weight, pack_gemm_weight(weight, 0, transposed=True).to(x.device))
-        _LINEAR_PACKED[key] = hit
+        return F.linear(x, weight.to(x.device), None if bias is None else bias.to(x.device))
+    packed = cache.get(key) if cache is not None and key is not None else None
+    if packed is None or packed.device != x.device:
+        packed = pack_gemm_weight(weight, 0, transposed=True).to(x.device)
+        if cache is not None and key is not None:
+            cache[key] = packed
     lead = x.shape[:-1]
     a = x.reshape(-1, K).to(torch.float32).contiguous()
-    out = gemm(a, hit[1], None if bias is None else bias.to(x.device, torch.float32).contiguous(), N, 0)
+    out = gemm(a, packed, None if bias is None else bias.to(x.device, torch.float32).contiguous(), N, 0)
     return out.reshape(*lead, N)
 
 
-def _spk_proj(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+def _spk_proj(x: torch.Tensor, w64: torch.Tensor, b64: torch.Tensor) -> torch.Tensor:
     """spk_emb_proj (model_v2.py:754): a (B, 192) x (192, D) projection, once per batch, outside every loop.  Evaluated in float64 on the host and
     rounded once: the result does not depend on any library's summation order.  That matters: the reference-minted `typical_greedy` fixture holds a
     token whose margin is below f32 summation noise of this projection -- the engine's f32 MFMA GEMM (another order than the reference's CPU sgemm)
-    flips it, the correctly rounded value keeps it (profiles/r05d/status.txt).  No vendor BLAS call either way."""
-    y = x.detach().to("cpu", torch.float64) @ weight.detach().to("cpu", torch.float64).t() + bias.detach().to("cpu", torch.float64)
+    flips it, the correctly rounded value keeps it (profiles/r05d/status.txt).  No vendor BLAS call either way.  w64 / b64: the float64 host copies
+    `UnifiedVoice._spk_proj_params()` keeps per model (made once, not per call); only the (B, 192) input crosses to the host."""
+    y = x.detach().to("cpu", torch.float64) @ w64.t() + b64
     return y.to(torch.float32).to(x.device)
 
 

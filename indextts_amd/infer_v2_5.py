@@ -511,7 +511,7 @@ class IndexTTS2:
             text[i, : t.numel()] = t.reshape(-1).to(torch.int32)
         langs = torch.tensor(lang_ids, dtype=torch.long)
         inflight_slots = gk.pop("inflight_slots", None)    # engine extension: decode `inflight_slots` rows at a time, admit waiting segments into
-        inflight_kw = {k: gk.pop(k) for k in ("chunk_tokens", "admit_room") if k in gk}            # slots whose row has stopped
+        inflight_kw = {k: gk.pop(k) for k in ("chunk_tokens", "min_free") if k in gk}              # slots whose row has stopped
         t0 = time.perf_counter()
         if inflight_slots and num_beams == 1 and len(segment_tokens) > int(inflight_slots):
             codes, _ = self.gpt.inference_speech_inflight(bundle["spk_cond_emb"], text.to(dev), langs.to(dev), emo_vec=emovec,

@@ -85,6 +85,7 @@ class CFM:
         with _lib.on_device(self.device):
             _lib.check(_lib.lib().itts_s2mel_create(C.byref(cfg), C.byref(self._h)), "itts_s2mel_create")
         self._p: Dict[str, torch.Tensor] = {}
+        self._lin_packed: Dict[str, torch.Tensor] = {}         # packed weights of the host-side projections, by parameter name (`_linear`)
         self._loaded = False
         self._ws = None
         self.estimator = self._estimator_call
@@ -101,6 +102,7 @@ class CFM:
         """Reference `s2mel.pth` names for the `cfm` model (`estimator.*`; weight-norm tensors are folded here)."""
         L = _lib.lib()
         sd = fold_weight_norm({k: v for k, v in sd.items()})
+        self._lin_packed.clear()
         P = "estimator."
         ignored = []
         with _lib.on_device(self.device):
@@ -156,12 +158,19 @@ class CFM:
         return self
 
     # ---- per-step vectors (host torch, f32) ------------------------------------------------------------------------
+    def _linear(self, x: torch.Tensor, name: str) -> torch.Tensor:
+        """`F.linear(x, p[name + ".weight"], p[name + ".bias"])` on the engine's f32 GEMM; the packed weight is kept on THIS model under the
+        parameter's name (dropped by load_state_dict)"""
+        w = self._p[name + ".weight"]
+        return linear_f32(x, w.reshape(w.shape[0], -1), self._p[name + ".bias"], cache=self._lin_packed, key=name)
+
+
     def _timestep_embed(self, prefix: str, t: torch.Tensor) -> torch.Tensor:      # diffusion_transformer.py:20-60
         p = self._p
         args = 1000 * t[:, None].float() * p[prefix + "freqs"][None]
         emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
-        h = F.silu(linear_f32(emb, p[prefix + "mlp.0.weight"], p[prefix + "mlp.0.bias"]))
-        return linear_f32(h, p[prefix + "mlp.2.weight"], p[prefix + "mlp.2.bias"])
+        h = F.silu(self._linear(emb, prefix + "mlp.0"))
+        return self._linear(h, prefix + "mlp.2")
 
     def _mods(self, t: torch.Tensor) -> torch.Tensor:
         """t (n_steps,) -> (n_steps, mods_per_step) in the order itts_s2mel_mods_per_step documents."""
@@ -172,11 +181,10 @@ class CFM:
         for i in range(self.depth):
             L = f"transformer.layers.{i}."
             for nm in ("attention_norm.", "ffn_norm."):
-                parts.append(linear_f32(t1, p[L + nm + "project_layer.weight"], p[L + nm + "project_layer.bias"]))
-        parts.append(linear_f32(t1, p["transformer.norm.project_layer.weight"], p["transformer.norm.project_layer.bias"]))
-        wc = p["wavenet.cond_layer.conv.conv.weight"]
-        parts.append(linear_f32(t2, wc.reshape(wc.shape[0], -1), p["wavenet.cond_layer.conv.conv.bias"]))
-        parts.append(linear_f32(F.silu(t1), p["final_layer.adaLN_modulation.1.weight"], p["final_layer.adaLN_modulation.1.bias"]))
+                parts.append(self._linear(t1, L + nm + "project_layer"))
+        parts.append(self._linear(t1, "transformer.norm.project_layer"))
+        parts.append(self._linear(t2, "wavenet.cond_layer.conv.conv"))                       # (a k = 1 conv: its weight as (out, in))
+        parts.append(self._linear(F.silu(t1), "final_layer.adaLN_modulation.1"))
         out = torch.cat(parts, dim=-1).contiguous()
         assert out.shape[1] == _lib.lib().itts_s2mel_mods_per_step(self._h), out.shape
         return out

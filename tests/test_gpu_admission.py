@@ -1,7 +1,8 @@
 """Admission of new utterances into a running decode batch (`gpt.DecodeSession`, `itts_gpt_admit_rows`; design reference: the in-flight batching of
 the reference's serving path, backends/trt/serving/triton_server.py:96-305, backends/trt/pipeline/pipeline.py:459-548).  The contract: a row
-admitted at step k produces, bit for bit, the ids the same row produces decoded ALONE (with the same left padding), and the rows that were already
-running are not disturbed -- in the f32 engine and in the bf16 engine."""
+admitted at ANY step k produces, bit for bit, the ids the same row produces decoded ALONE (every slot keeps its own cache position and its own
+step), the rows that were already running are not disturbed, and a session outlives max_new_tokens / the mel position table -- in the f32 engine and
+in the bf16 engine."""
 import os
 
 import numpy as np
@@ -63,35 +64,79 @@ def test_admitted_row_equals_the_row_alone(golden_dir, prec):
     lens = [int(v.numel()) for v in alone_batch]
     assert min(lens) < max_new - 12, f"no row finishes early enough to free a slot: {lens}"
 
+    # (0) the new utterance alone, exactly as it will be handed to admit(): the reference ids of every admission below
+    with gpt.DecodeSession(m, emb_n, mask_n, mn, **hf) as s2:
+        while s2.steps < max_new and not s2.finished():
+            s2.run(8)
+        solo = s2.codes(0).cpu()
+    assert solo.numel() >= 6
+
     # (2) the same batch; as soon as a row has finished the new utterance takes its slot
     with gpt.DecodeSession(m, emb, mask, mn, **hf) as s1:
         while not s1.finished():
             s1.run(8)
         slot = s1.finished()[0]
         before = s1.codes(slot).cpu()
-        k, S_new = s1.steps, s1.position()
+        k = s1.steps
         s1.admit([slot], emb_n, mask_n)
-        assert s1.col0[slot] == k - 1
-        while s1.steps < max_new and len(s1.finished()) < B:
+        assert s1.step0[slot] == k - 1 and s1.codes(slot).numel() == 1          # its first id sits in column 0 of its code row
+        while len(s1.finished()) < B and s1.steps < 4 * max_new:
             s1.run(8)
         admitted = s1.codes(slot).cpu()
         others = {b: s1.codes(b).cpu() for b in range(B) if b != slot}
+        # (3) the session keeps running: the same utterance once more, far past the first batch's max_new_tokens (the old shared position counter
+        # had no room left there), into another slot
+        while s1.steps < max_new + 9:
+            s1.run(8)
+        late_slot = [b for b in s1.finished() if b != slot][0]
+        k2 = s1.steps
+        s1.admit([late_slot], emb_n, mask_n)
+        while late_slot not in s1.finished() and s1.steps < k2 + 2 * max_new:
+            s1.run(8)
+        late = s1.codes(late_slot).cpu()
     assert torch.equal(before, alone_batch[slot])
     for b, v in others.items():
         assert torch.equal(v, alone_batch[b]), f"row {b} was disturbed by the admission"
+    print(f"{prec}: admitted at step {k} into slot {slot} and at step {k2} (max_new_tokens {max_new}) into slot {late_slot}: {admitted.numel()} / "
+          f"{late.numel()} codes, alone {solo.numel()}; first ids {admitted[:8].tolist()}")
+    assert k2 > max_new
+    assert torch.equal(admitted, solo), "a row admitted into a running batch must generate the ids it generates alone"
+    assert torch.equal(late, solo), "... also when it joins after the session's step counter has passed max_new_tokens"
 
-    # (3) the new utterance alone, left-padded to the position it joined at: same ids, bit for bit
-    extra = S_new - (emb_n.shape[1] + 1)
-    emb_p = torch.cat([torch.zeros(1, extra, emb_n.shape[2], device=emb_n.device), emb_n.to(torch.float32)], dim=1)
-    mask_p = torch.cat([torch.zeros(1, extra, dtype=mask_n.dtype, device=mask_n.device), mask_n], dim=1)
-    with gpt.DecodeSession(m, emb_p, mask_p, mn, **hf) as s2:
-        while s2.steps < max_new - (k - 1) and not s2.finished():
-            s2.run(8)
-        solo = s2.codes(0).cpu()
-    n = min(int(solo.numel()), int(admitted.numel()))
-    print(f"{prec}: admitted at step {k} into slot {slot} (position {S_new}): {admitted.numel()} codes, alone {solo.numel()}; first ids {admitted[:8].tolist()}")
-    assert n >= 6 and torch.equal(admitted[:n], solo[:n])
-    assert admitted.numel() == solo.numel() or admitted.numel() >= max_new - k     # (the admitted row may run into the batch's token budget)
+
+def test_rejected_admission_leaves_the_running_rows_caps_alone(golden_dir):
+    """`itts_gpt_admit_rows` writes the new utterances' token caps itself, after its checks: a call it rejects (slot still generating) must not
+    have touched the cap of the row that is running there."""
+    from indextts_amd import gpt, _lib
+    z = np.load(os.path.join(golden_dir, "gpt_greedy.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]), max_mel_tokens=int(c[4]),
+                      number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))                          # no EOS bias: the rows run to their caps
+    m = _engine(cfg, sd, "fp32")
+    style, emo = torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"])
+    text, langs = torch.from_numpy(z["text"]), torch.from_numpy(z["langs"])
+    max_new = min(40, cfg.max_mel_tokens - 2)
+    emb, mask, mn, hf = m.inference_speech_stream(None, text, langs=langs, emo_vec=emo, campplus_embedding=style, max_generate_length=max_new,
+                                                  do_sample=False, num_beams=1, repetition_penalty=10.0)
+    B = text.shape[0]
+    with gpt.DecodeSession(m, emb, mask, mn, **hf) as s:                       # uncapped: how far the rows run on their own
+        while len(s.finished()) < B and s.steps < max_new:
+            s.run(8)
+        natural = [int(s.codes(b).numel()) for b in range(B)]
+    assert natural[0] > 9 and natural[1] > 12, natural
+    caps = [6] + [30] * (B - 1)
+    with gpt.DecodeSession(m, emb, mask, mn, row_max_new=caps, **hf) as s:
+        s.run(8)
+        assert 0 in s.finished() and 1 not in s.finished()
+        with pytest.raises(_lib.HipEngineError):
+            s.admit([1], emb[:1], mask[:1], row_max_new=[3])            # slot 1 is still generating
+        assert s._lim.tolist() == caps
+        s.admit([0], emb[:1], mask[:1], row_max_new=[9])
+        assert s._lim.tolist() == [9] + caps[1:]
+        while len(s.finished()) < B and s.steps < 3 * max_new:
+            s.run(8)
+        assert s.codes(1).numel() == min(30, natural[1]) and s.codes(0).numel() == 9
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -116,10 +161,10 @@ def test_inflight_equals_one_batch(golden_dir, prec):
     assert style.shape[0] == 1 and emo.shape[0] == 1 and n == 7              # one voice / emotion vector for every row, as in the fixture
     ref, _ = m.inference_speech(None, text, langs, emo_vec=emo, campplus_embedding=style, max_generate_length=max_new, **kw)
     got, _ = m.inference_speech_inflight(None, text, langs, emo_vec=emo, campplus_embedding=style, max_generate_length=max_new, slots=2,
-                                         chunk_tokens=4, admit_room=24, **kw)
+                                         chunk_tokens=4, **kw)
     st = m.last_inflight
     print(f"{prec}: in-flight schedule {st}; one batch {tuple(ref.shape)}, in flight {tuple(got.shape)}")
-    assert st["admitted"] >= 2 and st["truncated"] == 0
+    assert st["admitted"] == n - 2 and st["sessions"] == 1 and st["truncated"] == 0
     assert got.shape == ref.shape and torch.equal(got.cpu(), ref.cpu())
     again, _ = m.inference_speech(None, text[:3], langs[:3], emo_vec=emo, campplus_embedding=style, max_generate_length=max_new, **kw)
     assert torch.equal(again.cpu()[:, : ref.shape[1]], ref.cpu()[:3, : again.shape[1]])          # the engine is idle and usable again

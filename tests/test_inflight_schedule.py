@@ -16,7 +16,8 @@ def _ids(utt, length):
 
 
 class _FakeSession:
-    """Rows emit _ids(utt, len) then STOP for ever; one shared step counter; admit() starts a row at column steps - 1 (as the engine does)."""
+    """Rows emit _ids(utt, len) then STOP for ever; one session step counter that runs for as long as it is asked to; every slot keeps its own
+    step (`step0`) and writes its codes from column 0 of its code row (as the engine does); a row stores nothing past its max_new columns."""
     log = []
 
     def __init__(self, model, emb, mask, max_new, row_max_new=None, **kw):
@@ -27,7 +28,7 @@ class _FakeSession:
                 self.lens[u] = min(self.lens[u], int(c))
         self.capped = row_max_new is not None
         self.B, self.max_new, self.steps = len(self.utts), int(max_new), 0
-        self.col0 = [0] * self.B
+        self.step0 = [0] * self.B
         self._codes = torch.full((self.B, self.max_new), STOP, dtype=torch.int64)
         self.S = emb.shape[1] + 1
         _FakeSession.log.append(("open", list(self.utts), self.max_new))
@@ -39,37 +40,38 @@ class _FakeSession:
         _FakeSession.log.append(("close", self.steps))
 
     def run(self, n):
-        limit = min(self.max_new, self.steps + n)
-        for col in range(self.steps, limit):
+        limit = self.steps + n if self.steps else min(self.max_new, n)
+        for step in range(self.steps, limit):
             for b, u in enumerate(self.utts):
-                t = col - self.col0[b]
-                self._codes[b, col] = _ids(u, self.lens[u])[t] if t < self.lens[u] else STOP
+                t = step - self.step0[b]
+                if t < self.max_new:
+                    self._codes[b, t] = _ids(u, self.lens[u])[t] if t < self.lens[u] else STOP
         self.steps = limit
         return self.steps
 
+    def _own(self, b):
+        return self.steps - self.step0[b]
+
     def finished(self):
-        return [b for b in range(self.B) if bool((self._codes[b, self.col0[b]:self.steps] == STOP).any())]
+        return [b for b in range(self.B) if bool((self._codes[b, :min(self._own(b), self.max_new)] == STOP).any()) or self._own(b) > self.max_new]
 
     def codes(self, b):
-        row = self._codes[b, self.col0[b]:self.steps]
+        row = self._codes[b, :min(self._own(b), self.max_new)]
         hit = (row == STOP).nonzero()
         return row[: int(hit[0])].clone() if hit.numel() else row.clone()
 
-    def position(self):
-        return self.S + self.steps - 1
-
     def admit(self, slots, emb, mask, row_max_new=None):
-        assert self.steps >= 1 and emb.shape[1] + 1 <= self.position()
+        assert self.steps >= 1 and emb.shape[1] + 1 <= self.S
         assert (row_max_new is not None) == self.capped
         for b, i in zip(slots, range(emb.shape[0])):
             u = int(emb[i, 0, 0])
             assert b in self.finished(), "admitted into a slot whose row is still running"
-            self.utts[b], self.lens[u], self.col0[b] = u, int(emb[i, 0, 1]), self.steps - 1
+            self.utts[b], self.lens[u], self.step0[b] = u, int(emb[i, 0, 1]), self.steps - 1
             if row_max_new is not None:
                 self.lens[u] = min(self.lens[u], int(row_max_new[i]))
-            self._codes[b, self.steps - 1:] = STOP
-            # the admitted row's first id is sampled by the admission prefill into column steps - 1
-            self._codes[b, self.steps - 1] = _ids(u, self.lens[u])[0] if self.lens[u] > 0 else STOP
+            self._codes[b, :] = STOP
+            # the admitted row's first id is sampled by the admission prefill into column 0 of its code row
+            self._codes[b, 0] = _ids(u, self.lens[u])[0] if self.lens[u] > 0 else STOP
         _FakeSession.log.append(("admit", list(slots), self.steps))
 
 
@@ -110,10 +112,13 @@ def test_every_utterance_comes_back_complete_and_in_order(monkeypatch, slots, ch
     assert st["steps"] <= drained + chunk * len(opened) + chunk * st["admitted"]
 
 
-def test_row_budget_and_session_budget(monkeypatch):
+def test_row_budget_is_per_row_and_one_session_serves_the_call(monkeypatch):
+    """The mel position table bounds a ROW, not the session: with a table of 60 steps and 30-token budgets, six utterances on two slots run in ONE
+    session whose step counter passes the table, every admitted utterance gets its full budget, and the default call (no `row_max_new`, no
+    scheduling arguments) does admit."""
     monkeypatch.setattr(gpt, "DecodeSession", _FakeSession)
     lengths = [50, 20, 20, 20, 20, 20]
-    m = _model(lengths, table=60)                            # a session holds 60 steps
+    m = _model(lengths, table=60)
     _FakeSession.log = []
     codes, _ = m.inference_speech_inflight(None, None, max_generate_length=30, slots=2, chunk_tokens=4, do_sample=False)
     st = m.last_inflight
@@ -121,14 +126,28 @@ def test_row_budget_and_session_budget(monkeypatch):
     assert codes.shape[1] == 30 and codes[0].tolist() == _ids(0, 50)[:30]
     for u in range(1, 6):
         assert codes[u, :20].tolist() == _ids(u, 20) and int(codes[u, 20]) == STOP
-    assert st["sessions"] >= 2                               # admissions stop when fewer than 30 steps are left under the table; the rest start a new session
-    for e in _FakeSession.log:
-        if e[0] == "admit":
-            assert e[2] + 30 <= 60
+    assert st["sessions"] == 1 and st["admitted"] == 4 and len([e for e in _FakeSession.log if e[0] == "open"]) == 1
+    assert st["steps"] > 60                                  # past the table: 5 x 20-token rows + polls on one of the slots
+    assert max(e[2] for e in _FakeSession.log if e[0] == "admit") + 30 > 60          # an utterance joined where the old shared counter had no room left
     with pytest.raises(ValueError):
         m.inference_speech_inflight(None, None, max_generate_length=61, slots=2)
     with pytest.raises(NotImplementedError):
         m.inference_speech_inflight(None, None, max_generate_length=30, slots=2, num_beams=3)
+
+
+def test_default_serving_budget_admits(monkeypatch):
+    """The pipeline's defaults (max_mel_tokens 1500 under a 1815-row table; `infer_batch(inflight_slots=)` passes no caps): admission must fire for
+    every waiting utterance -- the budget of a late one is its own."""
+    monkeypatch.setattr(gpt, "DecodeSession", _FakeSession)
+    lengths = [700, 300, 650, 400, 500, 620, 80, 900, 800, 750, 640]
+    m = _model(lengths, table=1815)
+    _FakeSession.log = []
+    codes, _ = m.inference_speech_inflight(None, None, max_generate_length=1500, slots=3, chunk_tokens=16, do_sample=False)
+    st = m.last_inflight
+    assert st["sessions"] == 1 and st["admitted"] == 8 and st["truncated"] == 0
+    for u, n in enumerate(lengths):
+        assert codes[u, :n].tolist() == _ids(u, n) and int(codes[u, n]) == STOP
+    assert st["steps"] > 1815                                # the session outlives the table
 
 
 def test_batcher_passes_the_slot_count_for_single_beam_requests():
@@ -163,22 +182,24 @@ def test_per_utterance_caps_and_admission_batching(monkeypatch):
         m.inference_speech_inflight(None, None, max_generate_length=36, slots=4, row_max_new=caps[:3])
 
 
-def test_session_finished_and_codes_respect_the_slot_columns():
-    """`DecodeSession.finished()` / `codes()` look only at the columns of the utterance that occupies the slot NOW (from `col0` on): the stop tokens a
-    previous occupant left in the row do not count."""
+def test_session_finished_and_codes_respect_the_slot_steps():
+    """`DecodeSession.finished()` / `codes()` look only at the columns the utterance that occupies the slot NOW has produced (its own steps, from
+    `step0` on): what sits further right in the row does not count; a row past its last column counts as finished."""
     class M:
         stop_mel_token = STOP
     s = object.__new__(gpt.DecodeSession)
-    s.m, s.dev, s.B = M(), "cpu", 4
+    s.m, s.dev, s.B, s.max_new = M(), "cpu", 4, 8
     s._codes = torch.tensor([[1, 2, STOP, STOP, STOP, STOP, STOP, STOP],      # slot 0: first occupant stopped after 2 ids
                              [1, 2, 3, 4, 5, 6, 7, 8],                          # slot 1: still running
-                             [STOP, STOP, STOP, 7, 8, 9, STOP, STOP],           # slot 2: an utterance admitted at column 3, stopped after 3 ids
-                             [4, STOP, STOP, STOP, 5, 6, 7, 8]], dtype=torch.int64)   # slot 3: admitted at column 4, still running
-    s.col0 = [0, 0, 3, 4]
+                             [7, 8, 9, STOP, STOP, STOP, STOP, STOP],           # slot 2: an utterance admitted at step 3 (its first id), stopped after 3 ids
+                             [5, 6, 7, 8, STOP, STOP, STOP, STOP]], dtype=torch.int64)   # slot 3: admitted at step 4, still running
+    s.step0 = [0, 0, 3, 4]
     s.steps = 8
     assert s.finished() == [0, 2]
     assert s.codes(0).tolist() == [1, 2] and s.codes(2).tolist() == [7, 8, 9] and s.codes(3).tolist() == [5, 6, 7, 8] and s.codes(1).numel() == 8
     s.steps = 5                                                                  # earlier in time: slot 2 has produced 7, 8 so far, slot 3 its first id
     assert s.finished() == [0] and s.codes(2).tolist() == [7, 8] and s.codes(3).tolist() == [5]
+    s.steps = 9                                                                  # slot 1 is past its last column: the engine has it as stopped
+    assert s.finished() == [0, 1, 2, 3] and s.codes(1).numel() == 8 and s.codes(3).tolist() == [5, 6, 7, 8]      # (slot 3's fifth column holds a stop token)
     s.steps = 0
     assert s.finished() == []

@@ -201,17 +201,17 @@ def test_inflight_slots_route_the_gpt_stage_through_the_inflight_call():
             super().__init__()
             self.inflight = []
 
-        def inference_speech_inflight(self, cond, text, langs, slots=None, chunk_tokens=16, admit_room=None, **kw):
-            self.inflight.append((text.shape[0], slots, chunk_tokens, admit_room, kw))
+        def inference_speech_inflight(self, cond, text, langs, slots=None, chunk_tokens=16, min_free=1, **kw):
+            self.inflight.append((text.shape[0], slots, chunk_tokens, min_free, kw))
             return FakeGPT.inference_speech(self, cond, text, langs, **kw)
 
     fe = StubFrontend(64)
     tts = IndexTTS2(cfg={"gpt": {"stop_mel_token": 8193}}, device="cpu", frontend=fe, gpt=GPT(), bigvgan=FakeVoc())
     texts = ["one.", "two two.", "three three three.", "four.", "five five."]
-    out = tts.infer_batch("spk.wav", texts, "en", num_beams=1, inflight_slots=2, chunk_tokens=8)
+    out = tts.infer_batch("spk.wav", texts, "en", num_beams=1, inflight_slots=2, chunk_tokens=8, min_free=2)
     assert len(out) == 5 and len(tts.gpt.inflight) == 1
-    n, slots, chunk, room, kw = tts.gpt.inflight[0]
-    assert (n, slots, chunk, room) == (5, 2, 8, None) and kw["num_beams"] == 1 and "inflight_slots" not in kw and "chunk_tokens" not in kw
+    n, slots, chunk, min_free, kw = tts.gpt.inflight[0]
+    assert (n, slots, chunk, min_free) == (5, 2, 8, 2) and kw["num_beams"] == 1 and "inflight_slots" not in kw and "chunk_tokens" not in kw
     plain = len(tts.gpt.calls)
     tts.infer_batch("spk.wav", texts, "en", num_beams=1, inflight_slots=8)           # everything fits the slots: one ordinary batch
     tts.infer_batch("spk.wav", texts, "en", num_beams=3, inflight_slots=2)           # the reference's default beam search: ordinary batch
