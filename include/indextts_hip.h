@@ -324,6 +324,11 @@ int itts_gpt_graph_stats(const itts_gpt* h, int32_t* captures, int32_t* hits);
  * (cache rows stay in place behind a row map) and the step is replayed from the graph of the smaller batch, in buckets of
  * `granularity` rows (default on, 8).  Results are unchanged: a row's arithmetic does not depend on the batch it runs in. */
 int itts_gpt_set_compaction(itts_gpt* h, int enable, int granularity);
+/* In-flight batching (with itts_gpt_admit_rows): the following itts_gpt_generate_chunk calls return early -- at one of the finished-flag checks the
+ * loop makes every 8 steps anyway -- once at least `finished_rows` utterances of the batch have finished (those finished before the call count),
+ * so the caller refills their slots without polling in short chunks.  0 = off.  No counterpart in the HF loop; TRT-LLM's in-flight batcher does
+ * this inside its executor (backends/trt/serving/triton_server.py:96-305). */
+int itts_gpt_set_chunk_return(itts_gpt* h, int finished_rows);
 /* Per-utterance caps on generated tokens for the following generate / generate_chunk calls of exactly n utterances (one batch merges
  * requests carrying their own `max_mel_tokens`, infer_v2_5.py:740): utterance u emits the stop token from token index limits[u] on.
  * limits: DEVICE int32 [n], caller-owned, must outlive those calls; NULL clears. */

@@ -121,6 +121,7 @@ SIGNATURES = {
     "itts_gpt_graph_stats": (C.c_int, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "itts_gpt_set_compaction": (C.c_int, [vp, C.c_int, C.c_int]),
     "itts_gpt_set_row_limits": (C.c_int, [vp, vp, C.c_int]),
+    "itts_gpt_set_chunk_return": (C.c_int, [vp, C.c_int]),
     "itts_gpt_compaction_stats": (C.c_int, [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "itts_gpt_forward_latent": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
     "itts_gemm_tile_occupancy": (C.c_int, [C.c_int, C.POINTER(C.c_int32)]),

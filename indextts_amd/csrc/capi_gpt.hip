@@ -119,6 +119,7 @@ struct itts_gpt {
     int last_compactions = 0;
     const int32_t* row_limits = nullptr;   // device [row_limits_n] per-utterance token caps for the next generate calls, or null
     int row_limits_n = 0;
+    int chunk_return_finished = 0;         // itts_gpt_set_chunk_return: a chunk call returns at a flag check once that many utterances have finished
 };
 #define GRAPH_CACHE_MAX 24        // a ragged batch replays one graph per live-row bucket (8 at the bench shape) beside the callers' own shapes
 // prompt lengths are bucketed to multiples of 32 for the workspace carve and the cache stride, so that prompts of nearby lengths
@@ -570,6 +571,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
     // The first call's step counter is bounded by max_new_tokens.  A resumed loop's is not: every row is bounded by its OWN step (the sampler emits
     // the stop token from the row's step max_new_tokens / its row limit on and stores nothing; a finished row's K / V stay inside its cache row), so a
     // session runs for as long as the caller keeps admitting rows (itts_gpt_admit_rows).
+    const bool chunked = step_limit > 0;                               // itts_gpt_generate_chunk (itts_gpt_generate passes 0)
     if (step_limit < 1 || (step_limit > gp.max_new_tokens && !resume)) step_limit = gp.max_new_tokens;
     if (resume && (h->chunk_steps < 1 || h->chunk_nseq != nseq || h->chunk_S != S || h->chunk_max_new != gp.max_new_tokens ||
                    h->chunk_ws != workspace)) {
@@ -709,6 +711,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
             int live = 0;
             for (int i = 0; i < nseq; ++i) live += h->host_fin[i] ? 0 : 1;
             if (live == 0) break;
+            if (chunked && h->chunk_return_finished > 0 && nseq - live >= h->chunk_return_finished) break;        // slots to refill
             const int g = h->compact_gran < 1 ? 1 : h->compact_gran;
             const int want = ((live + g - 1) / g) * g;
             if (compact && want < rows) {
@@ -1099,6 +1102,15 @@ extern "C" int itts_gpt_set_compaction(itts_gpt* h, int enable, int granularity)
     if (!h) { itts_set_error("gpt_set_compaction: null"); return ITTS_ERR_ARG; }
     h->compact = enable != 0;
     if (granularity > 0) h->compact_gran = granularity;
+    return ITTS_OK;
+}
+
+// In-flight batching: a chunk call returns early -- at one of the finished-flag checks the loop makes every 8 steps anyway -- once at least
+// `finished_rows` utterances of the batch have finished (counting the ones that had finished before the call), so the caller can refill their slots
+// (itts_gpt_admit_rows) without polling in short chunks.  0 = off (run to step_limit).
+extern "C" int itts_gpt_set_chunk_return(itts_gpt* h, int finished_rows) {
+    if (!h || finished_rows < 0) { itts_set_error("gpt_set_chunk_return: bad args"); return ITTS_ERR_ARG; }
+    h->chunk_return_finished = finished_rows;
     return ITTS_OK;
 }
 

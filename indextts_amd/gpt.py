@@ -650,7 +650,8 @@ class UnifiedVoice:
         with DecodeSession(self, emb[first], mask[first], max_new, row_max_new=caps_of(first), **hf) as sess:
             while any(o is not None for o in owner):
                 before = sess.steps
-                sess.run(chunk)
+                # while utterances wait, come back as soon as `min_free` slots can be refilled (the engine looks at its flags every 8 steps)
+                sess.run(chunk, return_when_finished=min(min_free, len(pending), B) if pending else 0)
                 stats["row_steps"] += (sess.steps - before) * sum(o is not None for o in owner)
                 if sess.steps == before:
                     raise _lib.HipEngineError("inference_speech_inflight: the decode session made no progress")
@@ -804,10 +805,13 @@ class DecodeSession:
             _lib.check(L.itts_gpt_set_row_limits(model._h, _lib.ptr(self._lim), B), "itts_gpt_set_row_limits")
         model._stream_open = True                    # the workspace holds this session's state until close()
 
-    def run(self, n_tokens: int) -> int:
-        """advance the batch by up to n_tokens steps; returns the session's step count (stops early when every row has finished)"""
+    def run(self, n_tokens: int, return_when_finished: int = 0) -> int:
+        """advance the batch by up to n_tokens steps; returns the session's step count (stops early when every row has finished -- or, with
+        return_when_finished = k > 0, at the engine's next flag check (every 8 steps) once k slots hold a finished utterance, counting the ones
+        that were finished before the call: the caller refills slots without polling in short chunks)"""
         L = _lib.lib()
         limit = self.steps + int(n_tokens) if not self._first else min(self.max_new, int(n_tokens))
+        _lib.check(L.itts_gpt_set_chunk_return(self.m._h, max(0, int(return_when_finished))), "itts_gpt_set_chunk_return")
         n = C.c_int32(0)
         _lib.check(L.itts_gpt_generate_chunk(self.m._h, _lib.ptr(self._x) if self._first else None, _lib.ptr(self._pad), self.B, self.S,
                                              C.byref(self._gp), self._pen, 2, None, _lib.ptr(self._codes), limit, C.byref(n), _lib.ptr(self._ws),
@@ -866,6 +870,7 @@ class DecodeSession:
             self.step0[int(v)] = self.steps - 1
 
     def close(self):
+        _lib.lib().itts_gpt_set_chunk_return(self.m._h, 0)
         if self._lim is not None:
             _lib.lib().itts_gpt_set_row_limits(self.m._h, None, 0)
             self._lim = None

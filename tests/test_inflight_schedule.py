@@ -39,14 +39,18 @@ class _FakeSession:
     def __exit__(self, *a):
         _FakeSession.log.append(("close", self.steps))
 
-    def run(self, n):
+    def run(self, n, return_when_finished=0):
         limit = self.steps + n if self.steps else min(self.max_new, n)
         for step in range(self.steps, limit):
             for b, u in enumerate(self.utts):
                 t = step - self.step0[b]
                 if t < self.max_new:
                     self._codes[b, t] = _ids(u, self.lens[u])[t] if t < self.lens[u] else STOP
-        self.steps = limit
+            self.steps = step + 1
+            if self.steps % 8 == 0 and self.steps < limit:       # the engine's flag check: every row finished, or enough slots to refill
+                fin = len(self.finished())
+                if fin == self.B or (return_when_finished > 0 and fin >= return_when_finished):
+                    break
         return self.steps
 
     def _own(self, b):
