@@ -1,5 +1,6 @@
 """GPU box: time the s2mel GEMM shapes through itts_gemm_forward in the native f32-MFMA mode (precision 0) and the f32x3 mode (2).
-usage: gemm_x3_bench.py [M] [reps]   (plain store epilogue; M = packed rows, default 39088 = 8 x 2 x 2443)"""
+usage: gemm_x3_bench.py [M] [reps] [option=value ...]   (plain store epilogue; M = packed rows, default 39088 = 8 x 2 x 2443; the options are engine
+options set for the whole run, e.g. x3_prio=1)"""
 import os
 import sys
 import time
@@ -7,10 +8,16 @@ import time
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from indextts_amd import gpt  # noqa: E402
+from indextts_amd import gpt, _lib  # noqa: E402
 
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 39088
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+_pos = [v for v in sys.argv[1:] if "=" not in v]
+_opts = {k: int(v) for k, v in (kv.split("=") for kv in sys.argv[1:] if "=" in kv)}
+M = int(_pos[0]) if len(_pos) > 0 else 39088
+reps = int(_pos[1]) if len(_pos) > 1 else 5
+for _k, _v in _opts.items():
+    _lib.set_option(_k, _v)
+if _opts:
+    print("options:", _opts, flush=True)
 g = torch.Generator().manual_seed(0)
 for N, K in ((1536, 512), (512, 512), (3072, 512), (512, 1536), (1024, 2560)):
     a = torch.randn(M, K, generator=g).cuda()

@@ -20,4 +20,21 @@ call1() {
     timeout 600 python tools/inflight_bench.py 512 64 16 4 120 560 > $O/inflight_512_120_c16.log 2>&1; tail -1 $O/inflight_512_120_c16.log
 }
 
+# round 6, GPU call 2: (a) the scheduler on the engine's own flag check (itts_gpt_set_chunk_return): admission tests again, in-flight vs drained;
+# (b) x3 GEMM with a raised wave priority on the MFMA / split section (option x3_prio): GEMM shapes and the 64-utterance solve, same box, alternating.
+call2() {
+    O=$PWD/gpurun_out/r06b
+    mkdir -p $O
+    timeout 600 python -m pytest tests/test_gpu_admission.py tests/test_gpu_compaction.py -x -q -s > $O/pytest_admission.log 2>&1; echo "pytest admission rc=$?" | tee $O/status.txt
+    grep -E "admitted at|in-flight schedule|passed|failed|Error|error" $O/pytest_admission.log | tail -8
+    for spec in "512 64 64 8 120 560" "512 64 64 8 280 560" "256 64 64 8 120 560" "512 64 64 4 120 560" "512 64 64 16 120 560"; do
+        timeout 600 python tools/inflight_bench.py $spec > $O/inflight_$(echo $spec | tr ' ' '_').log 2>&1; tail -1 $O/inflight_$(echo $spec | tr ' ' '_').log
+    done
+    for p in 0 1 2 3 0 1; do
+        timeout 300 python tools/gemm_x3_bench.py 312704 5 x3_prio=$p > $O/gemm_prio$p.log 2>&1; echo "x3_prio=$p: $(grep 'f32x3' $O/gemm_prio$p.log | sed 's/.*f32x3: //' | awk '{printf "%s ", $3}')"
+    done
+    timeout 900 python tools/s2mel_bench.py 64 517 1926 1 fp32x3 fp32x3:x3_prio=1 fp32x3:x3_prio=2 fp32x3:x3_prio=3 fp32x3 fp32x3:x3_prio=1 > $O/solve_prio.log 2>&1; echo "solve rc=$?" | tee -a $O/status.txt
+    grep "^B=" $O/solve_prio.log
+}
+
 "call$1"
