@@ -190,11 +190,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
             issue_a(kt + 1, (kt + 1) & 1);
             load_w(kt + 1, bn_);
         }
-        // option x3_prio: the MFMA / split section runs at a raised wave priority, the request section above at 0 (block-uniform branches at the
-        // section boundaries; the levels are immediates)
-        if (a.x3_prio == 1) __builtin_amdgcn_s_setprio(1);
-        else if (a.x3_prio == 2) __builtin_amdgcn_s_setprio(2);
-        else if (a.x3_prio == 3) __builtin_amdgcn_s_setprio(3);
+        // (A raised wave priority -- s_setprio 1 / 2 / 3 -- on the MFMA / split section from here to the end of the K tile, the request section above
+        // at 0, changes nothing: GEMM shapes within +-1.5 %, 64-utterance solve 321.8 vs 321.3 / 319.6 / 322.0 ms, profiles/r06b.  Not kept.)
         const char* base = pf_sm + (kt & 1) * STAGE;
         v4u ap[3], an[3];
         if constexpr (APL) {
@@ -244,7 +241,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
             }
             if (mt < 3) { ap[0] = an[0]; ap[1] = an[1]; ap[2] = an[2]; }
         }
-        if (a.x3_prio) __builtin_amdgcn_s_setprio(0);
     };
     v4u bw0[4][3], bw1[4][3];
     issue_a(0, 0);
@@ -280,9 +276,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
 }
 
 template <int EPI, bool CONV = false>
-static int launch_gemm_x3_e(const GemmArgs& a0, hipStream_t st) {
-    GemmArgs a = a0;
-    a.x3_prio = itts_opt(OPT_X3_PRIO);
+static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
     const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
     const int per = ceil_div(n_mt * n_nt, 8);
     const int nprod = itts_opt(OPT_X3_PRODUCTS) == 6 ? 6 : 8;

@@ -46,7 +46,6 @@ struct GemmArgs {
                                      // pos_shift[r] -- a row admitted into a running batch (itts_gpt_admit_rows) keeps its keys at its own positions
     size_t a_planes;                 // f32x3 tile GEMM: when non-zero, A is THREE bf16 planes (plane p at (u16*)A + p * a_planes, rows of lda elements, each
                                      // 32-column group stored in fragment order: ada_rmsnorm_planes_kernel) instead of f32 rows -- no in-register split
-    int x3_prio;                     // filled by the f32x3 GEMM launcher (option x3_prio): s_setprio level of the K tile's MFMA section, 0 = none
     int kb_slice;                    // filled by the decode-GEMM launcher: 32-wide k-blocks per K slice
     int dma_rot;                     // per-block rotation of the slab DMA issue order (ITTS_DECODE_ROT=0 turns it off: A/B switch)
     // LayerNorm fused into a decode GEMM's operand staging (gemm_decode_ln_kernel: at most 4 rows, K == model_dim, bf16): when ln_x is set the

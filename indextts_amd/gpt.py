@@ -655,10 +655,10 @@ class UnifiedVoice:
                 stats["row_steps"] += (sess.steps - before) * sum(o is not None for o in owner)
                 if sess.steps == before:
                     raise _lib.HipEngineError("inference_speech_inflight: the decode session made no progress")
-                for b in sess.finished():
+                for b, n_codes in sess.finished_lengths():           # one device reduction + one host synchronisation per poll
                     if owner[b] is None:
                         continue
-                    c = sess.codes(b)[:cap[owner[b]]]
+                    c = sess._codes[b, :min(n_codes, cap[owner[b]])].clone()
                     if c.numel() >= cap[owner[b]]:
                         stats["truncated"] += 1              # ran into its cap before a stop token of its own
                     if c.numel() < max_new:
@@ -839,6 +839,19 @@ class DecodeSession:
         got = ((self._codes == self.m.stop_mel_token) & live_cols).any(dim=1) | (own > self.max_new)      # (past its last column the engine has the row
                                                                                                           # as stopped: the sampler emits the stop token there)
         return [b for b, v in enumerate(got.tolist()) if v]
+
+    def finished_lengths(self) -> List[tuple]:
+        """[(slot, number of codes before its stop token)] of the slots `finished()` reports -- both from one device reduction and one host
+        synchronisation (the scheduler's poll: `finished()` + `codes()` per slot would synchronise once per slot)"""
+        if self.steps < 1:
+            return []
+        own = torch.as_tensor([self.steps - self.step0[b] for b in range(self.B)], device=self.dev)
+        cols = torch.arange(self.max_new, device=self.dev)[None, :]
+        stop = (self._codes == self.m.stop_mel_token) & (cols < own[:, None])
+        first = torch.where(stop.any(dim=1), stop.to(torch.int32).argmax(dim=1), own.clamp(max=self.max_new))       # first stop column, else all own columns
+        fin = stop.any(dim=1) | (own > self.max_new)
+        host = torch.stack([fin.to(torch.int64), first.to(torch.int64)]).tolist()
+        return [(b, int(host[1][b])) for b in range(self.B) if host[0][b]]
 
     def admit(self, slots: Sequence[int], inputs_embeds: torch.Tensor, attention_mask: torch.Tensor,
               row_max_new: Optional[Sequence[int]] = None) -> None:

@@ -64,6 +64,9 @@ class _FakeSession:
         hit = (row == STOP).nonzero()
         return row[: int(hit[0])].clone() if hit.numel() else row.clone()
 
+    def finished_lengths(self):
+        return [(b, int(self.codes(b).numel())) for b in self.finished()]
+
     def admit(self, slots, emb, mask, row_max_new=None):
         assert self.steps >= 1 and emb.shape[1] + 1 <= self.S
         assert (row_max_new is not None) == self.capped
@@ -203,7 +206,9 @@ def test_session_finished_and_codes_respect_the_slot_steps():
     assert s.codes(0).tolist() == [1, 2] and s.codes(2).tolist() == [7, 8, 9] and s.codes(3).tolist() == [5, 6, 7, 8] and s.codes(1).numel() == 8
     s.steps = 5                                                                  # earlier in time: slot 2 has produced 7, 8 so far, slot 3 its first id
     assert s.finished() == [0] and s.codes(2).tolist() == [7, 8] and s.codes(3).tolist() == [5]
+    assert s.finished_lengths() == [(0, 2)]
     s.steps = 9                                                                  # slot 1 is past its last column: the engine has it as stopped
     assert s.finished() == [0, 1, 2, 3] and s.codes(1).numel() == 8 and s.codes(3).tolist() == [5, 6, 7, 8]      # (slot 3's fifth column holds a stop token)
+    assert s.finished_lengths() == [(0, 2), (1, 8), (2, 3), (3, 4)]
     s.steps = 0
     assert s.finished() == []
