@@ -168,3 +168,37 @@ def test_inflight_equals_one_batch(golden_dir, prec):
     assert got.shape == ref.shape and torch.equal(got.cpu(), ref.cpu())
     again, _ = m.inference_speech(None, text[:3], langs[:3], emo_vec=emo, campplus_embedding=style, max_generate_length=max_new, **kw)
     assert torch.equal(again.cpu()[:, : ref.shape[1]], ref.cpu()[:3, : again.shape[1]])          # the engine is idle and usable again
+
+
+def test_inflight_at_production_widths_equals_one_batch():
+    """The in-flight schedule at the production GPT widths (24 x 1280, bf16, the benchmark's engine): 20 ragged utterances on 8 decode slots,
+    greedy, lengths given as per-utterance caps (the synthetic weights never emit the stop token) -- bit for bit the ids of one 20-row batch, with
+    every waiting utterance admitted into ONE session whose step counter passes the longest cap."""
+    from indextts_amd import gpt, synth
+    cfg = dict(synth.GPT_V25)
+    m = gpt.UnifiedVoice(**cfg, spk_cond_mode="campplus", precision="bf16", device=DEV)
+    m.load_state_dict(synth.gpt_weights(cfg, seed=1234, suppress_eos=True))
+    m.post_init_gpt2_config(kv_cache=True, half=True)
+    g = torch.Generator().manual_seed(77)
+    n, slots, hi = 20, 8, 40
+    caps = torch.randint(6, hi + 1, (n,), generator=g).tolist()
+    lens = torch.randint(20, 65, (n,), generator=g).tolist()                  # ragged texts: the prompts are left-padded among themselves
+    text = torch.ones(n, 65, dtype=torch.int32)
+    for i, L in enumerate(lens):
+        text[i, :L] = torch.randint(2, 12000, (L,), generator=g).to(torch.int32)
+    text = text.to(DEV)
+    langs = torch.full((n,), 3, dtype=torch.long, device=DEV)
+    style = (torch.randn(1, 192, generator=g) * 0.1).to(DEV)
+    emo = (torch.randn(1, cfg["model_dim"], generator=g) * 0.1).to(DEV)
+    kw = dict(emo_vec=emo, campplus_embedding=style, max_generate_length=hi, do_sample=False, num_beams=1, repetition_penalty=10.0)
+    ref, _ = m.inference_speech(None, text, langs=langs, row_max_new=caps, **kw)
+    got, _ = m.inference_speech_inflight(None, text, langs=langs, slots=slots, chunk_tokens=16, min_free=2, row_max_new=caps, **kw)
+    st = m.last_inflight
+    print(f"production widths: in-flight schedule {st}; caps {caps}")
+    assert st["sessions"] == 1 and st["admitted"] == n - slots and st["steps"] > hi
+    stop = m.stop_mel_token
+    for i in range(n):
+        a, b = ref[i].tolist(), got[i].tolist()
+        la = a.index(stop) if stop in a else len(a)
+        lb = b.index(stop) if stop in b else len(b)
+        assert la == lb == caps[i] and a[:la] == b[:lb], f"utterance {i}: one batch {a[:la]} vs in flight {b[:lb]}"

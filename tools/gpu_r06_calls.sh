@@ -37,4 +37,15 @@ call2() {
     grep "^B=" $O/solve_prio.log
 }
 
+# round 6, GPU call 3: the scheduler's single-synchronisation poll; the in-flight schedule at production widths against one batch; in-flight vs drained
+call3() {
+    O=$PWD/gpurun_out/r06c
+    mkdir -p $O
+    timeout 900 python -m pytest tests/test_gpu_admission.py -x -q -s > $O/pytest_admission.log 2>&1; echo "pytest admission rc=$?" | tee $O/status.txt
+    grep -E "production widths|in-flight schedule|passed|failed|Error|error" $O/pytest_admission.log | tail -8
+    for spec in "512 64 64 8 120 560" "512 64 64 8 280 560" "256 64 64 8 120 560"; do
+        timeout 600 python tools/inflight_bench.py $spec > $O/inflight_$(echo $spec | tr ' ' '_').log 2>&1; tail -1 $O/inflight_$(echo $spec | tr ' ' '_').log
+    done
+}
+
 "call$1"
