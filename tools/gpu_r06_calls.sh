@@ -48,4 +48,26 @@ call3() {
     done
 }
 
+# round 6, validation A (intermediate and final): every GPU test + smoke
+call4() {
+    O=$PWD/gpurun_out/${TAG:-r06d}
+    mkdir -p $O
+    timeout 2400 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest -m gpu rc=$?" | tee $O/status.txt
+    tail -6 $O/pytest_gpu.log
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/status.txt
+    tail -4 $O/smoke.log
+}
+
+# round 6, validation B: the bench line (every leg; 5 timed steps) + rocprofv3 kernel stats of the same command without the extra legs
+call5() {
+    T=${TAG:-r06e}
+    O=$PWD/gpurun_out/$T
+    mkdir -p $O
+    timeout 1500 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.log; echo "bench rc=$?" | tee $O/status.txt
+    tail -c 1800 $O/bench.json
+    timeout 900 bash tools/profile.sh $T --alt-steps 0 --no-configs --no-shards --no-extras > $O/profile.log 2>&1; echo "profile rc=$?" | tee -a $O/status.txt
+    cp gpurun_out/prof_$T/kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null; cp gpurun_out/prof_$T/bench.json $O/bench_profiled_run.json 2>/dev/null
+    head -12 $O/bench_kernel_stats.csv | cut -c1-150
+}
+
 "call$1"
