@@ -107,6 +107,7 @@ struct itts_gpt {
     // chunked generation (itts_gpt_generate_chunk): tokens generated so far and the shape / workspace of the call being resumed
     int chunk_steps = 0, chunk_nseq = 0, chunk_S = 0, chunk_max_new = 0;
     const void* chunk_ws = nullptr;
+    bool chunk_admitted = false;           // a row has been admitted into the suspended loop: the decode step reads the per-row position shifts
     // row compaction of a ragged decode batch (itts_gpt_set_compaction): finished utterances leave the running batch in steps of
     // `compact_gran` rows, so the step's cost follows the live rows.  cur_slots[i] = utterance carried by dense row i.
     bool compact = true;
@@ -543,11 +544,15 @@ static SampleArgs make_sample(itts_gpt* h, const GptWs& w, const itts_gen_params
 }
 
 // rows: the dense rows this step runs (= n_utts until finished utterances have been compacted away)
+// shifted: a row has been admitted into the batch (itts_gpt_admit_rows) -- the QKV epilogues and the attention read the per-row position shifts.
+// Until then they are all zero and the step does not load them (the load sits behind the slot-map load in the QKV epilogue: ~1 % of a
+// 1-8-row token step, profiles/r06e vs r05p).
 static int decode_step(itts_gpt* h, const GptWs& w, const itts_gen_params& gp, int rows, int n_utts, bool mapped, int Tmax, long long* tokens,
-                       const double* uniforms, hipStream_t st) {
+                       const double* uniforms, hipStream_t st, bool shifted) {
     bool pending = false;
     float* xc = w.x;
-    int rc = run_layers(h, w, rows, 1, Tmax, false, w.state + 1, w.pad, &pending, st, false, 1, mapped ? w.slot_map : nullptr, &xc, w.row_shift);
+    int rc = run_layers(h, w, rows, 1, Tmax, false, w.state + 1, w.pad, &pending, st, false, 1, mapped ? w.slot_map : nullptr, &xc,
+                        shifted ? w.row_shift : nullptr);
     if (rc) return rc;
     if ((rc = run_head(h, w, rows, 1, 0, pending, st, xc))) return rc;
     SampleArgs s = make_sample(h, w, gp, rows, tokens, uniforms, n_utts, mapped);
@@ -653,6 +658,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
         h->map_cap = nseq;
     }
     if (!resume) {
+        h->chunk_admitted = false;
         h->cur_slots.resize(nseq);
         for (int i = 0; i < nseq; ++i) h->cur_slots[i] = i;
         h->cur_mapped = false;
@@ -672,6 +678,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
         key.S = nseq;                                                  // utterances of the call (uniform stride, limits)
         key.aux0 = mapped ? (const void*)w.slot_map : nullptr;
         key.aux1 = (h->row_limits && h->row_limits_n == nseq) ? (const void*)h->row_limits : nullptr;
+        key.aux2 = h->chunk_admitted ? (const void*)w.row_shift : nullptr;
         exec = graph_lookup(h, key);
         graph_ok = exec != nullptr;
         if (graph_ok) return ITTS_OK;
@@ -680,7 +687,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
         int rcc = ITTS_OK;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
-            rcc = decode_step(h, w, gp, rows, nseq, mapped, Tmax, tokens, uniforms, st);
+            rcc = decode_step(h, w, gp, rows, nseq, mapped, Tmax, tokens, uniforms, st, h->chunk_admitted);
             e = hipStreamEndCapture(st, &graph);
             if (rcc == ITTS_OK && e == hipSuccess && graph) {
                 e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -702,7 +709,7 @@ static int gpt_generate_impl(itts_gpt* h, const float* prefix_embeds, const int3
     const int check_every = 8;
     while (steps < step_limit) {
         if (graph_ok) { HIP_TRY(hipGraphLaunch(exec, st)); }
-        else if ((rc = decode_step(h, w, gp, rows, nseq, mapped, Tmax, tokens, uniforms, st))) return rc;
+        else if ((rc = decode_step(h, w, gp, rows, nseq, mapped, Tmax, tokens, uniforms, st, h->chunk_admitted))) return rc;
         ++steps;
         h->last_row_steps += rows;
         if (steps % check_every == 0 && steps < step_limit) {
@@ -923,6 +930,7 @@ extern "C" int itts_gpt_admit_rows(itts_gpt* h, const float* prefix_embeds, cons
     h->cur_slots.resize(nseq);
     for (int i = 0; i < nseq; ++i) h->cur_slots[i] = i;
     h->cur_mapped = false;
+    h->chunk_admitted = true;
     return ITTS_OK;
 }
 
