@@ -70,4 +70,15 @@ call5() {
     head -12 $O/bench_kernel_stats.csv | cut -c1-150
 }
 
+# round 6, GPU call 6: (a) where the timed step's wall time goes that is not kernel time (kernel-trace gap report); (b) decode ms per token at 1 / 8 /
+# 64 rows with the position shifts read only after an admission; admission tests
+call6() {
+    O=$PWD/gpurun_out/r06f
+    mkdir -p $O
+    timeout 900 bash tools/gap_report.sh r06f > $O/gap_report.log 2>&1; echo "gap report rc=$?" | tee $O/status.txt
+    cat gpurun_out/gap_r06f/report.txt | cut -c1-220
+    timeout 600 python tools/decode_bench.py 400 1,8,64 > $O/decode_bench.log 2>&1; echo "decode bench rc=$?" | tee -a $O/status.txt; grep "^B=" $O/decode_bench.log
+    timeout 600 python -m pytest tests/test_gpu_admission.py tests/test_gpu_compaction.py -x -q > $O/pytest_admission.log 2>&1; echo "pytest admission rc=$?" | tee -a $O/status.txt; tail -2 $O/pytest_admission.log
+}
+
 "call$1"
