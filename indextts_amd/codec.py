@@ -26,13 +26,15 @@ F32 = 0
 
 
 def _tables(lens: Sequence[int], device):
-    """(tok_seq, tok_t, start, T) int32 device tensors of packed sequences of the given lengths, and the row count."""
-    T = torch.as_tensor(list(lens), dtype=torch.int32)
+    """(tok_seq, tok_t, start, T) int32 device tensors of packed sequences of the given lengths, and the row count.  Built on the device from the
+    lengths (the row tables are not computed on the host and copied: the device idles meanwhile, profiles/r06f/gap_report)."""
+    Th = torch.as_tensor(list(lens), dtype=torch.int32)
+    n = int(Th.sum())
+    T = Th.to(device)
     start = torch.cumsum(T, 0, dtype=torch.int32) - T
-    n = int(T.sum())
-    tok_seq = torch.repeat_interleave(torch.arange(T.numel(), dtype=torch.int32), T.long())
-    tok_t = torch.arange(n, dtype=torch.int32) - start[tok_seq.long()]
-    return tuple(t.to(device).contiguous() for t in (tok_seq, tok_t, start, T)), n
+    tok_seq = torch.repeat_interleave(torch.arange(T.numel(), dtype=torch.int32, device=device), T.long(), output_size=n)
+    tok_t = torch.arange(n, dtype=torch.int32, device=device) - start[tok_seq.long()]
+    return tuple(t.contiguous() for t in (tok_seq, tok_t, start, T)), n
 
 
 def _conv_matrix(w: torch.Tensor) -> torch.Tensor:

@@ -206,24 +206,27 @@ class CFM:
 
     # ---- packing -------------------------------------------------------------------------------------------------
     def _tables(self, frame_lens, x_lens, n_branch):
-        """Sequence tables for `n_branch` copies of the batch (branch-major)."""
+        """Sequence tables for `n_branch` copies of the batch (branch-major), built ON THE DEVICE from the per-sequence lengths (a few hundred bytes
+        cross to the device; the 2 x n_tok row tables -- 2.5 MB at 64 utterances -- used to be built by host torch ops and copied: ~100 ms of
+        idle device per 64-utterance solve, profiles/r06f/gap_report)."""
         dev = self.device
         fl = torch.as_tensor(frame_lens, dtype=torch.int32).reshape(-1)
         xl = torch.minimum(torch.as_tensor(x_lens, dtype=torch.int32).reshape(-1), fl)
-        seq_T = fl.repeat(n_branch)
-        seq_len = xl.repeat(n_branch)
+        n_tok, t_max = int(fl.sum()) * n_branch, int(fl.max())
+        seq_T = fl.repeat(n_branch).to(dev)
+        seq_len = xl.repeat(n_branch).to(dev)
         seq_start = torch.cumsum(seq_T, 0, dtype=torch.int32) - seq_T
-        n_tok = int(seq_T.sum())
-        tok_seq = torch.repeat_interleave(torch.arange(seq_T.numel(), dtype=torch.int32), seq_T.long())
-        tok_t = torch.arange(n_tok, dtype=torch.int32) - seq_start[tok_seq.long()]
+        tok_seq = torch.repeat_interleave(torch.arange(seq_T.numel(), dtype=torch.int32, device=dev), seq_T.long(), output_size=n_tok)
+        tok_t = torch.arange(n_tok, dtype=torch.int32, device=dev) - seq_start[tok_seq.long()]
         t = dict(seq_T=seq_T, seq_len=seq_len, seq_start=seq_start, tok_seq=tok_seq, tok_t=tok_t)
-        return {k: v.to(dev).contiguous() for k, v in t.items()}, n_tok, int(fl.max())
+        return {k: v.contiguous() for k, v in t.items()}, n_tok, t_max
 
     def _tail_tables(self, frame_lens, x_lens, prompt_lens, n_branch):
         """Tables of the TAIL layout for the solver's dead-row elimination (itts_s2mel_set_tail): of every sequence only the frames
         from `prompt_len - halo` on, halo = the WaveNet stack's one-sided receptive field (sum of (k - 1) / 2 * dilation per layer).  The
         Euler step never reads the estimator at prompt frames (flow_matching.py:107) and the stages after the last attention are
-        row-wise apart from that halo, so their outputs at the kept target frames are bit-identical.  None when nothing can be cut."""
+        row-wise apart from that halo, so their outputs at the kept target frames are bit-identical.  None when nothing can be cut.
+        Built on the device like `_tables`."""
         halo = sum((self.wavenet_kernel - 1) // 2 * self.wavenet_dilation_rate ** i for i in range(self.wavenet_layers))
         fl = [int(v) for v in frame_lens]
         xl = [min(int(v), f) for v, f in zip(torch.as_tensor(x_lens).reshape(-1).tolist(), fl)]
@@ -231,19 +234,21 @@ class CFM:
         span = (self.wavenet_kernel - 1) * self.wavenet_dilation_rate ** (self.wavenet_layers - 1)
         if not any(cuts) or any(f - c <= span for f, c in zip(fl, cuts)):          # nothing to cut / a tail shorter than one conv's padding
             return None
+        dev = self.device
         fl2 = [f - c for f, c in zip(fl, cuts)]
         xl2 = [max(0, x - c) for x, c in zip(xl, cuts)]
-        full_T = torch.tensor(fl * n_branch, dtype=torch.int64)
+        n_tok2 = sum(fl2) * n_branch
+        full_T = torch.tensor(fl * n_branch, dtype=torch.int64).to(dev)
         full_start = torch.cumsum(full_T, 0) - full_T
-        T2 = torch.tensor(fl2 * n_branch, dtype=torch.int64)
+        T2 = torch.tensor(fl2 * n_branch, dtype=torch.int64).to(dev)
         start2 = torch.cumsum(T2, 0) - T2
-        cut = torch.tensor(cuts * n_branch, dtype=torch.int64)
-        tok_seq = torch.repeat_interleave(torch.arange(T2.numel()), T2)
-        tok_t = torch.arange(int(T2.sum())) - start2[tok_seq]
-        t = dict(tok_seq=tok_seq, tok_t=tok_t, seq_start=start2, seq_T=T2, seq_len=torch.tensor(xl2 * n_branch),
+        cut = torch.tensor(cuts * n_branch, dtype=torch.int64).to(dev)
+        tok_seq = torch.repeat_interleave(torch.arange(T2.numel(), device=dev), T2, output_size=n_tok2)
+        tok_t = torch.arange(n_tok2, device=dev) - start2[tok_seq]
+        t = dict(tok_seq=tok_seq, tok_t=tok_t, seq_start=start2, seq_T=T2, seq_len=torch.tensor(xl2 * n_branch).to(dev),
                  tail_src=full_start[tok_seq] + cut[tok_seq] + tok_t, tail_base=start2 - cut)
-        out = {k: v.to(torch.int32).to(self.device).contiguous() for k, v in t.items()}
-        out["n_tok"], out["t_max"] = int(T2.sum()), int(max(fl2))
+        out = {k: v.to(torch.int32).contiguous() for k, v in t.items()}
+        out["n_tok"], out["t_max"] = n_tok2, int(max(fl2))
         self._tail_keep = out                                       # the engine reads the arrays during the solve
         return out
 
@@ -269,9 +274,16 @@ class CFM:
         return cin.contiguous()
 
     @staticmethod
-    def _pack_rows(x_bct: torch.Tensor, lens) -> torch.Tensor:
-        """(B, C, T) -> packed (sum lens, C)"""
-        return torch.cat([x_bct[b, :, : int(n)].t() for b, n in enumerate(lens)], 0).contiguous()
+    def _pack_rows(x_bct: torch.Tensor, seq: torch.Tensor, frame: torch.Tensor) -> torch.Tensor:
+        """(B, C, T) -> packed (n_rows, C): row i = frame frame[i] of sequence seq[i] (one gather through the row tables of the first branch)"""
+        return x_bct.transpose(1, 2)[seq, frame].contiguous()
+
+    @staticmethod
+    def _unpack_rows(rows: torch.Tensor, seq: torch.Tensor, frame: torch.Tensor, B: int, T: int) -> torch.Tensor:
+        """packed (n_rows, C) -> (B, C, T), frames beyond a sequence's rows left at 0 (one scatter)"""
+        out = torch.zeros(B, T, rows.shape[1], device=rows.device, dtype=rows.dtype)
+        out[seq, frame] = rows
+        return out.transpose(1, 2).contiguous()
 
     # ---- DiT.forward (one estimator call; used by the parity tests) -----------------------------------------------
     def _estimator_call(self, x, prompt_x, x_lens, t, style, cond, frame_lens=None):
@@ -287,10 +299,9 @@ class CFM:
         fl = [T] * B if frame_lens is None else [int(v) for v in frame_lens]
         tabs, n_tok, t_max = self._tables(fl, x_lens, 1)
         with _lib.on_device(dev):
-            xs = self._pack_rows(x.to(dev).float(), fl)
-            cin = self._const_in(self._pack_rows(prompt_x.to(dev).float(), fl),
-                                 torch.cat([cond[b, : fl[b]] for b in range(B)], 0).to(dev).float(),
-                                 torch.cat([style[b:b + 1].expand(fl[b], -1) for b in range(B)], 0).to(dev).float(), 0)
+            sq, fr = tabs["tok_seq"].long(), tabs["tok_t"].long()
+            xs = self._pack_rows(x.to(dev).float(), sq, fr)
+            cin = self._const_in(self._pack_rows(prompt_x.to(dev).float(), sq, fr), cond.to(dev).float()[sq, fr], style.to(dev).float()[sq], 0)
             tt = torch.as_tensor(t, dtype=torch.float32).reshape(-1).to(dev)
             if not bool((tt == tt[0]).all()):
                 raise NotImplementedError("one timestep per call (the solver never mixes timesteps in a batch)")
@@ -303,11 +314,7 @@ class CFM:
                                               _lib.ptr(tabs["tok_seq"]), _lib.ptr(tabs["tok_t"]), _lib.ptr(tabs["seq_start"]),
                                               _lib.ptr(tabs["seq_T"]), _lib.ptr(tabs["seq_len"]), B, n_tok, t_max, _lib.ptr(d),
                                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "itts_s2mel_estimator")
-            out = torch.zeros(B, Cc, T, device=dev)
-            o = 0
-            for b in range(B):
-                out[b, :, : fl[b]] = d[o:o + fl[b]].t()
-                o += fl[b]
+            out = self._unpack_rows(d, sq, fr, B, T)
         return out
 
     # ---- BASECFM.inference / solve_euler ----------------------------------------------------------------------------
@@ -344,20 +351,19 @@ class CFM:
                 prompt = prompt.expand(B, -1, -1)
             if style.shape[0] == 1 and B > 1:
                 style = style.expand(B, -1)
+            # flow_matching.py:84-89 for every row at once: prompt frames of x are zeroed, prompt_x holds the prompt there and zeros elsewhere
+            Tp = int(prompt.size(-1))
+            in_prompt = torch.arange(T, device=dev)[None, :] < torch.tensor(pl, device=dev)[:, None]            # (B, T)
             prompt_x = torch.zeros_like(x)
-            for b in range(B):
-                prompt_x[b, :, : pl[b]] = prompt[b, :, : pl[b]]
-                x[b, :, : pl[b]] = 0
+            prompt_x[:, :, :Tp] = prompt * in_prompt[:, None, :Tp]
+            x = torch.where(in_prompt[:, None, :], torch.zeros((), device=dev), x)
             mu = mu.to(dev).float()
             if self.zero_prompt_speech_token:
-                mu = mu.clone()
-                for b in range(B):
-                    mu[b, : pl[b]] = 0
-            xs = self._pack_rows(x, fl)
-            n_rows = xs.shape[0]
-            cin = self._const_in(self._pack_rows(prompt_x, fl), torch.cat([mu[b, : fl[b]] for b in range(B)], 0),
-                                 torch.cat([style[b:b + 1].to(dev).float().expand(fl[b], -1) for b in range(B)], 0),
-                                 n_rows if nb == 2 else 0)
+                mu = torch.where(in_prompt[:, :, None], torch.zeros((), device=dev), mu)
+            n_rows = n_tok // nb
+            sq, fr = tabs["tok_seq"][:n_rows].long(), tabs["tok_t"][:n_rows].long()                             # the first branch's rows
+            xs = self._pack_rows(x, sq, fr)
+            cin = self._const_in(self._pack_rows(prompt_x, sq, fr), mu[sq, fr], style.to(dev).float()[sq], n_rows if nb == 2 else 0)
             # t accumulates in fp32 exactly as the reference loop does (t = t + dt)
             ts = t_span.detach().to("cpu", torch.float32)
             t_list, t = [], ts[0].clone()
@@ -381,11 +387,7 @@ class CFM:
                                           _lib.ptr(tabs["tok_t"]), _lib.ptr(tabs["seq_start"]), _lib.ptr(tabs["seq_T"]),
                                           _lib.ptr(tabs["seq_len"]), _lib.ptr(plen), B * nb, n_tok, t_max, nb, n_steps, tsp,
                                           float(inference_cfg_rate), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)), "itts_s2mel_solve")
-            out = torch.zeros(B, Cc, T, device=dev)
-            o = 0
-            for b in range(B):
-                out[b, :, : fl[b]] = xs[o:o + fl[b]].t()
-                o += fl[b]
+            out = self._unpack_rows(xs, sq, fr, B, T)
         return out
 
     # ---- HIP-event profile of the last solve (bench.py) -----------------------------------------------------------

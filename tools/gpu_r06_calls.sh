@@ -81,4 +81,18 @@ call6() {
     timeout 600 python -m pytest tests/test_gpu_admission.py tests/test_gpu_compaction.py -x -q > $O/pytest_admission.log 2>&1; echo "pytest admission rc=$?" | tee -a $O/status.txt; tail -2 $O/pytest_admission.log
 }
 
+# round 6, GPU call 7: the flow-matching / codec host side with row tables built on the device and vectorised packing: s2mel + codec + pipeline
+# tests, then the gap report again
+call7() {
+    O=$PWD/gpurun_out/r06g
+    mkdir -p $O
+    timeout 1500 python -m pytest tests/test_gpu_s2mel.py tests/test_gpu_codec.py tests/test_gpu_cond.py tests/test_gpu_pipeline.py tests/test_gpu_pipeline_fullsize.py tests/test_gpu_fullsize.py -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee $O/status.txt
+    tail -3 $O/pytest.log
+    timeout 900 bash tools/gap_report.sh r06g > $O/gap_report.log 2>&1; echo "gap report rc=$?" | tee -a $O/status.txt
+    head -22 gpurun_out/gap_r06g/report.txt | cut -c1-200; grep -A12 "largest single" gpurun_out/gap_r06g/report.txt | cut -c1-200
+    timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --no-configs --no-shards --no-extras > $O/bench_short.json 2> $O/bench_short.err; echo "bench rc=$?" | tee -a $O/status.txt
+    python -c "
+import json; j=json.loads(open('$O/bench_short.json').read().strip().splitlines()[-1]); print('bench', j['value'], j['ms_per_step'], j['roofline']['frac'])"
+}
+
 "call$1"
