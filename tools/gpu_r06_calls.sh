@@ -95,4 +95,23 @@ call7() {
 import json; j=json.loads(open('$O/bench_short.json').read().strip().splitlines()[-1]); print('bench', j['value'], j['ms_per_step'], j['roofline']['frac'])"
 }
 
+# round 6, GPU call 8: same-box A/B of the host-side change (device-built row tables, vectorised packing): 3 timed steps each, alternating, against the
+# tree of the commit before it (tools/ab/base_tree: same library, old s2mel.py / codec.py)
+call8() {
+    O=$PWD/gpurun_out/r06h
+    mkdir -p $O
+    for rep in 1 2; do
+        (cd tools/ab/base_tree && timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --no-configs --no-shards --no-extras) > $O/base_$rep.json 2> $O/base_$rep.err
+        timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --no-configs --no-shards --no-extras > $O/new_$rep.json 2> $O/new_$rep.err
+    done
+    python - <<PY
+import json
+for n in ("base_1", "new_1", "base_2", "new_2"):
+    try:
+        j = json.loads(open("$O/" + n + ".json").read().strip().splitlines()[-1]); print(n, round(j["value"], 2), round(j["ms_per_step"], 1), round(j["roofline"]["frac"], 4))
+    except Exception as e:
+        print(n, "failed", e)
+PY
+}
+
 "call$1"
