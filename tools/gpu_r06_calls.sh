@@ -114,4 +114,16 @@ for n in ("base_1", "new_1", "base_2", "new_2"):
 PY
 }
 
+# round 6, GPU call 9: PMC refresh at the round's code (separate --pmc passes, --kernel-trace only): matrix-pipe busy / clock of the x3 kernels, HBM
+# traffic of the x3 GEMM at the bench shape, the GPT kernels at 64 rows, the vocoder conv traffic
+call9() {
+    O=$PWD/gpurun_out/r06i
+    mkdir -p $O
+    timeout 900 bash tools/pmc_x3.sh 8 > $O/pmc_x3.log 2>&1; echo "pmc_x3 rc=$?" | tee $O/status.txt; cp gpurun_out/pmc_x3/x3_pmc.json $O/ 2>/dev/null; tail -12 $O/pmc_x3.log | cut -c1-300
+    timeout 900 bash tools/pmc_s2mel_traffic.sh 64 fp32x3 > $O/pmc_s2mel.log 2>&1; echo "pmc_s2mel rc=$?" | tee -a $O/status.txt; tail -2 $O/pmc_s2mel.log | cut -c1-600
+    cp gpurun_out/pmc_s2mel/s2mel_gemm_traffic.json $O/ 2>/dev/null
+    timeout 900 bash tools/pmc_gpt.sh 64 24 > $O/pmc_gpt.log 2>&1; echo "pmc_gpt b64 rc=$?" | tee -a $O/status.txt; tail -3 $O/pmc_gpt.log | cut -c1-800
+    cp gpurun_out/pmc_gpt/gpt_pmc_b64.json $O/ 2>/dev/null
+}
+
 "call$1"
