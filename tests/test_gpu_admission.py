@@ -202,3 +202,35 @@ def test_inflight_at_production_widths_equals_one_batch():
         la = a.index(stop) if stop in a else len(a)
         lb = b.index(stop) if stop in b else len(b)
         assert la == lb == caps[i] and a[:la] == b[:lb], f"utterance {i}: one batch {a[:la]} vs in flight {b[:lb]}"
+
+
+def test_chunk_call_returns_at_the_flag_check_once_a_slot_can_be_refilled(golden_dir):
+    """`DecodeSession.run(n, return_when_finished=k)` (itts_gpt_set_chunk_return): the chunk comes back at one of the engine's own flag checks (every 8
+    steps) as soon as k utterances have finished, instead of running all n steps; without it the same call runs to n.  Ids are those of an undisturbed run."""
+    from indextts_amd import gpt
+    z = np.load(os.path.join(golden_dir, "gpt_greedy.npz"))
+    c = z["cfg"]
+    cfg = G.GPTConfig(layers=int(c[0]), model_dim=int(c[1]), heads=int(c[2]), max_text_tokens=int(c[3]), max_mel_tokens=int(c[4]),
+                      number_text_tokens=int(c[5]))
+    sd = G.synth_weights(cfg, seed=int(z["seed"]))
+    m = _engine(cfg, sd, "fp32")
+    style, emo = torch.from_numpy(z["style"]), torch.from_numpy(z["emo_vec"])
+    text, langs = torch.from_numpy(z["text"]), torch.from_numpy(z["langs"])
+    max_new = min(48, cfg.max_mel_tokens - 2)
+    emb, mask, mn, hf = m.inference_speech_stream(None, text, langs=langs, emo_vec=emo, campplus_embedding=style, max_generate_length=max_new,
+                                                  do_sample=False, num_beams=1, repetition_penalty=10.0)
+    B = text.shape[0]
+    caps = [5] + [40] * (B - 1)                                   # utterance 0 stops after 5 codes: finished at the flag check of step 8
+    with gpt.DecodeSession(m, emb, mask, mn, row_max_new=caps, **hf) as s:
+        assert s.run(40) == 40
+        full = [s.codes(b).cpu() for b in range(B)]
+    with gpt.DecodeSession(m, emb, mask, mn, row_max_new=caps, **hf) as s:
+        n = s.run(40, return_when_finished=1)
+        assert n == 8 and s.finished() == [0], (n, s.finished())
+        n = s.run(40, return_when_finished=2)                     # nobody else finishes before its cap
+        assert n == 48 or n % 8 == 0
+        while s.steps < 40:
+            s.run(40 - s.steps)
+        again = [s.codes(b).cpu()[:full[b].numel()] for b in range(B)]
+    for b in range(B):
+        assert torch.equal(again[b], full[b])
