@@ -126,4 +126,13 @@ call9() {
     cp gpurun_out/pmc_gpt/gpt_pmc_b64.json $O/ 2>/dev/null
 }
 
+# round 6, GPU call 10: x3 GEMM model with EIGHT waves per 128 x 128 block (32 x 64 wave tiles, 123 registers: four waves per SIMD at two blocks per
+# CU) against the product structure, with its own ablations (tools/microbench/x3_gemm_lab4.hip)
+call10() {
+    O=$PWD/gpurun_out/r06j
+    mkdir -p $O
+    timeout 600 tools/microbench/bin/x3_gemm_lab4 > $O/x3_gemm_lab4.log 2>&1; echo "x3_gemm_lab4 rc=$?" | tee $O/status.txt
+    cat $O/x3_gemm_lab4.log | cut -c1-170
+}
+
 "call$1"
