@@ -275,6 +275,184 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs a) {
     pf_store_tile<EPI, 128, 256, true>(a, ct, meta, m0, nt0 * 16, threadIdx.x);
 }
 
+
+// ================================================================================================================
+// The same GEMM with EIGHT waves per 128 x 128 block: 4 (rows) x 2 (columns), wave tile 32 x 64 -- two m-tiles instead of four, so the accumulators
+// (32 registers), ONE set of weight fragments (48) and the operand planes fit 128 registers and two resident blocks put FOUR waves on a SIMD instead
+// of two.  The product structure's ablations show its stalls as serialised per wave (requests, barrier, split, store: each +12 ... +25 % when removed,
+// profiles/r05b) and two waves per SIMD as too few to hide them; the standalone model of this form measured +2 ... +4 % on every s2mel shape
+// (tools/microbench/x3_gemm_lab4.hip, profiles/r06j).  Weights go through LDS (no register double buffer fits): one LDS-DMA'd copy of the K tile's 8
+// n-tiles x 3 planes per block (24 KiB, 3 pieces per wave) beside the A stage (16 KiB, 2 pieces per wave): 2 x 40 KiB of stages = 80 KiB, exactly two
+// blocks per CU; the epilogue image reuses it.  Per output element the MFMA sequence -- K tiles in order, plane pairs in order -- is the 4-wave kernel's:
+// the results are bit-identical (tests/test_gpu_gemm_x3.py).  6 plane products; option x3_waves = 4 selects the 4-wave kernel.
+#define X3W8_STAGE (16384 + 24576)
+#define X3W8_LDS (2 * X3W8_STAGE)
+template <int EPI, bool CONV = false>
+__global__ __launch_bounds__(512, 2) void gemm_x3w8_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char pf_sm[];      // [2][A 16 KiB | W 24 KiB]; the epilogue image is smaller
+    constexpr int NPROD = 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int n_mt = (a.M + PF_BM - 1) / PF_BM, n_nt = (a.N + PF_BN - 1) / PF_BN;
+    const int total = n_mt * n_nt, per = (total + 7) >> 3;
+    const int t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t >= total) return;
+    const int g0 = t / (PF_GM * n_nt), first_m = g0 * PF_GM;
+    const int gm = (n_mt - first_m) < PF_GM ? (n_mt - first_m) : PF_GM;
+    const int r = t - g0 * PF_GM * n_nt;
+    const int bn = r / gm, bm = first_m + (r - bn * gm);
+    const int m0 = bm * PF_BM, nt0 = bn * (PF_BN / 16);
+    const int nk = a.K >> 5;
+    const int ntiles = (a.N + 15) >> 4;
+
+    // A pieces of this wave: tile rows (2 w + i) * 8 .. + 7 (the 4-wave kernel's image and swizzle)
+    const char* asrc[2];
+    uint32_t aoff[2];
+    const char* abase = (const char*)a.A + (size_t)m0 * a.lda * 4;
+    int cv_t[2], cv_T[2];
+    const char* cv_base[2];
+    const char* cv_zero[2];
+    const int cv_kpt = CONV ? a.conv_W / 32 : 1;
+    const int cv_left = CONV ? (a.conv_taps - 1) * a.conv_dil - ((a.conv_taps - 1) * a.conv_dil) / 2 : 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = w * 2 + i;
+        const int row_t = c * 8 + (lane >> 3), row16 = row_t & 15;
+        const int piece = (lane & 7) ^ ((row16 >> 1) & 7);
+        int m = m0 + row_t;
+        m = m < a.M ? m : a.M - 1;
+        asrc[i] = (const char*)a.A + (size_t)m * a.lda * 4 + piece * 16;
+        aoff[i] = (uint32_t)(m - m0) * (uint32_t)a.lda * 4u + piece * 16;
+        if constexpr (CONV) {
+            const int sq = a.tok_seq[m];
+            cv_t[i] = a.tok_t[m];
+            cv_T[i] = a.seq_T[sq];
+            cv_base[i] = (const char*)a.A + (size_t)a.seq_start[sq] * a.lda * 4 + piece * 16;
+            cv_zero[i] = (const char*)a.zero_row + piece * 16;
+        }
+    }
+    // W pieces of this wave: q = w, w + 8, w + 16 of the block's 24 (n-tile q / 3, plane q % 3), each one contiguous KiB per K tile
+    const char* wdma[3];
+    const uint32_t lane16 = lane * 16;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int q = w + 8 * i;
+        int ntile = nt0 + q / 3;
+        ntile = ntile < ntiles ? ntile : ntiles - 1;
+        wdma[i] = (const char*)a.Wp + (size_t)ntile * nk * 3072 + (q % 3) * 1024;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = pf_sm + buf * X3W8_STAGE;
+        int tap = 0, rem = kt;
+        if constexpr (CONV) { tap = kt / cv_kpt; rem = kt - tap * cv_kpt; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (CONV) {
+                const int maxpad = cv_left;
+                const int Tv = cv_T[i] <= maxpad ? maxpad + 1 : cv_T[i];
+                int p = cv_t[i] + tap * a.conv_dil - cv_left;
+                p = p < 0 ? -p : p;
+                p = p >= Tv ? 2 * (Tv - 1) - p : p;
+                const bool ok = p >= 0 && p < cv_T[i];
+                const char* ap = ok ? cv_base[i] + ((size_t)p * a.lda + (size_t)rem * 32) * 4 : cv_zero[i];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap,
+                                                 (__attribute__((address_space(3))) void*)(base + (w * 2 + i) * 1024), 16, 0, 0);
+            } else {
+                (void)asrc;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pf_uni(abase + (size_t)kt * 128) + aoff[i]),
+                                                 (__attribute__((address_space(3))) void*)(base + (w * 2 + i) * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pf_uni(wdma[i] + (size_t)kt * 3072) + lane16),
+                                             (__attribute__((address_space(3))) void*)(base + 16384 + (w + 8 * i) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int row16 = lane & 15, kg = lane >> 4;
+    int a_off[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int pos = (s2 * 4 + kg) ^ ((row16 >> 1) & 7);
+        a_off[s2] = (row16 >> 3) * 1024 + ((row16 & 7) * 8 + pos) * 16;
+    }
+    const int a_wave = wr * 2 * 2048;
+
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this tile's A and W pieces have landed
+        __syncthreads();                                           // ... for every wave; the other stage is free again
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* base = pf_sm + (kt & 1) * X3W8_STAGE;
+        v4u bw[4][3];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bw[nt][p] = *(const v4u*)(base + 16384 + ((wc * 4 + nt) * 3 + p) * 1024 + lane16);
+        v4u ap[3], an[3];
+        {
+            const f32x4 p0 = *(const f32x4*)(base + a_wave + a_off[0]);
+            const f32x4 p1 = *(const f32x4*)(base + a_wave + a_off[1]);
+            x3_split8(p0, p1, ap[0], ap[1], ap[2]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (mt < 1) {
+                const f32x4 p0 = *(const f32x4*)(base + a_wave + (mt + 1) * 2048 + a_off[0]);
+                const f32x4 p1 = *(const f32x4*)(base + a_wave + (mt + 1) * 2048 + a_off[1]);
+                x3_split8(p0, p1, an[0], an[1], an[2]);
+            }
+            constexpr int PA[8] = {2, 1, 2, 0, 1, 1, 0, 0};
+            constexpr int PB[8] = {1, 2, 0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 8 - NPROD; q < 8; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ap[PA[q]]),
+                                                                          __builtin_bit_cast(bf16x8_t, bw[nt][PB[q]]), acc[mt][nt], 0, 0, 0);
+            if (mt < 1) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // the next m-tile's two fragment pieces
+#pragma unroll
+                for (int i = 0; i < 2 * NPROD; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+                ap[0] = an[0]; ap[1] = an[1]; ap[2] = an[2];
+            }
+        }
+    }
+    // epilogue: the 4-wave kernel's, with this kernel's wave tiles in the image and 512 storing threads
+    __syncthreads();
+    float* ct = (float*)pf_sm;
+    const int g = lane >> 4, c16 = lane & 15;
+    if (EPI == EPI_QKV_ROPE && a.D % 128 == 0 && nt0 * 16 >= 2 * a.D) {       // block-uniform: a V tile
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) *(f32x4*)(ct + (wc * 64 + nt * 16 + c16) * 132 + wr * 32 + mt * 16 + g * 4) = acc[mt][nt];
+        __syncthreads();
+        pf_store_vt<128, 512, true>(a, ct, m0, nt0 * 16, threadIdx.x);
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                ct[(wr * 32 + mt * 16 + g * 4 + rr) * 128 + ((wc * 64 + nt * 16 + c16) ^ (g << 4))] = acc[mt][nt][rr];
+    int* meta = (int*)(pf_sm + 65536);
+    pf_stage_meta<EPI, 128>(a, meta, m0, threadIdx.x);
+    __syncthreads();
+    pf_store_tile<EPI, 128, 512, true>(a, ct, meta, m0, nt0 * 16, threadIdx.x);
+}
+
 template <int EPI, bool CONV = false>
 static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
     const int n_mt = ceil_div(a.M, PF_BM), n_nt = ceil_div(a.N, PF_BN);
@@ -309,6 +487,17 @@ static int launch_gemm_x3_e(const GemmArgs& a, hipStream_t st) {
             return ITTS_OK;
         }
     } else if (a.a_planes) { itts_set_error("gemm (f32x3): plane operands are supported for the wqkv / SwiGLU GEMMs only"); return ITTS_ERR_ARG; }
+    if (nprod == 6 && sched && itts_opt(OPT_X3_WAVES) == 8 && itts_opt(OPT_X3_PIN) == 0) {     // the default: eight waves per block (gemm_x3w8_kernel)
+        static ItPerDevice<bool> w8_set_pd;
+        bool& w8_set = w8_set_pd.cur();
+        if (!w8_set) {
+            HIP_TRY(hipFuncSetAttribute((const void*)gemm_x3w8_kernel<EPI, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, X3W8_LDS));
+            w8_set = true;
+        }
+        hipLaunchKernelGGL((gemm_x3w8_kernel<EPI, CONV>), grid, dim3(512), X3W8_LDS, st, a);
+        HIP_TRY(hipGetLastError());
+        return ITTS_OK;
+    }
     if (nprod == 6 && sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, true>), grid, blk, lds, st, a);
     else if (nprod == 6) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 6, false>), grid, blk, lds, st, a);
     else if (sched) hipLaunchKernelGGL((gemm_x3_kernel<EPI, CONV, 8, true>), grid, blk, lds, st, a);

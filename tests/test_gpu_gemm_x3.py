@@ -82,3 +82,22 @@ def test_s2mel_solve_in_x3_mode_vs_reference(golden_dir):
         err = float((y - torch.from_numpy(z[f"euler_out{u}"])).abs().max())
         print(f"solve_euler f32x3 utt {u}: max|d| vs reference = {err:.3e}")
         assert err <= 1e-4
+
+
+@pytest.mark.parametrize("N,K", S2MEL_SHAPES)
+def test_x3_eight_wave_kernel_is_bitwise_the_four_wave_kernel(N, K):
+    """Option x3_waves = 8 (gemm_x3w8_kernel: 4 x 2 waves per 128 x 128 block, weights through LDS, four waves per SIMD) against the 4-wave kernel:
+    per output element the same MFMAs in the same order, so the results are equal bit for bit -- ragged M (a partial last tile), with bias."""
+    from indextts_amd import _lib, gpt
+    g = torch.Generator().manual_seed(N * 7 + K)
+    M = 128 * 9 + 37
+    a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(DEV)
+    w = torch.randn(K, N, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g).to(DEV)
+    wp = gpt.pack_gemm_weight(w, 2).to(DEV)
+    ys = []
+    for waves in (4, 8, 8):
+        with _lib.option_scope(x3_waves=waves, x3_products=6):
+            ys.append(gpt.gemm(a, wp, b, N, 2, prefill_tiles=True).cpu())
+    assert torch.isfinite(ys[0]).all() and float(ys[0].abs().max()) > 0
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[1], ys[2]), float((ys[0] - ys[1]).abs().max())

@@ -303,7 +303,8 @@ def test_dead_row_elimination_is_bit_identical(precision):
     print(f"{precision}: GEMM FLOPs of the solve {flops[False]:.3e} -> {flops[True]:.3e} with the prompt rows' dead tail work removed")
 
 
-@pytest.mark.parametrize("mode", ["fp32", "fp32x3", "fp32x3:x3_products=8", "fp32x3:x3_sched=0", "fp32x3:x3_attn=0,x3_products=8,x3_sched=0", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3", "fp32x3:x3_waves=8", "fp32x3:x3_waves=4", "fp32x3:x3_products=8", "fp32x3:x3_sched=0",
+                                  "fp32x3:x3_attn=0,x3_products=8,x3_sched=0", "bf16"])
 def test_estimator_is_bit_stable_run_to_run_at_solve_size(mode):
     """The production architecture on two utterances of 517 + 1926 frames (9772 packed rows with the CFG branch: every tile GEMM launch runs
     several blocks per CU): three estimator calls and three one-step solves on the same inputs return the same BITS, with the cached workspace
@@ -388,6 +389,33 @@ def test_bf16_estimator_is_bit_stable_run_to_run_with_stage_trace():
     firsts = [next((labels[i] for i in range(len(major)) if r[i] != major[i]), "length") for r in runs if r != major]
     print(f"bf16 estimator, {len(major)} stage checksums per call: {cnt} of {len(runs)} calls agree on all of them; first differing stages: {firsts}")
     assert len(major) > 100 and cnt == len(runs), firsts
+
+
+def test_x3_eight_wave_gemms_leave_the_estimator_bitwise_unchanged():
+    """fp32x3 with option x3_waves = 8 against 4: every fused epilogue (wqkv + RoPE with the K / V^T planes, SwiGLU, residual, the tap-mode WaveNet
+    conv with its gate, res-skip) runs on the 8-wave kernel and the estimator's output is BITWISE the 4-wave path's, at the production architecture
+    on a ragged pair of utterances."""
+    from indextts_amd import _lib, s2mel, synth
+    args = synth.S2MEL_V2
+    g = torch.Generator().manual_seed(5)
+    B, Tp, T = 2, 100, 100 + 411
+    x = torch.randn(B, 80, T, generator=g).to(DEV)
+    mu = torch.randn(B, T, args["DiT"]["content_dim"], generator=g).to(DEV)
+    prompt = (torch.randn(1, 80, Tp, generator=g) * 0.5 - 1.0).to(DEV)
+    style = torch.randn(1, args["style_encoder"]["dim"], generator=g).to(DEV)
+    lens = torch.tensor([T, T - 37])
+    px = torch.zeros_like(x)
+    px[..., :Tp] = prompt
+    outs = []
+    for waves in (4, 8):
+        with _lib.option_scope(x3_waves=waves):
+            m = s2mel.CFM(args, precision="fp32x3", device=DEV)
+            m.load_state_dict(synth.s2mel_weights(args, seed=1234))
+            outs.append(m.estimator(torch.cat([x, x]), torch.cat([px, torch.zeros_like(px)]), lens, torch.full((2 * B,), 0.3),
+                                    torch.cat([style.expand(B, -1), torch.zeros(B, style.shape[1], device=DEV)]), torch.cat([mu, torch.zeros_like(mu)]),
+                                    frame_lens=[T, T - 37] * 2).cpu())
+            del m
+    assert rms(outs[0]) > 1e-3 and torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
 
 
 def test_x3_plane_operands_are_bitwise_the_in_register_split():

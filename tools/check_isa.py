@@ -7,7 +7,7 @@ tile GEMMs' fused RoPE epilogue differ run to run in round 4 (found in round 5, 
 other than "low half from low, high half from high"): with a co-resident block on the CU one quarter-wave stored the un-updated product.  The
 source-level fix is `pf_rope4` (scalar fmas behind opaque register barriers, gemm_tile.h); this check is what keeps hipcc's SLP vectoriser -- or a
 compiler upgrade -- from re-introducing the form anywhere in the kernels that stage an accumulator tile through LDS (`pf_store_tile` /
-`pf_store_vt`: gemm_prefill_kernel, gemm_tile256_kernel, gemm_tile_4w_kernel, gemm_x3_kernel) without anyone noticing.
+`pf_store_vt`: gemm_prefill_kernel, gemm_tile256_kernel, gemm_tile_4w_kernel, gemm_x3_kernel, gemm_x3w8_kernel) without anyone noticing.
 
 usage: python tools/check_isa.py [--all-kernels] [--list]      exit code 1 when a flagged instruction is found
 `--all-kernels` applies the rule to every kernel of the library (informational: other kernels carry the form in code that never showed a difference).
@@ -21,7 +21,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 # kernels whose epilogue goes through gemm_tile.h's tile store (the family VERDICT r4 weak #1 / ADVICE r5 name)
-TILE_KERNELS = re.compile(r"gemm_prefill_kernel|gemm_tile256_kernel|gemm_tile_4w_kernel|gemm_x3_kernel")
+TILE_KERNELS = re.compile(r"gemm_prefill_kernel|gemm_tile256_kernel|gemm_tile_4w_kernel|gemm_x3_kernel|gemm_x3w8_kernel")
 PK = re.compile(r"^\s*(v_pk_(?:mul|fma|add)_f32)\s+(v\[\d+:\d+\])\s*,\s*(.*?)\s*(?://.*)?$")
 SEL = re.compile(r"(op_sel|op_sel_hi):\[([01,]+)\]")
 

@@ -135,4 +135,18 @@ call10() {
     cat $O/x3_gemm_lab4.log | cut -c1-170
 }
 
+# round 6, GPU call 11: the 8-wave x3 GEMM in the product (option x3_waves = 8): bitwise tests (GEMM shapes, estimator, run-to-run), GEMM shapes and
+# the 64-utterance solve against the 4-wave kernel, same box, alternating
+call11() {
+    O=$PWD/gpurun_out/r06k
+    mkdir -p $O
+    timeout 1500 python -m pytest tests/test_gpu_gemm_x3.py tests/test_gpu_s2mel.py -x -q > $O/pytest_x3.log 2>&1; echo "pytest x3 / s2mel rc=$?" | tee $O/status.txt
+    tail -4 $O/pytest_x3.log
+    for wv in 4 8 4 8; do
+        timeout 300 python tools/gemm_x3_bench.py 312704 5 x3_waves=$wv > $O/gemm_w$wv.log 2>&1; echo "x3_waves=$wv: $(grep 'f32x3' $O/gemm_w$wv.log | sed 's/.*f32x3: //' | awk '{printf "%s ", $3}')"
+    done
+    timeout 900 python tools/s2mel_bench.py 64 517 1926 1 fp32x3 fp32x3:x3_waves=8 fp32x3:x3_waves=4 fp32x3:x3_waves=8 fp32x3:x3_waves=4 fp32x3:x3_waves=8 > $O/solve_waves.log 2>&1; echo "solve rc=$?" | tee -a $O/status.txt
+    grep "^B=" $O/solve_waves.log | cut -c1-260
+}
+
 "call$1"
