@@ -1132,7 +1132,7 @@ def gpu_report(args, eng, B, n_text, n_gen, t_mel):
         gemm_roof = {"bound": "mfma",
                      "kernel": ("gemm_prefill_kernel<EPI, CONV, VEC, F32 = true> (s2mel DiT / WaveNet GEMMs, v_mfma_f32_16x16x4_f32, every "
                                 "epilogue instantiation)" if f32 else
-                                f"gemm_x3_kernel<EPI, CONV, {X3_PRODUCTS[0]}> (s2mel DiT / WaveNet GEMMs with f32 operands as three bf16 planes, "
+                                f"gemm_x3w8_kernel<EPI, CONV> / gemm_x3_kernel<EPI, CONV, {X3_PRODUCTS[0]}> (s2mel DiT / WaveNet GEMMs with f32 operands as three bf16 planes, "
                                 f"{X3_PRODUCTS[0]} x v_mfma_f32_16x16x32_bf16 per f32-equivalent MFMA; achieved / peak in f32-equivalent TFLOP/s, "
                                 f"peak = bf16 peak / {X3_PRODUCTS[0]})"
                                 if args.s2mel_precision == "fp32x3" else

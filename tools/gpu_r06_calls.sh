@@ -149,4 +149,22 @@ call11() {
     grep "^B=" $O/solve_waves.log | cut -c1-260
 }
 
+# round 6, GPU call 12: 8 waves per block as the x3 GEMM's default: s2mel / x3 / full-size tests, PMC of the new kernel (matrix-pipe busy, HBM traffic)
+call12() {
+    O=$PWD/gpurun_out/r06l
+    mkdir -p $O
+    timeout 1800 python -m pytest tests/test_gpu_gemm_x3.py tests/test_gpu_s2mel.py tests/test_gpu_attn_x3.py tests/test_gpu_fullsize.py tests/test_gpu_pipeline_fullsize.py -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee $O/status.txt
+    tail -3 $O/pytest.log
+    timeout 900 bash tools/pmc_x3.sh 8 > $O/pmc_x3.log 2>&1; echo "pmc_x3 rc=$?" | tee -a $O/status.txt; cp gpurun_out/pmc_x3/x3_pmc.json $O/ 2>/dev/null
+    python -c "
+import json; j=json.load(open('$O/x3_pmc.json'))
+for k,v in j.items():
+    if isinstance(v,dict): print(k, round(v['mfma_busy_of_own_cycles'],3), round(v['effective_clock_GHz'],3), v['dispatches'])"
+    timeout 900 bash tools/pmc_s2mel_traffic.sh 64 fp32x3 > $O/pmc_s2mel.log 2>&1; echo "pmc_s2mel rc=$?" | tee -a $O/status.txt; tail -1 $O/pmc_s2mel.log | cut -c1-400
+    cp gpurun_out/pmc_s2mel/s2mel_gemm_traffic.json $O/ 2>/dev/null
+    timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --no-configs --no-shards --no-extras > $O/bench_short.json 2> $O/bench_short.err; echo "bench rc=$?" | tee -a $O/status.txt
+    python -c "
+import json; j=json.loads(open('$O/bench_short.json').read().strip().splitlines()[-1]); print('bench', j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline']['achieved'])"
+}
+
 "call$1"

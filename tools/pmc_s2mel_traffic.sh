@@ -15,7 +15,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OUT/raw_$ctr" -o p -- python $ROOT/tools/s2mel_bench.py $B 517 1926 1 $PREC > "$OUT/run_$ctr.log" 2>&1
   grep -q "finite=True" "$OUT/run_$ctr.log" || { echo "pmc_s2mel_traffic: workload of pass $ctr failed: $(tail -3 "$OUT/run_$ctr.log")" >&2; exit 1; }
   f=$(find "$OUT/raw_$ctr" -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && grep -E "Counter_Name|gemm_prefill_kernel|gemm_x3_kernel|flash_attn_f32|flash_attn_x3" "$f" > "$OUT/cc_$ctr.csv"
+  [ -n "$f" ] && grep -E "Counter_Name|gemm_prefill_kernel|gemm_x3|flash_attn_f32|flash_attn_x3" "$f" > "$OUT/cc_$ctr.csv"
   rm -rf "$OUT/raw_$ctr"
 done
 python3 - "$OUT" "$B" "$PREC" <<'PY'
@@ -47,7 +47,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f"{out}/cc_{ctr}.csv")):
         if r.get("Counter_Name") == ctr:
-            k = "gemm" if ("gemm_prefill_kernel" in r["Kernel_Name"] or "gemm_x3_kernel" in r["Kernel_Name"]) else "attn"
+            k = "gemm" if ("gemm_prefill_kernel" in r["Kernel_Name"] or "gemm_x3" in r["Kernel_Name"]) else "attn"
             agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     res[ctr] = {k: {"kb_sum": v[0], "dispatches": v[1]} for k, v in agg.items()}
 n = res["FETCH_SIZE"].get("gemm", {}).get("dispatches", 0)

@@ -21,7 +21,7 @@ rm -rf "$OUT/raw"
 python3 - "$OUT" "$B" <<'PY'
 import csv, json, sys, collections
 out, B = sys.argv[1], int(sys.argv[2])
-FAM = ("gemm_x3_kernel", "flash_attn_x3_kernel", "gemm_prefill_kernel", "flash_attn_f32_kernel")
+FAM = ("gemm_x3", "flash_attn_x3_kernel", "gemm_prefill_kernel", "flash_attn_f32_kernel")      # gemm_x3: gemm_x3w8_kernel (8 waves, the default) and gemm_x3_kernel
 def fam(n):
     for k in FAM:
         if k in n: return k
@@ -43,7 +43,7 @@ for k in FAM:
     res[k] = {"dispatches": dur[k][1], "duration_ns": ns, "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE_sum_over_8_xcds": gui,
               "cycles_per_xcd": cyc, "mfma_busy_of_own_cycles": busy / (1024.0 * cyc) if cyc else None,
               "effective_clock_GHz": cyc / ns if ns else None, "mfma_busy_at_2p4GHz": busy / (1024.0 * ns * 2.4) if ns else None}
-if "gemm_x3_kernel" not in res: print("pmc_x3: no gemm_x3_kernel dispatches", file=sys.stderr); sys.exit(1)
+if "gemm_x3" not in res: print("pmc_x3: no gemm_x3 dispatches", file=sys.stderr); sys.exit(1)
 json.dump(res, open(f"{out}/x3_pmc.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
