@@ -167,4 +167,12 @@ for k,v in j.items():
 import json; j=json.loads(open('$O/bench_short.json').read().strip().splitlines()[-1]); print('bench', j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline']['achieved'])"
 }
 
+# round 6, GPU call 13: how fast does one block per CU fill its 160 KiB slab by LDS-DMA with 4 / 8 / 16 issuing waves (tools/microbench/slab_fill.hip)
+call13() {
+    O=$PWD/gpurun_out/r06o
+    mkdir -p $O
+    timeout 300 tools/microbench/bin/slab_fill > $O/slab_fill.log 2>&1; echo "slab_fill rc=$?" | tee $O/status.txt
+    cat $O/slab_fill.log
+}
+
 "call$1"
