@@ -175,4 +175,12 @@ call13() {
     cat $O/slab_fill.log
 }
 
+# round 6, GPU call 14: is the x3 vocoder conv at the power limit (clock ~2.0 GHz) or stalled below it?  matrix-pipe busy + clock per vocoder kernel
+call14() {
+    O=$PWD/gpurun_out/r06p
+    mkdir -p $O
+    timeout 900 bash tools/pmc_voc_x3.sh 16 > $O/pmc_voc_x3.log 2>&1; echo "pmc_voc_x3 rc=$?" | tee $O/status.txt
+    cp gpurun_out/pmc_voc_x3/voc_x3_pmc.json $O/ 2>/dev/null; cat $O/pmc_voc_x3.log | tail -45
+}
+
 "call$1"
