@@ -43,6 +43,14 @@ EULER_STEPS = 25                  # diffusion steps of cfm.inference in the pipe
 METRIC = "audio-seconds/sec (RTF) IndexTTS-2.5, 64-utt batch @1/2/4/8 MI355X"
 
 
+
+def x3_waves_opt(args, stub):
+    """waves per block of the fp32x3 GEMM the run used (engine option x3_waves; None outside that mode / in the launcher-test stub)"""
+    if stub or args.no_s2mel or args.s2mel_precision != "fp32x3":
+        return None
+    from indextts_amd import _lib
+    return int(_lib.get_option("x3_waves"))
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -642,6 +650,7 @@ def main():
                        "mel_frames": t_mel, "audio_seconds_per_utt": t_mel * HOP / SR, "parallelism": f"utterance-dp{world}",
                        "gpt_precision": args.precision, "s2mel_precision": None if args.no_s2mel else args.s2mel_precision,
                        "x3_products": args.x3_products if (not args.no_s2mel and args.s2mel_precision == "fp32x3") else None,
+                       "x3_gemm_waves_per_block": x3_waves_opt(args, stub),
                        "use_hipgraph": not args.no_graph,
                        "step_overlap": bool(args.overlap and args.steps > 1)},
         }
