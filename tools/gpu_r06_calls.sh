@@ -183,4 +183,14 @@ call14() {
     cp gpurun_out/pmc_voc_x3/voc_x3_pmc.json $O/ 2>/dev/null; cat $O/pmc_voc_x3.log | tail -45
 }
 
+# round 6, GPU call 15: the x3 vocoder conv with sixteen waves per block (option voc_x3_waves = 16): bitwise tests, forward + per-stage conv rates at
+# 16 x 1926 frames against the 8-wave kernel, alternating
+call15() {
+    O=$PWD/gpurun_out/r06r
+    mkdir -p $O
+    timeout 900 python -m pytest tests/test_gpu_bigvgan_x3.py -x -q > $O/pytest_voc_x3.log 2>&1; echo "pytest voc x3 rc=$?" | tee $O/status.txt; tail -3 $O/pytest_voc_x3.log
+    timeout 900 python tools/voc_h3_bench.py 16 bf16x3:96,bf16x3:96:voc_x3_waves=16,bf16x3:96,bf16x3:96:voc_x3_waves=16 > $O/voc_bench.log 2>&1; echo "voc bench rc=$?" | tee -a $O/status.txt
+    grep -v amdgpu.ids $O/voc_bench.log | cut -c1-150
+}
+
 "call$1"
