@@ -193,4 +193,7 @@ call15() {
     grep -v amdgpu.ids $O/voc_bench.log | cut -c1-150
 }
 
+# round 6, GPU call 15 (ran at commit "x3 vocoder conv with sixteen waves per block"; the variant was removed after it): pytest tests/test_gpu_bigvgan_x3.py
+# with the 16-vs-8-wave bitwise test, then  tools/voc_h3_bench.py 16 bf16x3:96,bf16x3:96:voc_x3_waves=16,bf16x3:96,bf16x3:96:voc_x3_waves=16  -> profiles/r06r
+
 "call$1"
