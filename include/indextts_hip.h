@@ -60,7 +60,6 @@ int itts_device_count(void);
  *   x3_pin               0     0..1    fp32x3 GEMM: 1 = non-default variants on one block per CU (round 4's workaround, diagnostic only)
  *   prefill_attn        -1    -1..1    GPT attention of S > 1 passes: -1 causal MFMA kernel (bf16 mode) / canonical streams (f32 mode), 0 canonical, 1 MFMA
  *   voc_act_planes       1     0..1    vocoder bf16x3 mode: activation writes the x3 conv's operand planes (0: f32 activation + split pass; same bits)
- *   voc_x3_waves         8     8..16   vocoder bf16x3 conv: waves per 256-frame block, 8 (wave tile 64 x 48) or 16 (32 x 48); same bits
  *   x3_waves             8     4..8    fp32x3 GEMM: waves per 128 x 128 block, 8 (wave tile 32 x 64, weights through LDS) or 4 (64 x 64, round 5's kernel); same bits
  * itts_option_count / _name / _doc / _default enumerate the table (index 0 .. count-1).
  * ---------------------------------------------------------------------------------------------------------- */

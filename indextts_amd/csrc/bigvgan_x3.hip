@@ -94,12 +94,8 @@ __device__ __forceinline__ void cx3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0
 // part of a K tile's LDS-DMA traffic -- at k = 3 a 96-wide block moved 60 + 54 KiB per 6 900 matrix-pipe cycles per SIMD and was bound by the
 // CU's fill rate (~12 B / clk), profiles/r05d/voc_bench.log -- so with NH = 2 the block walks (chunk, co half, tap): two accumulator sets, the same
 // weight bytes as two blocks, half the window bytes.
-// MTW = m-tiles (16 frames) per wave: 4 (the block's 256 frames on 4 x 2 waves, wave tile 64 x 48: two waves per SIMD) or 2 (8 x 2 = SIXTEEN waves,
-// wave tile 32 x 48: four waves per SIMD -- the x3 GEMM's round-6 lever, option voc_x3_waves = 16; the same MFMAs per output element in the same
-// order, bit-identical).
-template <int NH, int MTW = CX3_MT>
-__global__ __launch_bounds__(MTW == 4 ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(MTW == 4 ? 2 : 4, MTW == 4 ? 2 : 4))) void conv_x3w_kernel(ConvX3Args a) {
-    constexpr int NW = 8 * (4 / MTW);                                  // waves of the block
+template <int NH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_x3w_kernel(ConvX3Args a) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = w >> 1, wc = w & 1;
@@ -126,12 +122,12 @@ __global__ __launch_bounds__(MTW == 4 ? 512 : 1024) __attribute__((amdgpu_waves_
     const char* zr = (const char*)a.zero_row;
     // wave w stages window chunks w, w + 8, w + 16 (< nach): 2 or 3 chunks x 3 planes -- the count is wave-uniform and known up front, so the
     // counted wait below (how many of this wave's own LDS-DMA instructions may stay in flight) is exact per wave
-    const int my_ach = (nach - w + NW - 1) / NW;
+    const int my_ach = (nach - w + 7) >> 3;
     auto issue_a = [&](int kc_, int buf) {
         char* base = sm + buf * CX3_ABUF;
 #pragma unroll
-        for (int i = 0; i < (NW == 8 ? 3 : 2); ++i) {
-            const int c = w + NW * i;
+        for (int i = 0; i < 3; ++i) {
+            const int c = w + 8 * i;
             if (c < nach) {                                              // wave-uniform
                 const int t = m0 - pad + c * 16 + srow;
                 const bool ok = (unsigned)t < (unsigned)a.T;
@@ -160,11 +156,11 @@ __global__ __launch_bounds__(MTW == 4 ? 512 : 1024) __attribute__((amdgpu_waves_
                                              (__attribute__((address_space(3))) void*)(base + (pl * CX3_NWT + w) * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[NH][MTW][CX3_NT];
+    f32x4 acc[NH][CX3_MT][CX3_NT];
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int i = 0; i < MTW; ++i)
+        for (int i = 0; i < CX3_MT; ++i)
 #pragma unroll
             for (int jn = 0; jn < CX3_NT; ++jn) acc[h][i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -174,11 +170,11 @@ __global__ __launch_bounds__(MTW == 4 ? 512 : 1024) __attribute__((amdgpu_waves_
     issue_a(0, 0);
     issue_w(0);
     // window fragments of one K tile: tap j of chunk kc, three planes per m-tile
-    auto read_a = [&](int kc, int j, x3_v4u (&af)[MTW][3]) {
+    auto read_a = [&](int kc, int j, x3_v4u (&af)[CX3_MT][3]) {
         const char* abase = sm + (kc & 1) * CX3_ABUF;
-        const int rbase = wr * MTW * 16 + row16 + j * a.dil;            // window row of this lane's first frame for tap j
+        const int rbase = wr * CX3_MT * 16 + row16 + j * a.dil;         // window row of this lane's first frame for tap j
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
+        for (int mt = 0; mt < CX3_MT; ++mt) {
             const int rr = rbase + mt * 16;
             const char* ap = abase + (rr >> 4) * 1024 + kg * 256 + (rr & 15) * 16;
 #pragma unroll
@@ -193,9 +189,9 @@ __global__ __launch_bounds__(MTW == 4 ? 512 : 1024) __attribute__((amdgpu_waves_
     // (profiles/r05d: 213 TFLOP/s on the 768-channel stage); the next tile's window is resident by then -- the same chunk's, or the next chunk's,
     // which was requested k NH >= 3 tiles earlier and waited for (vmcnt(0) + barrier) two tiles after its request.
     bool a_recent = false;
-    x3_v4u afc[MTW][3];                                                 // this tile's window fragments (read during the previous tile)
-    auto ktile = [&](int g, int kc, int kc_n, int j_n, f32x4 (&ac)[MTW][CX3_NT], bool first_of_chunk) {
-        if (a_recent) { if (my_ach == 3) cx3_wait_vm<9>(); else if (my_ach == 2) cx3_wait_vm<6>(); else cx3_wait_vm<3>(); } else cx3_wait_vm<0>();
+    x3_v4u afc[CX3_MT][3];                                              // this tile's window fragments (read during the previous tile)
+    auto ktile = [&](int g, int kc, int kc_n, int j_n, f32x4 (&ac)[CX3_MT][CX3_NT], bool first_of_chunk) {
+        if (a_recent) { if (my_ach == 3) cx3_wait_vm<9>(); else cx3_wait_vm<6>(); } else cx3_wait_vm<0>();
         __builtin_amdgcn_s_barrier();                                   // ... for every wave; the other weight stage and window buffer are free again
         asm volatile("" ::: "memory");                                  // (raw barrier: __syncthreads' fence would drain the window request in flight)
         if (g + 1 < G) issue_w(g + 1);
@@ -209,10 +205,10 @@ __global__ __launch_bounds__(MTW == 4 ? 512 : 1024) __attribute__((amdgpu_waves_
             for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = *(const x3_v4u*)(wbase + pl * CX3_NWT * 1024 + b_off + nt * 1024);
         if (g == 0) read_a(0, 0, afc);                                  // the first tile's own fragments (its window landed with this barrier)
         const char* abase_n = sm + (kc_n & 1) * CX3_ABUF;
-        const int rbase_n = wr * MTW * 16 + row16 + j_n * a.dil;
+        const int rbase_n = wr * CX3_MT * 16 + row16 + j_n * a.dil;
         const bool more = g + 1 < G;
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
+        for (int mt = 0; mt < CX3_MT; ++mt) {
             // plane pairs, smallest terms first (x plane, w plane): l h, h l, m m, m h, h m, h h
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
             constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
@@ -255,8 +251,8 @@ __global__ __launch_bounds__(MTW == 4 ? 512 : 1024) __attribute__((amdgpu_waves_
         if (co >= a.Cout) continue;
         const float bias = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
-            const int t = m0 + (wr * MTW + mt) * 16 + (lane >> 4) * 4;
+        for (int mt = 0; mt < CX3_MT; ++mt) {
+            const int t = m0 + (wr * CX3_MT + mt) * 16 + (lane >> 4) * 4;
             if (t >= len) continue;
             f32x4 v;
 #pragma unroll
@@ -347,8 +343,7 @@ int launch_conv_x3(const ConvX3Args& a0, hipStream_t st) {
     }
     if ((long long)a0.Cout * a0.T >= (1ll << 31) || (long long)a0.Cin * a0.T >= (1ll << 31)) { itts_set_error("conv_x3: row plane too large"); return ITTS_ERR_ARG; }
     ConvX3Args a = a0;
-    const bool w16 = itts_opt(OPT_VOC_X3_WAVES) == 16;                 // sixteen waves per block: one co tile per window (two accumulator sets spill at 128 registers)
-    const int nh = (a.Cout > CX3_BN && !w16) ? 2 : 1;                  // two co tiles per staged window where there are two
+    const int nh = a.Cout > CX3_BN ? 2 : 1;                            // two co tiles per staged window where there are two
     a.n_mt = ceil_div(a.T, CX3_BM);
     a.n_co = ceil_div(a.Cout, CX3_BN * nh);
     const long long tiles8 = ((long long)a.n_mt * a.B + 7) / 8 * 8;
@@ -359,13 +354,7 @@ int launch_conv_x3(const ConvX3Args& a0, hipStream_t st) {
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)conv_x3w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CX3_LDS));
         HIP_TRY(hipFuncSetAttribute((const void*)conv_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, CX3_LDS));
-        HIP_TRY(hipFuncSetAttribute((const void*)conv_x3w_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, CX3_LDS));
         attr_set = true;
-    }
-    if (w16) {
-        hipLaunchKernelGGL((conv_x3w_kernel<1, 2>), dim3((unsigned)nblocks), dim3(1024), CX3_LDS, st, a);
-        HIP_TRY(hipGetLastError());
-        return ITTS_OK;
     }
     if (nh == 2) hipLaunchKernelGGL(conv_x3w_kernel<2>, dim3((unsigned)nblocks), dim3(512), CX3_LDS, st, a);
     else hipLaunchKernelGGL(conv_x3w_kernel<1>, dim3((unsigned)nblocks), dim3(512), CX3_LDS, st, a);

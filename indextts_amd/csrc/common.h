@@ -26,7 +26,7 @@ void itts_set_error(const char* fmt, ...);
 // current value at launch time; itts_opt_epoch() changes whenever any value does (cached hipGraphs are keyed on it).
 enum { OPT_DECODE_FUSE_LN, OPT_DECODE_GEMM, OPT_DECODE_ROT, OPT_DECODE_WNT, OPT_DECODE_NT, OPT_PREFILL_GEMM, OPT_TILE256, OPT_F32_TILE,
        OPT_X3_PRODUCTS, OPT_X3_SCHED, OPT_X3_ATTN, OPT_SAMPLE_RADIX, OPT_GPT_COMPACT, OPT_ATTN_WAVES, OPT_S2MEL_FUSED, OPT_FA_QS,
-       OPT_F32_ATTN_SCALAR, OPT_FA32_QS, OPT_AA_ACT, OPT_CONV_BM, OPT_H3_KERNEL, OPT_DECODE_LN_NT, OPT_X3_APLANES, OPT_X3_PIN, OPT_PREFILL_ATTN, OPT_VOC_ACT_PLANES, OPT_X3_WAVES, OPT_VOC_X3_WAVES, OPT_COUNT };
+       OPT_F32_ATTN_SCALAR, OPT_FA32_QS, OPT_AA_ACT, OPT_CONV_BM, OPT_H3_KERNEL, OPT_DECODE_LN_NT, OPT_X3_APLANES, OPT_X3_PIN, OPT_PREFILL_ATTN, OPT_VOC_ACT_PLANES, OPT_X3_WAVES, OPT_COUNT };
 int itts_opt(int id);
 unsigned itts_opt_epoch();
 

@@ -45,7 +45,6 @@ const OptDef kDefs[OPT_COUNT] = {
     {"prefill_attn", -1, -1, 1, "attention of S > 1 passes (prefill, latent pass): -1 causal MFMA kernel in the bf16 mode, canonical-stream kernel in the f32 parity mode; 0 canonical-stream kernel (one block per query) always; 1 MFMA kernel in both precisions"},
     {"voc_act_planes", 1, 0, 1, "vocoder, bf16x3 conv mode: the anti-aliased activation in front of an x3 conv writes the conv's three operand planes itself (aa_act_planes_kernel); 0: f32 activation + split pass (bit-identical planes)"},
     {"x3_waves", 8, 4, 8, "fp32x3 GEMM: waves per 128 x 128 block -- 8 (4 x 2, wave tile 32 x 64, weights through LDS: four waves per SIMD at two blocks per CU; 64-utterance solve 314.7 vs 323.0 ms per Euler step, profiles/r06k) or 4 (2 x 2, wave tile 64 x 64, weights in registers: round 5's kernel); bitwise equal", "4,8"},
-    {"voc_x3_waves", 8, 8, 16, "vocoder, bf16x3 conv (conv_x3w_kernel): waves per 256-frame block, 8 (wave tile 64 x 48) or 16 (32 x 48: four waves per SIMD); bitwise equal", "8,16"},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::atomic<unsigned> g_epoch{1};

@@ -140,27 +140,3 @@ def test_activation_written_as_operand_planes_is_bit_identical(frames, lens):
         a, c = out[1][b, ..., : n * 256], out[0][b, ..., : n * 256]
         assert torch.isfinite(a).all() and float(a.abs().max()) > 0
         assert torch.equal(a, c), f"row {b}: max |d| {float((a - c).abs().max()):.3e}"
-
-
-@pytest.mark.parametrize("Cin,Cout,k,d,T,B", X3_CASES)
-def test_conv1d_x3_sixteen_wave_kernel_is_bitwise_the_eight_wave_kernel(Cin, Cout, k, d, T, B):
-    """Option voc_x3_waves = 16 (conv_x3w_kernel<1, 2>: the block's 256 frames on 8 x 2 waves of 32 x 48, four waves per SIMD, one co tile per staged
-    window) against the 8-wave kernel: the same MFMAs per output element in the same order -> equal bit for bit, residual / accumulate epilogue too."""
-    from indextts_amd import _lib, bigvgan as bv
-    g = torch.Generator().manual_seed(Cin + 31 * Cout + k)
-    x = (torch.randn(B, Cin, T, generator=g) * 3).to(DEV)
-    w = torch.randn(Cout, Cin, k, generator=g) / (Cin * k) ** 0.5
-    bias = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
-    res = torch.randn(B, Cout, T, generator=g).to(DEV)
-    y0 = torch.randn(B, Cout, T, generator=g).to(DEV)
-    w3 = bv.pack_conv1d_x3_weight(w).to(DEV)
-    outs = []
-    for waves in (8, 16, 16):
-        with _lib.option_scope(voc_x3_waves=waves):
-            y = bv.conv1d_x3(x, w3, bias, Cout, k, d).cpu()
-            acc = y0.clone()
-            bv.conv1d_x3(x, w3, bias, Cout, k, d, res=res, out=acc, acc_mode=2, div=3.0)
-            outs.append((y, acc.cpu()))
-    assert torch.isfinite(outs[0][0]).all() and float(outs[0][0].abs().max()) > 0
-    for i in (1, 2):
-        assert torch.equal(outs[0][0], outs[i][0]) and torch.equal(outs[0][1], outs[i][1])
